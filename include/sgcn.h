@@ -1,0 +1,188 @@
+/* include/sgcn.h -- C-ABI of libsgcn.so: the MI355X-native (gfx950) drop-in for the training
+ * hot path of thu-ml/stochastic_gcn (sampled sparse-adjacency x dense-feature SpMM fwd/bwd,
+ * control-variate history gather/scatter, host neighbour sampler feeding a device CSR).
+ *
+ * The reference binds its native code through Cython (gcn/_scheduler.pyx, gcn/_history.pyx)
+ * and runs its sparse arithmetic as TensorFlow ops (gcn/layers.py:31-37,304-311;
+ * gcn/models.py:165).  This header is what a binding for the same seams targets instead:
+ * plain pointers and sizes, no torch / numpy types.  Each entry cites the reference
+ * interface it replaces as `file:line` relative to the reference tree.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; sgcn_last_error() returns a
+ *     thread-local message.  Nothing throws across the boundary (the reference aborts on a
+ *     C++ throw inside expand(): gcn/_scheduler.pyx:14-16 has no `except +`).
+ *   - "dev" pointers are HBM (device) addresses, "host" pointers are CPU addresses.
+ *   - values fp32, indices int32 (gcn/_scheduler.pyx:70-85, gcn/_history.pyx:27,38);
+ *     leading dimensions (ld*) are in elements and 64-bit.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels never
+ *     allocate; all buffers are caller-owned.
+ */
+#ifndef SGCN_H
+#define SGCN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGCN_OK 0
+#define SGCN_ERR_INVALID (-1)
+#define SGCN_ERR_HIP (-2)
+#define SGCN_ERR_EMPTY_PROB (-3) /* gcn/mult.cpp:17-18 "Prob is empty" */
+#define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
+
+const char* sgcn_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int sgcn_abi_version(void);
+
+/* ======================================================================================
+ * Device kernels (HIP, gfx950)
+ * ====================================================================================== */
+
+/* ---- work plan for power-law rows -------------------------------------------------------
+ * A gather SpMM is latency-bound per wavefront, so a 31k-nonzero hub row must not sit on one
+ * wavefront.  A plan cuts every CSR row into segments of at most T nonzeros.  Rows that fit
+ * in one segment are computed and stored directly; longer rows write per-segment partial
+ * sums to a caller-owned workspace slot and a fix-up pass adds the slots IN ORDER (results
+ * are deterministic, no float atomics).  The plan is pure host arithmetic on the row
+ * pointer (the sampler has it on host anyway; a static graph builds it once). */
+typedef struct { int32_t row, start, end, slot; } sgcn_seg_t;   /* slot < 0: direct row   */
+typedef struct { int32_t row, first_slot, nslots; } sgcn_fix_t; /* one per split row      */
+typedef struct {
+    const sgcn_seg_t* dev_seg; int64_t nseg;
+    const sgcn_fix_t* dev_fix; int64_t nfix;
+    int64_t nslots;            /* total workspace slots used by split rows               */
+    float* dev_ws;             /* [nslots x ldw] fp32, ldw = 4*ceil(d/4)                  */
+    int64_t ws_elems;          /* capacity of dev_ws in floats (checked against nslots)   */
+} sgcn_plan_t;
+/* Count, then fill (host arrays sized by the counts).  T <= 0 selects the default (256). */
+int sgcn_plan_count(const int32_t* host_rowptr, int32_t M, int32_t T,
+                    int64_t* nseg, int64_t* nfix, int64_t* nslots);
+int sgcn_plan_fill(const int32_t* host_rowptr, int32_t M, int32_t T,
+                   sgcn_seg_t* host_seg, sgcn_fix_t* host_fix);
+
+/* C[M x d] = rscale (.) ( A[M x K, CSR] * (cscale (.) B[g]) ) + beta * C
+ *   B row used for column c is  B + (gidx ? gidx[c] : c) * ldb;  rscale[M], cscale[K]
+ *   and gidx[K] are nullable; plan nullable (then one wavefront group per whole row).
+ * Replaces  dot(x, y, sparse=True) = tf.sparse_tensor_dense_matmul   gcn/layers.py:31-37
+ *           (K1 gcn/layers.py:253; K3/K4 :310-311; K5 :353-355; K11 gcn/utils.py:169-170,
+ *           321-322), fused with tf.gather(history, field) gcn/layers.py:304-305 when gidx
+ *           is given (K2+K7), and its TF-autodiff backward  dB = A^T dC  (K6) when called
+ *           with the transposed CSR. */
+int sgcn_spmm_csr_f32(const int32_t* dev_rowptr, const int32_t* dev_col, const float* dev_val,
+                      int32_t M, int32_t K, int32_t d,
+                      const float* dev_B, int64_t ldb, const int32_t* dev_gidx,
+                      const float* dev_rscale, const float* dev_cscale,
+                      float* dev_C, int64_t ldc, float beta,
+                      const sgcn_plan_t* plan, void* stream);
+
+/* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
+ *   "spmm_nv"   : float4 vectors per lane for wide rows (0 = auto)
+ *   "spmm_unroll": nonzeros in flight per group (1,2,4,8; 0 = auto) */
+int sgcn_tune(const char* key, int64_t value);
+
+/* Fused control-variate aggregator forward                    gcn/layers.py:298-319 (cvd)
+ *                                                             gcn/layers.py:350-362 (cv)
+ *   A  = sampled adjacency  [n1 x n0] CSR (a_rowptr,a_col,a_val)    placeholder 'adj'
+ *   P  = full-neighbour adj [n1 x nf] CSR (f_rowptr,f_col,f_val)    placeholder 'fadj'
+ *   Hbar [N x d] history (ldh), ifield[n0], ffield[nf], s[n1] = 'scales'
+ * cvd != 0 (inputs h, mu [n0 x d]):
+ *   mu_nbr = A (mu - Hbar[ifield]) + P Hbar[ffield]
+ *   h_nbr  = (A (h - mu)) (.) s[:,None] + mu_nbr
+ *   out_h[:, off:off+d] = h_nbr ; out_mu[:, off:off+d] = mu_nbr
+ * cvd == 0 (single stream x = h, mu ignored, out_mu ignored):
+ *   out_h[:, off:off+d] = A x - A Hbar[ifield] + P Hbar[ffield]
+ * concat_self != 0 (normalization != 'gcn'): off = d and out[:, 0:d] = h[:n1] (resp. mu[:n1]);
+ * else off = 0. */
+int sgcn_vr_aggregate_f32(const int32_t* dev_a_rowptr, const int32_t* dev_a_col,
+                          const float* dev_a_val, const int32_t* dev_f_rowptr,
+                          const int32_t* dev_f_col, const float* dev_f_val,
+                          int32_t n1, int32_t n0, int32_t nf, int32_t d,
+                          const float* dev_h, const float* dev_mu, int64_t ldx,
+                          const float* dev_Hbar, int64_t ldh,
+                          const int32_t* dev_ifield, const int32_t* dev_ffield,
+                          const float* dev_s,
+                          float* dev_out_h, float* dev_out_mu, int64_t ldo,
+                          int32_t cvd, int32_t concat_self,
+                          const sgcn_plan_t* f_plan /* plan over f_rowptr, nullable */,
+                          void* stream);
+
+/* out[i, 0:d] = in[r[i], 0:d]                  replaces history.dense_slice / c_dense_slice
+ *                                              gcn/_history.pyx:53-62, gcn/history.cpp:74-88
+ *                                              and tf.gather gcn/layers.py:304-305 */
+int sgcn_gather_rows_f32(const float* dev_in, int64_t ldi, const int32_t* dev_r, int32_t n,
+                         int32_t d, float* dev_out, int64_t ldo, void* stream);
+
+/* H[r[i], 0:d] = src[i, 0:d]   (r unique)       replaces tf.scatter_update gcn/models.py:165 */
+int sgcn_scatter_rows_f32(float* dev_H, int64_t ldh, const int32_t* dev_r, int32_t n,
+                          int32_t d, const float* dev_src, int64_t lds, void* stream);
+
+/* CSR row slice -> CSR of the n selected rows.          replaces history.slice / c_indptr +
+ *   phase 1 (host): o_p[0..n] prefix over deg(r[i])      c_slice  gcn/_history.pyx:25-51,
+ *   phase 2 (device): copy values + column ids           gcn/history.cpp:50-72
+ * The reference returns COO [nnz,2]; rows are grouped in order so (o_p, o_col) is the same
+ * matrix in CSR; o_row (nullable) additionally receives the COO row ids. */
+int sgcn_csr_slice_indptr(int32_t n, const int32_t* host_r, const int32_t* host_a_p,
+                          int32_t* host_o_p);
+int sgcn_csr_slice_f32(int32_t n, const int32_t* dev_r, const float* dev_a_d,
+                       const int32_t* dev_a_i, const int32_t* dev_a_p,
+                       const int32_t* dev_o_p, float* dev_o_d, int32_t* dev_o_col,
+                       int32_t* dev_o_row, void* stream);
+
+/* ======================================================================================
+ * Host neighbour sampler (stays on host: BASELINE.json north_star)
+ *   replaces class Scheduler gcn/scheduler.h:6-28, gcn/scheduler.cpp:11-189
+ *   (driven by PyScheduler.batch gcn/_scheduler.pyx:55-127).  Index output is bit-exact
+ *   with the reference for the same seed and call sequence; the RNG is an explicit
+ *   MT19937 + the libstdc++ float draw (no dependence on the box's <random>).
+ * ====================================================================================== */
+typedef struct sgcn_sched sgcn_sched_t;
+
+/* Copies the caller's CSR (gcn/scheduler.cpp:14-16); host_adj_p has num_data+1 entries. */
+int sgcn_sched_create(const float* host_adj_w, const int32_t* host_adj_i,
+                      const int32_t* host_adj_p, int32_t num_data, int32_t num_edges,
+                      int32_t L, int32_t cv, int32_t is, sgcn_sched_t** out);
+void sgcn_sched_destroy(sgcn_sched_t* s);
+int sgcn_sched_seed(sgcn_sched_t* s, int32_t seed);                   /* scheduler.cpp:37-39 */
+int sgcn_sched_start_batch(sgcn_sched_t* s, int32_t n, const int32_t* host_ids); /* :41-44 */
+int sgcn_sched_expand(sgcn_sched_t* s, int32_t degree);               /* :46-189 */
+
+/* Borrowed views of the last expand() result, valid until the next call on `s`. */
+enum {
+    SGCN_SCHED_FIELD = 0,   /* field    (input field of this layer)   int32 */
+    SGCN_SCHED_FFIELD = 1,  /* ffield                                  int32 */
+    SGCN_SCHED_EDG_S = 2,   /* COO row of adj  (non-decreasing)        int32 */
+    SGCN_SCHED_EDG_T = 3,   /* COO col of adj                          int32 */
+    SGCN_SCHED_FEDG_S = 4,  /* COO row of fadj                         int32 */
+    SGCN_SCHED_FEDG_T = 5,  /* COO col of fadj                         int32 */
+    SGCN_SCHED_EDG_P = 6,   /* CSR rowptr of adj  [n1+1]   (new: device CSR feed) */
+    SGCN_SCHED_FEDG_P = 7,  /* CSR rowptr of fadj [n1+1] */
+    SGCN_SCHED_ADJ_I = 8,   /* private (permuted) CSR column copy: statefulness probe */
+    SGCN_SCHED_TEDG_P = 9,  /* CSR rowptr of adj^T [n0+1]  (for the backward SpMM, K6) */
+    SGCN_SCHED_TEDG_T = 10  /* column ids of adj^T (= output-row ids i) */
+};
+enum {
+    SGCN_SCHED_SCALES = 0,  /* 1/sqrt(deg/sampled) per output row      fp32 */
+    SGCN_SCHED_EDG_W = 1,
+    SGCN_SCHED_MEDG_W = 2,
+    SGCN_SCHED_FEDG_W = 3,
+    SGCN_SCHED_ADJ_W = 4,
+    SGCN_SCHED_TEDG_W = 5   /* values of adj^T */
+};
+int sgcn_sched_view_i32(sgcn_sched_t* s, int32_t which, const int32_t** ptr, int64_t* len);
+int sgcn_sched_view_f32(sgcn_sched_t* s, int32_t which, const float** ptr, int64_t* len);
+
+/* Fenwick-tree multinomial sampler without replacement (IS mode only)
+ *   replaces struct Mult gcn/mult.h:8-27, gcn/mult.cpp:7-51 */
+typedef struct sgcn_mult sgcn_mult_t;
+int sgcn_mult_create(const float* host_prob, int32_t n, sgcn_mult_t** out);
+void sgcn_mult_destroy(sgcn_mult_t* m);
+int sgcn_mult_tree(sgcn_mult_t* m, const float** bit, int64_t* len); /* bit[0..N] */
+int sgcn_mult_query_u(sgcn_mult_t* m, float u, int32_t* result);     /* mult.cpp:38-51 */
+int sgcn_mult_query(sgcn_mult_t* m, int32_t* result);                /* mult.cpp:29-36 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGCN_H */

@@ -1,0 +1,98 @@
+// Device-side helpers shared by the HIP translation units of libsgcn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "sgcn_host.h"
+#include "../../include/sgcn.h"
+
+#define SGCN_HIP_TRY(expr)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return sgcn::fail(SGCN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));   \
+    } while (0)
+
+#define SGCN_REQUIRE(cond, ...)                                       \
+    do {                                                              \
+        if (!(cond)) return sgcn::fail(SGCN_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+namespace sgcn {
+
+constexpr int kWave = 64;      // gfx950 wavefront
+constexpr int kBlock = 256;    // 4 wavefronts per workgroup, one per SIMD
+
+template <int VW> struct Vec;
+template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<1> { typedef float type; };
+
+template <int VW>
+__device__ __forceinline__ typename Vec<VW>::type vzero() {
+    typename Vec<VW>::type z = {};
+    return z;
+}
+template <int VW>
+__device__ __forceinline__ typename Vec<VW>::type vload(const float* p) {
+    return *reinterpret_cast<const typename Vec<VW>::type*>(p);
+}
+template <int VW>
+__device__ __forceinline__ void vstore(float* p, typename Vec<VW>::type v) {
+    *reinterpret_cast<typename Vec<VW>::type*>(p) = v;
+}
+template <int VW>
+__device__ __forceinline__ float velem(const typename Vec<VW>::type& v, int e) {
+    if constexpr (VW == 1) return v; else return v[e];
+}
+// store the first `cnt` (< VW) elements only: the ragged tail when d % VW != 0
+template <int VW>
+__device__ __forceinline__ void vstore_head(float* p, typename Vec<VW>::type v, int cnt) {
+#pragma unroll
+    for (int e = 0; e < VW; e++)
+        if (e < cnt) p[e] = velem<VW>(v, e);
+}
+
+// Broadcast lane `j` of a G-lane group.  G == 64: the source lane is wave-uniform, so
+// v_readlane_b32 puts the value in an SGPR and the gathered row base becomes a scalar
+// address (global_load ... s[base:base+1]).  G < 64: ds_bpermute inside the group.
+template <int G>
+__device__ __forceinline__ int bcast_i(int x, int j) {
+    if constexpr (G == kWave) return __builtin_amdgcn_readlane(x, j);
+    else return __shfl(x, j, G);
+}
+template <int G>
+__device__ __forceinline__ float bcast_f(float x, int j) {
+    if constexpr (G == kWave) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
+    else return __shfl(x, j, G);
+}
+template <int G>
+__device__ __forceinline__ int uniform_i(int x) {
+    if constexpr (G == kWave) return __builtin_amdgcn_readfirstlane(x);
+    else return x;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// Pick the widest vector the operands allow.  A ragged last vector may over-READ up to
+// VW-1 floats inside the row pitch (never used) and is stored element-wise.
+inline int pick_vw(int d, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+    auto ok = [&](int vw) {
+        const int64_t span = ((int64_t)d + vw - 1) / vw * vw;
+        for (int64_t ld : lds)
+            if (ld % vw != 0 || ld < span) return false;
+        for (const void* p : ptrs) {
+            if (!p) continue;
+            if (vw == 4 && !aligned16(p)) return false;
+            if (vw == 2 && !aligned8(p)) return false;
+        }
+        return true;
+    };
+    if (ok(4)) return 4;
+    if (ok(2)) return 2;
+    return 1;
+}
+
+int tune_get(const char* key);  // sgcn_spmm.hip
+
+}  // namespace sgcn

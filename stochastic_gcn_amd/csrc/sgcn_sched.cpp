@@ -1,0 +1,391 @@
+// Host neighbour sampler of libsgcn.so (stays on host by design: BASELINE.json north_star).
+//
+// Semantics: one call to expand(degree) grows the receptive field by one hop exactly as the
+// reference `Scheduler::expand` does (gcn/scheduler.cpp:46-189; walk-through in SURVEY.md
+// §3.3): per output row a partial Fisher-Yates draw of min(deg, degree) neighbours without
+// replacement that permutes the sampler's PRIVATE copy of the CSR in place (state persists
+// across batches, gcn/scheduler.cpp:144-145), receptive-field dedup in first-seen order,
+// and -- in control-variate mode -- the full neighbour list of every output row in the
+// post-permutation order.  Index output is bit-exact with the reference for the same seed
+// and call sequence (tests/test_sampler.py, fixtures in tests/golden/).
+//
+// What is different from the reference (MI355X-first):
+//   * the result is emitted as CSR (rowptr built on the fly; rows come out grouped and in
+//     order, gcn/scheduler.cpp:126,153) next to the COO the reference exposes, because the
+//     HIP kernels consume CSR row tiles;
+//   * the transposed sampled adjacency (CSR of A^T) is produced here by a counting sort, so
+//     the backward SpMM dX = A^T dY is a gather kernel too (no float atomics on device);
+//   * explicit MT19937 / float draw (sgcn_host.h) instead of <random>.
+#include "sgcn_host.h"
+#include "../../include/sgcn.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace sgcn {
+
+char* error_slot() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+// ---- Fenwick multinomial (gcn/mult.h:8-27, gcn/mult.cpp:7-51) -------------------------------
+class FenwickMultinomial {
+public:
+    // Throws nothing; `ok()` is false for an empty probability vector (mult.cpp:17-18).
+    explicit FenwickMultinomial(const float* p, int n) : weight_(p, p + n), total_(0.f) {
+        cap_ = 1;
+        while (cap_ < n) cap_ <<= 1;          // smallest power of two >= n  (mult.cpp:9)
+        if (n == 0) cap_ = 0;
+        tree_.assign((size_t)cap_ + 1, 0.f);
+        for (int i = 0; i < n; i++) add(i + 1, weight_[i]);
+        last_ = n - 1;
+    }
+    bool ok() const { return !weight_.empty(); }
+    const std::vector<float>& tree() const { return tree_; }
+
+    // Largest prefix whose cumulative weight is <= u   (mult.cpp:38-51).
+    int descend(float u) const {
+        int pos = 0;
+        for (int step = cap_; step > 0; step >>= 1) {
+            int nxt = pos + step;
+            if (nxt <= cap_ && !(tree_[nxt] > u)) {
+                u -= tree_[nxt];
+                pos = nxt;
+            }
+        }
+        return pos;
+    }
+    // Draw one item and remove it   (mult.cpp:29-36).  The generator is the structure's
+    // own default-seeded engine (mult.h:25-26), i.e. independent of the sampler seed.
+    int draw() {
+        float u = rng_.u01() * total_;
+        int r = std::min(descend(u), last_);
+        add(r + 1, -weight_[r]);
+        weight_[r] = 0.f;
+        return r;
+    }
+
+private:
+    void add(int i, float v) {
+        for (; i <= cap_; i += i & (-i)) tree_[i] += v;
+        total_ += v;
+    }
+    std::vector<float> weight_, tree_;
+    float total_;
+    int cap_, last_;
+    Mt19937 rng_;
+};
+
+// ---- neighbour sampler ------------------------------------------------------------------------
+class NeighbourSampler {
+public:
+    NeighbourSampler(const float* w, const int32_t* idx, const int32_t* ptr, int32_t n,
+                     int32_t nnz, bool cv, bool is)
+        : n_(n), cv_(cv), is_(is), nbr_(idx, idx + nnz), wgt_(w, w + nnz), ptr_(ptr, ptr + n),
+          slot_(n, -1), fslot_(n, -1), importance_(n, 1.0f) {
+        ptr_.push_back(nnz);  // the reference trusts only the first n offsets (scheduler.cpp:16,20)
+        if (is_) {
+            // column-wise squared weight mass on top of 1e-6   (scheduler.cpp:18,22-25)
+            std::fill(importance_.begin(), importance_.end(), 1e-6f);
+            for (int32_t r = 0; r < n; r++)
+                for (int32_t p = ptr[r]; p < ptr[r + 1]; p++) importance_[idx[p]] += w[p] * w[p];
+        }
+    }
+
+    void seed(int32_t s) { rng_.reseed((uint32_t)s); }
+
+    void start_batch(int32_t n, const int32_t* ids) { field_.assign(ids, ids + n); }
+
+    int expand(int32_t degree) {
+        const size_t n_out = field_.size();
+        clear_outputs();
+        // output rows are the first |field| entries of the next field   (scheduler.cpp:50-52)
+        next_ = field_;
+        for (size_t i = 0; i < next_.size(); i++) slot_[next_[i]] = (int32_t)i;
+        edg_p_.push_back(0);
+        fedg_p_.push_back(0);
+
+        int rc = is_ ? expand_importance(degree) : expand_uniform(degree, n_out);
+
+        field_.swap(next_);
+        for (int32_t v : field_) slot_[v] = -1;
+        for (int32_t v : ffield_) fslot_[v] = -1;
+        transpose_ready_ = false;
+        return rc;
+    }
+
+    // CSR of A^T (A = last sampled adjacency, n_out x |field|): stable counting sort by column,
+    // so within a transposed row entries keep ascending output-row order (deterministic).
+    void build_transpose() {
+        if (transpose_ready_) return;
+        const size_t n_in = field_.size(), ne = edg_t_.size();
+        tedg_p_.assign(n_in + 1, 0);
+        for (size_t e = 0; e < ne; e++) tedg_p_[edg_t_[e] + 1]++;
+        for (size_t c = 0; c < n_in; c++) tedg_p_[c + 1] += tedg_p_[c];
+        tedg_t_.resize(ne);
+        tedg_w_.resize(ne);
+        std::vector<int32_t> cur(tedg_p_.begin(), tedg_p_.end() - 1);
+        for (size_t e = 0; e < ne; e++) {
+            int32_t q = cur[edg_t_[e]]++;
+            tedg_t_[q] = edg_s_[e];
+            tedg_w_[q] = edg_w_[e];
+        }
+        transpose_ready_ = true;
+    }
+
+    const std::vector<int32_t>* ivec(int which) {
+        switch (which) {
+            case SGCN_SCHED_FIELD: return &field_;
+            case SGCN_SCHED_FFIELD: return &ffield_;
+            case SGCN_SCHED_EDG_S: return &edg_s_;
+            case SGCN_SCHED_EDG_T: return &edg_t_;
+            case SGCN_SCHED_FEDG_S: return &fedg_s_;
+            case SGCN_SCHED_FEDG_T: return &fedg_t_;
+            case SGCN_SCHED_EDG_P: return &edg_p_;
+            case SGCN_SCHED_FEDG_P: return &fedg_p_;
+            case SGCN_SCHED_ADJ_I: return &nbr_;
+            case SGCN_SCHED_TEDG_P: build_transpose(); return &tedg_p_;
+            case SGCN_SCHED_TEDG_T: build_transpose(); return &tedg_t_;
+            default: return nullptr;
+        }
+    }
+    const std::vector<float>* fvec(int which) {
+        switch (which) {
+            case SGCN_SCHED_SCALES: return &scales_;
+            case SGCN_SCHED_EDG_W: return &edg_w_;
+            case SGCN_SCHED_MEDG_W: return &medg_w_;
+            case SGCN_SCHED_FEDG_W: return &fedg_w_;
+            case SGCN_SCHED_ADJ_W: return &wgt_;
+            case SGCN_SCHED_TEDG_W: build_transpose(); return &tedg_w_;
+            default: return nullptr;
+        }
+    }
+
+private:
+    void clear_outputs() {
+        ffield_.clear(); scales_.clear();
+        edg_s_.clear(); edg_t_.clear(); edg_w_.clear(); medg_w_.clear(); edg_p_.clear();
+        fedg_s_.clear(); fedg_t_.clear(); fedg_w_.clear(); fedg_p_.clear();
+    }
+    // position of vertex v in the growing next field (appending it on first sight)
+    int32_t place(int32_t v) {
+        int32_t& s = slot_[v];
+        if (s < 0) {
+            s = (int32_t)next_.size();
+            next_.push_back(v);
+        }
+        return s;
+    }
+    int32_t fplace(int32_t v) {
+        int32_t& s = fslot_[v];
+        if (s < 0) {
+            s = (int32_t)ffield_.size();
+            ffield_.push_back(v);
+        }
+        return s;
+    }
+
+    // Uniform sampling w/o replacement, optional control-variate extras (scheduler.cpp:125-180)
+    int expand_uniform(int32_t degree, size_t n_out) {
+        for (size_t i = 0; i < n_out; i++) {
+            const int32_t v = field_[i];
+            int32_t* cols = nbr_.data() + ptr_[v];
+            float* vals = wgt_.data() + ptr_[v];
+            const int32_t deg = ptr_[v + 1] - ptr_[v];
+            const int32_t take = std::min(deg, degree);
+            // amplification deg/take in fp32; isolated rows amplify by 1  (scheduler.cpp:132-133)
+            const float amp = deg == 0 ? 1.0f : (float)deg / (float)take;
+            // 1/sqrt(amp): fp32 sqrt, fp64 reciprocal, stored fp32        (scheduler.cpp:134)
+            scales_.push_back((float)(1.0 / (double)std::sqrt(amp)));
+
+            for (int32_t k = 0; k < take; k++) {
+                // pick a position in [k, deg) and move it to the front segment; the product
+                // and the sum are separate fp32 roundings (no FMA: built with -ffp-contract=off)
+                const float span = (float)(deg - k) * rng_.u01();
+                const float posf = (float)k + span;
+                const int32_t j = std::min((int32_t)posf, deg - 1);
+                std::swap(cols[k], cols[j]);
+                std::swap(vals[k], vals[j]);
+                const float w = vals[k] * amp;
+                edg_s_.push_back((int32_t)i);
+                edg_t_.push_back(place(cols[k]));
+                edg_w_.push_back(w);
+                if (cv_) medg_w_.push_back(vals[k] * w);
+            }
+            edg_p_.push_back((int32_t)edg_t_.size());
+
+            if (cv_) {
+                // every neighbour, in the row's current (post-swap) order   (scheduler.cpp:167-179)
+                for (int32_t k = 0; k < deg; k++) {
+                    fedg_s_.push_back((int32_t)i);
+                    fedg_t_.push_back(fplace(cols[k]));
+                    fedg_w_.push_back(vals[k]);
+                }
+                fedg_p_.push_back((int32_t)fedg_t_.size());
+            }
+        }
+        if (!cv_) fedg_p_.assign(n_out + 1, 0);
+        return SGCN_OK;
+    }
+
+    // Importance sampling of the joint neighbourhood (scheduler.cpp:63-123)
+    int expand_importance(int32_t degree) {
+        const size_t n_out = field_.size();
+        std::vector<int32_t> cand;
+        std::vector<float> prob;
+        std::vector<char> seen((size_t)n_, 0);
+        std::vector<int32_t> hits((size_t)n_, 0);
+        float mass = 0.f;
+        for (int32_t v : field_)
+            for (int32_t p = ptr_[v]; p < ptr_[v + 1]; p++) {
+                const int32_t t = nbr_[p];
+                if (!seen[t]) {
+                    seen[t] = 1;
+                    cand.push_back(t);
+                    mass += importance_[t];
+                    prob.push_back(importance_[t]);
+                }
+            }
+        if (prob.empty()) {
+            edg_p_.assign(n_out + 1, 0);
+            fedg_p_.assign(n_out + 1, 0);
+            return fail(SGCN_ERR_EMPTY_PROB, "Prob is empty");
+        }
+        FenwickMultinomial mult(prob.data(), (int)prob.size());
+        const int32_t draws = (int32_t)std::min(n_out * (size_t)degree, cand.size());
+        for (int32_t k = 0; k < draws; k++) {
+            const int32_t t = cand[mult.draw()];
+            hits[t]++;
+            place(t);
+        }
+        int rc = SGCN_OK;
+        for (size_t i = 0; i < n_out; i++) {
+            const int32_t v = field_[i];
+            for (int32_t p = ptr_[v]; p < ptr_[v + 1]; p++) {
+                const int32_t t = nbr_[p];
+                if (!hits[t]) continue;
+                // ((hits*w)*mass) / (importance*draws), all fp32, left to right (scheduler.cpp:107-108)
+                const float num = ((float)hits[t] * wgt_[p]) * mass;
+                const float den = importance_[t] * (float)draws;
+                const float w = num / den;
+                edg_s_.push_back((int32_t)i);
+                edg_t_.push_back(slot_[t]);
+                edg_w_.push_back(w);
+                if (std::isnan(w)) rc = fail(SGCN_ERR_NAN, "nan");
+            }
+            edg_p_.push_back((int32_t)edg_t_.size());
+        }
+        fedg_p_.assign(n_out + 1, 0);
+        return rc;
+    }
+
+    int32_t n_;
+    bool cv_, is_, transpose_ready_ = false;
+    std::vector<int32_t> nbr_;   // private, permuted in place
+    std::vector<float> wgt_;
+    std::vector<int32_t> ptr_;
+    std::vector<int32_t> slot_, fslot_;
+    std::vector<float> importance_;
+    std::vector<int32_t> field_, next_, ffield_;
+    std::vector<float> scales_;
+    std::vector<int32_t> edg_s_, edg_t_, edg_p_, fedg_s_, fedg_t_, fedg_p_;
+    std::vector<float> edg_w_, medg_w_, fedg_w_;
+    std::vector<int32_t> tedg_p_, tedg_t_;
+    std::vector<float> tedg_w_;
+    Mt19937 rng_;
+};
+
+}  // namespace sgcn
+
+// ---- C ABI --------------------------------------------------------------------------------------
+struct sgcn_sched { sgcn::NeighbourSampler impl; };
+struct sgcn_mult { sgcn::FenwickMultinomial impl; };
+
+extern "C" {
+
+const char* sgcn_last_error(void) { return sgcn::error_slot(); }
+int sgcn_abi_version(void) { return 1; }
+
+int sgcn_sched_create(const float* w, const int32_t* idx, const int32_t* ptr, int32_t num_data,
+                      int32_t num_edges, int32_t L, int32_t cv, int32_t is, sgcn_sched_t** out) {
+    (void)L;
+    if (!out || num_data < 0 || num_edges < 0 || (num_edges > 0 && (!w || !idx)) ||
+        (num_data > 0 && !ptr))
+        return sgcn::fail(SGCN_ERR_INVALID, "sgcn_sched_create: bad argument");
+    sgcn_sched* s = new (std::nothrow)
+        sgcn_sched{sgcn::NeighbourSampler(w, idx, ptr, num_data, num_edges, cv != 0, is != 0)};
+    if (!s) return sgcn::fail(SGCN_ERR_INVALID, "sgcn_sched_create: out of memory");
+    *out = s;
+    return SGCN_OK;
+}
+void sgcn_sched_destroy(sgcn_sched_t* s) { delete s; }
+int sgcn_sched_seed(sgcn_sched_t* s, int32_t seed) {
+    if (!s) return sgcn::fail(SGCN_ERR_INVALID, "null sampler");
+    s->impl.seed(seed);
+    return SGCN_OK;
+}
+int sgcn_sched_start_batch(sgcn_sched_t* s, int32_t n, const int32_t* ids) {
+    if (!s || n < 0 || (n > 0 && !ids)) return sgcn::fail(SGCN_ERR_INVALID, "start_batch: bad argument");
+    s->impl.start_batch(n, ids);
+    return SGCN_OK;
+}
+int sgcn_sched_expand(sgcn_sched_t* s, int32_t degree) {
+    if (!s) return sgcn::fail(SGCN_ERR_INVALID, "null sampler");
+    return s->impl.expand(degree);
+}
+int sgcn_sched_view_i32(sgcn_sched_t* s, int32_t which, const int32_t** ptr, int64_t* len) {
+    const std::vector<int32_t>* v = s ? s->impl.ivec(which) : nullptr;
+    if (!v || !ptr || !len) return sgcn::fail(SGCN_ERR_INVALID, "view_i32: bad selector %d", which);
+    *ptr = v->data();
+    *len = (int64_t)v->size();
+    return SGCN_OK;
+}
+int sgcn_sched_view_f32(sgcn_sched_t* s, int32_t which, const float** ptr, int64_t* len) {
+    const std::vector<float>* v = s ? s->impl.fvec(which) : nullptr;
+    if (!v || !ptr || !len) return sgcn::fail(SGCN_ERR_INVALID, "view_f32: bad selector %d", which);
+    *ptr = v->data();
+    *len = (int64_t)v->size();
+    return SGCN_OK;
+}
+
+int sgcn_mult_create(const float* prob, int32_t n, sgcn_mult_t** out) {
+    if (!out || n < 0) return sgcn::fail(SGCN_ERR_INVALID, "sgcn_mult_create: bad argument");
+    if (n == 0) return sgcn::fail(SGCN_ERR_EMPTY_PROB, "Prob is empty");
+    *out = new sgcn_mult{sgcn::FenwickMultinomial(prob, n)};
+    return SGCN_OK;
+}
+void sgcn_mult_destroy(sgcn_mult_t* m) { delete m; }
+int sgcn_mult_tree(sgcn_mult_t* m, const float** bit, int64_t* len) {
+    if (!m || !bit || !len) return sgcn::fail(SGCN_ERR_INVALID, "mult_tree: bad argument");
+    *bit = m->impl.tree().data();
+    *len = (int64_t)m->impl.tree().size();
+    return SGCN_OK;
+}
+int sgcn_mult_query_u(sgcn_mult_t* m, float u, int32_t* result) {
+    if (!m || !result) return sgcn::fail(SGCN_ERR_INVALID, "mult_query_u: bad argument");
+    *result = m->impl.descend(u);
+    return SGCN_OK;
+}
+int sgcn_mult_query(sgcn_mult_t* m, int32_t* result) {
+    if (!m || !result) return sgcn::fail(SGCN_ERR_INVALID, "mult_query: bad argument");
+    *result = m->impl.draw();
+    return SGCN_OK;
+}
+
+int sgcn_csr_slice_indptr(int32_t n, const int32_t* r, const int32_t* a_p, int32_t* o_p) {
+    if (n < 0 || (n > 0 && (!r || !a_p)) || !o_p)
+        return sgcn::fail(SGCN_ERR_INVALID, "csr_slice_indptr: bad argument");
+    int32_t run = 0;
+    for (int32_t i = 0; i < n; i++) {
+        o_p[i] = run;
+        run += a_p[r[i] + 1] - a_p[r[i]];
+    }
+    o_p[n] = run;
+    return SGCN_OK;
+}
+
+}  // extern "C"

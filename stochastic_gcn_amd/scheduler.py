@@ -1,0 +1,215 @@
+"""``scheduler.PyScheduler`` -- drop-in for the reference's Cython class
+(gcn/_scheduler.pyx:28-148) on top of the host sampler of libsgcn.so.
+
+Same constructor, ``shuffle / minibatch / batch / get_feed_dict / get_t`` and the same
+feed-dict: per layer ``adj=(idx[ne,2] int32, w f32, (n1,n0))``, ``madj``, ``fadj``, ``fields``
+(L+1), ``ffields`` (L), ``scales`` (L), index 0 = input-most layer (gcn/_scheduler.pyx:121-126),
+``labels[fields[-1]]`` (gcn/_scheduler.pyx:138).  Placeholders are opaque dict keys, exactly
+as the reference treats them (gcn/test_scheduler.py:25-33 uses plain strings).
+
+MI355X-first addition: next to every COO triple the feed-dict carries the same matrix as a
+device-ready CSR bundle under ``('csr', placeholder)`` -- row pointer, column ids, values,
+the transposed CSR for the backward SpMM and the host work plan for power-law rows -- which
+is what the HIP kernels consume (``stochastic_gcn_amd.ops``).  Index arrays are bit-exact
+with the reference for the same seed and call sequence (tests/test_sampler.py).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+
+# selectors of sgcn_sched_view_* (include/sgcn.h)
+(I_FIELD, I_FFIELD, I_EDG_S, I_EDG_T, I_FEDG_S, I_FEDG_T, I_EDG_P, I_FEDG_P, I_ADJ_I,
+ I_TEDG_P, I_TEDG_T) = range(11)
+F_SCALES, F_EDG_W, F_MEDG_W, F_FEDG_W, F_ADJ_W, F_TEDG_W = range(6)
+
+
+class HostCSR(object):
+    """A host CSR bundle emitted by the sampler for one layer (all numpy, owned copies)."""
+    __slots__ = ("shape", "rowptr", "col", "val", "t_rowptr", "t_col", "t_val")
+
+    def __init__(self, shape, rowptr, col, val, t_rowptr=None, t_col=None, t_val=None):
+        self.shape = shape
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.t_rowptr, self.t_col, self.t_val = t_rowptr, t_col, t_val
+
+    @property
+    def nnz(self):
+        return int(self.col.shape[0])
+
+
+def build_plan(rowptr, T=0):
+    """Host work plan (include/sgcn.h sgcn_plan_*): returns (seg[nseg,4] int32,
+    fix[nfix,3] int32, nslots)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    M = rowptr.shape[0] - 1
+    nseg, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib.sgcn_plan_count(rowptr.ctypes.data, M, T, C.byref(nseg), C.byref(nfix), C.byref(nslots)))
+    seg = np.empty((nseg.value, 4), dtype=np.int32)
+    fix = np.empty((nfix.value, 3), dtype=np.int32)
+    check(lib.sgcn_plan_fill(rowptr.ctypes.data, M, T, seg.ctypes.data,
+                             fix.ctypes.data if nfix.value else None))
+    return seg, fix, nslots.value
+
+
+class _Sampler(object):
+    """Thin owner of an ``sgcn_sched_t`` handle."""
+
+    def __init__(self, adj, num_data, L, cv, importance):
+        w = np.ascontiguousarray(adj.data, dtype=np.float32)
+        i = np.ascontiguousarray(adj.indices, dtype=np.int32)
+        p = np.ascontiguousarray(adj.indptr, dtype=np.int32)
+        if p.shape[0] != num_data + 1:
+            raise ValueError("adjacency has %d rows, labels have %d" % (p.shape[0] - 1, num_data))
+        self.cv = bool(cv)
+        self._h = C.c_void_p()
+        check(lib.sgcn_sched_create(w.ctypes.data, i.ctypes.data, p.ctypes.data, int(num_data),
+                                    int(w.shape[0]), int(L), int(cv), int(importance),
+                                    C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.sgcn_sched_destroy(h)
+            self._h = None
+
+    def seed(self, s):
+        check(lib.sgcn_sched_seed(self._h, int(s)))
+
+    def start_batch(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(lib.sgcn_sched_start_batch(self._h, int(ids.shape[0]), ids.ctypes.data))
+
+    def expand(self, degree):
+        check(lib.sgcn_sched_expand(self._h, int(degree)))
+
+    def ivec(self, which):
+        ptr, n = _ffi.c_i32p(), C.c_int64()
+        check(lib.sgcn_sched_view_i32(self._h, which, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.int32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    def fvec(self, which):
+        ptr, n = _ffi.c_f32p(), C.c_int64()
+        check(lib.sgcn_sched_view_f32(self._h, which, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.float32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+
+class PyScheduler(object):
+    def __init__(self, adj, labels, L, degrees, placeholders, seed, data=None, cv=False,
+                 importance=False):
+        self.c_sch = _Sampler(adj, labels.shape[0], L, cv, importance)
+        self.c_sch.seed(seed)
+        self.labels = labels
+        self.data = data
+        self.degrees = degrees
+        self.L = L
+        self.start = 0
+        self.placeholders = placeholders
+        self.t = 0
+
+    def shuffle(self):
+        # NumPy's global RNG, as the reference (gcn/_scheduler.pyx:50-53)
+        np.random.shuffle(self.data)
+        self.start = 0
+        self.t = 0
+
+    def batch(self, data):
+        s = self.c_sch
+        data = np.ascontiguousarray(data, dtype=np.int32)
+        fields, ffields, adjs, madjs, fadjs, scales = [data], [], [], [], [], []
+        csr_adj, csr_fadj = [], []
+        s.start_batch(data)
+        for l in range(self.L):
+            s.expand(self.degrees[self.L - l - 1])
+            fields.append(s.ivec(I_FIELD))
+            scales.append(s.fvec(F_SCALES))
+            edg_s, edg_t, edg_w = s.ivec(I_EDG_S), s.ivec(I_EDG_T), s.fvec(F_EDG_W)
+            edg_i = np.empty((edg_s.shape[0], 2), dtype=np.int32)
+            edg_i[:, 0] = edg_s
+            edg_i[:, 1] = edg_t
+            shape = (fields[-2].shape[0], fields[-1].shape[0])
+            adjs.append((edg_i, edg_w, shape))
+            csr_adj.append(HostCSR(shape, s.ivec(I_EDG_P), edg_t, edg_w,
+                                   s.ivec(I_TEDG_P), s.ivec(I_TEDG_T), s.fvec(F_TEDG_W)))
+            if s.cv:
+                ffields.append(s.ivec(I_FFIELD))
+                fedg_s, fedg_t, fedg_w = s.ivec(I_FEDG_S), s.ivec(I_FEDG_T), s.fvec(F_FEDG_W)
+                fedg_i = np.empty((fedg_s.shape[0], 2), dtype=np.int32)
+                fedg_i[:, 0] = fedg_s
+                fedg_i[:, 1] = fedg_t
+                fshape = (fields[-2].shape[0], ffields[-1].shape[0])
+                madjs.append((np.copy(edg_i), s.fvec(F_MEDG_W), np.copy(shape)))
+                fadjs.append((fedg_i, fedg_w, fshape))
+                csr_fadj.append(HostCSR(fshape, s.ivec(I_FEDG_P), fedg_t, fedg_w))
+        for lst in (fields, ffields, adjs, madjs, fadjs, scales, csr_adj, csr_fadj):
+            lst.reverse()
+        fd = self.get_feed_dict(fields, ffields, adjs, madjs, fadjs, scales)
+        ph = self.placeholders
+        for i in range(self.L):
+            fd[('csr', ph['adj'][i])] = csr_adj[i]
+        if s.cv:
+            for i in range(len(csr_fadj)):
+                fd[('csr', ph['fadj'][i])] = csr_fadj[i]
+        return fd
+
+    def minibatch(self, batch_size):
+        if self.start == self.data.shape[0]:
+            return None
+        end = min(self.data.shape[0], self.start + batch_size)
+        batch = self.data[self.start:end]
+        self.start = end
+        return self.batch(batch)
+
+    def get_feed_dict(self, fields, ffields, adjs, madjs, fadjs, scales):
+        ph = self.placeholders
+        labels = self.labels[fields[-1]]
+        feed_dict = {ph['adj'][i]: adjs[i] for i in range(self.L)}
+        feed_dict.update({ph['scales'][i]: scales[i] for i in range(len(scales))})
+        if self.c_sch.cv:
+            feed_dict.update({ph['madj'][i]: madjs[i] for i in range(len(madjs))})
+            feed_dict.update({ph['fadj'][i]: fadjs[i] for i in range(len(fadjs))})
+            feed_dict.update({ph['ffields'][i]: ffields[i] for i in range(len(ffields))})
+        feed_dict[ph['labels']] = labels
+        for i in range(self.L + 1):
+            feed_dict[ph['fields'][i]] = fields[i]
+        return feed_dict
+
+    def get_t(self):
+        return self.t
+
+
+class Mult(object):
+    """Fenwick multinomial sampler (gcn/mult.h:8-27) -- exposed for parity tests."""
+
+    def __init__(self, prob):
+        p = np.ascontiguousarray(prob, dtype=np.float32)
+        self._h = C.c_void_p()
+        check(lib.sgcn_mult_create(p.ctypes.data, int(p.shape[0]), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.sgcn_mult_destroy(h)
+            self._h = None
+
+    @property
+    def bit(self):
+        ptr, n = _ffi.c_f32p(), C.c_int64()
+        check(lib.sgcn_mult_tree(self._h, C.byref(ptr), C.byref(n)))
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    def query_u(self, u):
+        r = C.c_int32()
+        check(lib.sgcn_mult_query_u(self._h, float(u), C.byref(r)))
+        return r.value
+
+    def query(self):
+        r = C.c_int32()
+        check(lib.sgcn_mult_query(self._h, C.byref(r)))
+        return r.value
