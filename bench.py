@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- the headline measurement (BASELINE.json: "training edges/s (SpMM) + epoch time,
+Reddit CVD+PP, 1/2/4/8 MI355X").
+
+A *step* is one pass of the SpMM hot path over the Reddit-shape synthetic CSR (S-Reddit,
+SURVEY.md §8d: N=232,965, nnz~23.17 M, 602-dim fp32 features, row pitch 608):
+    forward   C  = A  . X        (K1/K11: tf.sparse_tensor_dense_matmul, gcn/layers.py:31-37)
+    backward  dX = A^T . dC      (K6: its autodiff, run on the transposed CSR)
+and, when N > 1, the RCCL all-reduce of the model's weight-gradient buffer (the path's one
+exchange step).  `value` = edges (nonzeros) pushed through the SpMM kernels per
+second, whole job, inputs resident in HBM.  Weak scaling: every rank owns one Reddit-shape
+vertex-range shard.
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline      dominant kernel (forward SpMM): algorithmic bytes per launch
+                nnz*8 + (M+1)*4 + 2*N*d*4 / mean launch time from HIP events
+                recorded on the launch stream inside the timed region, vs the 8 TB/s HBM peak.
+  cpu_baseline  the oracle's OpenMP C restatement of the same product (oracle/oracle_c.c) on a
+                bounded row sample of the same matrix, all host cores.
+  train_epoch   (when available) the CVD+PP minibatch epoch on the same graph.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md:35)
+HBM_COPY = 6.29e12         # measured float4-copy ceiling (ibid.)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="reddit", choices=["reddit", "reddit-small", "rmat"])
+    p.add_argument("--d", type=int, default=602)
+    p.add_argument("--pitch", type=int, default=0, help="row pitch of X/C in floats (0: d rounded up to 32)")
+    p.add_argument("--plan-t", type=int, default=0)
+    p.add_argument("--tune", action="append", default=[], help="key=value passed to sgcn_tune")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-epoch", action="store_true")
+    p.add_argument("--no-backward", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=40000)
+    p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
+    return p.parse_args()
+
+
+def make_graph(args, rank):
+    from stochastic_gcn_amd import synthetic
+    if args.workload == "reddit":
+        n, _, full_adj, *_ = synthetic.reddit_like(seed=1 + rank, with_features=False)
+        name = "S-Reddit full-graph CSR x dense (N=232965, Zipf(0.6) x uniform)"
+    elif args.workload == "reddit-small":
+        n, _, full_adj, *_ = synthetic.reddit_like(n=23296, m=1160000, splits=(15241, 2369, 5533),
+                                                   seed=1 + rank, with_features=False)
+        name = "S-Reddit/10 (N=23296)"
+    else:
+        n = 1 << 20
+        full_adj = synthetic.rmat_like(n, 20 * n, seed=1 + rank)
+        name = "S-RMAT 2^20 vertices, 20 M edges"
+    return n, full_adj, name
+
+
+def reddit_grad_floats(d_in=602, hidden=128, classes=41):
+    """Weight count of the Reddit CVD+PP stack:
+    [2*602 -> 128] -> [128 -> 128] -> agg -> [256 -> 128] -> [128 -> 41] + LN offset/scale."""
+    return 2 * d_in * hidden + hidden * hidden + 2 * hidden * hidden + hidden * classes + 6 * hidden
+
+
+def cpu_baseline(full_adj, d, rows, seed=0):
+    from oracle import oracle_np as onp
+    n = full_adj.shape[0]
+    rows = min(rows, n)
+    sub = full_adj[:rows].tocsr()
+    B = np.random.RandomState(seed).standard_normal((n, d)).astype(np.float32)
+    onp.spmm(sub.indptr[:65], sub.indices, sub.data, B)          # warm the library / threads
+    t0 = time.time()
+    reps = 0
+    while True:
+        onp.spmm(sub.indptr, sub.indices, sub.data, B)
+        reps += 1
+        el = time.time() - t0
+        if el > 10.0 or reps >= 50:
+            break
+    return {"value": sub.nnz * reps / el, "unit": "edges/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": "oracle_c.c OpenMP CSR SpMM, first %d rows (%d edges) of the same matrix, "
+                      "d=%d, %d reps in %.1f s" % (rows, sub.nnz, d, reps, el)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        g.build(quiet=True)
+    from stochastic_gcn_amd import ops, _ffi
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _ffi.tune(k, int(v))
+
+    n, full_adj, wname = make_graph(args, rank)
+    d = args.d
+    pitch = args.pitch or (d + 31) // 32 * 32
+    nnz = int(full_adj.nnz)
+    A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    Xp = torch.zeros((n, pitch), device=dev)
+    Xp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
+    dCp = torch.zeros((n, pitch), device=dev)
+    dCp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
+    X, dC = Xp[:, :d], dCp[:, :d]
+    C = torch.zeros((n, pitch), device=dev)[:, :d]
+    dX = torch.zeros((n, pitch), device=dev)[:, :d]
+    gfl = args.grad_floats or reddit_grad_floats()
+    grad = torch.randn(gfl, device=dev, generator=gen)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        ops.spmm(A, X, out=C)
+        if i is not None:
+            ev[i][1].record()
+        if not args.no_backward:
+            ops.spmm(A.transpose, dC, out=dX)
+        if world > 1:
+            dist.all_reduce(grad)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    edges_per_step = nnz * (1 if args.no_backward else 2)
+    value = edges_per_step * world * args.steps / el
+    bytes_alg = nnz * 8 + (n + 1) * 4 + 2 * n * d * 4
+    achieved = bytes_alg / (fwd_ms * 1e-3)
+    out = {
+        "metric": "training edges/s (SpMM)", "value": value, "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wname + ", fwd A.X%s, d=%d (pitch %d)%s" % (
+            "" if args.no_backward else " + bwd A^T.dC", d, pitch,
+            ", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else ""),
+            "N": n, "nnz": nnz, "d": d, "per_gpu": "one S-Reddit vertex-range shard",
+            "tune": args.tune},
+        "roofline": {"bound": "hbm", "kernel": "spmm_seg_kernel (forward A.X, incl. split-row fix-up)",
+                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
+                     "traffic": None, "bytes_alg_per_launch": bytes_alg,
+                     "ms_per_launch": fwd_ms, "edges_per_s_fwd": nnz / (fwd_ms * 1e-3),
+                     "gather_model_GBps": (nnz * (d * 4 + 8) + n * d * 4) / (fwd_ms * 1e-3) / 1e9},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+"""Device ops of the hot path: thin wrappers that hand raw HBM pointers of PyTorch-ROCm tensors
+to the C-ABI of libsgcn.so (include/sgcn.h).  PyTorch is used for device memory and streams
+only; every op here is a hand-written HIP kernel and raises if the library is unavailable or
+a tensor is not on a GPU (no eager / CPU fallback).
+
+Reference seams replaced:
+  spmm            dot(x, y, sparse=True)                    gcn/layers.py:31-37
+  vr_aggregate    VRAggregator._call                        gcn/layers.py:298-319,350-362
+  gather_rows     history.dense_slice / tf.gather           gcn/_history.pyx:53-62, layers.py:304
+  scatter_rows    tf.scatter_update                         gcn/models.py:165
+  csr_slice       history.slice                             gcn/_history.pyx:25-51
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import check, lib
+from .scheduler import build_plan
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must live in HBM (got a %s tensor): the SpMM/history path has no "
+                           "CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t, name):
+    """(ptr, ld) of a 2-D fp32 tensor whose rows are contiguous (row pitch may exceed width)."""
+    _dev(t, torch.float32, name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("%s must be 2-D with unit column stride" % name)
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+class DevicePlan(object):
+    """Device copy of a host work plan + its partial-sum workspace."""
+
+    def __init__(self, seg, fix, nslots, device):
+        self.nseg, self.nfix, self.nslots = int(seg.shape[0]), int(fix.shape[0]), int(nslots)
+        self.seg = torch.from_numpy(seg).to(device, non_blocking=True)
+        self.fix = torch.from_numpy(fix).to(device, non_blocking=True) if self.nfix else None
+        self.ws = None
+        self.device = device
+
+    def struct(self, d):
+        ldw = (d + 3) // 4 * 4
+        need = self.nslots * ldw
+        if need and (self.ws is None or self.ws.numel() < need):
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        return _ffi.Plan(self.seg.data_ptr(), self.nseg, _ptr(self.fix), self.nfix, self.nslots,
+                         _ptr(self.ws), 0 if self.ws is None else self.ws.numel())
+
+
+class DeviceCSR(object):
+    """CSR matrix resident in HBM (int32 rowptr/col, fp32 val) + optional plan / transpose."""
+
+    def __init__(self, shape, rowptr, col, val, plan=None, transpose=None, host_rowptr=None):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.plan, self.transpose, self.host_rowptr = plan, transpose, host_rowptr
+
+    @property
+    def nnz(self):
+        return int(self.col.shape[0])
+
+    @staticmethod
+    def from_arrays(shape, rowptr, col, val, device, plan_T=0, with_plan=True):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        plan = None
+        if with_plan:
+            seg, fix, nslots = build_plan(rowptr, plan_T)
+            plan = DevicePlan(seg, fix, nslots, device)
+        return DeviceCSR(shape, torch.from_numpy(rowptr).to(device, non_blocking=True),
+                         torch.from_numpy(col).to(device, non_blocking=True),
+                         torch.from_numpy(val).to(device, non_blocking=True), plan,
+                         host_rowptr=rowptr)
+
+    @staticmethod
+    def from_scipy(a, device, plan_T=0, with_plan=True, with_transpose=False):
+        a = a.tocsr()
+        m = DeviceCSR.from_arrays(a.shape, a.indptr, a.indices, a.data, device, plan_T, with_plan)
+        if with_transpose:
+            at = a.T.tocsr()
+            m.transpose = DeviceCSR.from_arrays(at.shape, at.indptr, at.indices, at.data, device,
+                                                plan_T, with_plan)
+        return m
+
+    @staticmethod
+    def from_host(h, device, plan_T=0, with_plan=True):
+        """From a scheduler.HostCSR bundle (adds the transposed CSR when the sampler built it)."""
+        m = DeviceCSR.from_arrays(h.shape, h.rowptr, h.col, h.val, device, plan_T, with_plan)
+        if h.t_rowptr is not None:
+            m.transpose = DeviceCSR.from_arrays((h.shape[1], h.shape[0]), h.t_rowptr, h.t_col,
+                                                h.t_val, device, plan_T, with_plan)
+        return m
+
+
+def spmm(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=None):
+    """out[M x d] = rscale (.) (A (cscale (.) B[gidx])) + beta * out   (sgcn_spmm_csr_f32)."""
+    M, K = A.shape
+    bptr, ldb = _rows2d(B, "B")
+    d = int(B.shape[1] if d is None else d)
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an existing `out`")
+        out = torch.empty((M, d), dtype=torch.float32, device=B.device)
+    cptr, ldc = _rows2d(out, "out")
+    if out.shape[0] != M or out.shape[1] < d:
+        raise ValueError("out has shape %s, need (%d, >=%d)" % (tuple(out.shape), M, d))
+    rows_needed = K if gidx is None else None
+    if rows_needed is not None and B.shape[0] < rows_needed:
+        raise ValueError("B has %d rows, A has %d columns" % (B.shape[0], K))
+    plan = A.plan.struct(d) if A.plan is not None else None
+    check(lib.sgcn_spmm_csr_f32(
+        A.rowptr.data_ptr(), _ptr(A.col), _ptr(A.val), M, K, d, bptr, ldb,
+        _ptr(_dev(gidx, torch.int32, "gidx")), _ptr(_dev(rscale, torch.float32, "rscale")),
+        _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),
+        C.byref(plan) if plan is not None else None, _stream()))
+    return out
+
+
+def vr_aggregate(A, P, h, mu, Hbar, ifield, ffield, s, cvd, concat_self, out_h=None, out_mu=None):
+    """Fused control-variate aggregator forward (sgcn_vr_aggregate_f32)."""
+    n1, n0 = A.shape
+    nf = P.shape[1]
+    hptr, ldx = _rows2d(h, "h")
+    d = int(h.shape[1])
+    width = 2 * d if concat_self else d
+    if cvd:
+        mptr, ldm = _rows2d(mu, "mu")
+        if ldm != ldx or tuple(mu.shape) != tuple(h.shape):
+            raise ValueError("h and mu must share shape and row pitch")
+    else:
+        mptr = None
+    Hptr, ldh = _rows2d(Hbar, "Hbar")
+    if out_h is None:
+        out_h = torch.empty((n1, width), dtype=torch.float32, device=h.device)
+    if cvd and out_mu is None:
+        out_mu = torch.empty((n1, width), dtype=torch.float32, device=h.device)
+    ohp, ldo = _rows2d(out_h, "out_h")
+    omp = None
+    if cvd:
+        omp, ldo2 = _rows2d(out_mu, "out_mu")
+        if ldo2 != ldo:
+            raise ValueError("out_h and out_mu must share row pitch")
+    plan = P.plan.struct(d) if P.plan is not None else None
+    check(lib.sgcn_vr_aggregate_f32(
+        A.rowptr.data_ptr(), _ptr(A.col), _ptr(A.val), P.rowptr.data_ptr(), _ptr(P.col),
+        _ptr(P.val), n1, n0, nf, d, hptr, mptr, ldx, Hptr, ldh,
+        _ptr(_dev(ifield, torch.int32, "ifield")), _ptr(_dev(ffield, torch.int32, "ffield")),
+        _ptr(_dev(s, torch.float32, "s")), ohp, omp, ldo, int(bool(cvd)), int(bool(concat_self)),
+        C.byref(plan) if plan is not None else None, _stream()))
+    return out_h, out_mu
+
+
+def gather_rows(inp, idx, out=None, d=None):
+    """out[i, :d] = inp[idx[i], :d]   (sgcn_gather_rows_f32)."""
+    iptr, ldi = _rows2d(inp, "inp")
+    _dev(idx, torch.int32, "idx")
+    n = int(idx.shape[0])
+    d = int(inp.shape[1] if d is None else d)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=inp.device)
+    optr, ldo = _rows2d(out, "out")
+    check(lib.sgcn_gather_rows_f32(iptr, ldi, idx.data_ptr(), n, d, optr, ldo, _stream()))
+    return out
+
+
+def scatter_rows(H, idx, src, d=None):
+    """H[idx[i], :d] = src[i, :d]  (idx unique)   (sgcn_scatter_rows_f32)."""
+    hptr, ldh = _rows2d(H, "H")
+    sptr, lds = _rows2d(src, "src")
+    _dev(idx, torch.int32, "idx")
+    n = int(idx.shape[0])
+    d = int(src.shape[1] if d is None else d)
+    check(lib.sgcn_scatter_rows_f32(hptr, ldh, idx.data_ptr(), n, d, sptr, lds, _stream()))
+    return H
+
+
+def csr_slice(A, rows_host, rows_dev=None, with_coo_rows=False):
+    """CSR row slice A[rows] -> DeviceCSR   (sgcn_csr_slice_indptr + sgcn_csr_slice_f32).
+
+    ``A.host_rowptr`` (kept by DeviceCSR.from_*) feeds the host prefix pass, mirroring the
+    reference's two-phase c_indptr / c_slice (gcn/history.cpp:50-72)."""
+    if A.host_rowptr is None:
+        raise ValueError("csr_slice needs A.host_rowptr")
+    rows_host = np.ascontiguousarray(rows_host, dtype=np.int32)
+    n = int(rows_host.shape[0])
+    o_p = np.empty(n + 1, dtype=np.int32)
+    check(lib.sgcn_csr_slice_indptr(n, rows_host.ctypes.data, A.host_rowptr.ctypes.data,
+                                    o_p.ctypes.data))
+    nnz = int(o_p[n])
+    dev = A.val.device
+    if rows_dev is None:
+        rows_dev = torch.from_numpy(rows_host).to(dev, non_blocking=True)
+    o_p_dev = torch.from_numpy(o_p).to(dev, non_blocking=True)
+    o_d = torch.empty(nnz, dtype=torch.float32, device=dev)
+    o_c = torch.empty(nnz, dtype=torch.int32, device=dev)
+    o_r = torch.empty(nnz, dtype=torch.int32, device=dev) if with_coo_rows else None
+    check(lib.sgcn_csr_slice_f32(n, rows_dev.data_ptr(), A.val.data_ptr(), A.col.data_ptr(),
+                                 A.rowptr.data_ptr(), o_p_dev.data_ptr(), o_d.data_ptr(),
+                                 o_c.data_ptr(), _ptr(o_r), _stream()))
+    out = DeviceCSR((n, A.shape[1]), o_p_dev, o_c, o_d, host_rowptr=o_p)
+    out.coo_rows = o_r
+    return out

@@ -1,0 +1,181 @@
+"""Deterministic synthetic stand-ins for the reference's datasets (no datasets and no network
+on the box).  Shapes and statistics follow SURVEY.md §8d; normalisations follow the
+reference loaders (gcn/utils.py:120-136 GCN sets, :299-309 GraphSAGE sets).  The return
+value of ``load_data`` has the reference's 10-tuple layout (gcn/utils.py:183,335):
+
+    num_data, train_adj, full_adj, feats, train_feats, test_feats, labels,
+    train_data, val_data, test_data
+
+``train_feats`` / ``test_feats`` (the PP products  train_adj . feats, full_adj . feats,
+gcn/utils.py:169-170,321-322) are left as ``None`` here: the training driver computes them
+on the GPU with the SpMM kernel (that product is K11 of the hot path).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def _row_normalize(adj):
+    """D^-1 A  (gcn/utils.py:120-126, :304-309)."""
+    rowsum = np.array(adj.sum(1)).flatten()
+    d_inv = 1.0 / (rowsum + 1e-20)
+    out = sp.diags(d_inv, 0).dot(adj).tocsr().astype(np.float32)
+    out.sort_indices()
+    return out
+
+
+def _gcn_normalize(adj):
+    """D^-1/2 (A + I) D^-1/2  (gcn/utils.py:127-136)."""
+    adj = adj + sp.eye(adj.shape[0], dtype=np.float32)
+    rowsum = np.array(adj.sum(1)).flatten() + 1e-20
+    d = np.power(rowsum, -0.5)
+    d[np.isinf(d)] = 0.0
+    dm = sp.diags(d, 0)
+    out = adj.dot(dm).transpose().dot(dm).tocsr().astype(np.float32)
+    out.sort_indices()
+    return out
+
+
+def zipf_uniform_edges(n, m, s, rng):
+    """m undirected edges: source ~ bounded Zipf(s) over a random vertex order, destination
+    uniform (SURVEY.md §8d S-Reddit generator).  Returns a symmetric 0/1 CSR without
+    duplicates."""
+    w = np.arange(1, n + 1, dtype=np.float64) ** (-s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    rank = np.searchsorted(cdf, rng.random_sample(m)).astype(np.int64)
+    np.minimum(rank, n - 1, out=rank)
+    perm = rng.permutation(n)              # hubs get arbitrary vertex ids, as in real data
+    src = perm[rank]
+    dst = rng.randint(0, n, m)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    a = sp.coo_matrix((np.ones(src.shape[0], dtype=np.float32), (src, dst)), shape=(n, n)).tocsr()
+    a = a + a.T
+    a.data[:] = 1.0
+    a.sort_indices()
+    return a
+
+
+def er_edges(n, m, rng):
+    src = rng.randint(0, n, m)
+    dst = rng.randint(0, n, m)
+    keep = src != dst
+    a = sp.coo_matrix((np.ones(int(keep.sum()), dtype=np.float32), (src[keep], dst[keep])),
+                      shape=(n, n)).tocsr()
+    a = a + a.T
+    a.data[:] = 1.0
+    a.sort_indices()
+    return a
+
+
+def _splits(n, n_train, n_val, n_test, rng):
+    perm = rng.permutation(n)
+    tr = np.sort(perm[:n_train]).astype(np.int32)
+    va = np.sort(perm[n_train:n_train + n_val]).astype(np.int32)
+    te = np.sort(perm[n_train + n_val:n_train + n_val + n_test]).astype(np.int32)
+    return tr, va, te
+
+
+def _onehot(n, c, rng):
+    y = np.zeros((n, c), dtype=np.float32)
+    y[np.arange(n), rng.randint(0, c, n)] = 1.0
+    return y
+
+
+def _sparse_features(n, f, per_row, rng):
+    """Row-normalised sparse bag-of-words like the Planetoid sets (gcn/utils.py:138-143)."""
+    cols = rng.randint(0, f, (n, per_row))
+    rows = np.repeat(np.arange(n), per_row)
+    x = sp.coo_matrix((np.ones(n * per_row, dtype=np.float32), (rows, cols.ravel())),
+                      shape=(n, f)).tocsr()
+    x.data[:] = 1.0
+    rowsum = np.array(x.sum(1)).flatten() + 1e-9
+    x = sp.diags(1.0 / rowsum, 0).dot(x).tocsr().astype(np.float32)
+    x.sort_indices()
+    return x
+
+
+def reddit_like(n=232965, m=11600000, f=602, classes=41, splits=(152410, 23699, 55334),
+                seed=1, with_features=True):
+    """S-Reddit: Zipf(0.6)-source x uniform-destination graph, D^-1 A,
+    dense N(0,1) features.  Defaults give nnz ~= 23.17 M, avg degree ~= 99.5."""
+    rng = np.random.RandomState(seed)
+    a = zipf_uniform_edges(n, m, 0.6, rng)
+    full_adj = _row_normalize(a)
+    tr, va, te = _splits(n, splits[0], splits[1], splits[2], rng)
+    # training graph = edges among non-val/test vertices (GraphSAGE "train_removed")
+    is_train = np.ones(n, dtype=bool)
+    is_train[va] = False
+    is_train[te] = False
+    dm = sp.diags(is_train.astype(np.float32), 0)
+    at = dm.dot(a).dot(dm).tocsr()
+    at.eliminate_zeros()
+    train_adj = _row_normalize(at)
+    labels = _onehot(n, classes, rng)
+    feats = rng.standard_normal((n, f)).astype(np.float32) if with_features else None
+    return n, train_adj, full_adj, feats, None, None, labels, tr, va, te
+
+
+def planetoid_like(n, m, f, per_row, classes, n_train, n_val, n_test, normalization, seed):
+    rng = np.random.RandomState(seed)
+    a = er_edges(n, m, rng)
+    adj = _gcn_normalize(a) if normalization == 'gcn' else _row_normalize(a)
+    feats = _sparse_features(n, f, per_row, rng)
+    labels = _onehot(n, classes, rng)
+    tr = np.arange(n_train, dtype=np.int32)
+    va = np.arange(n_train, n_train + n_val, dtype=np.int32)
+    te = np.arange(n - n_test, n, dtype=np.int32)
+    return n, adj, adj.copy(), feats, None, None, labels, tr, va, te
+
+
+def cora_like(normalization='gcn', seed=123):
+    """S-Cora: N=2,708, 5,278 undirected edges, 1,433 sparse features (~18/row), 7 classes."""
+    return planetoid_like(2708, 5278, 1433, 18, 7, 140, 500, 1000, normalization, seed)
+
+
+def pubmed_like(normalization='gcn', seed=123):
+    """S-PubMed: N=19,717, 44,324 undirected edges, 500 sparse features (~50/row), 3 classes."""
+    return planetoid_like(19717, 44324, 500, 50, 3, 60, 500, 1000, normalization, seed)
+
+
+def rmat_edges(scale_log2, m, rng, abcd=(0.57, 0.19, 0.19, 0.05)):
+    """R-MAT directed edge list on 2^scale vertices (S-RMAT)."""
+    a, b, c, _ = abcd
+    src = np.zeros(m, dtype=np.int64)
+    dst = np.zeros(m, dtype=np.int64)
+    for _bit in range(scale_log2):
+        r = rng.random_sample(m)
+        right = (r >= a) & ((r < a + b) | (r >= a + b + c))     # quadrants b, d
+        down = r >= a + b                                        # quadrants c, d
+        src = (src << 1) | down
+        dst = (dst << 1) | right
+    return src, dst
+
+
+def rmat_like(n, m, seed=1):
+    """S-RMAT: n vertices (ids folded from the next power of two), m directed edges, values
+    U(0,1) row-normalised."""
+    rng = np.random.RandomState(seed)
+    scale = int(np.ceil(np.log2(n)))
+    src, dst = rmat_edges(scale, m, rng)
+    src %= n
+    dst %= n
+    val = rng.random_sample(m).astype(np.float32)
+    a = sp.coo_matrix((val, (src, dst)), shape=(n, n)).tocsr()   # sums duplicates
+    a.sort_indices()
+    return _row_normalize(a)
+
+
+def load_data(dataset, normalization='gcn', scale=1.0, seed=None):
+    """Synthetic counterpart of gcn/utils.py:466-473 ``load_data(dataset)``."""
+    if dataset in ('cora', 's-cora'):
+        return cora_like(normalization, 123 if seed is None else seed)
+    if dataset in ('pubmed', 's-pubmed'):
+        return pubmed_like(normalization, 123 if seed is None else seed)
+    if dataset in ('reddit', 's-reddit'):
+        n = int(232965 * scale)
+        m = int(11600000 * scale)
+        sp_ = tuple(int(x * scale) for x in (152410, 23699, 55334))
+        return reddit_like(n, m, 602, 41, sp_, 1 if seed is None else seed)
+    raise ValueError("no synthetic generator for dataset '%s' (real datasets are not on this box)"
+                     % dataset)

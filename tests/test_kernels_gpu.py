@@ -1,0 +1,258 @@
+"""GPU parity tests: every HIP kernel of libsgcn.so, called through the C-ABI (ops.py ->
+ctypes), against the CPU oracle on the same seeded inputs.  Tolerance: 1e-4 relative
+(max|x-ref| / max|ref|) for fp32 sums; bit-exact for pure copies / indices."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import golden_util as gu
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def rand_csr(m, k, density, seed, long_rows=()):
+    rng = np.random.RandomState(seed)
+    a = sp.random(m, k, density=density, format='lil', random_state=rng, dtype=np.float32)
+    for r, n in long_rows:
+        cols = rng.choice(k, min(n, k), replace=False)
+        a[r, cols] = rng.rand(len(cols)).astype(np.float32) + 0.1
+    a = a.tocsr()
+    a.sort_indices()
+    return a
+
+
+SPMM_SHAPES = [
+    # (M, K, d, density, pitch_pad)
+    (1, 1, 1, 1.0, 0), (37, 53, 7, 0.2, 0), (200, 300, 32, 0.05, 0), (300, 200, 128, 0.05, 0),
+    (128, 400, 602, 0.05, 0), (128, 400, 602, 0.05, 6), (90, 90, 256, 0.1, 0),
+    (64, 64, 1024, 0.2, 0), (50, 70, 33, 0.2, 3), (40, 40, 130, 0.3, 2), (33, 44, 2, 0.3, 0),
+]
+
+
+@pytest.mark.parametrize("M,K,d,dens,pad", SPMM_SHAPES)
+@pytest.mark.parametrize("use_plan", [False, True])
+def test_spmm_vs_oracle(dev, M, K, d, dens, pad, use_plan):
+    from stochastic_gcn_amd import ops
+    a = rand_csr(M, K, dens, M + d, long_rows=[(0, min(K, 300))] if M > 1 else [])
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((K, d + pad)).astype(np.float32)
+    A = ops.DeviceCSR.from_scipy(a, dev, plan_T=16 if use_plan else 0, with_plan=use_plan)
+    Bd = T(B, dev)[:, :d]                       # row pitch d+pad, logical width d
+    out_full = torch.full((M, d + pad), 7.0, device=dev)
+    out = ops.spmm(A, Bd, out=out_full[:, :d])
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    assert onp.rel_err(out.cpu().numpy(), ref) <= TOL
+    if pad:                                     # the pitch padding of C is never written
+        assert torch.all(out_full[:, d:] == 7.0)
+
+
+@pytest.mark.parametrize("d", [32, 128, 602])
+def test_spmm_fusions(dev, d):
+    from stochastic_gcn_amd import ops
+    a = rand_csr(150, 120, 0.1, 5, long_rows=[(3, 120), (77, 100)])
+    rng = np.random.RandomState(1)
+    H = rng.standard_normal((1000, d)).astype(np.float32)
+    g = rng.choice(1000, 120, replace=False).astype(np.int32)
+    rs, cs = rng.rand(150).astype(np.float32), rng.rand(120).astype(np.float32)
+    c0 = rng.standard_normal((150, d)).astype(np.float32)
+    for plan in (False, True):
+        A = ops.DeviceCSR.from_scipy(a, dev, plan_T=32, with_plan=plan)
+        out = T(c0, dev)
+        ops.spmm(A, T(H, dev), out=out, gidx=T(g, dev), rscale=T(rs, dev), cscale=T(cs, dev), beta=0.5)
+        ref = onp.spmm(a.indptr, a.indices, a.data, H, gidx=g, rscale=rs, cscale=cs, C_in=c0, beta=0.5)
+        assert onp.rel_err(out.cpu().numpy(), ref) <= TOL
+
+
+def test_spmm_tuning_variants_agree(dev):
+    from stochastic_gcn_amd import ops, _ffi
+    a = rand_csr(200, 300, 0.2, 9)
+    B = np.random.RandomState(2).standard_normal((300, 608)).astype(np.float32)
+    A = ops.DeviceCSR.from_scipy(a, dev, plan_T=64)
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :602])
+    try:
+        for nv in (0, 1, 2, 3):
+            for un in (0, 2, 4, 8):
+                for sm in (0, 1):
+                    _ffi.tune("spmm_nv", nv); _ffi.tune("spmm_unroll", un); _ffi.tune("spmm_slabmajor", sm)
+                    out = ops.spmm(A, T(B, dev)[:, :602])
+                    assert onp.rel_err(out.cpu().numpy(), ref) <= TOL, (nv, un, sm)
+    finally:
+        _ffi.tune("spmm_nv", 0); _ffi.tune("spmm_unroll", 0); _ffi.tune("spmm_slabmajor", 1)
+
+
+def test_spmm_edge_cases(dev):
+    from stochastic_gcn_amd import ops
+    # all-empty matrix -> zeros (and beta keeps C)
+    a = sp.csr_matrix((5, 9), dtype=np.float32)
+    A = ops.DeviceCSR.from_scipy(a, dev)
+    out = ops.spmm(A, torch.ones(9, 12, device=dev))
+    assert torch.all(out == 0)
+    c = torch.full((5, 12), 2.0, device=dev)
+    ops.spmm(A, torch.ones(9, 12, device=dev), out=c, beta=1.0)
+    assert torch.all(c == 2.0)
+    # zero rows: no launch, no error
+    A0 = ops.DeviceCSR.from_scipy(sp.csr_matrix((0, 9), dtype=np.float32), dev)
+    assert ops.spmm(A0, torch.ones(9, 4, device=dev)).shape == (0, 4)
+    # transposed backward product equals the dense transpose
+    a = rand_csr(60, 80, 0.1, 4)
+    A = ops.DeviceCSR.from_scipy(a, dev, with_transpose=True)
+    g = np.random.RandomState(0).standard_normal((60, 128)).astype(np.float32)
+    dx = ops.spmm(A.transpose, T(g, dev))
+    assert onp.rel_err(dx.cpu().numpy(), a.T.dot(g.astype(np.float64))) <= TOL
+
+
+def _sampled_case(seed, n=3000, batch=200, degree=1, d=32, L=1):
+    from stochastic_gcn_amd import synthetic
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    _, train_adj, _, _, _, _, labels, tr, _, _ = synthetic.reddit_like(
+        n=n, m=30000, f=4, classes=3, splits=(2000, 300, 700), seed=seed, with_features=False)
+    ph = gu.placeholders(L)
+    sch = PyScheduler(train_adj, labels, L, [degree] * L, ph, seed, data=tr.copy(), cv=True)
+    fd = sch.minibatch(batch)
+    return train_adj, ph, fd
+
+
+@pytest.mark.parametrize("cvd", [True, False])
+@pytest.mark.parametrize("concat", [True, False])
+@pytest.mark.parametrize("d,degree", [(32, 1), (128, 1), (128, 5), (602, 2), (30, 3)])
+def test_vr_aggregate_vs_oracle(dev, cvd, concat, d, degree):
+    from stochastic_gcn_amd import ops
+    n = 3000
+    _, ph, fd = _sampled_case(11, n=n, degree=degree, d=d)
+    rng = np.random.RandomState(d + degree)
+    Hbar = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    f0, ff0, s0 = fd[ph['fields'][0]], fd[ph['ffields'][0]], fd[ph['scales'][0]]
+    h = rng.standard_normal((len(f0), d)).astype(np.float32)
+    mu = rng.standard_normal((len(f0), d)).astype(np.float32)
+    adj, fadj = onp.coo_to_csr(fd[ph['adj'][0]]), onp.coo_to_csr(fd[ph['fadj'][0]])
+    ref_h, ref_mu, _ = onp.vr_aggregate(adj, fadj, h, mu if cvd else None, Hbar, f0, ff0, s0, cvd, concat)
+    for plan_T in (0, 8):                         # 8 forces split rows + the ordered fix-up pass
+        A = ops.DeviceCSR.from_host(fd[('csr', ph['adj'][0])], dev)
+        P = ops.DeviceCSR.from_host(fd[('csr', ph['fadj'][0])], dev, plan_T=plan_T)
+        if plan_T:
+            assert P.plan.nfix > 0
+        oh, om = ops.vr_aggregate(A, P, T(h, dev), T(mu, dev) if cvd else None, T(Hbar, dev),
+                                  T(f0, dev), T(ff0, dev), T(s0, dev), cvd, concat)
+        assert onp.rel_err(oh.cpu().numpy(), ref_h) <= TOL
+        if cvd:
+            assert onp.rel_err(om.cpu().numpy(), ref_mu) <= TOL
+        if concat:                                # self rows are exact copies
+            np.testing.assert_array_equal(oh.cpu().numpy()[:, :d], h[:adj.shape[0]])
+
+
+def test_vr_aggregate_fresh_history_identity(dev):
+    """Hbar[ifield] == mu and h == mu  =>  h_nbr == mu_nbr == P Hbar[ffield]."""
+    from stochastic_gcn_amd import ops
+    n, d = 3000, 128
+    train_adj, ph, fd = _sampled_case(5, n=n, degree=2, d=d)
+    rng = np.random.RandomState(0)
+    act = rng.standard_normal((n, d)).astype(np.float32)
+    f0, f1, ff0, s0 = fd[ph['fields'][0]], fd[ph['fields'][1]], fd[ph['ffields'][0]], fd[ph['scales'][0]]
+    A = ops.DeviceCSR.from_host(fd[('csr', ph['adj'][0])], dev)
+    P = ops.DeviceCSR.from_host(fd[('csr', ph['fadj'][0])], dev)
+    x = T(act[f0], dev)
+    oh, om = ops.vr_aggregate(A, P, x, x.clone(), T(act, dev), T(f0, dev), T(ff0, dev), T(s0, dev), True, False)
+    exact = train_adj[f1].dot(act.astype(np.float64))
+    assert onp.rel_err(om.cpu().numpy(), exact) <= TOL
+    assert onp.rel_err(oh.cpu().numpy(), exact) <= TOL
+
+
+@pytest.mark.parametrize("d,pad", [(1, 0), (19, 0), (32, 0), (128, 0), (602, 0), (602, 6), (1204, 0), (33, 3)])
+def test_gather_scatter_rows(dev, d, pad):
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(d)
+    N, n = 500, 123
+    a = rng.standard_normal((N, d + pad)).astype(np.float32)
+    r = rng.choice(N, n, replace=False).astype(np.int32)
+    ad = T(a, dev)[:, :d]
+    out = ops.gather_rows(ad, T(r, dev))
+    np.testing.assert_array_equal(out.cpu().numpy(), onp.gather_rows(a[:, :d], r))
+    src = rng.standard_normal((n, d)).astype(np.float32)
+    Hd = T(a, dev)
+    ops.scatter_rows(Hd[:, :d], T(r, dev), T(src, dev))
+    want = a.copy()
+    onp.scatter_rows(want[:, :d], r, src)
+    np.testing.assert_array_equal(Hd.cpu().numpy(), want)      # padding columns untouched
+
+
+def test_gather_rows_golden_dense_slice(dev):
+    from stochastic_gcn_amd import ops
+    z = gu.load("slice.npz")
+    a = T(z["dense/a"], dev)
+    for n in sorted({k.split("/")[1] for k in z.files if k.startswith("slice/")}):
+        r = z["slice/%s/r" % n]
+        out = ops.gather_rows(a, T(r, dev))
+        assert gu.bits_equal(out.cpu().numpy(), z["dense/%s/out" % n]), n
+
+
+def test_csr_slice_golden(dev):
+    from stochastic_gcn_amd import ops
+    z = gu.load("slice.npz")
+    a = sp.csr_matrix((z["a/data"], z["a/indices"], z["a/indptr"]), shape=tuple(z["a/shape"]))
+    A = ops.DeviceCSR.from_scipy(a, dev, with_plan=False)
+    for n in sorted({k.split("/")[1] for k in z.files if k.startswith("slice/")}):
+        r = z["slice/%s/r" % n]
+        s = ops.csr_slice(A, r, with_coo_rows=True)
+        if ("slice/%s/is_empty_csr" % n) in z.files:
+            assert s.nnz == 0 and s.shape == tuple(z["slice/%s/is_empty_csr" % n])
+            continue
+        idx = np.stack([s.coo_rows.cpu().numpy(), s.col.cpu().numpy()], axis=1)
+        assert gu.bits_equal(idx, z["slice/%s/indices" % n]), n
+        assert gu.bits_equal(s.val.cpu().numpy(), z["slice/%s/data" % n]), n
+        assert s.shape == tuple(z["slice/%s/shape" % n])
+        # the slice is a usable CSR: SpMM with it equals the oracle on the sliced rows
+        B = np.random.RandomState(1).standard_normal((a.shape[1], 32)).astype(np.float32)
+        out = ops.spmm(s, T(B, dev))
+        assert onp.rel_err(out.cpu().numpy(), a[r].dot(B)) <= TOL
+
+
+def test_full_size_reddit_shape_properties(dev):
+    """BASELINE config 3 at full size (N=232,965, nnz~23.2 M, d=602): size-independent
+    properties + oracle comparison on a row sample."""
+    from stochastic_gcn_amd import ops, synthetic
+    n, _, full_adj, _, _, _, _, _, _, _ = synthetic.reddit_like(with_features=False)
+    d, ld = 602, 608
+    A = ops.DeviceCSR.from_scipy(full_adj, dev)
+    assert A.plan.nfix > 1000                    # power-law rows really are split
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    Bfull = torch.zeros((n, ld), device=dev)
+    Bfull[:, :d] = torch.randn((n, d), device=dev, generator=g)
+    B = Bfull[:, :d]
+    C = ops.spmm(A, B)
+    # (1) oracle on 1500 sampled rows incl. the longest rows
+    deg = np.diff(full_adj.indptr)
+    rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.random.RandomState(0).choice(n, 1500)]))
+    sub = full_adj[rows].tocsr()
+    ref = onp.spmm(sub.indptr, sub.indices, sub.data, B.cpu().numpy())
+    assert onp.rel_err(C[torch.from_numpy(rows).to(dev)].cpu().numpy(), ref) <= TOL
+    # (2) constant columns: A (row-normalised) times ones == 1 on every non-isolated row
+    ones = torch.ones((n, 8), device=dev)
+    r1 = ops.spmm(A, ones).cpu().numpy()
+    want = (deg > 0).astype(np.float32)[:, None] * np.ones((1, 8), np.float32)
+    assert np.abs(r1 - want).max() <= 1e-4
+    # (3) linearity: A (2x + y) == 2 A x + A y
+    y = torch.randn((n, 128), device=dev, generator=g)
+    x = torch.randn((n, 128), device=dev, generator=g)
+    lhs = ops.spmm(A, 2 * x + y)
+    rhs = 2 * ops.spmm(A, x) + ops.spmm(A, y)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL
+    # (4) checksum of checksums: sum_i C[i,:] == (column sums of A) . B   (fp64 on host)
+    colsum = np.asarray(full_adj.sum(axis=0)).ravel()
+    want = colsum.astype(np.float64) @ x.cpu().numpy().astype(np.float64)
+    got = ops.spmm(A, x).double().sum(dim=0).cpu().numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() <= 1e-4
+    # (5) determinism: the split-row fix-up is ordered, two runs are bit-identical
+    assert torch.equal(ops.spmm(A, B), C)
