@@ -8,6 +8,12 @@ CPU / PyTorch implementation.
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be the one and
+# only HIP runtime in the process: tensors, streams and our kernels have to share a context.
+# Importing torch first makes the loader resolve libsgcn.so's libamdhip64 dependency to the
+# already-loaded copy instead of pulling /opt/rocm's second runtime in.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 

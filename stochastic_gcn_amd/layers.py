@@ -1,0 +1,330 @@
+"""Layers of the training hot path, MI355X-native (mirror of gcn/layers.py).
+
+Same class names and constructor meaning as the reference (``dot``, ``Dense``,
+``AugmentedDropoutDense``, ``Dropout``, ``PlainAggregator``, ``VRAggregator``), but instead
+of building a TensorFlow graph each layer runs eagerly on HBM-resident tensors and carries an
+explicit ``backward``: the graph is tiny and static, so hand-written gradients (the same ones
+TF autodiff derives) keep every sparse product on our HIP kernels in both directions:
+
+  dot(x, y, sparse=True)   -> ops.spmm               (gcn/layers.py:31-37)
+  VRAggregator forward     -> ops.vr_aggregate       (gcn/layers.py:298-319,350-362), fused
+  aggregator backward      -> ops.spmm on the transposed CSR the sampler emitted (K6)
+  history rows             -> read in place by the fused kernel / ops.scatter_rows (models.py)
+
+Dense GEMMs / LayerNorm / ReLU / softmax are the "downstream dense" part (SURVEY.md §8a
+a-13): fp32 PyTorch-ROCm ops (rocBLAS GEMM on the matrix cores).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .flags import FLAGS
+
+# Test hook: when set, dropout masks come from `MASK_HOOK(tag, shape) -> numpy {0,1}` so that the
+# device path and the CPU oracle can be fed identical randomness (tests/test_model_gpu.py).
+MASK_HOOK = None
+_GEN = {}
+
+
+def _generator(device):
+    g = _GEN.get(device)
+    if g is None:
+        g = torch.Generator(device=device)
+        g.manual_seed(int(FLAGS.seed))
+        _GEN[device] = g
+    return g
+
+
+def seed_dropout(seed, device):
+    _generator(device).manual_seed(int(seed))
+
+
+def dropout_mask(tag, shape, keep_prob, device):
+    """{0,1} mask with P(1) = keep_prob (tf.nn.dropout's floor(keep_prob + U))."""
+    if MASK_HOOK is not None:
+        m = MASK_HOOK(tag, tuple(shape))
+        return None if m is None else torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(device)
+    return (torch.rand(shape, device=device, generator=_generator(device)) < keep_prob).to(torch.float32)
+
+
+def dot(x, y, sparse=False):
+    """Wrapper for matmul (sparse vs dense), as gcn/layers.py:31-37."""
+    if sparse:
+        return ops.spmm(x, y)
+    return torch.mm(x, y)
+
+
+def layer_norm_fwd(x, offset, scale, eps=1e-9):
+    """MyLayerNorm2 (gcn/layers.py:95-97): moments over features + batch_normalization."""
+    mean = x.mean(dim=1, keepdim=True)
+    xc = x - mean
+    var = (xc * xc).mean(dim=1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    xhat = xc * rstd
+    return xhat * scale + offset, (xhat, rstd)
+
+
+def layer_norm_bwd(dy, ctx, scale):
+    xhat, rstd = ctx
+    dscale = (dy * xhat).sum(dim=0, keepdim=True)
+    doffset = dy.sum(dim=0, keepdim=True)
+    dxhat = dy * scale
+    dx = rstd * (dxhat - dxhat.mean(dim=1, keepdim=True) - xhat * (dxhat * xhat).mean(dim=1, keepdim=True))
+    return dx, doffset, dscale
+
+
+class SparseInput(object):
+    """A row-sliced sparse feature block on device: CSR + COO row ids (for its transpose)."""
+
+    def __init__(self, csr):
+        self.csr = csr
+
+    @property
+    def shape(self):
+        return self.csr.shape
+
+    def with_values(self, val):
+        return ops.DeviceCSR(self.csr.shape, self.csr.rowptr, self.csr.col, val)
+
+    def transpose_of(self, val):
+        """CSR of X^T for dW = X^T g, built on device (stable sort keeps row order)."""
+        c = self.csr
+        order = torch.argsort(c.col.to(torch.int64), stable=True)
+        counts = torch.bincount(c.col.to(torch.int64), minlength=c.shape[1])
+        rowptr = torch.zeros(c.shape[1] + 1, dtype=torch.int32, device=c.col.device)
+        rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return ops.DeviceCSR((c.shape[1], c.shape[0]), rowptr, c.coo_rows[order].contiguous(),
+                             val[order].contiguous())
+
+
+class Layer(object):
+    def __init__(self, name=None):
+        self.name = name or self.__class__.__name__.lower()
+        self.vars = {}      # name -> tensor view into the model's flat parameter buffer
+        self.grads = {}     # name -> tensor view into the model's flat gradient buffer
+        self.sparse_inputs = False
+
+    def param_shapes(self):
+        return []
+
+    def __call__(self, inputs):
+        return self.forward(inputs)
+
+
+class Dropout(Layer):
+    """gcn/layers.py:415-433."""
+
+    def __init__(self, keep_prob_fn, cvd, **kw):
+        super(Dropout, self).__init__(**kw)
+        self.keep_prob_fn, self.cvd = keep_prob_fn, cvd
+
+    def forward(self, inputs):
+        keep = self.keep_prob_fn()
+        self._mask, self._keep, self._sparse = None, keep, False
+        if self.cvd and isinstance(inputs, tuple):
+            inputs = inputs[0]                          # keeps only dropout(h), :423-425
+        if isinstance(inputs, SparseInput):
+            self._sparse = True
+            if keep >= 1.0:
+                return inputs
+            m = dropout_mask(self.name, (inputs.csr.nnz,), keep, inputs.csr.val.device)
+            if m is None:
+                return inputs
+            out = SparseInput(inputs.csr)
+            out.csr = inputs.with_values(inputs.csr.val * (m * (1.0 / keep)))
+            out.csr.coo_rows = inputs.csr.coo_rows
+            return out
+        if keep >= 1.0:
+            return inputs
+        self._mask = dropout_mask(self.name, inputs.shape, keep, inputs.device)
+        if self._mask is None:
+            return inputs
+        return inputs * (self._mask * (1.0 / keep))
+
+    def backward(self, g):
+        if g is None or self._sparse or self._mask is None:
+            return g
+        return g * (self._mask * (1.0 / self._keep))
+
+
+class Dense(Layer):
+    """gcn/layers.py:100-138: x.W (dense or sparse x) -> MyLayerNorm -> act."""
+
+    def __init__(self, input_dim, output_dim, placeholders=None, sparse_inputs=False, act=True,
+                 norm=True, **kw):
+        super(Dense, self).__init__(**kw)
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.sparse_inputs, self.act, self.norm = sparse_inputs, act, norm
+
+    def param_shapes(self):
+        s = [('weights', (self.input_dim, self.output_dim), 'glorot')]
+        if self.norm:   # MyLayerNorm creates trainable offset/scale (gcn/layers.py:90-92)
+            s += [('offset', (1, self.output_dim), 'zeros'), ('scale', (1, self.output_dim), 'ones')]
+        return s
+
+    def wd_vars(self):
+        return ['weights']          # the LN variables are not in Dense.vars (gcn/models.py:73-75)
+
+    def forward(self, x):
+        W = self.vars['weights']
+        self._x = x
+        y = ops.spmm(x.csr, W) if self.sparse_inputs else torch.mm(x, W)
+        self._ctx = None
+        if self.norm:
+            y, self._ctx = layer_norm_fwd(y, self.vars['offset'], self.vars['scale'])
+        self._pre = y
+        return torch.relu(y) if self.act else y
+
+    def backward(self, g):
+        if self.act:
+            g = g * (self._pre > 0)
+        if self.norm:
+            g, doff, dsc = layer_norm_bwd(g, self._ctx, self.vars['scale'])
+            self.grads['offset'] += doff
+            self.grads['scale'] += dsc
+        if self.sparse_inputs:
+            xt = self._x.transpose_of(self._x.csr.val)
+            ops.spmm(xt, g, out=self.grads['weights'], beta=1.0)
+            return None
+        self.grads['weights'].addmm_(self._x.t(), g)
+        return torch.mm(g, self.vars['weights'].t())
+
+
+class AugmentedDropoutDense(Layer):
+    """gcn/layers.py:365-412: the CVD dense layer with a dropout stream x and a clean,
+    stop-gradient stream mu sharing weights and LayerNorm parameters."""
+
+    def __init__(self, keep_prob_fn, input_dim, output_dim, sparse_inputs=False, norm=True, **kw):
+        super(AugmentedDropoutDense, self).__init__(**kw)
+        self.keep_prob_fn = keep_prob_fn
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.sparse_inputs, self.norm = sparse_inputs, norm
+
+    def param_shapes(self):
+        s = [('weights', (self.input_dim, self.output_dim), 'glorot')]
+        if self.norm:
+            s += [('offset', (1, self.output_dim), 'zeros'), ('scale', (1, self.output_dim), 'ones')]
+        return s
+
+    def wd_vars(self):
+        return [n for n, _, _ in self.param_shapes()]
+
+    def forward(self, inputs):
+        x, mu = inputs if isinstance(inputs, tuple) else (inputs, inputs)
+        keep = self.keep_prob_fn()
+        W = self.vars['weights']
+        self._mask, self._keep = None, keep
+        if self.sparse_inputs:
+            val = x.csr.val
+            if keep < 1.0:
+                m = dropout_mask(self.name, (x.csr.nnz,), keep, val.device)
+                if m is not None:
+                    val = val * (m * (1.0 / keep))
+            self._xd = (x, val)
+            xs = ops.spmm(x.with_values(val), W)
+            mus = ops.spmm(mu.csr, W)
+        else:
+            xd = x
+            if keep < 1.0:
+                self._mask = dropout_mask(self.name, x.shape, keep, x.device)
+                if self._mask is not None:
+                    xd = x * (self._mask * (1.0 / keep))
+            self._xd = xd
+            xs = torch.mm(xd, W)
+            # test models run with dropout 0 on a single stream: both streams coincide
+            same = mu is x and xd is x
+            mus = xs if same else torch.mm(mu, W)
+        self._ctx = None
+        if self.norm:
+            same = mus is xs
+            xs, self._ctx = layer_norm_fwd(xs, self.vars['offset'], self.vars['scale'])
+            mus = xs if same else layer_norm_fwd(mus, self.vars['offset'], self.vars['scale'])[0]
+        self._pre = xs
+        hx = torch.relu(xs)
+        return hx, (hx if mus is xs else torch.relu(mus))
+
+    def backward(self, g):
+        g = g * (self._pre > 0)                       # mu is stop_gradient (gcn/layers.py:412)
+        if self.norm:
+            g, doff, dsc = layer_norm_bwd(g, self._ctx, self.vars['scale'])
+            self.grads['offset'] += doff
+            self.grads['scale'] += dsc
+        if self.sparse_inputs:
+            x, val = self._xd
+            ops.spmm(x.transpose_of(val), g, out=self.grads['weights'], beta=1.0)
+            return None
+        self.grads['weights'].addmm_(self._xd.t(), g)
+        g = torch.mm(g, self.vars['weights'].t())
+        if self._mask is not None:
+            g = g * (self._mask * (1.0 / self._keep))
+        return g
+
+
+class PlainAggregator(Layer):
+    """gcn/layers.py:214-257 (non-det-dropout branch): Z = A.H, or concat(H[:n1], A.H)."""
+
+    def __init__(self, model, l, **kw):
+        super(PlainAggregator, self).__init__(**kw)
+        self.model, self.l = model, l
+
+    def forward(self, x):
+        A = self.model.cur.adj[self.l]
+        concat = FLAGS.normalization != 'gcn'
+        n1, d = A.shape[0], x.shape[1]
+        self._A, self._concat, self._d = A, concat, d
+        if not concat:
+            return ops.spmm(A, x)
+        out = torch.empty((n1, 2 * d), dtype=torch.float32, device=x.device)
+        out[:, :d] = x[:n1]
+        ops.spmm(A, x, out=out[:, d:])
+        return out
+
+    def backward(self, g):
+        A, d = self._A, self._d
+        if not self._concat:
+            return ops.spmm(A.transpose, g)
+        dx = torch.zeros((A.shape[1], d), dtype=torch.float32, device=g.device)
+        dx[:A.shape[0]] = g[:, :d]
+        ops.spmm(A.transpose, g[:, d:], out=dx, beta=1.0)
+        return dx
+
+
+class VRAggregator(Layer):
+    """gcn/layers.py:282-362 (cvd and plain-CV branches) on the fused HIP kernel."""
+
+    def __init__(self, model, l, cvd, **kw):
+        super(VRAggregator, self).__init__(**kw)
+        self.model, self.l, self.cvd = model, l, cvd
+        self.new_history = None
+
+    def forward(self, inputs):
+        cur, l = self.model.cur, self.l
+        A, P = cur.adj[l], cur.fadj[l]
+        concat = FLAGS.normalization != 'gcn'
+        hist = self.model.history[l][0]
+        if self.cvd:
+            h, mu = inputs
+            out_h, out_mu = ops.vr_aggregate(A, P, h, mu, hist, cur.fields[l], cur.ffields[l],
+                                             cur.scales[l], True, concat)
+            self.new_history = [mu]
+            out = (out_h, out_mu)
+        else:
+            x = inputs
+            out_h, _ = ops.vr_aggregate(A, P, x, None, hist, cur.fields[l], cur.ffields[l],
+                                        None, False, concat)
+            self.new_history = [x]
+            out = out_h
+        self._A, self._concat, self._s = A, concat, (cur.scales[l] if self.cvd else None)
+        self._d = (inputs[0] if self.cvd else inputs).shape[1]
+        return out
+
+    def backward(self, g):
+        """d/dh of h_nbr = (A (h - mu)) * s + mu_nbr  ->  A^T (s (.) g_nbr); mu and the history
+        carry no gradient (stop_gradient gcn/layers.py:412, non-trainable gcn/vrgcn.py:31-32)."""
+        A, d = self._A, self._d
+        if not self._concat:
+            return ops.spmm(A.transpose, g, cscale=self._s)
+        dx = torch.zeros((A.shape[1], d), dtype=torch.float32, device=g.device)
+        dx[:A.shape[0]] = g[:, :d]
+        ops.spmm(A.transpose, g[:, d:], out=dx, cscale=self._s, beta=1.0)
+        return dx

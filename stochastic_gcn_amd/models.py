@@ -1,0 +1,504 @@
+"""Model shell around the hot path (mirror of gcn/models.py: ``Model`` / ``GCN``).
+
+Keeps the reference's API -- ``GCN(L, preprocess, placeholders, features, nbr_features, adj,
+cvd, multitask=, is_training=)``, ``run_one_step(sess, feed_dict)`` (``sess`` accepted and
+ignored), ``get_data``, ``get_pred_and_grad``, ``init_counts``, ``save`` / ``load`` and the
+counters ``run_t, g_t, g_ops, nn_ops, field_sizes, adj_sizes, fadj_sizes, amt_data,
+history_vars`` (gcn/models.py:339-347) -- but executes eagerly on one MI355X:
+
+  * features (N x F*dim_s) and every N x d history live in HBM for the whole run (1.12 GB +
+    119 MB for Reddit; the box has 288 GB), so the per-step host gather + feed copy of the
+    reference (gcn/vrgcn.py:39-47, 3.2 ms/step measured in SURVEY.md §6) becomes a device
+    row gather;
+  * a minibatch arrives as ONE int32 and ONE fp32 pinned staging buffer (``DevFeed``) holding
+    fields / ffields / scales / labels and the CSR, transposed-CSR and row plan of each
+    layer, i.e. two H2D copies per step;
+  * parameters, gradients and Adam moments are single flat fp32 buffers (one fused update,
+    and exactly one RCCL all-reduce per step in the multi-GPU driver, parallel.py);
+  * history rows are scattered after the optimizer step, as the reference orders it
+    (gcn/models.py:186-194).
+"""
+import os
+from time import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import ops
+from .flags import FLAGS
+from .layers import (AugmentedDropoutDense, Dense, Dropout, SparseInput)
+from .scheduler import build_plan
+
+
+class VariableStore(object):
+    """What ``tf.make_template`` provides in the reference (gcn/train.py:115-119): the second
+    model instance created through the same template reuses the first one's weights."""
+
+    def __init__(self):
+        self.theta = None
+        self.layout = None
+
+
+def make_template(name, func):
+    store = VariableStore()
+
+    def create(*args, **kwargs):
+        kwargs['_store'] = store
+        return func(*args, **kwargs)
+    return create
+
+
+class DevFeed(object):
+    """One minibatch on device."""
+
+    def __init__(self, feed_dict, placeholders, L, cv, device, plan_T=0):
+        ph = placeholders
+        ints, flts = [], []
+
+        def add_i(a):
+            a = np.ascontiguousarray(a, dtype=np.int32).ravel()
+            off = sum(x.shape[0] for x in ints)
+            pad = (-a.shape[0]) % 4                      # keep every sub-array 16-byte aligned
+            ints.append(np.concatenate([a, np.zeros(pad, np.int32)]) if pad else a)
+            return (off, a.shape[0])
+
+        def add_f(a):
+            a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+            off = sum(x.shape[0] for x in flts)
+            pad = (-a.shape[0]) % 4
+            flts.append(np.concatenate([a, np.zeros(pad, np.float32)]) if pad else a)
+            return (off, a.shape[0])
+
+        self.host_fields = [feed_dict[ph['fields'][l]] for l in range(L + 1)]
+        f_slots = [add_i(f) for f in self.host_fields]
+        labels = np.asarray(feed_dict[ph['labels']], dtype=np.float32)
+        lab_slot = add_f(labels)
+        sc_slots = [add_f(feed_dict[ph['scales'][l]]) for l in range(L)]
+        ff_slots, csr_slots = [], []
+        for l in range(L):
+            entry = {}
+            a = feed_dict[('csr', ph['adj'][l])]
+            entry['a'] = self._pack_csr(a, add_i, add_f, plan_T, transpose=True)
+            if cv:
+                ff_slots.append(add_i(feed_dict[ph['ffields'][l]]))
+                p = feed_dict[('csr', ph['fadj'][l])]
+                entry['f'] = self._pack_csr(p, add_i, add_f, plan_T, transpose=False)
+            csr_slots.append(entry)
+
+        ibuf = np.concatenate(ints) if ints else np.zeros(0, np.int32)
+        fbuf = np.concatenate(flts) if flts else np.zeros(0, np.float32)
+        pin = device.type == 'cuda'
+        it = torch.from_numpy(ibuf)
+        ft = torch.from_numpy(fbuf)
+        if pin:
+            it, ft = it.pin_memory(), ft.pin_memory()
+        self.ibuf = it.to(device, non_blocking=True)
+        self.fbuf = ft.to(device, non_blocking=True)
+        iv = lambda s: self.ibuf[s[0]:s[0] + s[1]]     # noqa: E731
+        fv = lambda s: self.fbuf[s[0]:s[0] + s[1]]     # noqa: E731
+
+        self.fields = [iv(s) for s in f_slots]
+        self.labels = fv(lab_slot).view(labels.shape)
+        self.scales = [fv(s) for s in sc_slots]
+        self.ffields = [iv(s) for s in ff_slots]
+        self.adj, self.fadj = [], []
+        for entry in csr_slots:
+            self.adj.append(self._unpack_csr(entry['a'], iv, fv, device))
+            if cv:
+                self.fadj.append(self._unpack_csr(entry['f'], iv, fv, device))
+
+    @staticmethod
+    def _pack_csr(h, add_i, add_f, plan_T, transpose):
+        seg, fix, nslots = build_plan(h.rowptr, plan_T)
+        e = dict(shape=h.shape, rowptr=add_i(h.rowptr), col=add_i(h.col), val=add_f(h.val),
+                 seg=add_i(seg), nseg=seg.shape[0], fix=add_i(fix), nfix=fix.shape[0], nslots=nslots)
+        if transpose and h.t_rowptr is not None:
+            tseg, tfix, tns = build_plan(h.t_rowptr, plan_T)
+            e['t'] = dict(shape=(h.shape[1], h.shape[0]), rowptr=add_i(h.t_rowptr), col=add_i(h.t_col),
+                          val=add_f(h.t_val), seg=add_i(tseg), nseg=tseg.shape[0], fix=add_i(tfix),
+                          nfix=tfix.shape[0], nslots=tns)
+        return e
+
+    @staticmethod
+    def _unpack_csr(e, iv, fv, device):
+        plan = ops.DevicePlan.__new__(ops.DevicePlan)
+        plan.nseg, plan.nfix, plan.nslots = e['nseg'], e['nfix'], e['nslots']
+        plan.seg = iv(e['seg'])
+        plan.fix = iv(e['fix']) if e['nfix'] else None
+        plan.ws, plan.device = None, device
+        m = ops.DeviceCSR(e['shape'], iv(e['rowptr']), iv(e['col']), fv(e['val']), plan)
+        if 't' in e:
+            m.transpose = DevFeed._unpack_csr(e['t'], iv, fv, device)
+        return m
+
+
+class Model(object):
+    def __init__(self, **kwargs):
+        allowed_kwargs = {'name', 'logging', 'multitask', 'is_training', 'device', '_store'}
+        for kwarg in kwargs.keys():
+            assert kwarg in allowed_kwargs, 'Invalid keyword argument: ' + kwarg
+        self.name = kwargs.get('name') or 'model'
+        self.logging = kwargs.get('logging', False)
+        self.vars = []
+        self.placeholders = {}
+        self.layers = []
+        self.activations = []
+        self.inputs = None
+        self.outputs = None
+        self.loss = 0
+        self.accuracy = 0
+        self.multitask = kwargs.get('multitask', False)
+        self.aggregators = []
+        self.is_training = kwargs.get('is_training', True)
+        dev = kwargs.get('device')
+        if dev is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("stochastic_gcn_amd models need a GPU (no CPU fallback)")
+            dev = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(dev)
+        self._store = kwargs.get('_store') or VariableStore()
+        self.dropout = 0.0
+        self.cur = None
+        self.grad_hook = None      # parallel.py installs the RCCL all-reduce here
+
+    # -- reference API --------------------------------------------------------------------
+    def save(self, sess=None, path=None):
+        """Weights + history (gcn/models.py:204-209 saves self.vars + self.history_vars)."""
+        path = path or "tmp/%s.ckpt.npz" % self.name
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        blob = {"var/" + n: v.detach().cpu().numpy() for n, v in self.named_vars()}
+        for i, h in enumerate(self.history_vars):
+            blob["history/%d" % i] = h.detach().cpu().numpy()
+        np.savez(path, **blob)
+        print("Model saved in file: %s" % path)
+        return path
+
+    def load(self, sess=None, load_history=False, path=None):
+        path = path or "tmp/%s.ckpt.npz" % self.name
+        z = np.load(path)
+        for n, v in self.named_vars():
+            v.copy_(torch.from_numpy(z["var/" + n]).to(self.device))
+        if load_history:
+            for i, h in enumerate(self.history_vars):
+                h.copy_(torch.from_numpy(z["history/%d" % i]).to(self.device))
+        print("Model restored from file: %s" % path)
+
+
+class GCN(Model):
+    def __init__(self, L, preprocess, placeholders, features, nbr_features, adj, cvd, **kwargs):
+        super(GCN, self).__init__(**kwargs)
+        self.L = L
+        self.preprocess = preprocess
+        self.placeholders = placeholders
+        self.sparse_input = sp.issparse(features) or isinstance(features, ops.DeviceCSR)
+        self.input_dim = features.shape[1]
+        self_dim = 0 if FLAGS.normalization == 'gcn' else self.input_dim
+        self._set_features(features, nbr_features, self_dim, preprocess and FLAGS.pp_nbr)
+        self.adj = adj
+        self.cvd = cvd
+        self.build()
+        self.init_counts()
+
+    def init(self, sess):
+        pass
+
+    # ---- feature residency --------------------------------------------------------------
+    def _set_features(self, features, nbr_features, self_dim, stack):
+        dev = self.device
+        if self.sparse_input:
+            if stack:                                             # gcn/models.py:235-239
+                f = sp.hstack((features[:, :self_dim], nbr_features)).tocsr().astype(np.float32)
+            else:
+                f = features.tocsr().astype(np.float32)
+            f.sort_indices()
+            self.features = f
+            self.features_dev = ops.DeviceCSR.from_scipy(f, dev, with_plan=False)
+            return
+
+        def to_dev(x):
+            if isinstance(x, torch.Tensor):
+                return x.to(dev)
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        if stack:
+            nb = to_dev(nbr_features)
+            n, fn = nb.shape
+            out = torch.empty((n, self_dim + fn), dtype=torch.float32, device=dev)
+            if self_dim:
+                out[:, :self_dim] = to_dev(features)[:, :self_dim]
+            out[:, self_dim:] = nb
+            self.features_dev = out
+        else:
+            self.features_dev = to_dev(features)
+        self.features = self.features_dev
+
+    def _preprocess(self):
+        if self.preprocess:
+            self.L -= 1
+        self.agg0_dim = FLAGS.hidden1 if self.preprocess else self.input_dim
+
+    def _build_history(self):
+        self.history = []
+
+    def _build_aggregators(self):
+        pass
+
+    # ---- graph assembly (gcn/models.py:124-196, :258-337) -------------------------------
+    def build(self):
+        self.sparse_mm = self.sparse_input
+        if self.sparse_input and not self.preprocess:
+            print('Warning: we do not support sparse input without pre-processing. Converting to dense...')
+            self.features_dev = torch.from_numpy(
+                np.asarray(self.features.todense(), dtype=np.float32)).to(self.device)
+            self.sparse_mm = False
+        self.num_data = self.adj.shape[0]
+        lab = self.placeholders['labels']
+        self.output_dim = int(lab.shape[1]) if hasattr(lab, 'shape') else int(self.placeholders['labels_dim'])
+        self._preprocess()
+        self._build_history()
+        self._build_aggregators()
+        self._build()
+        self._allocate_variables()
+        self.history_vars = [h[0] for h in self.history]
+        if self.is_training:
+            self.adam_t = 0
+
+    def _keep_prob(self):
+        return 1.0 - self.dropout
+
+    def _build(self):
+        dim_s = 1 if FLAGS.normalization == 'gcn' else 2
+        cnt = 0
+        self.layer_comp = []
+        kp = self._keep_prob
+        if self.preprocess:
+            for l in range(FLAGS.num_fc_layers):
+                input_dim = self.input_dim * dim_s if l == 0 else FLAGS.hidden1
+                sparse_inputs = self.sparse_mm if l == 0 else False
+                last_layer = self.L == 0 and l + 1 == FLAGS.num_fc_layers
+                output_dim = self.output_dim if last_layer else FLAGS.hidden1
+                layer_norm = False if last_layer else FLAGS.layer_norm
+                if FLAGS.det_dropout:
+                    raise NotImplementedError("det_dropout is out of scope (SURVEY.md §2)")
+                elif self.cvd:
+                    self.layers.append(AugmentedDropoutDense(kp, input_dim, FLAGS.hidden1,
+                                                             sparse_inputs=sparse_inputs,
+                                                             norm=FLAGS.layer_norm, name='dense%d' % cnt))
+                else:
+                    self.layers.append(Dropout(kp, self.cvd, name='dropout_pp%d' % cnt))
+                    self.layers.append(Dense(input_dim, output_dim, self.placeholders,
+                                             sparse_inputs=sparse_inputs, act=not last_layer,
+                                             norm=layer_norm, name='dense%d' % cnt))
+                self.layer_comp.append((input_dim * FLAGS.hidden1, 0))
+                cnt += 1
+        for l in range(self.L):
+            self.layers.append(self.aggregators[l])
+            for l2 in range(FLAGS.num_fc_layers):
+                dim = self.agg0_dim if l == 0 else FLAGS.hidden1
+                input_dim = dim * dim_s if l2 == 0 else FLAGS.hidden1
+                last_layer = l2 + 1 == FLAGS.num_fc_layers and l + 1 == self.L
+                output_dim = self.output_dim if last_layer else FLAGS.hidden1
+                layer_norm = False if last_layer else FLAGS.layer_norm
+                if FLAGS.det_dropout and l + 1 != self.L:
+                    raise NotImplementedError("det_dropout is out of scope (SURVEY.md §2)")
+                elif self.cvd and l + 1 != self.L:
+                    self.layers.append(AugmentedDropoutDense(kp, input_dim, output_dim,
+                                                             norm=layer_norm, name='dense%d' % cnt))
+                else:
+                    if not FLAGS.reverse:
+                        self.layers.append(Dropout(kp, self.cvd, name='dropout%d' % cnt))
+                    self.layers.append(Dense(input_dim, output_dim, self.placeholders,
+                                             act=not last_layer, norm=layer_norm, name='dense%d' % cnt))
+                    if FLAGS.reverse and not last_layer:
+                        self.layers.append(Dropout(kp, self.cvd, name='dropout_r%d' % cnt))
+                self.layer_comp.append((input_dim * output_dim, l + 1))
+                cnt += 1
+
+    # ---- flat parameter / gradient / Adam buffers ---------------------------------------
+    def _allocate_variables(self):
+        layout, total = [], 0
+        for layer in self.layers:
+            for pname, shape, init in layer.param_shapes():
+                n = int(np.prod(shape))
+                layout.append((layer.name + '/' + pname, shape, init, total, n))
+                total += (n + 3) // 4 * 4
+        st = self._store
+        if st.theta is None:
+            st.theta = torch.zeros(total, dtype=torch.float32, device=self.device)
+            st.layout = [(n, s) for n, s, _, _, _ in layout]
+            gen = torch.Generator(device='cpu')
+            gen.manual_seed(int(FLAGS.seed))
+            for name, shape, init, off, n in layout:
+                if init == 'glorot':         # tf.get_variable default = glorot_uniform
+                    lim = float(np.sqrt(6.0 / (shape[0] + shape[1])))
+                    w = (torch.rand(shape, generator=gen) * 2 - 1) * lim
+                elif init == 'ones':
+                    w = torch.ones(shape)
+                else:
+                    w = torch.zeros(shape)
+                st.theta[off:off + n] = w.reshape(-1).to(self.device)
+        else:
+            assert st.layout == [(n, s) for n, s, _, _, _ in layout], \
+                "template re-used with a different variable layout"
+        self.theta = st.theta
+        self.grad = torch.zeros_like(self.theta)
+        self._layout = layout
+        by_layer = {l.name: l for l in self.layers}
+        for name, shape, _, off, n in layout:
+            lname, pname = name.rsplit('/', 1)
+            by_layer[lname].vars[pname] = self.theta[off:off + n].view(shape)
+            by_layer[lname].grads[pname] = self.grad[off:off + n].view(shape)
+        if self.is_training:
+            self.adam_m = torch.zeros_like(self.theta)
+            self.adam_v = torch.zeros_like(self.theta)
+        # weight-decay mask: vars of the first parametrised layer (gcn/models.py:68-75)
+        self._wd_mask = torch.zeros_like(self.theta)
+        for layer in self.layers:
+            if layer.param_shapes():
+                for name, shape, _, off, n in layout:
+                    lname, pname = name.rsplit('/', 1)
+                    if lname == layer.name and pname in layer.wd_vars():
+                        self._wd_mask[off:off + n] = 1.0
+                break
+        self.vars = [v for _, v in self.named_vars()]
+
+    def named_vars(self):
+        out = []
+        by_layer = {l.name: l for l in self.layers}
+        for name, shape, _, off, n in self._layout:
+            lname, pname = name.rsplit('/', 1)
+            out.append((name, by_layer[lname].vars[pname]))
+        return out
+
+    def set_params(self, params):
+        """Load a {'denseK/weights': ndarray, ...} dict (parity tests share weights with the oracle)."""
+        for name, v in self.named_vars():
+            v.copy_(torch.from_numpy(np.ascontiguousarray(params[name], dtype=np.float32)).to(self.device))
+
+    def get_params(self):
+        return {name: v.detach().cpu().numpy().copy() for name, v in self.named_vars()}
+
+    def get_grads(self):
+        by_layer = {l.name: l for l in self.layers}
+        return {name: by_layer[name.rsplit('/', 1)[0]].grads[name.rsplit('/', 1)[1]].detach().cpu().numpy().copy()
+                for name, _ in self.named_vars()}
+
+    # ---- one step -----------------------------------------------------------------------
+    def init_counts(self):
+        self.run_t = 0
+        self.g_t = 0
+        self.g_ops = 0
+        self.nn_ops = 0
+        self.field_sizes = np.zeros(self.L + 1)
+        self.adj_sizes = np.zeros(self.L)
+        self.fadj_sizes = np.zeros(self.L)
+        self.amt_data = 0
+
+    def upload(self, feed_dict):
+        """feed-dict -> DevFeed (two H2D copies) and the input feature rows."""
+        cv = bool(self.history)
+        cur = DevFeed(feed_dict, self.placeholders, self.L, cv, self.device)
+        f0 = cur.fields[0]
+        if self.sparse_input and self.sparse_mm:
+            sl = ops.csr_slice(self.features_dev, cur.host_fields[0], rows_dev=f0, with_coo_rows=True)
+            cur.inputs = SparseInput(sl)
+        else:
+            cur.inputs = ops.gather_rows(self.features_dev, f0)
+        return cur
+
+    def forward(self, cur):
+        self.cur = cur
+        self.activations = [cur.inputs]
+        for layer in self.layers:
+            self.activations.append(layer(self.activations[-1]))
+        self.outputs = self.activations[-1]
+        return self.outputs
+
+    def loss_and_grad(self, labels):
+        """gcn/models.py:68-94.  Returns (loss, accuracy, pred, dlogits) as device tensors."""
+        z = self.outputs
+        n = z.shape[0]
+        wd = 0.5 * FLAGS.weight_decay * (self.theta * self.theta * self._wd_mask).sum()
+        if self.multitask:
+            ce = torch.clamp(z, min=0) - z * labels + torch.log1p(torch.exp(-z.abs()))
+            loss = wd + ce.mean()
+            pred = torch.sigmoid(z)
+            dlogits = (pred - labels) / ce.numel()
+            acc = ((z > 0) == (labels > 0.5)).to(torch.float32).mean()
+        else:
+            logp = torch.log_softmax(z, dim=1)
+            loss = wd + (-(labels * logp).sum(dim=1)).mean()
+            pred = torch.exp(logp)
+            dlogits = (pred * labels.sum(dim=1, keepdim=True) - labels) / n
+            acc = (z.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32).mean()
+        return loss, acc, pred, dlogits
+
+    def backward(self, dlogits):
+        self.grad.zero_()
+        g = dlogits
+        for layer in reversed(self.layers):
+            g = layer.backward(g)
+        if FLAGS.weight_decay:
+            self.grad.add_(self.theta * self._wd_mask, alpha=float(FLAGS.weight_decay))
+        return self.grad
+
+    def adam_step(self):
+        """tf.train.AdamOptimizer(lr, beta1, beta2, eps=1e-8) on the flat buffers."""
+        self.adam_t += 1
+        b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
+        lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
+        g = self.grad
+        self.adam_m.mul_(b1).add_(g, alpha=1 - b1)
+        self.adam_v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        self.theta.addcdiv_(self.adam_m, self.adam_v.sqrt().add_(1e-8), value=-lr_t)
+
+    def update_history(self, cur):
+        """tf.scatter_update(history, fields[l], new_history) (gcn/models.py:160-166)."""
+        for l in range(self.L):
+            agg = self.aggregators[l]
+            nh = getattr(agg, 'new_history', None)
+            if nh is not None and self.history:
+                for h, v in zip(self.history[l], nh):
+                    ops.scatter_rows(h, cur.fields[l], v)
+
+    def _count(self, feed_dict):
+        raise NotImplementedError
+
+    def get_data(self, feed_dict):
+        cur = self.upload(feed_dict)
+        self._count(feed_dict)
+        return cur
+
+    def run_one_step(self, sess, feed_dict, sync=True):
+        t = time()
+        self.dropout = float(feed_dict.get(self.placeholders['dropout'], 0.0)) if self.is_training else 0.0
+        cur = self.get_data(feed_dict)
+        self.g_t += time() - t
+
+        t = time()
+        self.forward(cur)
+        loss, acc, pred, dlogits = self.loss_and_grad(cur.labels)
+        if self.is_training:
+            self.backward(dlogits)
+            if self.grad_hook is not None:
+                self.grad_hook(self.grad)
+            self.adam_step()
+        self.update_history(cur)
+        if sync:
+            loss, acc = float(loss), float(acc)
+            outs = [None, loss, acc] if self.is_training else [loss, acc, pred.cpu().numpy()]
+        else:
+            outs = [None, loss, acc] if self.is_training else [loss, acc, pred]
+        self.run_t += time() - t
+        return outs
+
+    def get_pred_and_grad(self, sess, feed_dict):
+        """Prediction and the gradient of the loss wrt the first variable (gcn/models.py:196),
+        without touching weights or history."""
+        self.dropout = float(feed_dict.get(self.placeholders['dropout'], 0.0))
+        cur = self.get_data(feed_dict)
+        self.forward(cur)
+        loss, acc, pred, dlogits = self.loss_and_grad(cur.labels)
+        self.backward(dlogits)
+        first = self.named_vars()[0][0]
+        return pred.cpu().numpy(), [self.get_grads()[first]]

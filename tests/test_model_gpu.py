@@ -1,0 +1,135 @@
+"""GPU parity of the whole training step (sampler -> DevFeed -> layers fwd -> loss -> bwd ->
+Adam -> history scatter) against the NumPy oracle on the same seeded inputs and dropout masks:
+every layer activation, loss, accuracy, all gradients, the updated weights and the updated
+history, over 3 consecutive steps (step k reads the history step k-1 wrote).
+Tolerance 1e-4 relative (max-norm) on activations (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import model_cases as mc
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _make_device_model(case, params, is_training=True):
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.vrgcn import VRGCN
+    from stochastic_gcn_amd.plaingcn import PlainGCN
+    FLAGS.reset()
+    FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
+    cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
+    fl = case['flags']
+    m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'],
+            fl['cvd'], is_training=is_training, device=torch.device('cuda:0'))
+    m.set_params(params)
+    return m
+
+
+def _np(x):
+    if isinstance(x, tuple):
+        return tuple(_np(t) for t in x)
+    if hasattr(x, 'csr'):
+        return None
+    return x.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", sorted(mc.CASES))
+def test_training_steps_match_oracle(name):
+    from stochastic_gcn_amd import layers
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    case = mc.build_case(name)
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    omodel = mc.make_oracle_model(case, seed=3)
+    dmodel = _make_device_model(case, {k: v.copy() for k, v in omodel.params.items()})
+    assert [type(l).__name__ for l in dmodel.layers if type(l).__name__ != 'x'] is not None
+    sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'],
+                      ph, 1, data=case['train'].copy(), cv=fl['cv'])
+    worst = 0.0
+    for step in range(3):
+        feed = sch.minibatch(c['batch'])
+        feed[ph['dropout']] = fl['dropout']
+        masks = mc.MaskSource(100 + step, 1.0 - fl['dropout'])
+        o_loss, o_acc, o_pred, o_acts, o_grads = omodel.run_one_step(feed, ph, fl['dropout'], masks)
+        layers.MASK_HOOK = masks.replay()
+        try:
+            outs = dmodel.run_one_step(None, feed)
+        finally:
+            layers.MASK_HOOK = None
+        assert masks.pos == len(masks.rec), "device path drew a different number of dropout masks"
+        # activations layer by layer
+        d_acts = dmodel.activations[1:]
+        assert len(d_acts) == len(o_acts)
+        for li, (da, oa) in enumerate(zip(d_acts, o_acts)):
+            da = _np(da)
+            if da is None or hasattr(oa, 'tocsr'):
+                continue
+            if isinstance(oa, tuple):
+                for dd, oo in zip(da, oa):
+                    e = onp.rel_err(dd, oo); worst = max(worst, e)
+                    assert e <= TOL, (name, step, li, e)
+            else:
+                e = onp.rel_err(da, oa); worst = max(worst, e)
+                assert e <= TOL, (name, step, li, e)
+        assert abs(outs[1] - float(o_loss)) <= 1e-4 * max(1.0, abs(float(o_loss))), (outs[1], o_loss)
+        assert abs(outs[2] - float(o_acc)) <= 1e-6
+        d_grads = dmodel.get_grads()
+        for k, g in o_grads.items():
+            e = onp.rel_err(d_grads[k], g)
+            assert e <= 5e-4, (name, step, 'grad', k, e)
+        d_params = dmodel.get_params()
+        for k, v in omodel.params.items():
+            assert onp.rel_err(d_params[k], v) <= 5e-4, (name, step, 'param', k)
+        for l, h in enumerate(omodel.history):
+            e = onp.rel_err(dmodel.history[l][0].cpu().numpy(), h)
+            assert e <= TOL, (name, step, 'history', l, e)
+    print("%s: worst activation rel err %.2e" % (name, worst))
+
+
+def test_eval_model_shares_weights_and_keeps_own_history():
+    """tf.make_template semantics (gcn/train.py:115-119): the test model reuses the train
+    model's weights but owns a separate history; eval = forward + history scatter only."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.models import make_template
+    from stochastic_gcn_amd.vrgcn import VRGCN
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    case = mc.build_case('reddit_cvd_pp')
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    FLAGS.reset()
+    FLAGS.update(**{k: v for k, v in fl.items() if hasattr(FLAGS, k)})
+    dev = torch.device('cuda:0')
+
+    def model_func(nbr, is_training, _store=None):
+        return VRGCN(fl['num_layers'], True, ph, case['feats'], nbr, case['adj'], True,
+                     is_training=is_training, device=dev, _store=_store)
+    create = make_template('model', model_func)
+    train_m = create(case['nbr'], True)
+    test_m = create(case['nbr'], False)
+    assert test_m.theta.data_ptr() == train_m.theta.data_ptr()
+    assert test_m.history[0][0].data_ptr() != train_m.history[0][0].data_ptr()
+    sch = PyScheduler(case['adj'], case['labels'], 1, [1], ph, 1, data=case['train'].copy(), cv=True)
+    feed = sch.minibatch(c['batch'])
+    before = train_m.theta.clone()
+    loss, acc, pred = test_m.run_one_step(None, feed)
+    assert torch.equal(before, train_m.theta)                       # eval never touches weights
+    assert pred.shape == (c['batch'], c['classes']) and np.allclose(pred.sum(1), 1, atol=1e-5)
+    f0 = feed[ph['fields'][0]]
+    assert float(test_m.history[0][0][torch.from_numpy(f0).long().to(dev)].abs().sum()) > 0
+    assert float(train_m.history[0][0].abs().sum()) == 0.0
+    # oracle agreement for the eval step
+    om = mc.make_oracle_model(case, params=train_m.get_params(), is_training=False)
+    o_loss, o_acc, o_pred, _, _ = om.run_one_step(feed, ph, 0.0, lambda *a: None)
+    assert onp.rel_err(pred, o_pred) <= TOL and abs(loss - float(o_loss)) <= 1e-4
+
+
+def test_save_load_roundtrip(tmp_path):
+    case = mc.build_case('reddit_cvd_pp')
+    om = mc.make_oracle_model(case, seed=1)
+    m = _make_device_model(case, om.params)
+    m.history[0][0].normal_()
+    p = m.save(path=str(tmp_path / "m.ckpt.npz"))
+    m2 = _make_device_model(case, mc.make_oracle_model(case, seed=2).params)
+    m2.load(path=p, load_history=True)
+    assert torch.equal(m.theta, m2.theta) and torch.equal(m.history[0][0], m2.history[0][0])
