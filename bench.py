@@ -54,19 +54,70 @@ def parse():
 
 
 def make_graph(args, rank):
+    """Returns (n, full_adj, name, data10) -- data10 is the reference-style 10-tuple when the
+    workload is a trainable dataset (used by the train_epoch leg), else None."""
     from stochastic_gcn_amd import synthetic
     if args.workload == "reddit":
-        n, _, full_adj, *_ = synthetic.reddit_like(seed=1 + rank, with_features=False)
+        data = synthetic.reddit_like(seed=1 + rank, with_features=False)
         name = "S-Reddit full-graph CSR x dense (N=232965, Zipf(0.6) x uniform)"
     elif args.workload == "reddit-small":
-        n, _, full_adj, *_ = synthetic.reddit_like(n=23296, m=1160000, splits=(15241, 2369, 5533),
-                                                   seed=1 + rank, with_features=False)
+        data = synthetic.reddit_like(n=23296, m=1160000, splits=(15241, 2369, 5533),
+                                     seed=1 + rank, with_features=False)
         name = "S-Reddit/10 (N=23296)"
     else:
         n = 1 << 20
-        full_adj = synthetic.rmat_like(n, 20 * n, seed=1 + rank)
-        name = "S-RMAT 2^20 vertices, 20 M edges"
-    return n, full_adj, name
+        return n, synthetic.rmat_like(n, 20 * n, seed=1 + rank), "S-RMAT 2^20 vertices, 20 M edges", None
+    return data[0], data[2], name, data
+
+
+def train_epoch_leg(data, dev, epochs=3):
+    """The CVD+PP minibatch epoch of BASELINE config 3 on the same synthetic graph: reddit.config
+    flags (gcn/config/reddit.config:2) + --cv --cvd --degree=1 (README.md:46-55), 298 steps of
+    batch 512, the real training path (sampler thread -> packed H2D -> fused step -> Adam ->
+    history scatter), validation excluded (the reference reports time - ttime)."""
+    import torch
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+    FLAGS.reset()
+    FLAGS.update(dataset='reddit', normalization='graphsage', weight_decay=0.0, dropout=0.2,
+                 layer_norm=True, hidden1=128, num_fc_layers=2, batch_size=512, test_batch_size=512,
+                 cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, seed=1)
+    n, train_adj, full_adj, _, _, _, labels, tr, va, te = data
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    feats = torch.randn((n, 602), device=dev, generator=g)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # keep stdout to the single JSON line
+        trn = Trainer(data=(n, train_adj, full_adj, feats, None, None, labels, tr, va, te), verbose=False)
+    walls = []
+    for _ in range(epochs):
+        trn.train_epoch()
+        walls.append(trn.last_epoch['train_wall_s'])
+    le = trn.last_epoch
+    best = min(walls[1:]) if len(walls) > 1 else walls[0]
+    edges = le['sampled_edges'] + le['full_edges']
+    # each aggregation edge is used by the forward aggregate; sampled edges again by the backward
+    return {"epoch_time_s": best, "epoch_times_s": walls, "steps": le['steps'], "batch_size": 512,
+            "ms_per_step": best / le['steps'] * 1e3, "sch_wait_s": le['sch_wait_s'],
+            "agg_edges_per_epoch": edges, "agg_edges_per_s": edges / best,
+            "recipe": "reddit.config + --cv --cvd --degree=1 (CVD+PP), validation excluded"}
+
+
+def profiled_traffic(kernel_prefix, nnz, d):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, written by profiles/summarize.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction applied).  None when no
+    profile of this kernel/shape is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("kernel", "").startswith(kernel_prefix) and j.get("nnz") == nnz and j.get("d") == d:
+            best = (j, os.path.basename(f))
+    return best
 
 
 def reddit_grad_floats(d_in=602, hidden=128, classes=41):
@@ -104,21 +155,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        g.build(quiet=True)
-    from stochastic_gcn_amd import ops, _ffi
-
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    if local_rank == 0:
+        g.build(quiet=True)          # no-op when the in-tree .so files travelled with the snapshot
+    if world > 1:
+        dist.barrier()
+    from stochastic_gcn_amd import ops, _ffi
     for kv in args.tune:
         k, v = kv.split("=")
         _ffi.tune(k, int(v))
 
-    n, full_adj, wname = make_graph(args, rank)
+    n, full_adj, wname, data10 = make_graph(args, rank)
     d = args.d
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
@@ -188,12 +240,21 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "spmm_seg_kernel (forward A.X, incl. split-row fix-up)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
-                     "traffic": None, "bytes_alg_per_launch": bytes_alg,
+                     "traffic": None, "traffic_source": None, "bytes_alg_per_launch": bytes_alg,
                      "ms_per_launch": fwd_ms, "edges_per_s_fwd": nnz / (fwd_ms * 1e-3),
                      "gather_model_GBps": (nnz * (d * 4 + 8) + n * d * 4) / (fwd_ms * 1e-3) / 1e9},
     }
+    tr = profiled_traffic("void sgcn::spmm", nnz, d) if not args.tune else None
+    if tr is not None:
+        out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
+            tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
+    if world == 1 and not args.no_epoch and data10 is not None:
+        del A, Xp, dCp, X, dC, C, dX
+        torch.cuda.empty_cache()
+        out["train_epoch"] = train_epoch_leg(data10, dev)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -130,6 +130,32 @@ int sgcn_csr_slice_f32(int32_t n, const int32_t* dev_r, const float* dev_a_d,
                        const int32_t* dev_o_p, float* dev_o_d, int32_t* dev_o_col,
                        int32_t* dev_o_row, void* stream);
 
+/* ---- fused row-wise kernels of the dense part of the step --------
+ * y = act(LN(x) * scale + offset), eps as MyLayerNorm2 (1e-9)     gcn/layers.py:95-97,134-137
+ *   offset/scale NULL -> no normalisation (y = act(x)); relu != 0 -> ReLU.
+ *   xhat [n x d] and rstd [n] are kept for the backward. */
+int sgcn_ln_act_fwd_f32(const float* dev_x, int64_t ldx, const float* dev_offset,
+                        const float* dev_scale, int32_t n, int32_t d, float eps, int32_t relu,
+                        float* dev_y, int64_t ldy, float* dev_xhat, float* dev_rstd, void* stream);
+/* Backward of the above: dx, and doffset[d] += / dscale[d] += column sums (two-stage, fixed
+ * order).  ws: sgcn_ln_act_bwd_ws_floats(n, d) floats of scratch.  scale NULL -> no norm. */
+int64_t sgcn_ln_act_bwd_ws_floats(int32_t n, int32_t d);
+int sgcn_ln_act_bwd_f32(const float* dev_dy, int64_t lddy, const float* dev_y, int64_t ldy,
+                        const float* dev_xhat, const float* dev_rstd, const float* dev_scale,
+                        int32_t n, int32_t d, int32_t relu, float* dev_dx, int64_t lddx,
+                        float* dev_doffset, float* dev_dscale, float* dev_ws, void* stream);
+/* Softmax cross-entropy over n rows: stats[0] = sum_i CE_i, stats[1] = #rows whose arg-max
+ * matches the label arg-max; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
+ * pred (nullable) = softmax.                                   gcn/models.py:68-94,198-202 */
+int sgcn_softmax_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,
+                        int32_t n, int32_t c, float* dev_dlogits, int64_t lddz, float* dev_pred,
+                        int64_t ldp, float* dev_stats, void* stream);
+/* tf.train.AdamOptimizer step on flat buffers: m,v updated in place,
+ * theta -= lr_t * m / (sqrt(v) + eps)  with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
+ * caller.                                                       gcn/models.py:50-51 */
+int sgcn_adam_f32(float* dev_theta, const float* dev_grad, float* dev_m, float* dev_v, int64_t n,
+                  float lr_t, float beta1, float beta2, float eps, void* stream);
+
 /* ======================================================================================
  * Host neighbour sampler (stays on host: BASELINE.json north_star)
  *   replaces class Scheduler gcn/scheduler.h:6-28, gcn/scheduler.cpp:11-189
@@ -172,6 +198,25 @@ enum {
 };
 int sgcn_sched_view_i32(sgcn_sched_t* s, int32_t which, const int32_t** ptr, int64_t* len);
 int sgcn_sched_view_f32(sgcn_sched_t* s, int32_t which, const float** ptr, int64_t* len);
+
+/* One call = PyScheduler.batch (gcn/_scheduler.pyx:55-127): start_batch + L x expand with
+ * degrees[L-l-1] (:66), the list reversal (:121-126) and labels[fields[-1]] (:138), plus what
+ * the device step needs on top: CSR of adj / adj^T / fadj and their row plans.  Everything is
+ * laid into two internal staging arrays (int32 / fp32, every sub-array 16-byte aligned) that
+ * sgcn_sched_packed_copy() copies into caller-owned (pinned) buffers of *n_i32 / *n_f32
+ * elements; `meta` (int64, length sgcn_sched_packed_meta_len(L)) receives the descriptors:
+ *   [0]=L [1]=cv [2]=n_classes [3]=0
+ *   fields  (L+1) x {off,len}      scales  L x {off,len}       ffields L x {off,len}
+ *   labels  {off,rows,cols}        medg_w  L x {off,len}
+ *   csr     L x {adj, adj^T, fadj} x {nrows,ncols,nnz,rowptr,col,val,seg,nseg,fix,nfix,nslots}
+ * (offsets into the int32 buffer for index arrays, into the fp32 buffer for values; layer 0 =
+ * input-most).  Touches no Python state, so a prefetch thread runs it outside the GIL. */
+int sgcn_sched_batch_packed(sgcn_sched_t* s, int32_t n, const int32_t* host_ids, int32_t L,
+                            const int32_t* host_degrees, const float* host_labels,
+                            int32_t n_classes, int32_t plan_T, int64_t* meta, int64_t meta_cap,
+                            int64_t* n_i32, int64_t* n_f32);
+int64_t sgcn_sched_packed_meta_len(int32_t L);
+int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32);
 
 /* Fenwick-tree multinomial sampler without replacement (IS mode only)
  *   replaces struct Mult gcn/mult.h:8-27, gcn/mult.cpp:7-51 */

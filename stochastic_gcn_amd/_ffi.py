@@ -55,6 +55,14 @@ SIGNATURES = {
     "sgcn_scatter_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),
     "sgcn_csr_slice_f32": (C.c_int, [C.c_int32, P, P, P, P, P, P, P, P, P]),
+    "sgcn_ln_act_fwd_f32": (C.c_int, [P, C.c_int64, P, P, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                      P, C.c_int64, P, P, P]),
+    "sgcn_ln_act_bwd_ws_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "sgcn_ln_act_bwd_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, P, P, P, C.c_int32, C.c_int32,
+                                      C.c_int32, P, C.c_int64, P, P, P, P]),
+    "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
+                                      P, C.c_int64, P, P]),
+    "sgcn_adam_f32": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "sgcn_sched_create": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.POINTER(C.c_void_p)]),
     "sgcn_sched_destroy": (None, [C.c_void_p]),
@@ -63,6 +71,11 @@ SIGNATURES = {
     "sgcn_sched_expand": (C.c_int, [C.c_void_p, C.c_int32]),
     "sgcn_sched_view_i32": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(c_i32p), C.POINTER(C.c_int64)]),
     "sgcn_sched_view_f32": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(c_f32p), C.POINTER(C.c_int64)]),
+    "sgcn_sched_batch_packed": (C.c_int, [C.c_void_p, C.c_int32, P, C.c_int32, P, P, C.c_int32,
+                                          C.c_int32, P, C.c_int64, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64)]),
+    "sgcn_sched_packed_meta_len": (C.c_int64, [C.c_int32]),
+    "sgcn_sched_packed_copy": (C.c_int, [C.c_void_p, P, P]),
     "sgcn_mult_create": (C.c_int, [P, C.c_int32, C.POINTER(C.c_void_p)]),
     "sgcn_mult_destroy": (None, [C.c_void_p]),
     "sgcn_mult_tree": (C.c_int, [C.c_void_p, C.POINTER(c_f32p), C.POINTER(C.c_int64)]),

@@ -1,0 +1,242 @@
+// Fused row-wise kernels of the "downstream dense" part of the step,
+// gfx950.  The GEMMs themselves stay on rocBLAS (matrix cores); what is fused here is the chain
+// of small elementwise / row-reduction ops around them, because at minibatch sizes
+// (~1,000 x 128 fp32) the step is launch-latency-bound, not bandwidth-bound:
+//   ln_act_fwd   MyLayerNorm2 + ReLU            gcn/layers.py:95-97,134-137,404-411
+//   ln_act_bwd   their backward (+ column sums for d(offset), d(scale))
+//   softmax_ce   softmax-CE mean loss, accuracy, softmax "pred", dlogits   gcn/models.py:68-94,198-202
+//   adam         tf.train.AdamOptimizer update on the flat parameter buffer   gcn/models.py:50-51
+// One wavefront per row; lanes stride the row (coalesced 256-byte pieces); wave reductions by
+// DPP shuffles (__shfl_xor over 64 lanes).
+#include "sgcn_dev.h"
+
+namespace sgcn {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// y = act(LN(x) * scale + offset); keeps xhat and rstd for the backward.  norm == 0: y = act(x).
+__global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ offset,
+    const float* __restrict__ scale, int32_t n, int32_t d, float eps, int32_t norm, int32_t relu,
+    float* __restrict__ y, int64_t ldy, float* __restrict__ xhat, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (row >= n) return;
+    const float* xr = x + row * ldx;
+    float* yr = y + row * ldy;
+    if (!norm) {
+        for (int c = lane; c < d; c += kWave) { const float v = xr[c]; yr[c] = relu ? fmaxf(v, 0.f) : v; }
+        return;
+    }
+    float s = 0.f;
+    for (int c = lane; c < d; c += kWave) s += xr[c];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += kWave) { const float t = xr[c] - mean; q += t * t; }
+    const float r = rsqrtf(wave_sum(q) / (float)d + eps);
+    if (lane == 0) rstd[row] = r;
+    float* hr = xhat + row * (int64_t)d;
+    for (int c = lane; c < d; c += kWave) {
+        const float h = (xr[c] - mean) * r;
+        hr[c] = h;
+        const float v = h * scale[c] + offset[c];
+        yr[c] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// dx = LN-backward(dy masked by y > 0); per-block column partials of d(offset), d(scale).
+constexpr int kBwdRowsPerWave = 8;
+__global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
+    const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
+    const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ scale,
+    int32_t n, int32_t d, int32_t norm, int32_t relu, float* __restrict__ dx, int64_t lddx,
+    float* __restrict__ partial /* [gridDim.x][2][d] */) {
+    extern __shared__ float lds[];      // [4 waves][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / kWave;
+    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kBwdRowsPerWave;
+    float* my = lds + (size_t)wave * 2 * d;
+    if (norm) for (int c = lane; c < 2 * d; c += kWave) my[c] = 0.f;
+    for (int k = 0; k < kBwdRowsPerWave; k++) {
+        const int64_t row = row0 + k;
+        if (row >= n) break;
+        const float* gr = dy + row * lddy;
+        const float* yr = y + row * ldy;
+        float* dr = dx + row * lddx;
+        if (!norm) {
+            for (int c = lane; c < d; c += kWave) dr[c] = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
+            continue;
+        }
+        const float* hr = xhat + row * (int64_t)d;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < d; c += kWave) {
+            const float g = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
+            const float h = hr[c];
+            my[c] += g;               // d(offset) column sum (lane-private columns: no race)
+            my[d + c] += g * h;       // d(scale)
+            const float t = g * scale[c];
+            s1 += t;
+            s2 += t * h;
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d, r = rstd[row];
+        for (int c = lane; c < d; c += kWave) {
+            const float g = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
+            dr[c] = r * (g * scale[c] - m1 - hr[c] * m2);
+        }
+    }
+    if (!norm) return;
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * 2 * d;
+    for (int c = threadIdx.x; c < 2 * d; c += kBlock)
+        out[c] = (lds[c] + lds[2 * d + c]) + (lds[4 * d + c] + lds[6 * d + c]);
+}
+
+// doffset[c] += sum_b partial[b][0][c]; dscale[c] += sum_b partial[b][1][c]   (fixed order)
+__global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_t nblk, int32_t d,
+                                       float* __restrict__ doffset, float* __restrict__ dscale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; b++) s += partial[(size_t)b * 2 * d + c];
+    if (c < d) doffset[c] += s; else dscale[c - d] += s;
+}
+
+// One workgroup: rows strided over its 4 wavefronts.  stats = {sum of CE, #correct}.
+__global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
+    const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
+    int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
+    float* __restrict__ stats) {
+    __shared__ float red[2][kBlock / kWave];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / kWave;
+    float loss = 0.f, correct = 0.f;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + wave; row < n;
+         row += (int64_t)gridDim.x * (kBlock / kWave)) {
+        const float* zr = z + row * ldz;
+        const float* lr = lab + row * ldl;
+        float m = -INFINITY, lm = -INFINITY;
+        int am = 0, alm = 0;
+        for (int k = lane; k < c; k += kWave) {
+            if (zr[k] > m) { m = zr[k]; am = k; }
+            if (lr[k] > lm) { lm = lr[k]; alm = k; }
+        }
+        // wave arg-max with lowest-index tie break (np.argmax / tf.argmax semantics)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, 64); const int oa = __shfl_xor(am, o, 64);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+            const float ol = __shfl_xor(lm, o, 64); const int ola = __shfl_xor(alm, o, 64);
+            if (ol > lm || (ol == lm && ola < alm)) { lm = ol; alm = ola; }
+        }
+        float se = 0.f, sl = 0.f;
+        for (int k = lane; k < c; k += kWave) { se += __expf(zr[k] - m); sl += lr[k]; }
+        se = wave_sum(se); sl = wave_sum(sl);
+        const float lse = m + __logf(se);
+        float l = 0.f;
+        for (int k = lane; k < c; k += kWave) {
+            const float logp = zr[k] - lse, p = __expf(logp);
+            l -= lr[k] * logp;
+            if (dz) dz[row * lddz + k] = (p * sl - lr[k]) * inv_n;
+            if (pred) pred[row * ldp + k] = p;
+        }
+        loss += wave_sum(l);
+        correct += (am == alm) ? 1.f : 0.f;
+    }
+    if (lane == 0) { red[0][wave] = loss; red[1][wave] = correct; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < kBlock / kWave; w++) { a += red[0][w]; b += red[1][w]; }
+        stats[0] = a; stats[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
+                                                      const float* __restrict__ grad,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      int64_t n, float lr_t, float b1, float b2,
+                                                      float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float g = grad[i];
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi; v[i] = vi;
+        theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace sgcn
+
+using namespace sgcn;
+
+extern "C" int sgcn_ln_act_fwd_f32(const float* x, int64_t ldx, const float* offset,
+                                   const float* scale, int32_t n, int32_t d, float eps,
+                                   int32_t relu, float* y, int64_t ldy, float* xhat, float* rstd,
+                                   void* stream) {
+    SGCN_REQUIRE(n >= 0 && d >= 0, "ln_act_fwd: negative size");
+    if (n == 0 || d == 0) return SGCN_OK;
+    const int norm = (offset && scale) ? 1 : 0;
+    SGCN_REQUIRE(x && y && (!norm || (xhat && rstd)), "ln_act_fwd: null operand");
+    const unsigned blocks = (unsigned)((n + 3) / 4);
+    hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx,
+                       offset, scale, n, d, eps, norm, relu, y, ldy, xhat, rstd);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int64_t sgcn_ln_act_bwd_ws_floats(int32_t n, int32_t d) {
+    const int64_t blocks = ((int64_t)n + 4 * kBwdRowsPerWave - 1) / (4 * kBwdRowsPerWave);
+    return blocks * 2 * d;
+}
+
+extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                                   const float* xhat, const float* rstd, const float* scale,
+                                   int32_t n, int32_t d, int32_t relu, float* dx, int64_t lddx,
+                                   float* doffset, float* dscale, float* ws, void* stream) {
+    SGCN_REQUIRE(n >= 0 && d >= 0, "ln_act_bwd: negative size");
+    if (n == 0 || d == 0) return SGCN_OK;
+    const int norm = scale ? 1 : 0;
+    SGCN_REQUIRE(dy && y && dx && (!norm || (xhat && rstd && doffset && dscale && ws)),
+                 "ln_act_bwd: null operand");
+    SGCN_REQUIRE(!norm || (size_t)d * 8 * sizeof(float) <= 64 * 1024, "ln_act_bwd: d too large for LDS");
+    const int rows_per_block = 4 * kBwdRowsPerWave;
+    const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ln_act_bwd_kernel, dim3(blocks), dim3(kBlock), norm ? (size_t)d * 8 * sizeof(float) : 0,
+                       st, dy, lddy, y, ldy, xhat, rstd, scale, n, d, norm, relu, dx, lddx, ws);
+    if (norm)
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, ws,
+                           (int32_t)blocks, d, doffset, dscale);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float* labels,
+                                   int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
+                                   float* pred, int64_t ldp, float* stats, void* stream) {
+    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats, "softmax_ce: bad operand");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, logits, ldz,
+                       labels, ldl, n, c, dlogits, lddz, pred, ldp, stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_adam_f32(float* theta, const float* grad, float* m, float* v, int64_t n,
+                             float lr_t, float beta1, float beta2, float eps, void* stream) {
+    SGCN_REQUIRE(n >= 0, "adam: negative size");
+    if (n == 0) return SGCN_OK;
+    SGCN_REQUIRE(theta && grad && m && v, "adam: null operand");
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m,
+                       v, n, lr_t, beta1, beta2, eps);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}

@@ -5,11 +5,35 @@
 // touch neighbouring rows of C.
 #include "sgcn_host.h"
 #include "../../include/sgcn.h"
+#include <vector>
 
 namespace {
 constexpr int32_t kDefaultT = 256;
 inline int32_t pick_t(int32_t T) { return T > 0 ? T : kDefaultT; }
 }  // namespace
+
+namespace sgcn {
+// vector-based variant used by the sampler's packed batch (same rules as sgcn_plan_fill)
+void plan_build(const int32_t* rowptr, int32_t M, int32_t T, std::vector<int32_t>& seg,
+                std::vector<int32_t>& fix, int64_t& nslots) {
+    T = pick_t(T);
+    seg.clear(); fix.clear();
+    int32_t slot = 0;
+    for (int32_t r = 0; r < M; r++) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (e - b <= T) { seg.insert(seg.end(), {r, b, e, -1}); continue; }
+        const int32_t first = slot;
+        const int32_t c = (int32_t)(((int64_t)e - b + T - 1) / T);
+        for (int32_t q = 0; q < c; q++) {
+            const int32_t qb = b + (int32_t)(((int64_t)(e - b) * q) / c);
+            const int32_t qe = b + (int32_t)(((int64_t)(e - b) * (q + 1)) / c);
+            seg.insert(seg.end(), {r, qb, qe, slot++});
+        }
+        fix.insert(fix.end(), {r, first, c});
+    }
+    nslots = slot;
+}
+}  // namespace sgcn
 
 extern "C" {
 

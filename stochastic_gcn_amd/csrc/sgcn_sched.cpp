@@ -27,6 +27,10 @@
 
 namespace sgcn {
 
+// sgcn_plan.cpp
+void plan_build(const int32_t* rowptr, int32_t M, int32_t T, std::vector<int32_t>& seg,
+                std::vector<int32_t>& fix, int64_t& nslots);
+
 char* error_slot() {
     static thread_local char buf[512] = {0};
     return buf;
@@ -165,6 +169,66 @@ public:
         }
     }
 
+    // ---- packed minibatch (one call = PyScheduler.batch, gcn/_scheduler.pyx:55-127) ----------
+    // Runs the L expansions and lays every array the device step needs into two growable
+    // staging vectors (int32 / fp32), each sub-array 16-byte aligned: fields, ffields, scales,
+    // labels[fields[-1]], and per layer the CSR of adj, adj^T and fadj with their row plans.
+    // `meta` receives (offset, length) descriptors, layer 0 = input-most layer (the reversal of
+    // gcn/_scheduler.pyx:121-126).  No Python objects are touched: the call runs without the GIL.
+    enum { kCsrDesc = 11 };   // nrows ncols nnz rowptr col val seg nseg fix nfix nslots
+    int pack_batch(int32_t n, const int32_t* ids, int32_t L, const int32_t* degrees,
+                   const float* labels, int32_t n_classes, int32_t plan_T, int64_t* meta,
+                   int64_t meta_cap, int64_t* n_i32, int64_t* n_f32) {
+        const int64_t need = meta_len(L);
+        if (meta_cap < need) return fail(SGCN_ERR_INVALID, "batch_packed: meta too small (%lld < %lld)",
+                                         (long long)meta_cap, (long long)need);
+        pi_.clear(); pf_.clear();
+        std::fill(meta, meta + need, 0);
+        meta[0] = L; meta[1] = cv_ ? 1 : 0; meta[2] = n_classes;
+        start_batch(n, ids);
+        int64_t* fields_d = meta + 4;                    // (L+1) x (off,len)
+        int64_t* scales_d = fields_d + 2 * (L + 1);      // L x (off,len)
+        int64_t* ffields_d = scales_d + 2 * L;           // L x (off,len)
+        int64_t* labels_d = ffields_d + 2 * L;           // off, rows, cols
+        int64_t* medg_d = labels_d + 3;                  // L x (off,len)
+        int64_t* csr_d = medg_d + 2 * L;                 // L x 3 x kCsrDesc  (adj, adjT, fadj)
+        put_i(field_, fields_d + 2 * L);                 // fields[L] = the batch itself
+        int rc = SGCN_OK;
+        for (int32_t l = 0; l < L; l++) {
+            const int32_t slot = L - 1 - l;              // position after the reversal
+            const int r = expand(degrees[L - l - 1]);    // gcn/_scheduler.pyx:66
+            if (r != SGCN_OK) rc = r;
+            const int32_t n1 = (int32_t)edg_p_.size() - 1, n0 = (int32_t)field_.size();
+            put_i(field_, fields_d + 2 * slot);
+            put_f(scales_, scales_d + 2 * slot);
+            put_f(medg_w_, medg_d + 2 * slot);
+            build_transpose();
+            put_csr(csr_d + (3 * slot + 0) * kCsrDesc, n1, n0, edg_p_, edg_t_, edg_w_, plan_T);
+            put_csr(csr_d + (3 * slot + 1) * kCsrDesc, n0, n1, tedg_p_, tedg_t_, tedg_w_, plan_T);
+            if (cv_) {
+                put_i(ffield_, ffields_d + 2 * slot);
+                put_csr(csr_d + (3 * slot + 2) * kCsrDesc, n1, (int32_t)ffield_.size(), fedg_p_,
+                        fedg_t_, fedg_w_, plan_T);
+            }
+        }
+        if (labels && n_classes > 0) {                   // labels[fields[-1]]  (_scheduler.pyx:138)
+            labels_d[0] = (int64_t)pf_.size(); labels_d[1] = n; labels_d[2] = n_classes;
+            for (int32_t i = 0; i < n; i++) {
+                const float* src = labels + (int64_t)ids[i] * n_classes;
+                pf_.insert(pf_.end(), src, src + n_classes);
+            }
+            pad_f();
+        }
+        *n_i32 = (int64_t)pi_.size();
+        *n_f32 = (int64_t)pf_.size();
+        return rc;
+    }
+    static int64_t meta_len(int32_t L) { return 4 + 2 * (L + 1) + 2 * L + 2 * L + 3 + 2 * L + 3 * L * kCsrDesc; }
+    void packed_copy(int32_t* di, float* df) const {
+        if (di && !pi_.empty()) memcpy(di, pi_.data(), pi_.size() * sizeof(int32_t));
+        if (df && !pf_.empty()) memcpy(df, pf_.data(), pf_.size() * sizeof(float));
+    }
+
 private:
     void clear_outputs() {
         ffield_.clear(); scales_.clear();
@@ -283,6 +347,34 @@ private:
         return rc;
     }
 
+    void pad_i() { while (pi_.size() & 3) pi_.push_back(0); }
+    void pad_f() { while (pf_.size() & 3) pf_.push_back(0.f); }
+    void put_i(const std::vector<int32_t>& v, int64_t* d) {
+        d[0] = (int64_t)pi_.size(); d[1] = (int64_t)v.size();
+        pi_.insert(pi_.end(), v.begin(), v.end());
+        pad_i();
+    }
+    void put_f(const std::vector<float>& v, int64_t* d) {
+        d[0] = (int64_t)pf_.size(); d[1] = (int64_t)v.size();
+        pf_.insert(pf_.end(), v.begin(), v.end());
+        pad_f();
+    }
+    void put_csr(int64_t* d, int32_t nrows, int32_t ncols, const std::vector<int32_t>& rowptr,
+                 const std::vector<int32_t>& col, const std::vector<float>& val, int32_t plan_T) {
+        int64_t tmp[2];
+        d[0] = nrows; d[1] = ncols; d[2] = (int64_t)col.size();
+        put_i(rowptr, tmp); d[3] = tmp[0];
+        put_i(col, tmp); d[4] = tmp[0];
+        put_f(val, tmp); d[5] = tmp[0];
+        int64_t nslots = 0;
+        plan_build(rowptr.data(), nrows, plan_T, seg_, fix_, nslots);
+        put_i(seg_, tmp); d[6] = tmp[0]; d[7] = (int64_t)seg_.size() / 4;
+        put_i(fix_, tmp); d[8] = tmp[0]; d[9] = (int64_t)fix_.size() / 3;
+        d[10] = nslots;
+    }
+
+    std::vector<int32_t> pi_, seg_, fix_;
+    std::vector<float> pf_;
     int32_t n_;
     bool cv_, is_, transpose_ready_ = false;
     std::vector<int32_t> nbr_;   // private, permuted in place
@@ -349,6 +441,21 @@ int sgcn_sched_view_f32(sgcn_sched_t* s, int32_t which, const float** ptr, int64
     if (!v || !ptr || !len) return sgcn::fail(SGCN_ERR_INVALID, "view_f32: bad selector %d", which);
     *ptr = v->data();
     *len = (int64_t)v->size();
+    return SGCN_OK;
+}
+
+int sgcn_sched_batch_packed(sgcn_sched_t* s, int32_t n, const int32_t* ids, int32_t L,
+                            const int32_t* degrees, const float* labels, int32_t n_classes,
+                            int32_t plan_T, int64_t* meta, int64_t meta_cap, int64_t* n_i32,
+                            int64_t* n_f32) {
+    if (!s || n < 0 || (n > 0 && !ids) || L < 0 || (L > 0 && !degrees) || !meta || !n_i32 || !n_f32)
+        return sgcn::fail(SGCN_ERR_INVALID, "batch_packed: bad argument");
+    return s->impl.pack_batch(n, ids, L, degrees, labels, n_classes, plan_T, meta, meta_cap, n_i32, n_f32);
+}
+int64_t sgcn_sched_packed_meta_len(int32_t L) { return sgcn::NeighbourSampler::meta_len(L); }
+int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32) {
+    if (!s) return sgcn::fail(SGCN_ERR_INVALID, "null sampler");
+    s->impl.packed_copy(dst_i32, dst_f32);
     return SGCN_OK;
 }
 

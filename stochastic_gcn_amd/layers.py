@@ -47,6 +47,29 @@ def dropout_mask(tag, shape, keep_prob, device):
     return (torch.rand(shape, device=device, generator=_generator(device)) < keep_prob).to(torch.float32)
 
 
+def dropout_fwd(x, keep, tag):
+    """tf.nn.dropout.  Returns (out, ctx); ctx feeds dropout_bwd.  Native path: one fused
+    Philox kernel (mask + scale); hook path: explicit {0,1} masks shared with the oracle."""
+    if keep >= 1.0:
+        return x, None
+    if MASK_HOOK is not None:
+        m = dropout_mask(tag, x.shape, keep, x.device)
+        if m is None:
+            return x, None
+        m = m * (1.0 / keep)
+        return x * m, ('mul', m)
+    out, mask = torch.native_dropout(x, 1.0 - keep, True)
+    return out, ('native', mask, 1.0 / keep)
+
+
+def dropout_bwd(g, ctx):
+    if g is None or ctx is None:
+        return g
+    if ctx[0] == 'mul':
+        return g * ctx[1]
+    return torch.ops.aten.native_dropout_backward(g, ctx[1], ctx[2])
+
+
 def dot(x, y, sparse=False):
     """Wrapper for matmul (sparse vs dense), as gcn/layers.py:31-37."""
     if sparse:
@@ -103,6 +126,7 @@ class Layer(object):
         self.vars = {}      # name -> tensor view into the model's flat parameter buffer
         self.grads = {}     # name -> tensor view into the model's flat gradient buffer
         self.sparse_inputs = False
+        self.need_dx = True  # models.py clears it on the first parametrised layer (no consumer)
 
     def param_shapes(self):
         return []
@@ -134,17 +158,13 @@ class Dropout(Layer):
             out.csr = inputs.with_values(inputs.csr.val * (m * (1.0 / keep)))
             out.csr.coo_rows = inputs.csr.coo_rows
             return out
-        if keep >= 1.0:
-            return inputs
-        self._mask = dropout_mask(self.name, inputs.shape, keep, inputs.device)
-        if self._mask is None:
-            return inputs
-        return inputs * (self._mask * (1.0 / keep))
+        out, self._mask = dropout_fwd(inputs, keep, self.name)
+        return out
 
     def backward(self, g):
-        if g is None or self._sparse or self._mask is None:
+        if g is None or self._sparse:
             return g
-        return g * (self._mask * (1.0 / self._keep))
+        return dropout_bwd(g, self._mask)
 
 
 class Dense(Layer):
@@ -170,23 +190,23 @@ class Dense(Layer):
         self._x = x
         y = ops.spmm(x.csr, W) if self.sparse_inputs else torch.mm(x, W)
         self._ctx = None
-        if self.norm:
-            y, self._ctx = layer_norm_fwd(y, self.vars['offset'], self.vars['scale'])
-        self._pre = y
-        return torch.relu(y) if self.act else y
+        if self.norm or self.act:          # fused LayerNorm + ReLU (one kernel)
+            y, self._ctx = ops.ln_act_fwd(y, self.vars.get('offset') if self.norm else None,
+                                          self.vars.get('scale') if self.norm else None, self.act)
+        self._out = y
+        return y
 
     def backward(self, g):
-        if self.act:
-            g = g * (self._pre > 0)
-        if self.norm:
-            g, doff, dsc = layer_norm_bwd(g, self._ctx, self.vars['scale'])
-            self.grads['offset'] += doff
-            self.grads['scale'] += dsc
+        if self.norm or self.act:
+            g = ops.ln_act_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None,
+                               self.act, self.grads.get('offset'), self.grads.get('scale'))
         if self.sparse_inputs:
             xt = self._x.transpose_of(self._x.csr.val)
             ops.spmm(xt, g, out=self.grads['weights'], beta=1.0)
             return None
         self.grads['weights'].addmm_(self._x.t(), g)
+        if not self.need_dx:
+            return None
         return torch.mm(g, self.vars['weights'].t())
 
 
@@ -224,40 +244,33 @@ class AugmentedDropoutDense(Layer):
             xs = ops.spmm(x.with_values(val), W)
             mus = ops.spmm(mu.csr, W)
         else:
-            xd = x
-            if keep < 1.0:
-                self._mask = dropout_mask(self.name, x.shape, keep, x.device)
-                if self._mask is not None:
-                    xd = x * (self._mask * (1.0 / keep))
+            xd, self._mask = dropout_fwd(x, keep, self.name)
             self._xd = xd
             xs = torch.mm(xd, W)
             # test models run with dropout 0 on a single stream: both streams coincide
             same = mu is x and xd is x
             mus = xs if same else torch.mm(mu, W)
-        self._ctx = None
-        if self.norm:
-            same = mus is xs
-            xs, self._ctx = layer_norm_fwd(xs, self.vars['offset'], self.vars['scale'])
-            mus = xs if same else layer_norm_fwd(mus, self.vars['offset'], self.vars['scale'])[0]
-        self._pre = xs
-        hx = torch.relu(xs)
-        return hx, (hx if mus is xs else torch.relu(mus))
+        same = mus is xs
+        off = self.vars.get('offset') if self.norm else None
+        sc = self.vars.get('scale') if self.norm else None
+        hx, self._ctx = ops.ln_act_fwd(xs, off, sc, True)       # fused LN + ReLU
+        hmu = hx if same else ops.ln_act_fwd(mus, off, sc, True)[0]
+        self._out = hx
+        return hx, hmu
 
     def backward(self, g):
-        g = g * (self._pre > 0)                       # mu is stop_gradient (gcn/layers.py:412)
-        if self.norm:
-            g, doff, dsc = layer_norm_bwd(g, self._ctx, self.vars['scale'])
-            self.grads['offset'] += doff
-            self.grads['scale'] += dsc
+        # only the x stream carries gradient: mu is stop_gradient (gcn/layers.py:412)
+        g = ops.ln_act_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None, True,
+                           self.grads.get('offset'), self.grads.get('scale'))
         if self.sparse_inputs:
             x, val = self._xd
             ops.spmm(x.transpose_of(val), g, out=self.grads['weights'], beta=1.0)
             return None
         self.grads['weights'].addmm_(self._xd.t(), g)
+        if not self.need_dx:
+            return None
         g = torch.mm(g, self.vars['weights'].t())
-        if self._mask is not None:
-            g = g * (self._mask * (1.0 / self._keep))
-        return g
+        return dropout_bwd(g, self._mask)
 
 
 class PlainAggregator(Layer):

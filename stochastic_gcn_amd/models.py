@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .flags import FLAGS
 from .layers import (AugmentedDropoutDense, Dense, Dropout, SparseInput)
-from .scheduler import build_plan
+from .scheduler import PackedBatch, build_plan
 
 
 class VariableStore(object):
@@ -108,6 +108,51 @@ class DevFeed(object):
             if cv:
                 self.fadj.append(self._unpack_csr(entry['f'], iv, fv, device))
 
+    @classmethod
+    def from_packed(cls, pb, device):
+        """Fast path: the sampler already laid the batch out (sgcn_sched_batch_packed); two H2D
+        copies out of the (pinned) staging slot, then views."""
+        self = cls.__new__(cls)
+        if pb.slot is not None:
+            it, ft = pb.slot.ibuf[:max(pb.n_i, 1)], pb.slot.fbuf[:max(pb.n_f, 1)]
+        else:
+            it, ft = torch.from_numpy(pb.ibuf[:max(pb.n_i, 1)]), torch.from_numpy(pb.fbuf[:max(pb.n_f, 1)])
+        self.ibuf = it.to(device, non_blocking=True)
+        self.fbuf = ft.to(device, non_blocking=True)
+        if pb.slot is not None and device.type == 'cuda':
+            ev = torch.cuda.Event()
+            ev.record()
+            pb.slot.event = ev                       # the producer waits on it before reusing the slot
+        iv = lambda off, n: self.ibuf[off:off + n]   # noqa: E731
+        fv = lambda off, n: self.fbuf[off:off + n]   # noqa: E731
+        L = pb.L
+        self.host_fields = [pb.field(l) for l in range(L + 1)]
+        self.fields = [iv(*pb._fields[l]) for l in range(L + 1)]
+        lo, lr, lc = (int(x) for x in pb._labels)
+        self.labels = fv(lo, lr * lc).view(lr, lc)
+        self.scales = [fv(*pb._scales[l]) for l in range(L)]
+        self.ffields = [iv(*pb._ffields[l]) for l in range(L)] if pb.cv else []
+
+        def csr(d):
+            d = [int(x) for x in d]
+            plan = ops.DevicePlan.__new__(ops.DevicePlan)
+            plan.nseg, plan.nfix, plan.nslots = d[7], d[9], d[10]
+            plan.seg = iv(d[6], 4 * d[7])
+            plan.fix = iv(d[8], 3 * d[9]) if d[9] else None
+            plan.ws, plan.device = None, device
+            return ops.DeviceCSR((d[0], d[1]), iv(d[3], d[0] + 1), iv(d[4], d[2]), fv(d[5], d[2]), plan)
+        self.adj, self.fadj = [], []
+        for l in range(L):
+            a = csr(pb._csr[l, 0])
+            a.transpose = csr(pb._csr[l, 1])
+            self.adj.append(a)
+            if pb.cv:
+                self.fadj.append(csr(pb._csr[l, 2]))
+        self.sizes = dict(adj=[int(pb._csr[l, 0, 2]) for l in range(L)],
+                          fadj=[int(pb._csr[l, 2, 2]) for l in range(L)],
+                          fields=[int(pb._fields[l, 1]) for l in range(L + 1)])
+        return self
+
     @staticmethod
     def _pack_csr(h, add_i, add_f, plan_T, transpose):
         seg, fix, nslots = build_plan(h.rowptr, plan_T)
@@ -160,7 +205,9 @@ class Model(object):
         self._store = kwargs.get('_store') or VariableStore()
         self.dropout = 0.0
         self.cur = None
+        self._want_grad = False
         self.grad_hook = None      # parallel.py installs the RCCL all-reduce here
+        self.history_hook = None   # parallel.py: all-gather + apply every rank's history rows
 
     # -- reference API --------------------------------------------------------------------
     def save(self, sess=None, path=None):
@@ -262,6 +309,10 @@ class GCN(Model):
         self.history_vars = [h[0] for h in self.history]
         if self.is_training:
             self.adam_t = 0
+        # nothing upstream of the first parametrised layer needs a gradient
+        self._first_param = next((i for i, l in enumerate(self.layers) if l.param_shapes()), len(self.layers))
+        if self._first_param < len(self.layers):
+            self.layers[self._first_param].need_dx = False
 
     def _keep_prob(self):
         return 1.0 - self.dropout
@@ -397,7 +448,10 @@ class GCN(Model):
     def upload(self, feed_dict):
         """feed-dict -> DevFeed (two H2D copies) and the input feature rows."""
         cv = bool(self.history)
-        cur = DevFeed(feed_dict, self.placeholders, self.L, cv, self.device)
+        if isinstance(feed_dict, PackedBatch):
+            cur = DevFeed.from_packed(feed_dict, self.device)
+        else:
+            cur = DevFeed(feed_dict, self.placeholders, self.L, cv, self.device)
         f0 = cur.fields[0]
         if self.sparse_input and self.sparse_mm:
             sl = ops.csr_slice(self.features_dev, cur.host_fields[0], rows_dev=f0, with_coo_rows=True)
@@ -418,7 +472,8 @@ class GCN(Model):
         """gcn/models.py:68-94.  Returns (loss, accuracy, pred, dlogits) as device tensors."""
         z = self.outputs
         n = z.shape[0]
-        wd = 0.5 * FLAGS.weight_decay * (self.theta * self.theta * self._wd_mask).sum()
+        wd = 0.5 * FLAGS.weight_decay * (self.theta * self.theta * self._wd_mask).sum() \
+            if FLAGS.weight_decay else 0.0
         if self.multitask:
             ce = torch.clamp(z, min=0) - z * labels + torch.log1p(torch.exp(-z.abs()))
             loss = wd + ce.mean()
@@ -426,17 +481,16 @@ class GCN(Model):
             dlogits = (pred - labels) / ce.numel()
             acc = ((z > 0) == (labels > 0.5)).to(torch.float32).mean()
         else:
-            logp = torch.log_softmax(z, dim=1)
-            loss = wd + (-(labels * logp).sum(dim=1)).mean()
-            pred = torch.exp(logp)
-            dlogits = (pred * labels.sum(dim=1, keepdim=True) - labels) / n
-            acc = (z.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32).mean()
+            stats, dlogits, pred = ops.softmax_ce(z, labels, want_grad=self.is_training or self._want_grad,
+                                                  want_pred=not self.is_training or self._want_grad)
+            loss = wd + stats[0] / n
+            acc = stats[1] / n
         return loss, acc, pred, dlogits
 
     def backward(self, dlogits):
         self.grad.zero_()
         g = dlogits
-        for layer in reversed(self.layers):
+        for layer in reversed(self.layers[self._first_param:]):
             g = layer.backward(g)
         if FLAGS.weight_decay:
             self.grad.add_(self.theta * self._wd_mask, alpha=float(FLAGS.weight_decay))
@@ -447,10 +501,7 @@ class GCN(Model):
         self.adam_t += 1
         b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
         lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
-        g = self.grad
-        self.adam_m.mul_(b1).add_(g, alpha=1 - b1)
-        self.adam_v.mul_(b2).addcmul_(g, g, value=1 - b2)
-        self.theta.addcdiv_(self.adam_m, self.adam_v.sqrt().add_(1e-8), value=-lr_t)
+        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, b1, b2, 1e-8)
 
     def update_history(self, cur):
         """tf.scatter_update(history, fields[l], new_history) (gcn/models.py:160-166)."""
@@ -459,19 +510,51 @@ class GCN(Model):
             nh = getattr(agg, 'new_history', None)
             if nh is not None and self.history:
                 for h, v in zip(self.history[l], nh):
-                    ops.scatter_rows(h, cur.fields[l], v)
+                    if self.history_hook is not None:
+                        self.history_hook(h, cur.fields[l], v, ops.scatter_rows)
+                    else:
+                        ops.scatter_rows(h, cur.fields[l], v)
 
     def _count(self, feed_dict):
         raise NotImplementedError
 
     def get_data(self, feed_dict):
         cur = self.upload(feed_dict)
-        self._count(feed_dict)
+        if isinstance(feed_dict, PackedBatch):
+            self._count_sizes(cur.sizes)
+        else:
+            self._count(feed_dict)
         return cur
+
+    def _count_sizes(self, sizes):
+        """The epoch counters of gcn/vrgcn.py:50-69 / gcn/plaingcn.py:41-50 from batch sizes."""
+        cv = bool(self.history)
+        for l in range(self.L):
+            dim = self.agg0_dim if l == 0 else FLAGS.hidden1
+            g_ops = ((sizes['fadj'][l] if cv else 0) + sizes['adj'][l]) * dim * 4
+            if self.cvd and cv:
+                g_ops *= 2
+            self.g_ops += g_ops
+            self.adj_sizes[l] += sizes['adj'][l]
+            if cv:
+                self.fadj_sizes[l] += sizes['fadj'][l]
+            self.amt_data += sizes['adj'][l]
+        for l in range(self.L + 1):
+            self.field_sizes[l] += sizes['fields'][l]
+        for c, l in self.layer_comp:
+            nn_ops = c * sizes['fields'][l] * 4
+            if self.cvd and cv:
+                nn_ops *= 2
+            self.nn_ops += nn_ops
 
     def run_one_step(self, sess, feed_dict, sync=True):
         t = time()
-        self.dropout = float(feed_dict.get(self.placeholders['dropout'], 0.0)) if self.is_training else 0.0
+        if not self.is_training:
+            self.dropout = 0.0
+        elif isinstance(feed_dict, PackedBatch):
+            self.dropout = float(getattr(feed_dict, 'dropout', 0.0) or 0.0)
+        else:
+            self.dropout = float(feed_dict.get(self.placeholders['dropout'], 0.0))
         cur = self.get_data(feed_dict)
         self.g_t += time() - t
 
@@ -498,7 +581,11 @@ class GCN(Model):
         self.dropout = float(feed_dict.get(self.placeholders['dropout'], 0.0))
         cur = self.get_data(feed_dict)
         self.forward(cur)
-        loss, acc, pred, dlogits = self.loss_and_grad(cur.labels)
+        self._want_grad = True
+        try:
+            loss, acc, pred, dlogits = self.loss_and_grad(cur.labels)
+        finally:
+            self._want_grad = False
         self.backward(dlogits)
         first = self.named_vars()[0][0]
         return pred.cpu().numpy(), [self.get_grads()[first]]

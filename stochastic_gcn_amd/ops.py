@@ -220,3 +220,54 @@ def csr_slice(A, rows_host, rows_dev=None, with_coo_rows=False):
     out = DeviceCSR((n, A.shape[1]), o_p_dev, o_c, o_d, host_rowptr=o_p)
     out.coo_rows = o_r
     return out
+
+
+# ---- fused dense-side kernels (sgcn_dense.hip) ---------------------------------------------------
+def ln_act_fwd(x, offset, scale, relu, eps=1e-9):
+    """y = act(LN(x)*scale + offset) (norm skipped when offset/scale are None).
+    Returns (y, ctx) with ctx = (xhat, rstd) or None."""
+    xp, ldx = _rows2d(x, "x")
+    n, d = int(x.shape[0]), int(x.shape[1])
+    y = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    norm = offset is not None
+    xhat = torch.empty((n, d), dtype=torch.float32, device=x.device) if norm else None
+    rstd = torch.empty((n,), dtype=torch.float32, device=x.device) if norm else None
+    check(lib.sgcn_ln_act_fwd_f32(xp, ldx, _ptr(offset), _ptr(scale), n, d, float(eps), int(bool(relu)),
+                                  y.data_ptr(), d, _ptr(xhat), _ptr(rstd), _stream()))
+    return y, ((xhat, rstd) if norm else None)
+
+
+def ln_act_bwd(dy, y, ctx, scale, relu, doffset=None, dscale=None):
+    """dx of ln_act_fwd; accumulates the LN parameter gradients into doffset/dscale."""
+    gp, ldg = _rows2d(dy, "dy")
+    yp, ldy = _rows2d(y, "y")
+    n, d = int(dy.shape[0]), int(dy.shape[1])
+    dx = torch.empty((n, d), dtype=torch.float32, device=dy.device)
+    norm = ctx is not None
+    ws = None
+    if norm:
+        ws = torch.empty(int(lib.sgcn_ln_act_bwd_ws_floats(n, d)), dtype=torch.float32, device=dy.device)
+    check(lib.sgcn_ln_act_bwd_f32(gp, ldg, yp, ldy, _ptr(ctx[0]) if norm else None,
+                                  _ptr(ctx[1]) if norm else None, _ptr(scale) if norm else None, n, d,
+                                  int(bool(relu)), dx.data_ptr(), d, _ptr(doffset), _ptr(dscale),
+                                  _ptr(ws), _stream()))
+    return dx
+
+
+def softmax_ce(logits, labels, want_grad=True, want_pred=False):
+    """(stats[2] = {sum CE, #correct}, dlogits or None, pred or None)   (sgcn_softmax_ce_f32)."""
+    zp, ldz = _rows2d(logits, "logits")
+    lp, ldl = _rows2d(labels, "labels")
+    n, c = int(logits.shape[0]), int(logits.shape[1])
+    stats = torch.empty(2, dtype=torch.float32, device=logits.device)
+    dz = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
+    pred = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_pred else None
+    check(lib.sgcn_softmax_ce_f32(zp, ldz, lp, ldl, n, c, _ptr(dz), c, _ptr(pred), c, stats.data_ptr(),
+                                  _stream()))
+    return stats, dz, pred
+
+
+def adam_step(theta, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
+    check(lib.sgcn_adam_f32(theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                            int(theta.numel()), float(lr_t), float(beta1), float(beta2), float(eps),
+                            _stream()))

@@ -213,3 +213,132 @@ class Mult(object):
         r = C.c_int32()
         check(lib.sgcn_mult_query(self._h, C.byref(r)))
         return r.value
+
+
+# ---- packed minibatch: the fast path of the training loop ----------------------------------------
+CSR_DESC = 11   # nrows ncols nnz rowptr col val seg nseg fix nfix nslots  (include/sgcn.h)
+
+
+class StagingSlot(object):
+    """Reusable (pinned when CUDA is present) host staging buffers for one in-flight batch."""
+
+    def __init__(self, pin):
+        self.pin = pin
+        self.ibuf = self.fbuf = None       # torch tensors
+        self.event = None                  # recorded by the consumer after its H2D copies
+
+    def ensure(self, n_i, n_f):
+        import torch
+        if self.event is not None:         # the previous H2D copy out of this slot must be done
+            self.event.synchronize()
+            self.event = None
+        if self.ibuf is None or self.ibuf.numel() < n_i:
+            self.ibuf = torch.empty(max(int(n_i * 1.5), 1024), dtype=torch.int32, pin_memory=self.pin)
+        if self.fbuf is None or self.fbuf.numel() < n_f:
+            self.fbuf = torch.empty(max(int(n_f * 1.5), 1024), dtype=torch.float32, pin_memory=self.pin)
+
+
+class PackedBatch(object):
+    """One minibatch as two flat host arrays + a descriptor table (sgcn_sched_batch_packed)."""
+
+    def __init__(self, L, cv, meta, ibuf, fbuf, n_i, n_f, slot=None):
+        self.L, self.cv, self.meta = L, cv, meta
+        self.ibuf, self.fbuf, self.n_i, self.n_f = ibuf, fbuf, n_i, n_f
+        self.slot = slot
+        m = meta
+        self._fields = m[4:4 + 2 * (L + 1)].reshape(L + 1, 2)
+        o = 4 + 2 * (L + 1)
+        self._scales = m[o:o + 2 * L].reshape(L, 2); o += 2 * L
+        self._ffields = m[o:o + 2 * L].reshape(L, 2); o += 2 * L
+        self._labels = m[o:o + 3]; o += 3
+        self._medg = m[o:o + 2 * L].reshape(L, 2); o += 2 * L
+        self._csr = m[o:o + 3 * L * CSR_DESC].reshape(L, 3, CSR_DESC)
+
+    # numpy views (host) -------------------------------------------------------------------------
+    def _i(self, off, n):
+        return self.ibuf[off:off + n]
+
+    def _f(self, off, n):
+        return self.fbuf[off:off + n]
+
+    def field(self, l):
+        return self._i(*self._fields[l])
+
+    def ffield(self, l):
+        return self._i(*self._ffields[l])
+
+    def scale(self, l):
+        return self._f(*self._scales[l])
+
+    def labels(self):
+        off, r, c = self._labels
+        return self._f(off, r * c).reshape(r, c)
+
+    def csr(self, l, which):
+        """HostCSR view of layer l: which = 0 adj, 1 adj^T, 2 fadj."""
+        d = self._csr[l, which]
+        return HostCSR((int(d[0]), int(d[1])), self._i(d[3], d[0] + 1), self._i(d[4], d[2]),
+                       self._f(d[5], d[2]))
+
+    def feed_dict(self, placeholders, labels=None):
+        """The reference-format feed-dict (gcn/_scheduler.pyx:137-148) rebuilt from the packed
+        arrays (tests compare it with PyScheduler.batch)."""
+        ph, L = placeholders, self.L
+        fd = {}
+        for l in range(L):
+            a = self.csr(l, 0)
+            rows = np.repeat(np.arange(a.shape[0], dtype=np.int32), np.diff(a.rowptr))
+            idx = np.stack([rows, a.col], axis=1).astype(np.int32).reshape(-1, 2)
+            fd[ph['adj'][l]] = (idx, a.val.copy(), a.shape)
+            fd[ph['scales'][l]] = self.scale(l).copy()
+            if self.cv:
+                p = self.csr(l, 2)
+                prow = np.repeat(np.arange(p.shape[0], dtype=np.int32), np.diff(p.rowptr))
+                fd[ph['fadj'][l]] = (np.stack([prow, p.col], axis=1).astype(np.int32).reshape(-1, 2),
+                                     p.val.copy(), p.shape)
+                fd[ph['madj'][l]] = (idx.copy(), self._f(*self._medg[l]).copy(), np.array(a.shape))
+                fd[ph['ffields'][l]] = self.ffield(l).copy()
+        for l in range(L + 1):
+            fd[ph['fields'][l]] = self.field(l).copy()
+        fd[ph['labels']] = self.labels().copy() if self._labels[1] else (
+            labels[self.field(L)] if labels is not None else None)
+        return fd
+
+
+def _batch_packed(self, data, plan_T=0, slot=None):
+    """One C call for the whole minibatch (no per-array Python work, runs without the GIL)."""
+    data = np.ascontiguousarray(data, dtype=np.int32)
+    L = self.L
+    if getattr(self, "_deg32", None) is None:
+        self._deg32 = np.ascontiguousarray(self.degrees, dtype=np.int32)
+        lab = self.labels
+        self._lab32 = lab if (isinstance(lab, np.ndarray) and lab.dtype == np.float32
+                              and lab.flags['C_CONTIGUOUS']) else np.ascontiguousarray(lab, dtype=np.float32)
+        self._meta_len = int(lib.sgcn_sched_packed_meta_len(L))
+    meta = np.zeros(self._meta_len, dtype=np.int64)
+    n_i, n_f = C.c_int64(), C.c_int64()
+    check(lib.sgcn_sched_batch_packed(self.c_sch._h, int(data.shape[0]), data.ctypes.data, L,
+                                      self._deg32.ctypes.data, self._lab32.ctypes.data,
+                                      int(self._lab32.shape[1]), int(plan_T), meta.ctypes.data,
+                                      meta.shape[0], C.byref(n_i), C.byref(n_f)))
+    if slot is not None:
+        slot.ensure(n_i.value, n_f.value)
+        ib, fb = slot.ibuf.numpy(), slot.fbuf.numpy()
+    else:
+        ib = np.empty(max(n_i.value, 1), dtype=np.int32)
+        fb = np.empty(max(n_f.value, 1), dtype=np.float32)
+    check(lib.sgcn_sched_packed_copy(self.c_sch._h, ib.ctypes.data, fb.ctypes.data))
+    return PackedBatch(L, self.c_sch.cv, meta, ib, fb, n_i.value, n_f.value, slot)
+
+
+def _minibatch_packed(self, batch_size, plan_T=0, slot=None):
+    if self.start == self.data.shape[0]:
+        return None
+    end = min(self.data.shape[0], self.start + batch_size)
+    batch = self.data[self.start:end]
+    self.start = end
+    return self.batch_packed(batch, plan_T, slot)
+
+
+PyScheduler.batch_packed = _batch_packed
+PyScheduler.minibatch_packed = _minibatch_packed

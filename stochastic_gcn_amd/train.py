@@ -1,0 +1,292 @@
+"""Training driver -- drop-in for gcn/train.py (same flags, same flow, same log lines).
+
+    python -m stochastic_gcn_amd.train --dataset reddit --normalization graphsage --weight_decay 0 \\
+        --dropout 0.2 --layer_norm --hidden1 128 --num_fc_layers 2 --epochs 30 --early_stopping 30 \\
+        --batch_size=512 --test_batch_size=512 --cv --cvd --test_cv --degree=1 --test_degree=1
+
+(= gcn/config/reddit.config:2 + the CVD+PP switches of README.md:46-55.)  Multi-GPU: launch with
+``python -m torch.distributed.run --nproc-per-node N -m stochastic_gcn_amd.train ...``.
+
+Flow (gcn/train.py:73-383): load_data -> PP products on the GPU (K11) -> placeholders ->
+train/test models from one template (shared weights) -> two schedulers -> SGDTrain epochs with
+validation, the reference's two log lines per epoch, early stopping -> Test().
+"""
+from __future__ import division, print_function
+
+import queue
+import sys
+import threading
+from time import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import ops
+from .flags import FLAGS
+from .models import make_template
+from .parallel import DataParallel
+from .plaingcn import PlainGCN
+from .scheduler import PyScheduler
+from .utils import Averager, calc_f1, load_data
+from .vrgcn import VRGCN
+
+
+class Placeholder(object):
+    """Opaque feed-dict key (the reference uses tf.placeholder objects the same way)."""
+
+    def __init__(self, name, shape=None):
+        self.name, self.shape = name, shape
+
+    def __repr__(self):
+        return "<ph %s>" % self.name
+
+
+def make_placeholders(L, num_classes):
+    """gcn/train.py:89-103."""
+    return {
+        'adj': [Placeholder('adj_%d' % l) for l in range(L)],
+        'madj': [Placeholder('madj_%d' % l) for l in range(L)],
+        'fadj': [Placeholder('fadj_%d' % l) for l in range(L)],
+        'fields': [Placeholder('field_%d' % l) for l in range(L + 1)],
+        'ffields': [Placeholder('ffield_%d' % l) for l in range(L)],
+        'scales': [Placeholder('scale_%d' % l) for l in range(L)],
+        'labels': Placeholder('labels', (None, num_classes)),
+        'dropout': Placeholder('dropout', ()),
+    }
+
+
+def pp_products(train_adj, full_adj, features, device):
+    """train_feats = train_adj . feats, test_feats = full_adj . feats (gcn/utils.py:169-170,
+    321-322).  Dense features: the SpMM kernel on the GPU (K11).  Sparse features: a
+    sparse x sparse product, done once on the host with SciPy exactly like the reference."""
+    if sp.issparse(features):
+        return train_adj.dot(features).tocsr(), full_adj.dot(features).tocsr()
+    X = features.to(device) if isinstance(features, torch.Tensor) else \
+        torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(device)
+    out = []
+    for a in (train_adj, full_adj):
+        A = ops.DeviceCSR.from_scipy(a, device)
+        out.append(ops.spmm(A, X))
+    return out[0], out[1]
+
+
+class Prefetcher(object):
+    """Runs ``sch.minibatch`` on a host thread a few batches ahead of the GPU.  The sampler is
+    stateful, so there is exactly one producer and batches are consumed in call order -- the
+    sample sequence is identical to the synchronous loop."""
+
+    def __init__(self, sch, batch_size, depth, n_steps, slots=None):
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.t = threading.Thread(target=self._run, args=(sch, batch_size, n_steps, slots), daemon=True)
+        self.t.start()
+
+    def _run(self, sch, batch_size, n_steps, slots):
+        for i in range(n_steps):
+            self.q.put(next_minibatch(sch, batch_size, slots[i % len(slots)] if slots else None))
+        self.q.put(None)
+
+    def next(self):
+        return self.q.get()
+
+
+def next_minibatch(sch, batch_size, slot=None):
+    """The next minibatch as a PackedBatch (one C call: sampler + CSR/plan packing into a pinned
+    staging slot), wrapping to the start of the (already shuffled) shard when it runs out: in a
+    multi-GPU job every rank must take the same number of steps per epoch, and vertex-range
+    shards hold slightly different numbers of train ids."""
+    fd = sch.minibatch_packed(batch_size, 0, slot)
+    if fd is None:
+        sch.start = 0
+        fd = sch.minibatch_packed(batch_size, 0, slot)
+    return fd
+
+
+class Trainer(object):
+    """Everything gcn/train.py does between flag parsing and the end of training, as an object
+    (so bench.py can time epochs of the real training path).  FLAGS must be set before."""
+
+    def __init__(self, data=None, verbose=True):
+        np.random.seed(FLAGS.seed)
+        torch.manual_seed(FLAGS.seed)
+        if not torch.cuda.is_available():
+            raise RuntimeError("training needs an MI355X (no CPU fallback for the SpMM/history path)")
+        par = DataParallel(device=None, init=False)
+        torch.cuda.set_device(par.local_rank)
+        self.device = device = torch.device('cuda', par.local_rank)
+        self.par = par = DataParallel(device=device)
+        self.log = log = print if (par.rank == 0 and verbose) else (lambda *a, **k: None)
+
+        (num_data, train_adj, full_adj, features, train_features, test_features, labels,
+         train_d, val_d, test_d) = data if data is not None else load_data(FLAGS.dataset)
+        if train_features is None:
+            train_features, test_features = pp_products(train_adj, full_adj, features, device)
+        if FLAGS.gradvar:
+            log('Analyze mode...')
+            full_adj = train_adj.copy()
+            test_features = train_features
+        log('Features shape = {}, training edges = {}, testing edges = {}'.format(
+            features.shape, train_adj.nnz, full_adj.nnz))
+        log('{} training data, {} validation data, {} testing data.'.format(len(train_d), len(val_d), len(test_d)))
+        self.num_data, self.labels = num_data, labels
+        self.train_d, self.val_d, self.test_d = train_d, val_d, test_d
+
+        self.multitask = multitask = FLAGS.dataset == 'ppi'
+        L = FLAGS.num_layers - 1 if FLAGS.preprocess else FLAGS.num_layers
+        test_L = FLAGS.num_layers - 1 if FLAGS.test_preprocess else FLAGS.num_layers
+        self.placeholders = placeholders = make_placeholders(max(L, test_L), labels.shape[1])
+
+        t = time()
+        log('Building model...')
+        train_cls = VRGCN if FLAGS.cv else PlainGCN
+        test_cls = VRGCN if FLAGS.test_cv else PlainGCN
+
+        def model_func(model, nbr_features, adj, preprocess, is_training, cvd, _store=None):
+            return model(FLAGS.num_layers, preprocess, placeholders, features, nbr_features, adj, cvd,
+                         multitask=multitask, is_training=is_training, device=device, _store=_store)
+        create_model = make_template('model', model_func)
+        self.train_model = create_model(train_cls, nbr_features=train_features, adj=train_adj,
+                                        preprocess=FLAGS.preprocess, is_training=True, cvd=FLAGS.cvd)
+        self.test_model = create_model(test_cls, nbr_features=test_features, adj=full_adj,
+                                       preprocess=FLAGS.test_preprocess, is_training=False, cvd=FLAGS.test_cvd)
+        log('Finised in {} seconds'.format(time() - t))
+        if par.active:
+            par.attach(self.train_model)
+            self.train_d = par.shard_ids(train_d, num_data).astype(np.int32)
+
+        train_degrees = np.array([FLAGS.degree] * L, dtype=np.int32)
+        test_degrees = np.array([FLAGS.test_degree] * test_L, dtype=np.int32)
+        self.train_sch = PyScheduler(train_adj, labels, L, train_degrees, placeholders,
+                                     par.sampler_seed(FLAGS.seed), self.train_d, cv=FLAGS.cv,
+                                     importance=FLAGS.importance)
+        self.eval_sch = PyScheduler(full_adj, labels, test_L, test_degrees, placeholders,
+                                    par.sampler_seed(FLAGS.seed), cv=FLAGS.test_cv,
+                                    importance=FLAGS.test_importance)
+        self.sess = None   # API compatibility: run_one_step(sess, feed_dict)
+        from .scheduler import StagingSlot
+        self.slots = [StagingSlot(pin=True) for _ in range(max(FLAGS.prefetch, 0) + 3)]
+        self.eval_slots = [StagingSlot(pin=True) for _ in range(4)]
+        self.cost_val = []
+        self.avg_loss = Averager(1)
+        self.avg_acc = Averager(1)
+        self.last_epoch = {}
+
+    # ---- evaluation (gcn/train.py:133-160) ------------------------------------------------------
+    def evaluate(self, data):
+        total_pred, total_labs, stats = [], [], []
+        t_test = time()
+        N = len(data)
+        k = 0
+        for start in range(0, N, FLAGS.test_batch_size):
+            end = min(start + FLAGS.test_batch_size, N)
+            batch = self.eval_sch.batch_packed(data[start:end], 0, self.eval_slots[k % len(self.eval_slots)])
+            k += 1
+            los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
+            stats.append(torch.stack([los, acc]) * prd.shape[0])
+            total_pred.append(prd)
+            total_labs.append(self.test_model.cur.labels)
+        if not stats:
+            return 0.0, 0.0, 0.0, 0.0, time() - t_test
+        tot = torch.stack(stats).sum(dim=0).cpu().numpy() / max(N, 1)      # the only host sync
+        total_pred = torch.cat(total_pred).cpu().numpy()
+        total_labs = torch.cat(total_labs).cpu().numpy()
+        micro, macro = calc_f1(total_pred, total_labs, self.multitask)
+        return float(tot[0]), float(tot[1]), micro, macro, (time() - t_test)
+
+    # ---- one training epoch (gcn/train.py:182-209) ----------------------------------------------
+    def train_epoch(self):
+        par, train_model, train_sch = self.par, self.train_model, self.train_sch
+        train_sch.shuffle()
+        t = time()
+        train_model.init_counts()
+        tsch = 0
+        n_steps = -(-len(self.train_d) // FLAGS.batch_size)
+        if FLAGS.max_steps:
+            n_steps = min(n_steps, FLAGS.max_steps)
+        n_steps = int(par.max_scalar(n_steps))       # same step count on every rank
+        slots = self.slots
+        pre = Prefetcher(train_sch, FLAGS.batch_size, FLAGS.prefetch, n_steps, slots) \
+            if FLAGS.prefetch > 0 else None
+        outs = None
+        for it in range(1, n_steps + 1):
+            t1 = time()
+            batch = pre.next() if pre else next_minibatch(train_sch, FLAGS.batch_size, slots[it % len(slots)])
+            tsch += time() - t1
+            batch.dropout = FLAGS.dropout
+            # no host sync inside the epoch: loss / accuracy stay on the device
+            outs = train_model.run_one_step(self.sess, batch, sync=False)
+        if pre:
+            assert pre.next() is None
+        torch.cuda.synchronize()
+        if outs is not None:      # Averager(1) of the reference = the last step's values
+            self.avg_loss.add(float(outs[1]))
+            self.avg_acc.add(float(outs[2]))
+        self.last_epoch = dict(train_wall_s=time() - t, steps=n_steps, sch_wait_s=tsch,
+                               sampled_edges=float(train_model.adj_sizes.sum()),
+                               full_edges=float(train_model.fadj_sizes.sum()),
+                               field0=float(train_model.field_sizes[0]))
+        return t, tsch
+
+    def SGDTrain(self):
+        log, par, train_model = self.log, self.par, self.train_model
+        if FLAGS.load:
+            train_model.load(self.sess, load_history=FLAGS.gradvar)
+            for h1, h2 in zip(train_model.history_vars, self.test_model.history_vars):
+                h2.copy_(h1)
+            return
+        log('Start training...')
+        for epoch in range(100000000):
+            t, tsch = self.train_epoch()
+            cost, acc, micro, macro, duration = self.evaluate(self.val_d)
+            self.cost_val.append(cost)
+            cost_val = self.cost_val
+            # the reference's epoch lines (gcn/train.py:217-229); token positions are consumed by
+            # scripts/analyze-time.py:39-54 and scripts/plot-convergence.py:78-86
+            log("Epoch:", '%04d' % (epoch + 1),
+                "train_loss=", "{:.5f}".format(self.avg_loss.mean()),
+                "train_acc=", "{:.5f}".format(self.avg_acc.mean()),
+                "val_loss=", "{:.5f}".format(cost),
+                "val_acc=", "{:.5f}".format(acc),
+                "mi F1={:.5f} ma F1={:.5f} ".format(micro, macro),
+                "time=", "{:.5f}".format(time() - t),
+                "ttime=", "{:.5f}".format(duration),
+                "(sch {:.5f} s)".format(tsch),
+                "data = {}".format(train_model.amt_data))
+            G = float(2 ** 30)
+            log('TF time = {}, g time = {}, G GFLOPS = {}, NN GFLOPS = {}, field sizes = {}, adj sizes = {}, fadj sizes = {}'.format(
+                train_model.run_t, train_model.g_t, train_model.g_ops / G, train_model.nn_ops / G,
+                train_model.field_sizes, train_model.adj_sizes, train_model.fadj_sizes))
+            log('[sgcn] epoch train wall = {:.5f} s over {} steps ({} GPU(s))'.format(
+                self.last_epoch['train_wall_s'], self.last_epoch['steps'], par.world))
+            if epoch > FLAGS.early_stopping and cost_val[-1] > np.mean(cost_val[-(FLAGS.early_stopping + 1):-1]):
+                log("Early stopping...")
+                break
+            if train_model.amt_data >= FLAGS.data and epoch + 1 >= FLAGS.epochs:
+                break
+        log("Optimization Finished!")
+        if par.rank == 0:
+            train_model.save(self.sess)
+
+    def Test(self):
+        test_cost, test_acc, micro, macro, test_duration = self.evaluate(self.test_d)
+        self.log("Test set results:", "cost=", "{:.5f}".format(test_cost),
+                 "accuracy=", "{:.5f}".format(test_acc),
+                 "mi F1={:.5f} ma F1={:.5f} ".format(micro, macro),
+                 "time=", "{:.5f}".format(test_duration))
+        remaining = np.array(sorted(set(range(self.num_data)) - set(self.test_d.tolist())), dtype=np.int32)
+        if FLAGS.test_cv:
+            self.evaluate(remaining)
+
+
+def main(argv=None):
+    FLAGS.parse(argv)
+    tr = Trainer()
+    tr.SGDTrain()
+    num_runs = FLAGS.num_layers + 1 if FLAGS.test_cv else 1
+    for _ in range(num_runs):
+        tr.Test()
+    tr.par.shutdown()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

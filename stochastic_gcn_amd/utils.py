@@ -1,0 +1,95 @@
+"""Data loading / metrics helpers the training driver needs (subset of gcn/utils.py).
+
+``load_data(dataset)`` returns the reference's 10-tuple (gcn/utils.py:183,335).  It reads the
+reference's ``.npz`` dataset cache when one is present -- same file name and key schema
+(``data/<name>.npz`` for GraphSAGE sets, gcn/utils.py:325-333; ``data/<name>.<normalization>.npz``
+-style for the Planetoid sets, gcn/utils.py:172-181) -- so a cache produced by the reference
+drops in; otherwise it falls back to the deterministic synthetic stand-ins of synthetic.py
+(no datasets and no network on the box).  Raw-format parsers (networkx-1.11 JSON, Planetoid
+pickles) are out of scope.
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import synthetic
+from .flags import FLAGS
+
+
+def _csr(z, prefix):
+    shape = tuple(int(x) for x in z[prefix + '_shape'])
+    return sp.csr_matrix((z[prefix + '_data'], z[prefix + '_indices'], z[prefix + '_indptr']),
+                         shape=shape, dtype=np.float32)
+
+
+def load_npz_cache(path):
+    """The reference's dataset cache schema (gcn/utils.py:172-181, :325-333)."""
+    z = np.load(path)
+    num_data = int(z['num_data'])
+    train_adj, full_adj = _csr(z, 'train_adj'), _csr(z, 'full_adj')
+    if 'feats' in z.files:                                  # GraphSAGE sets: dense features
+        feats = z['feats'].astype(np.float32)
+        train_feats = z['train_feats'].astype(np.float32)
+        test_feats = z['test_feats'].astype(np.float32)
+    else:                                                   # Planetoid sets: sparse features
+        feats, train_feats, test_feats = _csr(z, 'feats'), _csr(z, 'train_feats'), _csr(z, 'test_feats')
+    return (num_data, train_adj, full_adj, feats, train_feats, test_feats,
+            z['labels'].astype(np.float32), z['train_data'].astype(np.int32),
+            z['val_data'].astype(np.int32), z['test_data'].astype(np.int32))
+
+
+def save_npz_cache(path, tup):
+    """Write a 10-tuple in the reference's cache schema (round-trips with load_npz_cache)."""
+    num_data, train_adj, full_adj, feats, train_feats, test_feats, labels, tr, va, te = tup
+    blob = dict(num_data=num_data, labels=labels, train_data=tr, val_data=va, test_data=te)
+    for name, m in (('train_adj', train_adj), ('full_adj', full_adj)):
+        blob.update({name + '_data': m.data, name + '_indices': m.indices,
+                     name + '_indptr': m.indptr, name + '_shape': m.shape})
+    if sp.issparse(feats):
+        for name, m in (('feats', feats), ('train_feats', train_feats), ('test_feats', test_feats)):
+            m = m.tocsr()
+            blob.update({name + '_data': m.data, name + '_indices': m.indices,
+                         name + '_indptr': m.indptr, name + '_shape': m.shape})
+    else:
+        blob.update(feats=feats, train_feats=train_feats, test_feats=test_feats)
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    with open(path, 'wb') as f:
+        np.savez(f, **blob)
+
+
+def load_data(dataset):
+    for cand in ('data/{}.npz'.format(dataset), 'data/{}.{}.npz'.format(dataset, FLAGS.normalization)):
+        if os.path.exists(cand):
+            print('Found preprocessed dataset {}, loading...'.format(cand))
+            return load_npz_cache(cand)
+    print('No dataset cache for "{}": using the synthetic stand-in (scale={})'.format(dataset, FLAGS.scale))
+    return synthetic.load_data(dataset, FLAGS.normalization, FLAGS.scale)
+
+
+class Averager(object):
+    """gcn/utils.py:500-511."""
+
+    def __init__(self, window_size):
+        self.window_size = window_size
+        self.window = []
+
+    def add(self, n):
+        self.window.append(n)
+        if len(self.window) > self.window_size:
+            self.window = self.window[1:]
+
+    def mean(self):
+        return np.mean(self.window)
+
+
+def calc_f1(y_pred, y_true, multitask):
+    """gcn/utils.py:521-529 (sklearn micro / macro F1)."""
+    from sklearn.metrics import f1_score
+    if multitask:
+        y_pred = (y_pred > 0.5).astype(np.int64)
+        y_true = (y_true > 0.5).astype(np.int64)
+    else:
+        y_true = np.argmax(y_true, axis=1)
+        y_pred = np.argmax(y_pred, axis=1)
+    return f1_score(y_true, y_pred, average="micro"), f1_score(y_true, y_pred, average="macro")

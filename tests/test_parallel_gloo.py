@@ -1,0 +1,141 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the data-parallel path in
+stochastic_gcn_amd/parallel.py: vertex-range sharding, the single flat gradient all-reduce
+(mean), replica-consistent history synchronisation, and a 2-rank training step whose compute
+leg is the NumPy oracle (the HIP kernels need a GPU; the distributed logic does not)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stochastic_gcn_amd.parallel import DataParallel
+    par = DataParallel(backend="gloo", device=torch.device("cpu"))
+    try:
+        res = globals()[fn](par)
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), **res)
+    finally:
+        par.shutdown()
+
+
+def _run(fn, tmp_path, world=2):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, fn, str(tmp_path)), nprocs=world, join=True)
+    return [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+
+
+# ---- workers ---------------------------------------------------------------------------------
+def w_shard_and_allreduce(par):
+    n = 1001
+    ids = np.random.RandomState(0).permutation(n)[:700]
+    mine = par.shard_ids(ids, n)
+    flat = torch.arange(10, dtype=torch.float32) * (par.rank + 1)
+    par.allreduce_mean_(flat)
+    theta = torch.full((5,), float(par.rank))
+    par.broadcast_(theta)
+    return dict(mine=mine, flat=flat.numpy(), theta=theta.numpy(), lo_hi=np.array(par.vertex_range(n)),
+                mx=np.array([par.max_scalar(3 + par.rank)]))
+
+
+def w_history(par):
+    from oracle import oracle_np as onp
+    N, d = 50, 6
+    H = torch.zeros((N, d))
+    rng = np.random.RandomState(10 + par.rank)
+    n = 7 + 3 * par.rank                                   # ragged sizes across ranks
+    idx = rng.choice(N, n, replace=False).astype(np.int32)
+    idx[0] = 5                                             # a vertex both ranks update
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+
+    def scatter(h, i, r):
+        onp.scatter_rows(h.numpy(), i.numpy(), r.numpy())
+    par.sync_history(H, torch.from_numpy(idx), torch.from_numpy(rows), scatter)
+    return dict(H=H.numpy(), idx=idx, rows=rows)
+
+
+def w_train_step(par):
+    import model_cases as mc
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    case = mc.build_case('reddit_cvd_pp')
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    om = mc.make_oracle_model(case, seed=3)
+    train = par.shard_ids(case['train'], c['n']).astype(np.int32)
+    sch = PyScheduler(case['adj'], case['labels'], 1, [1], ph, par.sampler_seed(1), data=train, cv=True)
+    names = sorted(om.params)
+    out = {}
+    for step in range(2):
+        feed = sch.minibatch(16)
+        logits, _ = om.forward(feed, ph, 0.0, lambda *a: None)
+        loss, acc, pred, dlogits = om.loss_and_grad(logits, feed[ph['labels']])
+        grads = om.backward(dlogits)
+        flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in names]))
+        out["local_grad%d" % step] = flat.numpy().copy()
+        par.allreduce_mean_(flat)                          # the ONE collective of the step
+        off = 0
+        for k in names:
+            sz = grads[k].size
+            grads[k] = flat.numpy()[off:off + sz].reshape(grads[k].shape).copy()
+            off += sz
+        om.adam_step(grads)
+        hist = torch.from_numpy(om.history[0])
+        par.sync_history(hist, torch.from_numpy(feed[ph['fields'][0]]), torch.from_numpy(om._new_hist[0]),
+                         lambda h, i, r: h.numpy().__setitem__(i.numpy(), r.numpy()))
+        out["avg_grad%d" % step] = flat.numpy().copy()
+    out["theta"] = np.concatenate([om.params[k].ravel() for k in names])
+    out["hist"] = om.history[0]
+    out["n_train"] = np.array([len(train)])
+    return out
+
+
+# ---- tests -----------------------------------------------------------------------------------
+def test_sharding_allreduce_broadcast(tmp_path):
+    r = _run("w_shard_and_allreduce", tmp_path)
+    ids = np.random.RandomState(0).permutation(1001)[:700]
+    assert sorted(np.concatenate([r[0]["mine"], r[1]["mine"]]).tolist()) == sorted(ids.tolist())
+    assert r[0]["lo_hi"].tolist() == [0, 500] and r[1]["lo_hi"].tolist() == [500, 1001]
+    assert r[0]["mine"].max() < 500 <= r[1]["mine"].min()
+    want = np.arange(10, dtype=np.float32) * 1.5           # mean of x*1 and x*2
+    for x in r:
+        np.testing.assert_allclose(x["flat"], want)
+        np.testing.assert_array_equal(x["theta"], np.zeros(5))      # rank 0's weights everywhere
+        assert x["mx"][0] == 4
+
+
+def test_history_sync_is_replica_consistent_and_rank_ordered(tmp_path):
+    r = _run("w_history", tmp_path)
+    np.testing.assert_array_equal(r[0]["H"], r[1]["H"])
+    want = np.zeros((50, 6), np.float32)
+    for x in r:                                            # rank order: 0 then 1
+        want[x["idx"]] = x["rows"]
+    np.testing.assert_array_equal(r[0]["H"], want)
+    np.testing.assert_array_equal(want[5], r[1]["rows"][0])         # higher rank wins the conflict
+
+
+def test_two_rank_training_step_matches_mean_gradient(tmp_path):
+    r = _run("w_train_step", tmp_path)
+    assert r[0]["n_train"][0] + r[1]["n_train"][0] == 64 * 3
+    for step in range(2):
+        mean = 0.5 * (r[0]["local_grad%d" % step] + r[1]["local_grad%d" % step])
+        np.testing.assert_allclose(r[0]["avg_grad%d" % step], mean, rtol=1e-6, atol=1e-8)
+        np.testing.assert_array_equal(r[0]["avg_grad%d" % step], r[1]["avg_grad%d" % step])
+    np.testing.assert_array_equal(r[0]["theta"], r[1]["theta"])     # replicas stay in lock-step
+    np.testing.assert_array_equal(r[0]["hist"], r[1]["hist"])
+    assert np.abs(r[0]["hist"]).sum() > 0
