@@ -48,6 +48,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true")
     p.add_argument("--no-backward", action="store_true")
+    p.add_argument("--kernel", default="cs", choices=["rows", "cs"],
+                   help="rows = row-gather SpMM (sgcn_spmm.hip); cs = column-sweep (sgcn_spmm_cs.hip)")
+    p.add_argument("--cs-t", type=int, default=0)
+    p.add_argument("--cs-r", type=int, default=16, choices=[8, 16, 32])
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
     return p.parse_args()
@@ -174,7 +178,13 @@ def main():
     d = args.d
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
-    A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)
+    if args.kernel == "cs":
+        A = ops.ColumnSweepCSR(full_adj, dev, R=args.cs_r, T=args.cs_t)
+        A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, R=args.cs_r, T=args.cs_t)
+        mm = ops.spmm_cs
+    else:
+        A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)
+        mm = ops.spmm
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     Xp = torch.zeros((n, pitch), device=dev)
@@ -184,6 +194,11 @@ def main():
     X, dC = Xp[:, :d], dCp[:, :d]
     C = torch.zeros((n, pitch), device=dev)[:, :d]
     dX = torch.zeros((n, pitch), device=dev)[:, :d]
+    tuned = None
+    if args.kernel == "cs" and not any(kv.startswith("cs_pace") for kv in args.tune):
+        tuned = {"fwd": A.autotune(X)}                  # untimed setup, once per plan and width
+        if not args.no_backward:
+            tuned["bwd"] = A.transpose.autotune(dC)
     gfl = args.grad_floats or reddit_grad_floats()
     grad = torch.randn(gfl, device=dev, generator=gen)
 
@@ -193,11 +208,11 @@ def main():
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        ops.spmm(A, X, out=C)
+        mm(A, X, out=C)
         if i is not None:
             ev[i][1].record()
         if not args.no_backward:
-            ops.spmm(A.transpose, dC, out=dX)
+            mm(A.transpose, dC, out=dX)
         if world > 1:
             dist.all_reduce(grad)
 
@@ -236,15 +251,18 @@ def main():
             "" if args.no_backward else " + bwd A^T.dC", d, pitch,
             ", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else ""),
             "N": n, "nnz": nnz, "d": d, "per_gpu": "one S-Reddit vertex-range shard",
-            "tune": args.tune},
-        "roofline": {"bound": "hbm", "kernel": "spmm_seg_kernel (forward A.X, incl. split-row fix-up)",
+            "kernel": args.kernel, "tune": args.tune,
+            "cs_autotune_ms_pace": tuned},
+        "roofline": {"bound": "hbm", "kernel": ("cs_spmm_kernel (column sweep, all slabs/rounds + fix-up)" if args.kernel == "cs"
+                                else "spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
                      "traffic": None, "traffic_source": None, "bytes_alg_per_launch": bytes_alg,
                      "ms_per_launch": fwd_ms, "edges_per_s_fwd": nnz / (fwd_ms * 1e-3),
                      "gather_model_GBps": (nnz * (d * 4 + 8) + n * d * 4) / (fwd_ms * 1e-3) / 1e9},
     }
-    tr = profiled_traffic("void sgcn::spmm", nnz, d) if not args.tune else None
+    tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
+        if not args.tune else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (

@@ -77,10 +77,50 @@ int sgcn_spmm_csr_f32(const int32_t* dev_rowptr, const int32_t* dev_col, const f
                       float* dev_C, int64_t ldc, float beta,
                       const sgcn_plan_t* plan, void* stream);
 
+/* ---- column-sweep plan for a STATIC graph (full-graph / PP products, K11) --------------------
+ * A row-gather SpMM re-fetches a B row for every nonzero (measured on S-Reddit: 55.6 GB of
+ * fabric traffic for 1.3 GB of algorithmic bytes, L2 hit rate 3 %, profiles/r01).  The column
+ * sweep makes the gathers hit L2 instead: R virtual rows form a TILE whose R x (64 float4)
+ * accumulators live in one wavefront's registers, the tile's nonzeros are merged and sorted by
+ * COLUMN, and all wavefronts of a launch walk the column space front to back together, so at
+ * any moment the chip touches one L2-sized window of B.  Rows longer than T are split into
+ * virtual rows (strided in column order, so each spans the whole sweep) that meet again in the
+ * ordered workspace fix-up (same deterministic scheme as sgcn_plan_t).  Built once on the host.
+ * colrow[p] = col | (local_row << 28) for R = 16 (K < 2^28), << 27 for R = 32 (K < 2^27). */
+typedef struct {
+    int32_t R;                      /* virtual rows per tile: 16 (float4/lane) or 32 (float2) */
+    int64_t ntiles;
+    const int64_t* dev_tile_ptr;    /* [ntiles+1] offsets into colrow/val                   */
+    const int32_t* dev_colrow;      /* [nnz]                                                */
+    const float* dev_val;           /* [nnz]                                                */
+    const int32_t* dev_tile_rows;   /* [ntiles*R] output row of each virtual row, -1 = pad  */
+    const int32_t* dev_tile_slots;  /* [ntiles*R] workspace slot, -1 = store to C directly  */
+    const sgcn_fix_t* dev_fix; int64_t nfix; int64_t nslots;
+    float* dev_ws; int64_t ws_elems;
+    int64_t round_tiles;            /* tiles per launch (0: derive from the device)         */
+    const int64_t* host_tile_nnz_hint; /* HOST array: nonzeros of the heaviest tile of every
+                                          launch, for clock pacing; nullable = unpaced          */
+    int32_t pace_ns_per_nnz;        /* sweep clock: a launch lasts (heaviest tile nnz) x this many
+                                       ns; found by timing a few values once per plan+width.
+                                       0 = library default knob, < 0 = unpaced                  */
+} sgcn_csplan_t;
+int sgcn_csplan_count(const int32_t* host_rowptr, int32_t M, int32_t R, int32_t T,
+                      int64_t* ntiles, int64_t* nfix, int64_t* nslots);
+int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val,
+                     int32_t M, int32_t R, int32_t T, int64_t* host_tile_ptr,
+                     int32_t* host_colrow, float* host_valout, int32_t* host_tile_rows,
+                     int32_t* host_tile_slots, sgcn_fix_t* host_fix);
+/* Same contract as sgcn_spmm_csr_f32 (C = rscale (.) (A (cscale (.) B[g])) + beta C). */
+int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K, int32_t d,
+                     const float* dev_B, int64_t ldb, const int32_t* dev_gidx,
+                     const float* dev_rscale, const float* dev_cscale,
+                     float* dev_C, int64_t ldc, float beta, void* stream);
+
 /* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
  *   "spmm_nv"   : float4 vectors per lane for wide rows (0 = auto)
  *   "spmm_unroll": nonzeros in flight per group (1,2,4,8; 0 = auto) */
 int sgcn_tune(const char* key, int64_t value);
+int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */
 
 /* Fused control-variate aggregator forward                    gcn/layers.py:298-319 (cvd)
  *                                                             gcn/layers.py:350-362 (cv)

@@ -29,6 +29,15 @@ class Fix(C.Structure):
     _fields_ = [("row", C.c_int32), ("first_slot", C.c_int32), ("nslots", C.c_int32)]
 
 
+class CsPlan(C.Structure):
+    _fields_ = [("R", C.c_int32), ("ntiles", C.c_int64), ("dev_tile_ptr", C.c_void_p),
+                ("dev_colrow", C.c_void_p), ("dev_val", C.c_void_p), ("dev_tile_rows", C.c_void_p),
+                ("dev_tile_slots", C.c_void_p), ("dev_fix", C.c_void_p), ("nfix", C.c_int64),
+                ("nslots", C.c_int64), ("dev_ws", C.c_void_p), ("ws_elems", C.c_int64),
+                ("round_tiles", C.c_int64), ("host_tile_nnz_hint", C.c_void_p),
+                ("pace_ns_per_nnz", C.c_int32)]
+
+
 class Plan(C.Structure):
     _fields_ = [("dev_seg", C.c_void_p), ("nseg", C.c_int64),
                 ("dev_fix", C.c_void_p), ("nfix", C.c_int64),
@@ -48,6 +57,12 @@ SIGNATURES = {
     "sgcn_spmm_csr_f32": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
                                     P, P, P, C.c_int64, C.c_float, C.POINTER(Plan), P]),
     "sgcn_tune": (C.c_int, [C.c_char_p, C.c_int64]),
+    "sgcn_tune_get": (C.c_int64, [C.c_char_p]),
+    "sgcn_csplan_count": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sgcn_csplan_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P]),
+    "sgcn_spmm_cs_f32": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
+                                   P, P, P, C.c_int64, C.c_float, P]),
     "sgcn_vr_aggregate_f32": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, P, P, C.c_int64, P, C.c_int64, P, P, P, P, P,
                                         C.c_int64, C.c_int32, C.c_int32, C.POINTER(Plan), P]),

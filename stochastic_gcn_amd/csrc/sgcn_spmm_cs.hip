@@ -1,0 +1,420 @@
+// Column-sweep SpMM for static graphs on gfx950 (plan: include/sgcn.h sgcn_csplan_t).
+//
+// Why: the row-gather kernel (sgcn_spmm.hip) is bound by XCD<->fabric bandwidth -- every nonzero
+// re-fetches its 2.4 KB B row because the 4 MiB L2 of an XCD holds 0.7 % of B (measured:
+// 55.6 GB fetched for 1.3 GB of algorithmic bytes, L2 hit 3 %).  Here one wavefront keeps the
+// accumulators of a TILE of 16 (virtual) rows x 64 float4 in 64 VGPRs and walks the tile's
+// nonzeros in COLUMN order; all wavefronts of a launch start together and advance through the
+// column space at the same average rate, so the B rows a wave needs were just fetched into its
+// XCD's L2 by a neighbour.  The leading wave pays the miss, the followers hit -- misses also
+// slow leaders down, which keeps the pack together.  B is fetched ~once per XCD per launch
+// instead of once per nonzero.
+//
+// The accumulator row is selected by a wave-uniform switch (the local row id travels in the top
+// 4 bits of the column word), i.e. scalar compare/branch -- no dynamic VGPR indexing, no LDS.
+// Split rows / ordered fix-up exactly as in sgcn_spmm.hip (deterministic, no atomics).
+#include "sgcn_dev.h"
+
+namespace sgcn {
+
+typedef Vec<4>::type f4;
+
+struct CsArgs {
+    const int64_t* tile_ptr;
+    const uint32_t* colrow;
+    const float* val;
+    const int32_t* tile_rows;
+    const int32_t* tile_slots;
+    int64_t tile_base, tile_end;
+    const float* B; int64_t ldb;
+    const int32_t* gidx; const float* rscale; const float* cscale;
+    float* C; int64_t ldc; float beta;
+    int32_t d, nvec, slab;
+    float* ws; int64_t ldw;
+    float cols_per_tick;   // pacing: columns the sweep may advance per 100 MHz tick (0 = unpaced)
+    float slack_cols;      // how far ahead of the clock a wave may run
+};
+
+#define SGCN_CS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+// R = 16, float4 specialisation with the accumulators PINNED to v[64:127] (x/y/z/w planes of 16
+// registers) and updated by one indexed FMA group per nonzero:
+//     s_set_gpr_idx_on lr, SRC2|DST ; 4 x v_fma_f32 v<plane>, val, b, v<plane> ; s_set_gpr_idx_off
+// i.e. 2 scalar + 4 vector instructions.  The generic kernel below lets hipcc lower `acc[e][lr]`,
+// which costs an on/off pair per extract AND per insert (16 scalar + 12 vector instructions per
+// nonzero); the CU's single scalar unit then caps the sweep (measured: ~36 CU-cycles per
+// nonzero-slab at any memory-level parallelism).
+template <int U, bool PIPE>
+__global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
+    constexpr int R = 16, VW = 4;
+    typedef typename Vec<VW>::type VT;
+    constexpr int kShift = (R <= 16) ? 28 : 27;                 // local row id lives above the column
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = a.tile_base + (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int vi = a.slab * kWave + lane;
+    const bool act = vi < a.nvec;
+    const uint32_t loff = (uint32_t)min(vi, a.nvec - 1) * (uint32_t)(VW * 4);
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const int64_t ldb_bytes = a.ldb * 4;
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t ax = {}, ay = {}, az = {}, aw = {};
+    // Clock-paced sweep: every wave of a launch starts within ~1 us and holds its column position
+    // to `elapsed * cols_per_tick` on the chip-wide constant 100 MHz counter (s_memrealtime), so
+    // all waves of an XCD gather from the same L2-sized window of B at the same time without
+    // exchanging a single message (counting nonzeros is not enough: a tile's position after k
+    // nonzeros jitters by ~N/(2 sqrt(nnz_tile)) columns, more than the window).
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t tnow = t0;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+    for (int64_t p0 = start; p0 < end; p0 += kWave) {
+        const int n = (int)min((int64_t)kWave, end - p0);
+        uint32_t mycr = 0;
+        float myv = 0.f;
+        if (lane < n) {
+            mycr = a.colrow[p0 + lane];
+            myv = a.val[p0 + lane];
+            uint32_t c = mycr & kColMask;
+            if (a.cscale) myv *= a.cscale[c];
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; mycr = (mycr & ~kColMask) | c; }
+        }
+#define SGCN_CS_APPLY(cr, v, b)                                                             \
+    {                                                                                       \
+        const int lr_ = (int)((cr) >> kShift);                                              \
+        asm volatile("s_set_gpr_idx_on %4, 0xc\n\t"                                         \
+                     "v_fma_f32 v64, %5, %6, v64\n\t"                                       \
+                     "v_fma_f32 v80, %5, %7, v80\n\t"                                       \
+                     "v_fma_f32 v96, %5, %8, v96\n\t"                                       \
+                     "v_fma_f32 v112, %5, %9, v112\n\t"                                     \
+                     "s_set_gpr_idx_off"                                                    \
+                     : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az),            \
+                       "+{v[112:127]}"(aw)                                                  \
+                     : "s"(lr_), "s"(v), "v"((b).x), "v"((b).y), "v"((b).z), "v"((b).w));   \
+    }
+        // software pipeline over the chunk's batches of U nonzeros: the loads of batch k+1 are in
+        // flight while batch k is applied (two staging buffers), so the wave never drains its
+        // memory queue inside a chunk.
+        const int nb = n / U;                       // full batches
+        VT bufA[U], bufB[U];
+        // The clock read (s_memrealtime) is a long-latency scalar memory op: it is issued right
+        // after a batch's gathers and consumed before the NEXT batch, so its latency overlaps the
+        // loads instead of serialising every batch (the stale reading only adds look-ahead).
+        auto pace = [&](int jj) {
+            if (a.cols_per_tick > 0.f) {
+                const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj) & kColMask);
+                float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
+                for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {   // bounded: never hangs
+                    __builtin_amdgcn_s_sleep(8);
+                    allowed = (float)(__builtin_amdgcn_s_memrealtime() - t0) * a.cols_per_tick + a.slack_cols;
+                }
+            }
+        };
+        auto issue = [&](int jj, VT* buf) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
+                buf[u] = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
+            }
+            if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
+        };
+        auto apply = [&](int jj, const VT* buf) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
+                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), jj + u));
+                const VT b = buf[u];
+                SGCN_CS_APPLY(cr, v, b)
+            }
+        };
+        if constexpr (PIPE) {
+            if (nb > 0) { pace(0); issue(0, bufA); }
+            int k = 0;
+            for (; k + 2 <= nb; k += 2) {
+                pace((k + 1) * U); issue((k + 1) * U, bufB);
+                apply(k * U, bufA);
+                if (k + 2 < nb) { pace((k + 2) * U); issue((k + 2) * U, bufA); }
+                apply((k + 1) * U, bufB);
+            }
+            if (k < nb) apply(k * U, bufA);
+        } else {
+            for (int k = 0; k < nb; k++) { pace(k * U); issue(k * U, bufA); apply(k * U, bufA); }
+        }
+        for (int j = nb * U; j < n; j++) {
+            const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, j);
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), j));
+            const VT b = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
+            SGCN_CS_APPLY(cr, v, b)
+        }
+#undef SGCN_CS_APPLY
+    }
+
+    if (!act) return;
+    const int32_t* rows = a.tile_rows + tile * R;
+    const int32_t* slots = a.tile_slots + tile * R;
+    const int left = a.d - vi * VW;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = rows[r];
+        if (row < 0) continue;
+        const VT accv = {ax[r], ay[r], az[r], aw[r]};
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc + (int64_t)vi * VW;
+            VT res = accv * (a.rscale ? a.rscale[row] : 1.0f);
+            if (a.beta != 0.f) {
+                if (left >= VW) res += a.beta * vload<VW>(out);
+                else for (int e = 0; e < left; e++) { if constexpr (VW == 1) res += a.beta * out[0]; else res[e] += a.beta * out[e]; }
+            }
+            if (left >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left);
+        }
+    }
+}
+
+template <int R, int VW, int U, bool PIPE>
+__global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
+    typedef typename Vec<VW>::type VT;
+    constexpr int kShift = (R <= 16) ? 28 : 27;                 // local row id lives above the column
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = a.tile_base + (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int vi = a.slab * kWave + lane;
+    const bool act = vi < a.nvec;
+    const uint32_t loff = (uint32_t)min(vi, a.nvec - 1) * (uint32_t)(VW * 4);
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const int64_t ldb_bytes = a.ldb * 4;
+
+    // R x VW accumulators as VW register vectors of R floats (one per vector component).  The
+    // row is selected by a wave-uniform DYNAMIC INDEX, which hipcc lowers to the gfx9 VGPR
+    // indexing mode (s_set_gpr_idx_on + v_mov): no branches and no register copies.  (A `switch`
+    // over named accumulators makes the structurizer shuffle v_mov_b64 copies at every merge,
+    // and a flat 64-float array goes to scratch -- both seen in the ISA.)
+    typedef float accv_t __attribute__((ext_vector_type(R)));
+    accv_t acc[VW];
+#pragma unroll
+    for (int e = 0; e < VW; e++) acc[e] = accv_t{};
+    // Clock-paced sweep: every wave of a launch starts within ~1 us and holds its column position
+    // to `elapsed * cols_per_tick` on the chip-wide constant 100 MHz counter (s_memrealtime), so
+    // all waves of an XCD gather from the same L2-sized window of B at the same time without
+    // exchanging a single message (counting nonzeros is not enough: a tile's position after k
+    // nonzeros jitters by ~N/(2 sqrt(nnz_tile)) columns, more than the window).
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t tnow = t0;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+    for (int64_t p0 = start; p0 < end; p0 += kWave) {
+        const int n = (int)min((int64_t)kWave, end - p0);
+        uint32_t mycr = 0;
+        float myv = 0.f;
+        if (lane < n) {
+            mycr = a.colrow[p0 + lane];
+            myv = a.val[p0 + lane];
+            uint32_t c = mycr & kColMask;
+            if (a.cscale) myv *= a.cscale[c];
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; mycr = (mycr & ~kColMask) | c; }
+        }
+#define SGCN_CS_APPLY(cr, v, b)                                                            \
+    {                                                                                      \
+        const int lr_ = (int)((cr) >> kShift);                                             \
+        _Pragma("unroll") for (int e_ = 0; e_ < VW; e_++)                                  \
+            acc[e_][lr_] += (v) * velem<VW>((b), e_);                                      \
+    }
+        // software pipeline over the chunk's batches of U nonzeros: the loads of batch k+1 are in
+        // flight while batch k is applied (two staging buffers), so the wave never drains its
+        // memory queue inside a chunk.
+        const int nb = n / U;                       // full batches
+        VT bufA[U], bufB[U];
+        // The clock read (s_memrealtime) is a long-latency scalar memory op: it is issued right
+        // after a batch's gathers and consumed before the NEXT batch, so its latency overlaps the
+        // loads instead of serialising every batch (the stale reading only adds look-ahead).
+        auto pace = [&](int jj) {
+            if (a.cols_per_tick > 0.f) {
+                const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj) & kColMask);
+                float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
+                for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {   // bounded: never hangs
+                    __builtin_amdgcn_s_sleep(8);
+                    allowed = (float)(__builtin_amdgcn_s_memrealtime() - t0) * a.cols_per_tick + a.slack_cols;
+                }
+            }
+        };
+        auto issue = [&](int jj, VT* buf) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
+                buf[u] = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
+            }
+            if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
+        };
+        auto apply = [&](int jj, const VT* buf) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
+                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), jj + u));
+                const VT b = buf[u];
+                SGCN_CS_APPLY(cr, v, b)
+            }
+        };
+        if constexpr (PIPE) {
+            if (nb > 0) { pace(0); issue(0, bufA); }
+            int k = 0;
+            for (; k + 2 <= nb; k += 2) {
+                pace((k + 1) * U); issue((k + 1) * U, bufB);
+                apply(k * U, bufA);
+                if (k + 2 < nb) { pace((k + 2) * U); issue((k + 2) * U, bufA); }
+                apply((k + 1) * U, bufB);
+            }
+            if (k < nb) apply(k * U, bufA);
+        } else {
+            for (int k = 0; k < nb; k++) { pace(k * U); issue(k * U, bufA); apply(k * U, bufA); }
+        }
+        for (int j = nb * U; j < n; j++) {
+            const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, j);
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), j));
+            const VT b = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
+            SGCN_CS_APPLY(cr, v, b)
+        }
+#undef SGCN_CS_APPLY
+    }
+
+    if (!act) return;
+    const int32_t* rows = a.tile_rows + tile * R;
+    const int32_t* slots = a.tile_slots + tile * R;
+    const int left = a.d - vi * VW;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = rows[r];
+        if (row < 0) continue;
+        VT accv;
+#pragma unroll
+        for (int e = 0; e < VW; e++) {
+            if constexpr (VW == 1) accv = acc[0][r]; else accv[e] = acc[e][r];
+        }
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc + (int64_t)vi * VW;
+            VT res = accv * (a.rscale ? a.rscale[row] : 1.0f);
+            if (a.beta != 0.f) {
+                if (left >= VW) res += a.beta * vload<VW>(out);
+                else for (int e = 0; e < left; e++) { if constexpr (VW == 1) res += a.beta * out[0]; else res[e] += a.beta * out[e]; }
+            }
+            if (left >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left);
+        }
+    }
+}
+
+// fix-up of split rows: ordered slot sum + epilogue (float4 path only)
+template <int VW>
+__global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix_t* fix, int64_t nfix) {
+    typedef typename Vec<VW>::type VT;
+    const int nvblk = (a.nvec + kBlock - 1) / kBlock;
+    const int64_t f = blockIdx.x / nvblk;
+    if (f >= nfix) return;
+    const sgcn_fix_t fx = fix[f];
+    const int vi = (int)(blockIdx.x % nvblk) * kBlock + threadIdx.x;
+    if (vi >= a.nvec) return;
+    const float* w = a.ws + (int64_t)fx.first_slot * a.ldw + (int64_t)vi * VW;
+    VT acc = vzero<VW>();
+    for (int q = 0; q < fx.nslots; q++) acc += vload<VW>(w + (int64_t)q * a.ldw);
+    float* out = a.C + (int64_t)fx.row * a.ldc + (int64_t)vi * VW;
+    VT res = acc * (a.rscale ? a.rscale[fx.row] : 1.0f);
+    const int left = a.d - vi * VW;
+    if (a.beta != 0.f) {
+        if (left >= VW) res += a.beta * vload<VW>(out);
+        else for (int e = 0; e < left; e++) { if constexpr (VW == 1) res += a.beta * out[0]; else res[e] += a.beta * out[e]; }
+    }
+    if (left >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left);
+}
+
+}  // namespace sgcn
+
+using namespace sgcn;
+
+extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K, int32_t d,
+                                const float* B, int64_t ldb, const int32_t* gidx,
+                                const float* rscale, const float* cscale, float* C, int64_t ldc,
+                                float beta, void* stream) {
+    SGCN_REQUIRE(plan && M >= 0 && K >= 0 && d >= 0, "spmm_cs: bad argument");
+    if (M == 0 || d == 0) return SGCN_OK;
+    SGCN_REQUIRE(plan->R == 8 || plan->R == 16 || plan->R == 32, "spmm_cs: R must be 8, 16 or 32");
+    SGCN_REQUIRE(plan->dev_tile_ptr && plan->dev_tile_rows && plan->dev_tile_slots && B && C,
+                 "spmm_cs: null operand");
+    SGCN_REQUIRE(K < (1 << (plan->R <= 16 ? 28 : 27)), "spmm_cs: K too large for the packed column word");
+    // R = 16: float4 per lane (1 KiB row slabs).  R = 32: float2 per lane (512 B row slabs, twice
+    // the rows per wave: denser tiles, narrower L2 window) -- same 64 accumulator VGPRs.
+    const int VW = plan->R <= 16 ? 4 : 2;
+    SGCN_REQUIRE(pick_vw(d, {B, C, plan->dev_ws}, {ldb, ldc}) >= VW,
+                 "spmm_cs: rows must be %d-byte aligned (pitch multiple of %d floats covering d)", VW * 4, VW);
+    hipStream_t st = (hipStream_t)stream;
+    CsArgs a{};
+    a.tile_ptr = plan->dev_tile_ptr; a.colrow = reinterpret_cast<const uint32_t*>(plan->dev_colrow);
+    a.val = plan->dev_val; a.tile_rows = plan->dev_tile_rows; a.tile_slots = plan->dev_tile_slots;
+    a.B = B; a.ldb = ldb; a.gidx = gidx; a.rscale = rscale; a.cscale = cscale;
+    a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
+    a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
+    if (plan->nfix > 0) {
+        SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
+                     "spmm_cs: workspace missing or too small");
+    }
+    int64_t round = plan->round_tiles;
+    if (round <= 0) {
+        const int tuned = tune_get("cs_round");
+        round = tuned > 0 ? tuned : 4096;       // 256 CUs x 4 SIMDs x 4 waves of 64 acc VGPRs
+    }
+    const int U = tune_get("cs_unroll") > 0 ? tune_get("cs_unroll") : 8;
+    // pace: plan value wins (set by the autotuner); 0 -> global knob; < 0 -> unpaced
+    const int pace_ns_per_nnz = plan->pace_ns_per_nnz != 0 ? (plan->pace_ns_per_nnz < 0 ? 0 : plan->pace_ns_per_nnz)
+                                                           : tune_get("cs_pace");
+    const int slack = tune_get("cs_slack") > 0 ? tune_get("cs_slack") : 512;
+    const int nslab = (a.nvec + kWave - 1) / kWave;
+    for (int slab = 0; slab < nslab; slab++) {
+        a.slab = slab;
+        for (int64_t t0 = 0; t0 < plan->ntiles; t0 += round) {
+            a.tile_base = t0;
+            a.tile_end = std::min(plan->ntiles, t0 + round);
+            a.cols_per_tick = 0.f;
+            a.slack_cols = (float)slack;
+            if (pace_ns_per_nnz > 0 && plan->host_tile_nnz_hint) {
+                const double launch_ns = (double)plan->host_tile_nnz_hint[t0 / round] * pace_ns_per_nnz;
+                a.cols_per_tick = (float)((double)K / (launch_ns / 10.0));   // 100 MHz: 10 ns per tick
+            }
+            const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
+#define SGCN_CS_LAUNCH(RR, VV, UU, PP) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU, PP>), dim3(blocks), dim3(kBlock), 0, st, a)
+            const bool pipe = tune_get("cs_pipe") > 0;
+#define SGCN_CS16(UU, PP) hipLaunchKernelGGL((cs_spmm16_kernel<UU, PP>), dim3(blocks), dim3(kBlock), 0, st, a)
+            if (plan->R == 16 && tune_get("cs_generic") <= 0) {
+                if (U == 4) { if (pipe) SGCN_CS16(4, true); else SGCN_CS16(4, false); }
+                else if (U == 16) SGCN_CS16(16, false);
+                else { if (pipe) SGCN_CS16(8, true); else SGCN_CS16(8, false); }
+            } else if (plan->R == 8) {
+                if (U == 4) SGCN_CS_LAUNCH(8, 4, 4, false); else SGCN_CS_LAUNCH(8, 4, 8, false);
+            } else if (plan->R == 16) {
+                if (U == 4) SGCN_CS_LAUNCH(16, 4, 4, false);
+                else if (U == 16) SGCN_CS_LAUNCH(16, 4, 16, false);
+                else SGCN_CS_LAUNCH(16, 4, 8, false);
+            } else if (U == 16) {
+                SGCN_CS_LAUNCH(32, 2, 16, false);
+            } else if (U == 32) {
+                SGCN_CS_LAUNCH(32, 2, 32, false);
+            } else {
+                if (U == 4) { if (pipe) SGCN_CS_LAUNCH(32, 2, 4, true); else SGCN_CS_LAUNCH(32, 2, 4, false); }
+                else { if (pipe) SGCN_CS_LAUNCH(32, 2, 8, true); else SGCN_CS_LAUNCH(32, 2, 8, false); }
+            }
+#undef SGCN_CS_LAUNCH
+#undef SGCN_CS16
+        }
+    }
+    SGCN_HIP_TRY(hipGetLastError());
+    if (plan->nfix > 0) {
+        const int64_t nfblk = (int64_t)((a.nvec + kBlock - 1) / kBlock) * plan->nfix;
+        SGCN_REQUIRE(nfblk < (1ll << 31), "spmm_cs: too many split rows");
+        if (VW == 4) hipLaunchKernelGGL(cs_fix_kernel<4>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
+        else hipLaunchKernelGGL(cs_fix_kernel<2>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
+        SGCN_HIP_TRY(hipGetLastError());
+    }
+    return SGCN_OK;
+}

@@ -271,3 +271,99 @@ def adam_step(theta, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
     check(lib.sgcn_adam_f32(theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
                             int(theta.numel()), float(lr_t), float(beta1), float(beta2), float(eps),
                             _stream()))
+
+
+# ---- column-sweep SpMM for static graphs (sgcn_spmm_cs.hip) --------------------------------------
+class ColumnSweepCSR(object):
+    """A static CSR re-laid for the column sweep (include/sgcn.h sgcn_csplan_t): built once on the
+    host (full-graph / PP products), then multiplied many times."""
+
+    def __init__(self, a, device, R=16, T=0, round_tiles=0):
+        a = a.tocsr()
+        rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(a.indices, dtype=np.int32)
+        val = np.ascontiguousarray(a.data, dtype=np.float32)
+        M = rowptr.shape[0] - 1
+        nt, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.sgcn_csplan_count(rowptr.ctypes.data, M, R, T, C.byref(nt), C.byref(nfix), C.byref(nslots)))
+        tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
+        colrow = np.empty(col.shape[0], dtype=np.int32)
+        valout = np.empty(col.shape[0], dtype=np.float32)
+        tile_rows = np.empty(nt.value * R, dtype=np.int32)
+        tile_slots = np.empty(nt.value * R, dtype=np.int32)
+        fix = np.empty((nfix.value, 3), dtype=np.int32)
+        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, R, T,
+                                   tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data,
+                                   tile_rows.ctypes.data, tile_slots.ctypes.data,
+                                   fix.ctypes.data if nfix.value else None))
+        self.shape = (int(a.shape[0]), int(a.shape[1]))
+        self.R, self.ntiles, self.nfix, self.nslots = R, nt.value, nfix.value, nslots.value
+        self.round_tiles = round_tiles
+        self._tile_nnz = np.diff(tile_ptr).astype(np.int64)
+        self._hint, self._hint_round = None, None
+        self.pace = {}          # d -> ns per nonzero of the heaviest tile (autotuned), -1 = unpaced
+        to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731
+        self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
+        self.tile_rows, self.tile_slots = to(tile_rows), to(tile_slots)
+        self.fix = to(fix) if nfix.value else None
+        self.ws, self.device = None, device
+        self.nnz = int(col.shape[0])
+
+    def struct(self, d):
+        ldw = (d + 3) // 4 * 4
+        need = self.nslots * ldw
+        if need and (self.ws is None or self.ws.numel() < need):
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        rnd = self.round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096)
+        if self._hint_round != rnd:         # heaviest tile of every launch, for pacing
+            nl = -(-self.ntiles // rnd)
+            pad = np.zeros(nl * rnd, dtype=np.int64)
+            pad[:self.ntiles] = self._tile_nnz
+            self._hint = np.ascontiguousarray(pad.reshape(nl, rnd).max(axis=1))
+            self._hint_round = rnd
+        return _ffi.CsPlan(self.R, self.ntiles, self.tile_ptr.data_ptr(), self.colrow.data_ptr(),
+                           self.val.data_ptr(), self.tile_rows.data_ptr(), self.tile_slots.data_ptr(),
+                           _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
+                           0 if self.ws is None else self.ws.numel(), rnd, self._hint.ctypes.data,
+                           int(self.pace.get(d, 0)))
+
+    def autotune(self, B, d=None, candidates=(-1, 200, 220, 240, 260, 280, 320, 380), reps=2):
+        """Pick the sweep clock for this plan and row width by timing a few candidates (the
+        sustainable pace depends on the graph, d and the chip's clocks; too fast loses the
+        lock-step and with it the L2 hits, too slow leaves the memory system idle)."""
+        d = int(B.shape[1] if d is None else d)
+        out = torch.empty((self.shape[0], (d + 3) // 4 * 4), dtype=torch.float32, device=B.device)[:, :d]
+        best = None
+        for p in candidates:
+            self.pace[d] = p
+            spmm_cs(self, B, out=out, d=d)                       # warm
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                spmm_cs(self, B, out=out, d=d)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            if best is None or t < best[0]:
+                best = (t, p)
+        self.pace[d] = best[1]
+        return best
+
+
+def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=None):
+    """Column-sweep variant of ``spmm`` for a ColumnSweepCSR (sgcn_spmm_cs_f32)."""
+    M, K = A.shape
+    bptr, ldb = _rows2d(B, "B")
+    d = int(B.shape[1] if d is None else d)
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an existing `out`")
+        pitch = (d + 3) // 4 * 4
+        out = torch.empty((M, pitch), dtype=torch.float32, device=B.device)[:, :d]
+    cptr, ldc = _rows2d(out, "out")
+    plan = A.struct(d)
+    check(lib.sgcn_spmm_cs_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(gidx, torch.int32, "gidx")),
+                               _ptr(_dev(rscale, torch.float32, "rscale")),
+                               _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),
+                               _stream()))
+    return out

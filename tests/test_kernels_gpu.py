@@ -256,3 +256,43 @@ def test_full_size_reddit_shape_properties(dev):
     assert np.abs(got - want).max() / np.abs(want).max() <= 1e-4
     # (5) determinism: the split-row fix-up is ordered, two runs are bit-identical
     assert torch.equal(ops.spmm(A, B), C)
+
+
+@pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6),
+                                         (500, 500, 256, 0), (64, 64, 1024, 0), (90, 70, 30, 2)])
+def test_spmm_column_sweep_vs_oracle(dev, M, K, d, pad):
+    from stochastic_gcn_amd import ops
+    a = rand_csr(M, K, 0.08, M + d, long_rows=[(0, min(K, 300)), (M // 2, min(K, 150))])
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((K, d + pad)).astype(np.float32)
+    A = ops.ColumnSweepCSR(a, dev, R=(32 if d % 2 == 0 and M > 100 else 16), T=32)
+    assert A.nfix >= 1
+    Bd = T(B, dev)[:, :d]
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    out = ops.spmm_cs(A, Bd)
+    assert onp.rel_err(out.cpu().numpy(), ref) <= TOL
+    # fusions + beta on the same plan
+    H = rng.standard_normal((1000, d + pad)).astype(np.float32)
+    g = rng.choice(1000, K, replace=False).astype(np.int32)
+    rs, cs = rng.rand(M).astype(np.float32), rng.rand(K).astype(np.float32)
+    c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
+    o2 = T(c0, dev)
+    ops.spmm_cs(A, T(H, dev)[:, :d], out=o2[:, :d], gidx=T(g, dev), rscale=T(rs, dev), cscale=T(cs, dev), beta=0.5)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, H[:, :d], gidx=g, rscale=rs, cscale=cs, C_in=c0[:, :d], beta=0.5)
+    assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
+    if pad:
+        np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
+
+
+def test_column_sweep_full_size_matches_row_gather(dev):
+    from stochastic_gcn_amd import ops, synthetic
+    n, _, full_adj, *_ = synthetic.reddit_like(with_features=False)
+    A = ops.DeviceCSR.from_scipy(full_adj, dev)
+    Acs = ops.ColumnSweepCSR(full_adj, dev)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    Bfull = torch.zeros((n, 608), device=dev)
+    Bfull[:, :602] = torch.randn((n, 602), device=dev, generator=g)
+    c1 = ops.spmm(A, Bfull[:, :602])
+    c2 = ops.spmm_cs(Acs, Bfull[:, :602])
+    assert float((c1 - c2).abs().max() / c1.abs().max()) <= TOL
+    assert torch.equal(ops.spmm_cs(Acs, Bfull[:, :602]), c2)       # deterministic
