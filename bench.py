@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--kernel", default="cs", choices=["rows", "cs"],
                    help="rows = row-gather SpMM (sgcn_spmm.hip); cs = column-sweep (sgcn_spmm_cs.hip)")
     p.add_argument("--cs-t", type=int, default=0)
+    p.add_argument("--colmod", type=int, default=0,
+                   help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-r", type=int, default=16, choices=[8, 16, 32])
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
@@ -175,6 +177,12 @@ def main():
         _ffi.tune(k, int(v))
 
     n, full_adj, wname, data10 = make_graph(args, rank)
+    if args.colmod:
+        import scipy.sparse as sp
+        coo = full_adj.tocoo()
+        full_adj = sp.csr_matrix((coo.data, (coo.row, coo.col % args.colmod)), shape=full_adj.shape)
+        full_adj.sort_indices()
+        wname += " [columns folded mod %d]" % args.colmod
     d = args.d
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
@@ -252,6 +260,7 @@ def main():
             ", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else ""),
             "N": n, "nnz": nnz, "d": d, "per_gpu": "one S-Reddit vertex-range shard",
             "kernel": args.kernel, "tune": args.tune,
+            "kernel_launches_per_spmm": (((d + 3) // 4 + 63) // 64) * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
             "cs_autotune_ms_pace": tuned},
         "roofline": {"bound": "hbm", "kernel": ("cs_spmm_kernel (column sweep, all slabs/rounds + fix-up)" if args.kernel == "cs"
                                 else "spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
@@ -264,7 +273,7 @@ def main():
     tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
         if not args.tune else None
     if tr is not None:
-        out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_launch"]
+        out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
             tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
     if not args.no_cpu_baseline:

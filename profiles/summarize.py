@@ -60,14 +60,18 @@ def main(src, tag):
         rec = {"kernel": f[0], "fetch_kib_raw": f[1], "write_kib": w[1],
                "fetch_bytes_corrected": f[1] * 1024 * 2, "write_bytes": w[1] * 1024,
                "hbm_bytes_per_launch": f[1] * 1024 * 2 + w[1] * 1024,
+               "kernel_launches_per_spmm": bj["config"].get("kernel_launches_per_spmm", 1),
+               "hbm_bytes_per_spmm": (f[1] * 1024 * 2 + w[1] * 1024) * bj["config"].get("kernel_launches_per_spmm", 1),
                "l2_hit_rate": hit / (hit + mis), "ns_per_launch_profiled": f[2],
                "nnz": bj["config"]["nnz"], "d": bj["config"]["d"],
                "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section; "
                        "calibrated on the 566.6 MB copy kernel of the same trace); WRITE_SIZE as reported"}
         json.dump(rec, open(os.path.join(out_dir, "%s_traffic.json" % tag), "w"), indent=1)
         lines.append("")
-        lines.append("== dominant kernel traffic per launch: fetch %.2f GB (corrected) + write %.2f GB, L2 hit %.3f"
-                     % (rec["fetch_bytes_corrected"] / 1e9, rec["write_bytes"] / 1e9, rec["l2_hit_rate"]))
+        lines.append("== dominant kernel traffic per launch: fetch %.2f GB (corrected) + write %.2f GB, L2 hit %.3f; "
+                     "%d launches per SpMM -> %.2f GB per SpMM"
+                     % (rec["fetch_bytes_corrected"] / 1e9, rec["write_bytes"] / 1e9, rec["l2_hit_rate"],
+                        rec["kernel_launches_per_spmm"], rec["hbm_bytes_per_spmm"] / 1e9))
     except Exception as e:   # partial profile directories are fine
         lines.append("(no traffic record: %s)" % e)
     path = os.path.join(out_dir, "%s_rocprof_summary.txt" % tag)

@@ -5,13 +5,20 @@
 
 #include <algorithm>
 #include <numeric>
+#include <queue>
+#include <functional>
 #include <vector>
 
 namespace {
 
 struct VRow { int32_t row, piece, npieces, nnz; };
 
-constexpr int32_t kDefaultT = 512;
+// default split threshold: a few times the mean degree, so that no single (virtual) row
+// dominates a 16-row tile, within [64, 512]
+inline int32_t default_t(const int32_t* rowptr, int32_t M) {
+    const int64_t avg = M > 0 ? ((int64_t)rowptr[M] - rowptr[0]) / M : 0;
+    return (int32_t)std::min<int64_t>(512, std::max<int64_t>(64, 4 * avg));
+}
 
 // virtual rows: a row with n <= T nonzeros is one; a longer row becomes ceil(n/T) strided pieces
 void make_vrows(const int32_t* rowptr, int32_t M, int32_t T, std::vector<VRow>& v) {
@@ -21,13 +28,28 @@ void make_vrows(const int32_t* rowptr, int32_t M, int32_t T, std::vector<VRow>& 
         const int32_t c = (n + T - 1) / T;
         for (int32_t q = 0; q < c; q++) v.push_back({r, q, c, (n - q + c - 1) / c});
     }
-    // sorted by weight; fill() deals them out boustrophedon so that every tile carries the same
-    // number of nonzeros (a paced sweep takes as long as its heaviest tile); ties keep row order
+    // sorted by weight for the LPT dealing in fill(); ties keep row order (deterministic)
     std::stable_sort(v.begin(), v.end(), [](const VRow& a, const VRow& b) { return a.nnz > b.nnz; });
 }
 
-// virtual row k of tile t: pass k of a snake over the weight-sorted list
-inline int64_t snake(int64_t t, int32_t k, int64_t nt) { return (int64_t)k * nt + ((k & 1) ? nt - 1 - t : t); }
+// Longest-processing-time dealing: the next heaviest virtual row goes to the lightest tile that
+// still has a free slot, so every tile carries (nearly) the same number of nonzeros -- a paced
+// sweep lasts as long as its heaviest tile.  Returns slot -> index into v (or -1).
+std::vector<int64_t> deal(const std::vector<VRow>& v, int32_t R, int64_t nt) {
+    std::vector<int64_t> assign((size_t)nt * R, -1);
+    std::vector<int32_t> fill((size_t)nt, 0);
+    typedef std::pair<int64_t, int64_t> WT;          // (weight, tile); min-heap, ties -> low tile id
+    std::priority_queue<WT, std::vector<WT>, std::greater<WT>> heap;
+    for (int64_t t = 0; t < nt; t++) heap.push({0, t});
+    for (size_t i = 0; i < v.size(); i++) {
+        WT top = heap.top();
+        heap.pop();
+        const int64_t t = top.second;
+        assign[(size_t)t * R + fill[t]++] = (int64_t)i;
+        if (fill[t] < R) heap.push({top.first + v[i].nnz, t});
+    }
+    return assign;
+}
 
 }  // namespace
 
@@ -37,7 +59,7 @@ int sgcn_csplan_count(const int32_t* rowptr, int32_t M, int32_t R, int32_t T, in
                       int64_t* nfix, int64_t* nslots) {
     if (M < 0 || (M > 0 && !rowptr) || R < 1 || R > 32 || !ntiles || !nfix || !nslots)
         return sgcn::fail(SGCN_ERR_INVALID, "csplan_count: bad argument");
-    if (T <= 0) T = kDefaultT;
+    if (T <= 0) T = default_t(rowptr, M);
     int64_t nv = 0, f = 0, s = 0;
     for (int32_t r = 0; r < M; r++) {
         const int64_t n = (int64_t)rowptr[r + 1] - rowptr[r];
@@ -56,7 +78,7 @@ int sgcn_csplan_fill(const int32_t* rowptr, const int32_t* col, const float* val
                      int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
     if (M < 0 || R < 1 || R > 32 || (M > 0 && (!rowptr || !tile_ptr || !tile_rows || !tile_slots)))
         return sgcn::fail(SGCN_ERR_INVALID, "csplan_fill: bad argument");
-    if (T <= 0) T = kDefaultT;
+    if (T <= 0) T = default_t(rowptr, M);
     std::vector<VRow> v;
     make_vrows(rowptr, M, T, v);
     // slots: consecutive per split row, in row order (the fix-up adds them in this order)
@@ -73,6 +95,7 @@ int sgcn_csplan_fill(const int32_t* rowptr, const int32_t* col, const float* val
         slot += c;
     }
     const int64_t nt = ((int64_t)v.size() + R - 1) / R;
+    const std::vector<int64_t> assign = deal(v, R, nt);
     struct Ent { int32_t col, lr; float val; };
     std::vector<Ent> ents;
     std::vector<std::pair<int32_t, float>> rowbuf;
@@ -81,8 +104,8 @@ int sgcn_csplan_fill(const int32_t* rowptr, const int32_t* col, const float* val
         tile_ptr[t] = out;
         ents.clear();
         for (int32_t k = 0; k < R; k++) {
-            const int64_t vi = snake(t, k, nt);
-            if (vi >= (int64_t)v.size()) { tile_rows[t * R + k] = -1; tile_slots[t * R + k] = -1; continue; }
+            const int64_t vi = assign[(size_t)t * R + k];
+            if (vi < 0) { tile_rows[t * R + k] = -1; tile_slots[t * R + k] = -1; continue; }
             const VRow& vr = v[vi];
             tile_rows[t * R + k] = vr.row;
             tile_slots[t * R + k] = vr.npieces > 1 ? first_slot[vr.row] + vr.piece : -1;

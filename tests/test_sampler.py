@@ -181,3 +181,88 @@ def test_plan_covers_every_nonzero_once():
         assert fix.shape[0] == int((deg > t).sum())
         for row, first, n in fix:
             assert n == -(-deg[row] // t)
+
+
+def test_packed_batch_equals_feed_dict_path():
+    """sgcn_sched_batch_packed (one C call, the training loop's fast path) must emit exactly the
+    arrays PyScheduler.batch emits: same sampler state evolution, fields, ffields, scales,
+    labels, COO/CSR of adj and fadj, madj weights, transposed CSR; plus a valid row plan."""
+    z = gu.load("sampler_big.npz")
+    adj = gu.graph(z, "pl2k")
+    labels = np.random.RandomState(0).rand(2000, 3).astype(np.float32)
+    for cv in (True, False):
+        for L in (1, 2):
+            ph = gu.placeholders(L)
+            a = PyScheduler(adj, labels, L, [2, 3][:L], ph, 4, cv=cv)
+            b = PyScheduler(adj, labels, L, [2, 3][:L], ph, 4, cv=cv)
+            for it in range(3):
+                ids = np.random.RandomState(it).choice(2000, 50, replace=False).astype(np.int32)
+                fa = a.batch(ids)
+                pb = b.batch_packed(ids, plan_T=8)
+                fb = pb.feed_dict(ph)
+                for k, v in fa.items():
+                    if isinstance(k, tuple):
+                        l = ph['adj'].index(k[1]) if k[1] in ph['adj'] else ph['fadj'].index(k[1])
+                        h = pb.csr(l, 0 if k[1] in ph['adj'] else 2)
+                        assert gu.bits_equal(h.rowptr, v.rowptr) and gu.bits_equal(h.col, v.col)
+                        assert gu.bits_equal(h.val, v.val)
+                        if v.t_rowptr is not None:
+                            t = pb.csr(l, 1)
+                            assert gu.bits_equal(t.rowptr, v.t_rowptr) and gu.bits_equal(t.col, v.t_col)
+                            assert gu.bits_equal(t.val, v.t_val)
+                        # the packed row plan covers every nonzero exactly once
+                        d = pb._csr[l, 0 if k[1] in ph['adj'] else 2]
+                        seg = pb._i(d[6], 4 * d[7]).reshape(-1, 4)
+                        cover = np.zeros(int(d[2]), np.int32)
+                        for row, s, e, slot in seg:
+                            cover[s:e] += 1
+                        assert np.all(cover == 1)
+                        continue
+                    w = fb[k]
+                    if isinstance(v, tuple):
+                        for x, y in zip(v, w):
+                            assert np.array_equal(np.asarray(x), np.asarray(y)), (cv, L, it, k)
+                    else:
+                        assert np.array_equal(v, w), (cv, L, it, k)
+            np.testing.assert_array_equal(a.c_sch.ivec(I_ADJ_I), b.c_sch.ivec(I_ADJ_I))
+
+
+def test_csplan_covers_matrix_and_balances_tiles():
+    """Column-sweep plan (sgcn_csplan_*): every nonzero appears exactly once with the right
+    output row, nonzeros inside a tile are column-sorted, tiles carry near-equal weight, and
+    split rows own consecutive workspace slots."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from stochastic_gcn_amd._ffi import lib, check
+    z = gu.load("sampler_big.npz")
+    a = gu.graph(z, "pl2k").tocsr()
+    a.sort_indices()
+    n = a.shape[0]
+    rowptr, col, val = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float32)
+    for R, T in ((16, 16), (32, 40), (16, 0)):
+        nt, nf, ns = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.sgcn_csplan_count(rowptr.ctypes.data, n, R, T, C.byref(nt), C.byref(nf), C.byref(ns)))
+        tp = np.empty(nt.value + 1, np.int64); cr = np.empty(a.nnz, np.int32); vo = np.empty(a.nnz, np.float32)
+        tr = np.empty(nt.value * R, np.int32); ts = np.empty(nt.value * R, np.int32)
+        fx = np.empty((max(nf.value, 1), 3), np.int32)
+        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, R, T,
+                                   tp.ctypes.data, cr.ctypes.data, vo.ctypes.data, tr.ctypes.data,
+                                   ts.ctypes.data, fx.ctypes.data))
+        shift = 28 if R <= 16 else 27
+        w = np.diff(tp)
+        tile = np.repeat(np.arange(nt.value), w)
+        lr = (cr.view(np.uint32) >> shift).astype(np.int64)
+        c = (cr.view(np.uint32) & ((1 << shift) - 1)).astype(np.int64)
+        orow = tr.reshape(-1, R)[tile, lr]
+        assert orow.min() >= 0
+        b = sp.coo_matrix((vo, (orow, c)), shape=a.shape).tocsr()
+        assert abs(b - a).max() == 0
+        for t in range(nt.value):                       # column-sorted inside every tile
+            assert np.all(np.diff(c[tp[t]:tp[t + 1]]) >= 0)
+        if nt.value > 4:                                # LPT dealing: within one (virtual) row of the mean
+            assert w.max() <= w.mean() + max(T, 64 if T == 0 else T) + R
+        slots = ts[ts >= 0]
+        assert sorted(slots.tolist()) == list(range(ns.value))
+        for row, first, cnt in fx[:nf.value]:
+            got = sorted(ts[(tr == row) & (ts >= 0)].tolist())
+            assert got == list(range(first, first + cnt))
