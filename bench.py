@@ -162,11 +162,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (SGCN_DIST_BACKEND=gloo lets a 1-GPU box smoke-test the N>1 code
+    # path with several ranks sharing cuda:0; RCCL itself refuses duplicate devices.)
+    backend = os.environ.get("SGCN_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if local_rank == 0:
         g.build(quiet=True)          # no-op when the in-tree .so files travelled with the snapshot
     if world > 1:

@@ -33,7 +33,8 @@ class DataParallel(object):
         if self.world > 1 and init and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            backend = backend or ("nccl" if (device is not None and device.type == "cuda") else "gloo")
+            backend = backend or os.environ.get("SGCN_DIST_BACKEND") or \
+                ("nccl" if (device is not None and device.type == "cuda") else "gloo")
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = device

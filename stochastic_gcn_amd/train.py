@@ -112,8 +112,9 @@ class Trainer(object):
         if not torch.cuda.is_available():
             raise RuntimeError("training needs an MI355X (no CPU fallback for the SpMM/history path)")
         par = DataParallel(device=None, init=False)
-        torch.cuda.set_device(par.local_rank)
-        self.device = device = torch.device('cuda', par.local_rank)
+        dev_index = par.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        self.device = device = torch.device('cuda', dev_index)
         self.par = par = DataParallel(device=device)
         self.log = log = print if (par.rank == 0 and verbose) else (lambda *a, **k: None)
 
