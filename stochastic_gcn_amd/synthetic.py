@@ -95,8 +95,19 @@ def _sparse_features(n, f, per_row, rng):
     return x
 
 
+def planted_labels(full_adj, feats, classes, rng):
+    """One-hot labels from a random linear teacher on the 1-hop aggregate, argmax((A X) W): a
+    learnable target, so end-to-end tests can check that training converges."""
+    w = rng.standard_normal((feats.shape[1], classes)).astype(np.float32)
+    z = full_adj.dot(feats if not sp.issparse(feats) else feats.tocsr()).dot(w) \
+        if not sp.issparse(feats) else np.asarray(full_adj.dot(feats).dot(w))
+    y = np.zeros((feats.shape[0], classes), dtype=np.float32)
+    y[np.arange(feats.shape[0]), np.asarray(z).argmax(axis=1)] = 1.0
+    return y
+
+
 def reddit_like(n=232965, m=11600000, f=602, classes=41, splits=(152410, 23699, 55334),
-                seed=1, with_features=True):
+                seed=1, with_features=True, planted=False):
     """S-Reddit: Zipf(0.6)-source x uniform-destination graph, D^-1 A,
     dense N(0,1) features.  Defaults give nnz ~= 23.17 M, avg degree ~= 99.5."""
     rng = np.random.RandomState(seed)
@@ -113,6 +124,8 @@ def reddit_like(n=232965, m=11600000, f=602, classes=41, splits=(152410, 23699, 
     train_adj = _row_normalize(at)
     labels = _onehot(n, classes, rng)
     feats = rng.standard_normal((n, f)).astype(np.float32) if with_features else None
+    if planted and with_features:
+        labels = planted_labels(full_adj, feats, classes, rng)
     return n, train_adj, full_adj, feats, None, None, labels, tr, va, te
 
 
