@@ -147,10 +147,43 @@ def cpu_baseline(full_adj, d, rows, seed=0):
         el = time.time() - t0
         if el > 10.0 or reps >= 50:
             break
-    return {"value": sub.nnz * reps / el, "unit": "edges/s", "cores": os.cpu_count(),
-            "kind": "port",
-            "sample": "oracle_c.c OpenMP CSR SpMM, first %d rows (%d edges) of the same matrix, "
-                      "d=%d, %d reps in %.1f s" % (rows, sub.nnz, d, reps, el)}
+    out = {"value": sub.nnz * reps / el, "unit": "edges/s", "cores": os.cpu_count(),
+           "kind": "port",
+           "sample": "oracle_c.c OpenMP CSR SpMM, first %d rows (%d edges) of the same matrix, "
+                     "d=%d, %d reps in %.1f s" % (rows, sub.nnz, d, reps, el)}
+    # B2: scipy.sparse csr @ dense, single thread -- literally what the reference
+    # uses for the PP product (gcn/utils.py:321-322)
+    small = full_adj[:min(8000, n)].tocsr()
+    t0 = time.time()
+    small.dot(B)
+    out["scipy_single_thread_edges_per_s"] = small.nnz / (time.time() - t0)
+    return out
+
+
+def sampler_baseline(data10):
+    """B3: host sampler ms per 512-vertex minibatch (cv, degree 1, L=1) -- this
+    build's sampler (incl. CSR/plan packing) and, when oracle/_ref travelled, the reference C++."""
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    n, train_adj, _, _, _, _, labels, tr, _, _ = data10
+    ph = {'adj': ['a'], 'madj': ['m'], 'fadj': ['f'], 'fields': ['f0', 'f1'], 'ffields': ['ff'],
+          'scales': ['s'], 'labels': 'l'}
+    res = {}
+    sch = PyScheduler(train_adj, labels, 1, [1], ph, 1, data=tr.copy(), cv=True)
+    t0, k = time.time(), 0
+    while k < 150 and sch.minibatch_packed(512) is not None:
+        k += 1
+    res["sgcn_packed_ms_per_batch"] = (time.time() - t0) / max(k, 1) * 1e3
+    try:
+        from oracle import ref_binding as rb
+        if rb.available():
+            ref = rb.RefPyScheduler(train_adj, labels, 1, [1], ph, 1, data=tr.copy(), cv=True)
+            t0, k = time.time(), 0
+            while k < 150 and ref.minibatch(512) is not None:
+                k += 1
+            res["reference_cpp_ms_per_batch"] = (time.time() - t0) / max(k, 1) * 1e3
+    except Exception as e:      # the checker is optional here
+        res["reference_cpp_ms_per_batch"] = None
+    return res
 
 
 def main():
@@ -285,6 +318,8 @@ def main():
             tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
+        if data10 is not None:
+            out["cpu_baseline"]["sampler"] = sampler_baseline(data10)
     if world == 1 and not args.no_epoch and data10 is not None:
         del A, Xp, dCp, X, dC, C, dX
         torch.cuda.empty_cache()

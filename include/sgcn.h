@@ -186,10 +186,11 @@ int sgcn_ln_act_bwd_f32(const float* dev_dy, int64_t lddy, const float* dev_y, i
                         float* dev_doffset, float* dev_dscale, float* dev_ws, void* stream);
 /* Softmax cross-entropy over n rows: stats[0] = sum_i CE_i, stats[1] = #rows whose arg-max
  * matches the label arg-max; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
- * pred (nullable) = softmax.                                   gcn/models.py:68-94,198-202 */
+ * pred (nullable) = softmax; rowstat: 2*n floats of scratch (per-row CE and hit flag, summed
+ * in a fixed order).                                           gcn/models.py:68-94,198-202 */
 int sgcn_softmax_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,
                         int32_t n, int32_t c, float* dev_dlogits, int64_t lddz, float* dev_pred,
-                        int64_t ldp, float* dev_stats, void* stream);
+                        int64_t ldp, float* dev_stats, float* dev_rowstat, void* stream);
 /* tf.train.AdamOptimizer step on flat buffers: m,v updated in place,
  * theta -= lr_t * m / (sqrt(v) + eps)  with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
  * caller.                                                       gcn/models.py:50-51 */

@@ -76,7 +76,7 @@ SIGNATURES = {
     "sgcn_ln_act_bwd_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, P, P, P, C.c_int32, C.c_int32,
                                       C.c_int32, P, C.c_int64, P, P, P, P]),
     "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
-                                      P, C.c_int64, P, P]),
+                                      P, C.c_int64, P, P, P]),
     "sgcn_adam_f32": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "sgcn_sched_create": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.POINTER(C.c_void_p)]),

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
 }
 
 // dx = LN-backward(dy masked by y > 0); per-block column partials of d(offset), d(scale).
-constexpr int kBwdRowsPerWave = 8;
+constexpr int kBwdRowsPerWave = 2;
 __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
     const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -109,54 +109,62 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
     if (c < d) doffset[c] += s; else dscale[c - d] += s;
 }
 
-// One workgroup: rows strided over its 4 wavefronts.  stats = {sum of CE, #correct}.
+// One wavefront per row, as many workgroups as rows need (a single-workgroup version spent
+// 277 us on 512 x 41 logits: ~40 dependent cross-lane shuffles per row, 128 rows per wave).
+// Per-row CE and hit flags go to `rowstat`; softmax_stats_kernel adds them in a fixed order
+// (deterministic loss / accuracy).
 __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
     int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
-    float* __restrict__ stats) {
-    __shared__ float red[2][kBlock / kWave];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x / kWave;
-    float loss = 0.f, correct = 0.f;
+    float* __restrict__ rowstat /* [2][n] */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (row >= n) return;
     const float inv_n = 1.0f / (float)n;
-    for (int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + wave; row < n;
-         row += (int64_t)gridDim.x * (kBlock / kWave)) {
-        const float* zr = z + row * ldz;
-        const float* lr = lab + row * ldl;
-        float m = -INFINITY, lm = -INFINITY;
-        int am = 0, alm = 0;
-        for (int k = lane; k < c; k += kWave) {
-            if (zr[k] > m) { m = zr[k]; am = k; }
-            if (lr[k] > lm) { lm = lr[k]; alm = k; }
-        }
-        // wave arg-max with lowest-index tie break (np.argmax / tf.argmax semantics)
+    const float* zr = z + row * ldz;
+    const float* lr = lab + row * ldl;
+    float m = -INFINITY, lm = -INFINITY;
+    int am = 0, alm = 0;
+    for (int k = lane; k < c; k += kWave) {
+        if (zr[k] > m) { m = zr[k]; am = k; }
+        if (lr[k] > lm) { lm = lr[k]; alm = k; }
+    }
+    // wave arg-max with lowest-index tie break (np.argmax / tf.argmax semantics)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float om = __shfl_xor(m, o, 64); const int oa = __shfl_xor(am, o, 64);
-            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
-            const float ol = __shfl_xor(lm, o, 64); const int ola = __shfl_xor(alm, o, 64);
-            if (ol > lm || (ol == lm && ola < alm)) { lm = ol; alm = ola; }
-        }
-        float se = 0.f, sl = 0.f;
-        for (int k = lane; k < c; k += kWave) { se += __expf(zr[k] - m); sl += lr[k]; }
-        se = wave_sum(se); sl = wave_sum(sl);
-        const float lse = m + __logf(se);
-        float l = 0.f;
-        for (int k = lane; k < c; k += kWave) {
-            const float logp = zr[k] - lse, p = __expf(logp);
-            l -= lr[k] * logp;
-            if (dz) dz[row * lddz + k] = (p * sl - lr[k]) * inv_n;
-            if (pred) pred[row * ldp + k] = p;
-        }
-        loss += wave_sum(l);
-        correct += (am == alm) ? 1.f : 0.f;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64); const int oa = __shfl_xor(am, o, 64);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        const float ol = __shfl_xor(lm, o, 64); const int ola = __shfl_xor(alm, o, 64);
+        if (ol > lm || (ol == lm && ola < alm)) { lm = ol; alm = ola; }
     }
-    if (lane == 0) { red[0][wave] = loss; red[1][wave] = correct; }
+    float se = 0.f, sl = 0.f;
+    for (int k = lane; k < c; k += kWave) { se += __expf(zr[k] - m); sl += lr[k]; }
+    se = wave_sum(se); sl = wave_sum(sl);
+    const float lse = m + __logf(se);
+    float l = 0.f;
+    for (int k = lane; k < c; k += kWave) {
+        const float logp = zr[k] - lse, p = __expf(logp);
+        l -= lr[k] * logp;
+        if (dz) dz[row * lddz + k] = (p * sl - lr[k]) * inv_n;
+        if (pred) pred[row * ldp + k] = p;
+    }
+    l = wave_sum(l);
+    if (lane == 0) { rowstat[row] = l; rowstat[n + row] = (am == alm) ? 1.f : 0.f; }
+}
+
+// stats[0] = sum_i CE_i, stats[1] = #correct: one workgroup, fixed summation order
+__global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float* __restrict__ rowstat,
+                                                               int32_t n, float* __restrict__ stats) {
+    __shared__ float red[2][kBlock];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += kBlock) { a += rowstat[i]; b += rowstat[n + i]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        for (int w = 0; w < kBlock / kWave; w++) { a += red[0][w]; b += red[1][w]; }
-        stats[0] = a; stats[1] = b;
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) { stats[0] = red[0][0]; stats[1] = red[1][0]; }
 }
 
 __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
@@ -221,10 +229,12 @@ extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y
 
 extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float* labels,
                                    int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
-                                   float* pred, int64_t ldp, float* stats, void* stream) {
-    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats, "softmax_ce: bad operand");
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, logits, ldz,
-                       labels, ldl, n, c, dlogits, lddz, pred, ldp, stats);
+                                   float* pred, int64_t ldp, float* stats, float* rowstat,
+                                   void* stream) {
+    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "softmax_ce: bad operand");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0,
+                       (hipStream_t)stream, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, rowstat);
+    hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, rowstat, n, stats);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }

@@ -246,10 +246,21 @@ class AugmentedDropoutDense(Layer):
         else:
             xd, self._mask = dropout_fwd(x, keep, self.name)
             self._xd = xd
-            xs = torch.mm(xd, W)
-            # test models run with dropout 0 on a single stream: both streams coincide
-            same = mu is x and xd is x
-            mus = xs if same else torch.mm(mu, W)
+            off = self.vars.get('offset') if self.norm else None
+            sc = self.vars.get('scale') if self.norm else None
+            if mu is x and xd is x:
+                # test models run with dropout 0 on a single stream: both streams coincide
+                hx, self._ctx = ops.ln_act_fwd(torch.mm(xd, W), off, sc, True)
+                self._out = hx
+                return hx, hx
+            # the dropout stream and the clean stream share W and the LayerNorm parameters: one
+            # stacked GEMM and one fused LN+ReLU launch over [x_dropped ; mu] (2n x d)
+            n = xd.shape[0]
+            stacked = torch.cat((xd, mu), dim=0)
+            h2, ctx2 = ops.ln_act_fwd(torch.mm(stacked, W), off, sc, True)
+            self._ctx = (ctx2[0][:n], ctx2[1][:n]) if ctx2 is not None else None
+            self._out = h2[:n]
+            return h2[:n], h2[n:]
         same = mus is xs
         off = self.vars.get('offset') if self.norm else None
         sc = self.vars.get('scale') if self.norm else None

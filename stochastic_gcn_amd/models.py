@@ -559,14 +559,18 @@ class GCN(Model):
         self.g_t += time() - t
 
         t = time()
-        self.forward(cur)
-        loss, acc, pred, dlogits = self.loss_and_grad(cur.labels)
-        if self.is_training:
-            self.backward(dlogits)
-            if self.grad_hook is not None:
-                self.grad_hook(self.grad)
-            self.adam_step()
-        self.update_history(cur)
+        ops.pin_stream()
+        try:
+            self.forward(cur)
+            loss, acc, pred, dlogits = self.loss_and_grad(cur.labels)
+            if self.is_training:
+                self.backward(dlogits)
+                if self.grad_hook is not None:
+                    self.grad_hook(self.grad)
+                self.adam_step()
+            self.update_history(cur)
+        finally:
+            ops.unpin_stream()
         if sync:
             loss, acc = float(loss), float(acc)
             outs = [None, loss, acc] if self.is_training else [loss, acc, pred.cpu().numpy()]
