@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
 }
 
 // dx = LN-backward(dy masked by y > 0); per-block column partials of d(offset), d(scale).
-constexpr int kBwdRowsPerWave = 2;
+constexpr int kBwdRowsPerWave = 4;
 __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
     const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -104,8 +104,17 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
                                        float* __restrict__ doffset, float* __restrict__ dscale) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= 2 * d) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; b++) s += partial[(size_t)b * 2 * d + c];
+    // four independent chains keep several loads in flight; combined in a fixed order
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        s0 += partial[(size_t)(b + 0) * 2 * d + c];
+        s1 += partial[(size_t)(b + 1) * 2 * d + c];
+        s2 += partial[(size_t)(b + 2) * 2 * d + c];
+        s3 += partial[(size_t)(b + 3) * 2 * d + c];
+    }
+    for (; b < nblk; b++) s0 += partial[(size_t)b * 2 * d + c];
+    const float s = (s0 + s1) + (s2 + s3);
     if (c < d) doffset[c] += s; else dscale[c - d] += s;
 }
 

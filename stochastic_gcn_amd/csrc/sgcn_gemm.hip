@@ -1,0 +1,187 @@
+// fp32 MFMA GEMM for the dense weight layers of the step, gfx950.
+//
+//   C[M x N] = op(A)[M x K] . op(B)[K x N] (+ C)        op = identity or transpose
+//   optional fused epilogue  Y = act(LN(C) * scale + offset)   (MyLayerNorm2 + ReLU,
+//                                                                gcn/layers.py:95-97,404-411)
+//
+// These GEMMs are small (Reddit step: 2042 x 1204 x 128 and smaller) and sit between the sparse
+// kernels of a launch-latency-bound step, so the point is one cheap launch per layer with the
+// LayerNorm fused, not peak FLOPs: exact-fp32 v_mfma_f32_32x32x2_f32 (the f32 matrix-core op of
+// CDNA4: bitwise a k-ordered fmaf chain), a 32 x 128 block tile (4 wavefronts x one 32 x 32
+// accumulator), K stepped by 32 through LDS (A tile padded to 33 floats/row so the per-lane
+// column reads of the A fragment are bank-conflict free), epilogue through LDS so a wavefront
+// owns whole rows for the LayerNorm statistics.
+#include "sgcn_dev.h"
+
+namespace sgcn {
+
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+constexpr int kTM = 32, kTN = 128, kTK = 32;
+
+struct GemmArgs {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int32_t M, N, K;
+    int32_t accumulate;              // C += instead of C =
+    // fused LN/act epilogue (N <= 128 only): Y = act(LN(C)*scale + offset)
+    const float* offset; const float* scale; float eps; int32_t relu;
+    float* xhat; float* rstd;        // [M x N], [M]   kept for the backward when LN is on
+    int32_t epi;                     // 0 plain, 1 act only, 2 LN + act
+};
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
+    __shared__ float As[kTM][kTK + 1];          // [i][kk]
+    __shared__ float Bs[kTK][kTN + 4];          // [kk][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * kTM, n0 = blockIdx.y * kTN;
+    f16acc acc = {};
+
+    for (int k0 = 0; k0 < g.K; k0 += kTK) {
+        // ---- A tile -> As[i][kk]
+        if (!TA) {          // A is [M x K]: thread reads 4 consecutive k of one row
+            const int i = tid >> 3, kq = (tid & 7) * 4;
+            const int row = m0 + i;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int k = k0 + kq + e;
+                As[i][kq + e] = (row < g.M && k < g.K) ? g.A[(int64_t)row * g.lda + k] : 0.f;
+            }
+        } else {            // A is [K x M]: thread reads 4 consecutive m of one k
+            const int kk = tid >> 3, iq = (tid & 7) * 4;
+            const int k = k0 + kk;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = m0 + iq + e;
+                As[iq + e][kk] = (row < g.M && k < g.K) ? g.A[(int64_t)k * g.lda + row] : 0.f;
+            }
+        }
+        // ---- B tile -> Bs[kk][j]
+        if (!TB) {          // B is [K x N]
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4;
+                const int k = k0 + kk;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int col = n0 + jq + e;
+                    Bs[kk][jq + e] = (k < g.K && col < g.N) ? g.B[(int64_t)k * g.ldb + col] : 0.f;
+                }
+            }
+        } else {            // B is [N x K]
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = (tid >> 3) + 32 * r, kq = (tid & 7) * 4;
+                const int col = n0 + j;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k = k0 + kq + e;
+                    Bs[kq + e][j] = (k < g.K && col < g.N) ? g.B[(int64_t)col * g.ldb + k] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 16 x (32x32x2) MFMAs: lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+        const int fi = lane & 31, fk = lane >> 5;
+#pragma unroll
+        for (int kk2 = 0; kk2 < kTK / 2; kk2++) {
+            const float a = As[fi][kk2 * 2 + fk];
+            const float b = Bs[kk2 * 2 + fk][wave * 32 + fi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int cj = wave * 32 + (lane & 31);
+    if (g.epi == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + cj;
+            if (row < g.M && col < g.N) {
+                float* p = g.C + (int64_t)row * g.ldc + col;
+                *p = g.accumulate ? *p + acc[r] : acc[r];
+            }
+        }
+        return;
+    }
+    // ---- fused epilogue: tile -> LDS, then one wavefront per row (needs the whole row: N <= 128)
+    float (*Cs)[kTN + 4] = Bs;            // 32 x 132 floats fit in Bs
+#pragma unroll
+    for (int r = 0; r < 16; r++) Cs[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][cj] = acc[r];
+    __syncthreads();
+    for (int rr = wave; rr < kTM; rr += kBlock / kWave) {
+        const int row = m0 + rr;
+        if (row >= g.M) break;
+        float* yr = g.C + (int64_t)row * g.ldc;
+        if (g.epi == 1) {
+            for (int c = lane; c < g.N; c += kWave) { const float v = Cs[rr][c]; yr[c] = g.relu ? fmaxf(v, 0.f) : v; }
+            continue;
+        }
+        float s = 0.f;
+        for (int c = lane; c < g.N; c += kWave) s += Cs[rr][c];
+        const float mean = wsum(s) / (float)g.N;
+        float q = 0.f;
+        for (int c = lane; c < g.N; c += kWave) { const float t = Cs[rr][c] - mean; q += t * t; }
+        const float rs = rsqrtf(wsum(q) / (float)g.N + g.eps);
+        if (lane == 0) g.rstd[row] = rs;
+        float* hr = g.xhat + (int64_t)row * g.N;
+        for (int c = lane; c < g.N; c += kWave) {
+            const float h = (Cs[rr][c] - mean) * rs;
+            hr[c] = h;
+            const float v = h * g.scale[c] + g.offset[c];
+            yr[c] = g.relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+}  // namespace sgcn
+
+using namespace sgcn;
+
+static int launch_gemm(const GemmArgs& g, int ta, int tb, hipStream_t st) {
+    dim3 grid((unsigned)((g.M + kTM - 1) / kTM), (unsigned)((g.N + kTN - 1) / kTN));
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(kBlock), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(kBlock), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(kBlock), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(kBlock), 0, st, g);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K,
+                             const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                             int64_t ldc, int32_t accumulate, void* stream) {
+    SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
+    if (M == 0 || N == 0) return SGCN_OK;
+    SGCN_REQUIRE(A && B && C, "gemm: null operand");
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.accumulate = accumulate; g.epi = 0;
+    return launch_gemm(g, trans_a, trans_b, (hipStream_t)stream);
+}
+
+extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
+                                  const float* W, int64_t ldw, const float* offset,
+                                  const float* scale, float eps, int32_t relu, float* Y, int64_t ldy,
+                                  float* xhat, float* rstd, void* stream) {
+    SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "dense_fwd: negative size");
+    if (M == 0 || N == 0) return SGCN_OK;
+    SGCN_REQUIRE(X && W && Y, "dense_fwd: null operand");
+    const int norm = (offset && scale) ? 1 : 0;
+    SGCN_REQUIRE(!norm || (xhat && rstd), "dense_fwd: LayerNorm needs xhat / rstd");
+    SGCN_REQUIRE(N <= kTN || (!norm && !relu), "dense_fwd: fused epilogue needs N <= 128");
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+    g.M = M; g.N = N; g.K = K; g.offset = offset; g.scale = scale; g.eps = eps; g.relu = relu;
+    g.xhat = xhat; g.rstd = rstd; g.epi = norm ? 2 : (relu ? 1 : 0);
+    return launch_gemm(g, 0, 0, (hipStream_t)stream);
+}

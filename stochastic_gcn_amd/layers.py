@@ -188,11 +188,17 @@ class Dense(Layer):
     def forward(self, x):
         W = self.vars['weights']
         self._x = x
-        y = ops.spmm(x.csr, W) if self.sparse_inputs else torch.mm(x, W)
+        off = self.vars.get('offset') if self.norm else None
+        sc = self.vars.get('scale') if self.norm else None
         self._ctx = None
-        if self.norm or self.act:          # fused LayerNorm + ReLU (one kernel)
-            y, self._ctx = ops.ln_act_fwd(y, self.vars.get('offset') if self.norm else None,
-                                          self.vars.get('scale') if self.norm else None, self.act)
+        if self.sparse_inputs:
+            y = ops.spmm(x.csr, W)
+            if self.norm or self.act:      # fused LayerNorm + ReLU (one kernel)
+                y, self._ctx = ops.ln_act_fwd(y, off, sc, self.act)
+        elif self.output_dim <= 128 or not (self.norm or self.act):
+            y, self._ctx = ops.dense_fwd(x, W, off, sc, self.act)      # GEMM + LN + ReLU, one launch
+        else:
+            y, self._ctx = ops.ln_act_fwd(ops.gemm(x, W), off, sc, self.act)
         self._out = y
         return y
 
@@ -204,10 +210,10 @@ class Dense(Layer):
             xt = self._x.transpose_of(self._x.csr.val)
             ops.spmm(xt, g, out=self.grads['weights'], beta=1.0)
             return None
-        self.grads['weights'].addmm_(self._x.t(), g)
+        ops.gemm(self._x, g, out=self.grads['weights'], trans_a=True, accumulate=True)   # dW += x^T g
         if not self.need_dx:
             return None
-        return torch.mm(g, self.vars['weights'].t())
+        return ops.gemm(g, self.vars['weights'], trans_b=True)                            # dx = g W^T
 
 
 class AugmentedDropoutDense(Layer):
@@ -248,16 +254,19 @@ class AugmentedDropoutDense(Layer):
             self._xd = xd
             off = self.vars.get('offset') if self.norm else None
             sc = self.vars.get('scale') if self.norm else None
+            fused = self.output_dim <= 128
             if mu is x and xd is x:
                 # test models run with dropout 0 on a single stream: both streams coincide
-                hx, self._ctx = ops.ln_act_fwd(torch.mm(xd, W), off, sc, True)
+                hx, self._ctx = ops.dense_fwd(xd, W, off, sc, True) if fused else \
+                    ops.ln_act_fwd(ops.gemm(xd, W), off, sc, True)
                 self._out = hx
                 return hx, hx
             # the dropout stream and the clean stream share W and the LayerNorm parameters: one
             # stacked GEMM and one fused LN+ReLU launch over [x_dropped ; mu] (2n x d)
             n = xd.shape[0]
             stacked = torch.cat((xd, mu), dim=0)
-            h2, ctx2 = ops.ln_act_fwd(torch.mm(stacked, W), off, sc, True)
+            h2, ctx2 = ops.dense_fwd(stacked, W, off, sc, True) if fused else \
+                ops.ln_act_fwd(ops.gemm(stacked, W), off, sc, True)
             self._ctx = (ctx2[0][:n], ctx2[1][:n]) if ctx2 is not None else None
             self._out = h2[:n]
             return h2[:n], h2[n:]
@@ -277,10 +286,10 @@ class AugmentedDropoutDense(Layer):
             x, val = self._xd
             ops.spmm(x.transpose_of(val), g, out=self.grads['weights'], beta=1.0)
             return None
-        self.grads['weights'].addmm_(self._xd.t(), g)
+        ops.gemm(self._xd, g, out=self.grads['weights'], trans_a=True, accumulate=True)
         if not self.need_dx:
             return None
-        g = torch.mm(g, self.vars['weights'].t())
+        g = ops.gemm(g, self.vars['weights'], trans_b=True)
         return dropout_bwd(g, self._mask)
 
 

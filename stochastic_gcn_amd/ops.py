@@ -385,3 +385,54 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
                                _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),
                                _stream()))
     return out
+
+
+# ---- fp32 MFMA GEMM / fused dense layer (sgcn_gemm.hip) ------------------------------------------
+# Above this many multiply-adds a GEMM is no longer launch-latency-bound and the library GEMM
+# (rocBLAS via torch, "plain library GEMM") is the better tool; below it our one-launch kernels
+# (and the fused GEMM+LayerNorm+ReLU) win on launch count and dispatch cost.
+GEMM_LIBRARY_THRESHOLD = 96 * 1024 * 1024
+
+
+def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False):
+    """out = op(A) @ op(B) (+ out)   (sgcn_gemm_f32; exact fp32 on the matrix cores)."""
+    if A.shape[0] * A.shape[1] * (B.shape[0] if trans_b else B.shape[1]) >= GEMM_LIBRARY_THRESHOLD:
+        a = A.t() if trans_a else A
+        b = B.t() if trans_b else B
+        if out is None:
+            return torch.mm(a, b)
+        if accumulate:
+            return out.addmm_(a, b)
+        return torch.mm(a, b, out=out)
+    ap, lda = _rows2d(A, "A")
+    bp, ldb = _rows2d(B, "B")
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, K2))
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing `out`")
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    cp, ldc = _rows2d(out, "out")
+    check(lib.sgcn_gemm_f32(int(trans_a), int(trans_b), int(M), int(N), int(K), ap, lda, bp, ldb, cp, ldc,
+                            int(accumulate), _stream()))
+    return out
+
+
+def dense_fwd(x, W, offset, scale, relu, eps=1e-9):
+    """y = act(LN(x @ W) * scale + offset) in ONE launch (sgcn_dense_fwd_f32).
+    Returns (y, ctx) like ln_act_fwd; falls back to gemm for N > 128 without epilogue."""
+    M, K, N = int(x.shape[0]), int(x.shape[1]), int(W.shape[1])
+    if M * K * N >= GEMM_LIBRARY_THRESHOLD:
+        return ln_act_fwd(torch.mm(x, W), offset, scale, relu, eps) if (offset is not None or relu) \
+            else (torch.mm(x, W), None)
+    xp, ldx = _rows2d(x, "x")
+    wp, ldw = _rows2d(W, "W")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    norm = offset is not None
+    xhat = torch.empty((M, N), dtype=torch.float32, device=x.device) if norm else None
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device) if norm else None
+    check(lib.sgcn_dense_fwd_f32(M, N, K, xp, ldx, wp, ldw, _ptr(offset), _ptr(scale), float(eps),
+                                 int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), _stream()))
+    return y, ((xhat, rstd) if norm else None)

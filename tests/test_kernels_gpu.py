@@ -296,3 +296,49 @@ def test_column_sweep_full_size_matches_row_gather(dev):
     c2 = ops.spmm_cs(Acs, Bfull[:, :602])
     assert float((c1 - c2).abs().max() / c1.abs().max()) <= TOL
     assert torch.equal(ops.spmm_cs(Acs, Bfull[:, :602]), c2)       # deterministic
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 41, 70), (512, 128, 256), (1021, 128, 1204), (200, 300, 50),
+                                   (64, 128, 128), (31, 7, 33)])
+def test_gemm_all_transposes_vs_numpy(dev, M, N, K):
+    """fp32 MFMA GEMM vs float64 NumPy; asymmetric operands (a swapped row/col map must fail)."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    for ta in (False, True):
+        for tb in (False, True):
+            a = T(A.T.copy() if ta else A, dev)
+            b = T(B.T.copy() if tb else B, dev)
+            out = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+            assert onp.rel_err(out.cpu().numpy(), ref) <= 1e-5, (ta, tb)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    out = T(c0, dev)
+    ops.gemm(T(A, dev), T(B, dev), out=out, accumulate=True)
+    assert onp.rel_err(out.cpu().numpy(), ref + c0) <= 1e-5
+    # identity check with an asymmetric B
+    eye = T(np.eye(K, dtype=np.float32), dev)
+    np.testing.assert_array_equal(ops.gemm(eye, T(B, dev)).cpu().numpy(), B)
+
+
+@pytest.mark.parametrize("M,N,K,norm,relu", [(257, 128, 96, True, True), (40, 41, 128, False, False),
+                                             (100, 16, 20, True, True), (65, 128, 1204, False, True),
+                                             (50, 32, 64, True, False)])
+def test_dense_fwd_fused_vs_oracle(dev, M, N, K, norm, relu):
+    from stochastic_gcn_amd import ops
+    from oracle import model_np as mnp
+    rng = np.random.RandomState(M + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    off = rng.standard_normal((1, N)).astype(np.float32) * 0.1
+    sc = (1 + 0.1 * rng.standard_normal((1, N))).astype(np.float32)
+    y, ctx = ops.dense_fwd(T(X, dev), T(W, dev), T(off, dev) if norm else None, T(sc, dev) if norm else None, relu)
+    ref = (X @ W).astype(np.float32)
+    if norm:
+        ref, (xhat, rstd) = mnp.layer_norm_fwd(ref, off, sc)
+        assert onp.rel_err(ctx[0].cpu().numpy(), xhat) <= TOL
+        assert onp.rel_err(ctx[1].cpu().numpy(), rstd.ravel()) <= TOL
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert onp.rel_err(y.cpu().numpy(), ref) <= TOL
