@@ -300,7 +300,9 @@ def main():
             ", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else ""),
             "N": n, "nnz": nnz, "d": d, "per_gpu": "one S-Reddit vertex-range shard",
             "kernel": args.kernel, "tune": args.tune,
-            "kernel_launches_per_spmm": (((d + 3) // 4 + 63) // 64) * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
+            # column sweep: ceil(d/320) passes (64 float4 + <= 64 extra floats per lane row) x rounds of 4096 tiles
+            "kernel_launches_per_spmm": (-(-((d + 3) // 4 * 4) // 320) if (d + 3) // 4 > 64 else 1)
+            * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
             "cs_autotune_ms_pace": tuned},
         "roofline": {"bound": "hbm", "kernel": ("cs_spmm_kernel (column sweep, all slabs/rounds + fix-up)" if args.kernel == "cs"
                                 else "spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),

@@ -30,6 +30,7 @@ struct CsArgs {
     const int32_t* gidx; const float* rscale; const float* cscale;
     float* C; int64_t ldc; float beta;
     int32_t d, nvec, slab;
+    int32_t slab_floats;   // columns per pass of the pinned kernel: 64 float4 (+ up to 64 extra floats)
     float* ws; int64_t ldw;
     float cols_per_tick;   // pacing: columns the sweep may advance per 100 MHz tick (0 = unpaced)
     float slack_cols;      // how far ahead of the clock a wave may run
@@ -37,30 +38,39 @@ struct CsArgs {
 
 #define SGCN_CS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
-// R = 16, float4 specialisation with the accumulators PINNED to v[64:127] (x/y/z/w planes of 16
-// registers) and updated by one indexed FMA group per nonzero:
-//     s_set_gpr_idx_on lr, SRC2|DST ; 4 x v_fma_f32 v<plane>, val, b, v<plane> ; s_set_gpr_idx_off
-// i.e. 2 scalar + 4 vector instructions.  The generic kernel below lets hipcc lower `acc[e][lr]`,
-// which costs an on/off pair per extract AND per insert (16 scalar + 12 vector instructions per
-// nonzero); the CU's single scalar unit then caps the sweep (measured: ~36 CU-cycles per
-// nonzero-slab at any memory-level parallelism).
-template <int U, bool PIPE>
+// R = 16 specialisation with the accumulators PINNED to fixed VGPRs and updated by ONE indexed FMA
+// group per nonzero:
+//     s_set_gpr_idx_on lr, SRC2|DST ; v_fma_f32 v<plane>, val, b, v<plane> x 4 (or 5) ; s_set_gpr_idx_off
+// The generic kernel below lets hipcc lower `acc[e][lr]`, which costs an on/off pair per extract
+// AND per insert (16 scalar + 12 vector instructions per nonzero instead of 2 + 4).
+//
+// EXTRA: a sweep costs the same whatever the slab width (measured: 1.45 ms per pass at d = 256,
+// 512, 602 or 768 on S-Reddit), so a 602-wide row must not take three 256-float passes.  With
+// EXTRA every lane carries one more fp32 column next to its float4 -- a slab is 64 float4 + up to
+// 64 floats = up to 320 columns -- and d = 602 (pitch 608) is covered by TWO passes of 304.
+// Planes: x,y,z,w (+ e) of 16 registers each at v[64:127] (v[48:127] with EXTRA).
+template <int U, bool EXTRA>
 __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
-    constexpr int R = 16, VW = 4;
-    typedef typename Vec<VW>::type VT;
-    constexpr int kShift = (R <= 16) ? 28 : 27;                 // local row id lives above the column
+    typedef Vec<4>::type VT;
+    constexpr int kShift = 28;
     constexpr uint32_t kColMask = (1u << kShift) - 1u;
     const int lane = threadIdx.x & 63;
     const int64_t tile = a.tile_base + (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (tile >= a.tile_end) return;
-    const int vi = a.slab * kWave + lane;
-    const bool act = vi < a.nvec;
-    const uint32_t loff = (uint32_t)min(vi, a.nvec - 1) * (uint32_t)(VW * 4);
+    const int fbase = a.slab * a.slab_floats;                    // first column of this pass
+    const int f4 = fbase + lane * 4;                             // my float4
+    const bool act4 = lane * 4 < min(a.slab_floats, 256) && f4 < a.d;
+    const int fe = fbase + 256 + lane;                           // my extra column
+    const bool acte = EXTRA && lane < a.slab_floats - 256 && fe < a.d;
+    // inactive lanes re-read a valid address of the row instead of branching around the load
+    const uint32_t off4 = (uint32_t)(act4 ? f4 : fbase) * 4u;
+    const uint32_t offe = (uint32_t)(acte ? fe : fbase) * 4u;
     const char* Bb = reinterpret_cast<const char*>(a.B);
     const int64_t ldb_bytes = a.ldb * 4;
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
-    accv_t ax = {}, ay = {}, az = {}, aw = {};
+    accv_t ax = {}, ay = {}, az = {}, aw = {}, ae = {};
+
     // Clock-paced sweep: every wave of a launch starts within ~1 us and holds its column position
     // to `elapsed * cols_per_tick` on the chip-wide constant 100 MHz counter (s_memrealtime), so
     // all waves of an XCD gather from the same L2-sized window of B at the same time without
@@ -80,28 +90,35 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
             if (a.cscale) myv *= a.cscale[c];
             if (a.gidx) { c = (uint32_t)a.gidx[c]; mycr = (mycr & ~kColMask) | c; }
         }
-#define SGCN_CS_APPLY(cr, v, b)                                                             \
-    {                                                                                       \
-        const int lr_ = (int)((cr) >> kShift);                                              \
-        asm volatile("s_set_gpr_idx_on %4, 0xc\n\t"                                         \
-                     "v_fma_f32 v64, %5, %6, v64\n\t"                                       \
-                     "v_fma_f32 v80, %5, %7, v80\n\t"                                       \
-                     "v_fma_f32 v96, %5, %8, v96\n\t"                                       \
-                     "v_fma_f32 v112, %5, %9, v112\n\t"                                     \
-                     "s_set_gpr_idx_off"                                                    \
-                     : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az),            \
-                       "+{v[112:127]}"(aw)                                                  \
-                     : "s"(lr_), "s"(v), "v"((b).x), "v"((b).y), "v"((b).z), "v"((b).w));   \
-    }
-        // software pipeline over the chunk's batches of U nonzeros: the loads of batch k+1 are in
-        // flight while batch k is applied (two staging buffers), so the wave never drains its
-        // memory queue inside a chunk.
-        const int nb = n / U;                       // full batches
-        VT bufA[U], bufB[U];
-        // The clock read (s_memrealtime) is a long-latency scalar memory op: it is issued right
-        // after a batch's gathers and consumed before the NEXT batch, so its latency overlaps the
-        // loads instead of serialising every batch (the stale reading only adds look-ahead).
-        auto pace = [&](int jj) {
+        auto apply = [&](uint32_t cr, float v, VT b, float be) {
+            const int lr = (int)(cr >> kShift);
+            if constexpr (EXTRA) {
+                asm volatile("s_set_gpr_idx_on %5, 0xc\n\t"
+                             "v_fma_f32 v48, %6, %7, v48\n\t"
+                             "v_fma_f32 v64, %6, %8, v64\n\t"
+                             "v_fma_f32 v80, %6, %9, v80\n\t"
+                             "v_fma_f32 v96, %6, %10, v96\n\t"
+                             "v_fma_f32 v112, %6, %11, v112\n\t"
+                             "s_set_gpr_idx_off"
+                             : "+{v[48:63]}"(ax), "+{v[64:79]}"(ay), "+{v[80:95]}"(az), "+{v[96:111]}"(aw),
+                               "+{v[112:127]}"(ae)
+                             : "s"(lr), "s"(v), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(be));
+            } else {
+                asm volatile("s_set_gpr_idx_on %4, 0xc\n\t"
+                             "v_fma_f32 v64, %5, %6, v64\n\t"
+                             "v_fma_f32 v80, %5, %7, v80\n\t"
+                             "v_fma_f32 v96, %5, %8, v96\n\t"
+                             "v_fma_f32 v112, %5, %9, v112\n\t"
+                             "s_set_gpr_idx_off"
+                             : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw)
+                             : "s"(lr), "s"(v), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+            }
+        };
+        const int nb = n / U;
+        for (int k = 0; k < nb; k++) {
+            const int jj = k * U;
+            // The clock read is a long-latency scalar memory op: issued right after a batch's
+            // gathers, consumed before the NEXT batch (the stale reading only adds look-ahead).
             if (a.cols_per_tick > 0.f) {
                 const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj) & kColMask);
                 float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
@@ -110,66 +127,59 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
                     allowed = (float)(__builtin_amdgcn_s_memrealtime() - t0) * a.cols_per_tick + a.slack_cols;
                 }
             }
-        };
-        auto issue = [&](int jj, VT* buf) {
+            VT bb[U];
+            float be[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
-                buf[u] = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
+                const char* src = Bb + (int64_t)(cr & kColMask) * ldb_bytes;
+                bb[u] = *reinterpret_cast<const VT*>(src + off4);
+                be[u] = EXTRA ? *reinterpret_cast<const float*>(src + offe) : 0.f;
             }
             if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
-        };
-        auto apply = [&](int jj, const VT* buf) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
                 const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), jj + u));
-                const VT b = buf[u];
-                SGCN_CS_APPLY(cr, v, b)
+                apply(cr, v, bb[u], be[u]);
             }
-        };
-        if constexpr (PIPE) {
-            if (nb > 0) { pace(0); issue(0, bufA); }
-            int k = 0;
-            for (; k + 2 <= nb; k += 2) {
-                pace((k + 1) * U); issue((k + 1) * U, bufB);
-                apply(k * U, bufA);
-                if (k + 2 < nb) { pace((k + 2) * U); issue((k + 2) * U, bufA); }
-                apply((k + 1) * U, bufB);
-            }
-            if (k < nb) apply(k * U, bufA);
-        } else {
-            for (int k = 0; k < nb; k++) { pace(k * U); issue(k * U, bufA); apply(k * U, bufA); }
         }
         for (int j = nb * U; j < n; j++) {
             const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, j);
             const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), j));
-            const VT b = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
-            SGCN_CS_APPLY(cr, v, b)
+            const char* src = Bb + (int64_t)(cr & kColMask) * ldb_bytes;
+            const VT b = *reinterpret_cast<const VT*>(src + off4);
+            const float e1 = EXTRA ? *reinterpret_cast<const float*>(src + offe) : 0.f;
+            apply(cr, v, b, e1);
         }
-#undef SGCN_CS_APPLY
     }
 
-    if (!act) return;
-    const int32_t* rows = a.tile_rows + tile * R;
-    const int32_t* slots = a.tile_slots + tile * R;
-    const int left = a.d - vi * VW;
+    const int32_t* rows = a.tile_rows + tile * 16;
+    const int32_t* slots = a.tile_slots + tile * 16;
+    const int left = a.d - f4;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r < 16; r++) {
         const int row = rows[r];
         if (row < 0) continue;
         const VT accv = {ax[r], ay[r], az[r], aw[r]};
+        const float acce = ae[r];
         const int slot = slots[r];
         if (slot >= 0) {
-            vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accv);
+            float* w = a.ws + (int64_t)slot * a.ldw;
+            if (act4) vstore<4>(w + f4, accv);
+            if (acte) w[fe] = acce;
         } else {
-            float* out = a.C + (int64_t)row * a.ldc + (int64_t)vi * VW;
-            VT res = accv * (a.rscale ? a.rscale[row] : 1.0f);
-            if (a.beta != 0.f) {
-                if (left >= VW) res += a.beta * vload<VW>(out);
-                else for (int e = 0; e < left; e++) { if constexpr (VW == 1) res += a.beta * out[0]; else res[e] += a.beta * out[e]; }
+            float* out = a.C + (int64_t)row * a.ldc;
+            const float rs = a.rscale ? a.rscale[row] : 1.0f;
+            if (act4) {
+                VT res = accv * rs;
+                if (a.beta != 0.f) {
+                    if (left >= 4) res += a.beta * vload<4>(out + f4);
+                    else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
+                }
+                if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
             }
-            if (left >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left);
+            if (acte) out[fe] = acce * rs + (a.beta != 0.f ? a.beta * out[fe] : 0.f);
         }
     }
 }
@@ -370,7 +380,21 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     const int pace_ns_per_nnz = plan->pace_ns_per_nnz != 0 ? (plan->pace_ns_per_nnz < 0 ? 0 : plan->pace_ns_per_nnz)
                                                            : tune_get("cs_pace");
     const int slack = tune_get("cs_slack") > 0 ? tune_get("cs_slack") : 512;
-    const int nslab = (a.nvec + kWave - 1) / kWave;
+    int nslab = (a.nvec + kWave - 1) / kWave;
+    const bool pinned = plan->R == 16 && tune_get("cs_generic") <= 0;
+    bool extra = false;
+    a.slab_floats = 256;
+    if (pinned) {
+        // a pass costs the same whatever its width: cover d in ceil(d / 320) passes of
+        // (64 float4 + extra floats) instead of ceil(d / 256) passes of 64 float4
+        const int dp = (d + 3) / 4 * 4;
+        const int np = (dp + 319) / 320;
+        if (np < nslab && tune_get("cs_noextra") <= 0) {
+            nslab = np;
+            a.slab_floats = ((dp + np - 1) / np + 3) / 4 * 4;
+            extra = a.slab_floats > 256;
+        }
+    }
     for (int slab = 0; slab < nslab; slab++) {
         a.slab = slab;
         for (int64_t t0 = 0; t0 < plan->ntiles; t0 += round) {
@@ -385,11 +409,12 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
 #define SGCN_CS_LAUNCH(RR, VV, UU, PP) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU, PP>), dim3(blocks), dim3(kBlock), 0, st, a)
             const bool pipe = tune_get("cs_pipe") > 0;
-#define SGCN_CS16(UU, PP) hipLaunchKernelGGL((cs_spmm16_kernel<UU, PP>), dim3(blocks), dim3(kBlock), 0, st, a)
-            if (plan->R == 16 && tune_get("cs_generic") <= 0) {
-                if (U == 4) { if (pipe) SGCN_CS16(4, true); else SGCN_CS16(4, false); }
-                else if (U == 16) SGCN_CS16(16, false);
-                else { if (pipe) SGCN_CS16(8, true); else SGCN_CS16(8, false); }
+#define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
+            (void)pipe;
+            if (pinned) {
+                // EXTRA at U = 8 needs 142 VGPRs (3 waves/SIMD, breaks the 4096-tile residency): U = 4
+                if (extra) { if (tune_get("cs_unroll") == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
+                else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }
             } else if (plan->R == 8) {
                 if (U == 4) SGCN_CS_LAUNCH(8, 4, 4, false); else SGCN_CS_LAUNCH(8, 4, 8, false);
             } else if (plan->R == 16) {
