@@ -95,10 +95,10 @@ def next_minibatch(sch, batch_size, slot=None):
     staging slot), wrapping to the start of the (already shuffled) shard when it runs out: in a
     multi-GPU job every rank must take the same number of steps per epoch, and vertex-range
     shards hold slightly different numbers of train ids."""
-    fd = sch.minibatch_packed(batch_size, 0, slot)
+    fd = sch.minibatch_packed(batch_size, FLAGS.plan_t, slot)
     if fd is None:
         sch.start = 0
-        fd = sch.minibatch_packed(batch_size, 0, slot)
+        fd = sch.minibatch_packed(batch_size, FLAGS.plan_t, slot)
     return fd
 
 
@@ -180,7 +180,7 @@ class Trainer(object):
         k = 0
         for start in range(0, N, FLAGS.test_batch_size):
             end = min(start + FLAGS.test_batch_size, N)
-            batch = self.eval_sch.batch_packed(data[start:end], 0, self.eval_slots[k % len(self.eval_slots)])
+            batch = self.eval_sch.batch_packed(data[start:end], FLAGS.plan_t, self.eval_slots[k % len(self.eval_slots)])
             k += 1
             los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
             stats.append(torch.stack([los, acc]) * prd.shape[0])

@@ -342,3 +342,23 @@ def test_dense_fwd_fused_vs_oracle(dev, M, N, K, norm, relu):
     if relu:
         ref = np.maximum(ref, 0)
     assert onp.rel_err(y.cpu().numpy(), ref) <= TOL
+
+
+@pytest.mark.parametrize("d,pad", [(300, 4), (320, 0), (330, 6), (602, 6), (700, 4), (260, 0)])
+def test_column_sweep_extra_plane_widths(dev, d, pad):
+    """Widths around the 256 / 320-column pass boundaries of the pinned sweep kernel (64 float4 +
+    up to 64 extra fp32 columns per pass), incl. ragged last vectors and pitch padding."""
+    from stochastic_gcn_amd import ops
+    a = rand_csr(400, 350, 0.06, d, long_rows=[(5, 300)])
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((350, d + pad)).astype(np.float32)
+    A = ops.ColumnSweepCSR(a, dev, T=40)
+    out_full = torch.full((400, d + pad), 3.0, device=dev)
+    ops.spmm_cs(A, T(B, dev)[:, :d], out=out_full[:, :d])
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    assert onp.rel_err(out_full[:, :d].cpu().numpy(), ref) <= TOL
+    if pad:
+        assert torch.all(out_full[:, d:] == 3.0)
+    A.pace[d] = 300                                   # paced and unpaced sweeps agree bit for bit
+    o2 = ops.spmm_cs(A, T(B, dev)[:, :d])
+    assert torch.equal(o2, out_full[:, :d])
