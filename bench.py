@@ -53,7 +53,7 @@ def parse():
     p.add_argument("--cs-t", type=int, default=0)
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
-    p.add_argument("--cs-r", type=int, default=16, choices=[8, 16, 32])
+    p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
     return p.parse_args()

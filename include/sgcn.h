@@ -117,8 +117,10 @@ int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K, int32_t d,
                      float* dev_C, int64_t ldc, float beta, void* stream);
 
 /* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
- *   "spmm_nv"   : float4 vectors per lane for wide rows (0 = auto)
- *   "spmm_unroll": nonzeros in flight per group (1,2,4,8; 0 = auto) */
+ *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)
+ *   cs_round (tiles per launch), cs_unroll (4|8), cs_pace (ns per nonzero of the heaviest tile,
+ *   0 = unpaced), cs_slack (columns), cs_generic (compiler-lowered indexing instead of the pinned
+ *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane) : column-sweep kernel */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */
 

@@ -34,7 +34,6 @@ int g_tune_cs_round = 0;
 int g_tune_cs_unroll = 0;
 int g_tune_cs_pace = 0;
 int g_tune_cs_slack = 0;
-int g_tune_cs_pipe = 0;
 int g_tune_cs_generic = 0;
 int g_tune_cs_noextra = 0;
 }  // namespace
@@ -47,7 +46,6 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_unroll")) return g_tune_cs_unroll;
     if (!strcmp(key, "cs_pace")) return g_tune_cs_pace;
     if (!strcmp(key, "cs_slack")) return g_tune_cs_slack;
-    if (!strcmp(key, "cs_pipe")) return g_tune_cs_pipe;
     if (!strcmp(key, "cs_generic")) return g_tune_cs_generic;
     if (!strcmp(key, "cs_noextra")) return g_tune_cs_noextra;
     return -1;
@@ -259,12 +257,11 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "spmm_slabmajor")) { g_tune_slabmajor = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_pace")) { SGCN_REQUIRE(value >= 0, "cs_pace >= 0"); g_tune_cs_pace = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_slack")) { SGCN_REQUIRE(value >= 0, "cs_slack >= 0"); g_tune_cs_slack = (int)value; return SGCN_OK; }
-    if (!strcmp(key, "cs_pipe")) { g_tune_cs_pipe = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_generic")) { g_tune_cs_generic = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_noextra")) { g_tune_cs_noextra = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_unroll")) {
-        SGCN_REQUIRE(value == 0 || value == 4 || value == 8 || value == 16 || value == 32, "cs_unroll in {0,4,8,16,32}");
+        SGCN_REQUIRE(value == 0 || value == 4 || value == 8, "cs_unroll in {0,4,8}");
         g_tune_cs_unroll = (int)value; return SGCN_OK;
     }
     return fail(SGCN_ERR_INVALID, "sgcn_tune: unknown key '%s'", key);

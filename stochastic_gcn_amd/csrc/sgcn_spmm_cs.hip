@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     }
 }
 
-template <int R, int VW, int U, bool PIPE>
+template <int R, int VW, int U>
 __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
     typedef typename Vec<VW>::type VT;
     constexpr int kShift = (R <= 16) ? 28 : 27;                 // local row id lives above the column
@@ -232,11 +232,9 @@ __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
         _Pragma("unroll") for (int e_ = 0; e_ < VW; e_++)                                  \
             acc[e_][lr_] += (v) * velem<VW>((b), e_);                                      \
     }
-        // software pipeline over the chunk's batches of U nonzeros: the loads of batch k+1 are in
-        // flight while batch k is applied (two staging buffers), so the wave never drains its
-        // memory queue inside a chunk.
+        // batches of U nonzeros: U gathers in flight, then U accumulations
         const int nb = n / U;                       // full batches
-        VT bufA[U], bufB[U];
+        VT bufA[U];
         // The clock read (s_memrealtime) is a long-latency scalar memory op: it is issued right
         // after a batch's gathers and consumed before the NEXT batch, so its latency overlaps the
         // loads instead of serialising every batch (the stale reading only adds look-ahead).
@@ -267,19 +265,7 @@ __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
                 SGCN_CS_APPLY(cr, v, b)
             }
         };
-        if constexpr (PIPE) {
-            if (nb > 0) { pace(0); issue(0, bufA); }
-            int k = 0;
-            for (; k + 2 <= nb; k += 2) {
-                pace((k + 1) * U); issue((k + 1) * U, bufB);
-                apply(k * U, bufA);
-                if (k + 2 < nb) { pace((k + 2) * U); issue((k + 2) * U, bufA); }
-                apply((k + 1) * U, bufB);
-            }
-            if (k < nb) apply(k * U, bufA);
-        } else {
-            for (int k = 0; k < nb; k++) { pace(k * U); issue(k * U, bufA); apply(k * U, bufA); }
-        }
+        for (int k = 0; k < nb; k++) { pace(k * U); issue(k * U, bufA); apply(k * U, bufA); }
         for (int j = nb * U; j < n; j++) {
             const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, j);
             const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), j));
@@ -350,7 +336,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
                                 float beta, void* stream) {
     SGCN_REQUIRE(plan && M >= 0 && K >= 0 && d >= 0, "spmm_cs: bad argument");
     if (M == 0 || d == 0) return SGCN_OK;
-    SGCN_REQUIRE(plan->R == 8 || plan->R == 16 || plan->R == 32, "spmm_cs: R must be 8, 16 or 32");
+    SGCN_REQUIRE(plan->R == 16 || plan->R == 32, "spmm_cs: R must be 16 or 32");
     SGCN_REQUIRE(plan->dev_tile_ptr && plan->dev_tile_rows && plan->dev_tile_slots && B && C,
                  "spmm_cs: null operand");
     SGCN_REQUIRE(K < (1 << (plan->R <= 16 ? 28 : 27)), "spmm_cs: K too large for the packed column word");
@@ -407,27 +393,16 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
                 a.cols_per_tick = (float)((double)K / (launch_ns / 10.0));   // 100 MHz: 10 ns per tick
             }
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
-#define SGCN_CS_LAUNCH(RR, VV, UU, PP) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU, PP>), dim3(blocks), dim3(kBlock), 0, st, a)
-            const bool pipe = tune_get("cs_pipe") > 0;
+#define SGCN_CS_LAUNCH(RR, VV, UU) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU>), dim3(blocks), dim3(kBlock), 0, st, a)
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
-            (void)pipe;
             if (pinned) {
                 // EXTRA at U = 8 needs 142 VGPRs (3 waves/SIMD, breaks the 4096-tile residency): U = 4
                 if (extra) { if (tune_get("cs_unroll") == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }
-            } else if (plan->R == 8) {
-                if (U == 4) SGCN_CS_LAUNCH(8, 4, 4, false); else SGCN_CS_LAUNCH(8, 4, 8, false);
-            } else if (plan->R == 16) {
-                if (U == 4) SGCN_CS_LAUNCH(16, 4, 4, false);
-                else if (U == 16) SGCN_CS_LAUNCH(16, 4, 16, false);
-                else SGCN_CS_LAUNCH(16, 4, 8, false);
-            } else if (U == 16) {
-                SGCN_CS_LAUNCH(32, 2, 16, false);
-            } else if (U == 32) {
-                SGCN_CS_LAUNCH(32, 2, 32, false);
-            } else {
-                if (U == 4) { if (pipe) SGCN_CS_LAUNCH(32, 2, 4, true); else SGCN_CS_LAUNCH(32, 2, 4, false); }
-                else { if (pipe) SGCN_CS_LAUNCH(32, 2, 8, true); else SGCN_CS_LAUNCH(32, 2, 8, false); }
+            } else if (plan->R == 16) {         // generic (hipcc-lowered indexing) reference path
+                if (U == 4) SGCN_CS_LAUNCH(16, 4, 4); else SGCN_CS_LAUNCH(16, 4, 8);
+            } else {                            // 32-row tiles, float2 per lane
+                if (U == 4) SGCN_CS_LAUNCH(32, 2, 4); else SGCN_CS_LAUNCH(32, 2, 8);
             }
 #undef SGCN_CS_LAUNCH
 #undef SGCN_CS16
