@@ -298,6 +298,13 @@ class Model(object):
         return []
 
     # ---- backward -------------------------------------------------------------------------
+    def _gate(self, name, pre):
+        """ReLU gate.  `relu_gate_hook(name, pre) -> bool array` lets a test take the gate of the
+        implementation under test where `pre` sits within fp32 rounding of the kink (there the
+        sign, and with it the whole gradient column, is decided by summation order)."""
+        hook = getattr(self, 'relu_gate_hook', None)
+        return (pre > 0) if hook is None else hook(name, pre)
+
     def backward(self, dout):
         grads = {k: np.zeros_like(v) for k, v in self.params.items()}
         g = dout
@@ -307,7 +314,7 @@ class Model(object):
                 _, s, xin, ctx, pre = rec
                 _, name, fin, fout, sparse_in, relu, norm = s
                 if relu:
-                    g = (g * (pre > 0)).astype(f32)
+                    g = (g * self._gate(name, pre)).astype(f32)
                 if norm:
                     g, doff, dsc = layer_norm_bwd(g, ctx, self.params[name + '/scale'])
                     grads[name + '/offset'] += doff
@@ -326,7 +333,7 @@ class Model(object):
             elif kind == 'add':
                 _, s, xd, m, keep, ctx, xs_n = rec
                 _, name, fin, fout, sparse_in, norm = s
-                g = (g * (xs_n > 0)).astype(f32)                   # only the x stream carries grad
+                g = (g * self._gate(name, xs_n)).astype(f32)       # only the x stream carries grad
                 if norm:
                     g, doff, dsc = layer_norm_bwd(g, ctx, self.params[name + '/scale'])
                     grads[name + '/offset'] += doff
@@ -351,6 +358,8 @@ class Model(object):
                 if concat:
                     dx[:adj.shape[0]] += g[:, :d]
                 g = dx.astype(f32)
+            if getattr(self, 'gtrace', None) is not None:          # test hook: dL/d(input) per record
+                self.gtrace.append((kind, g))
         wd = f32(self.flags['weight_decay'])
         for k in self._wd_names():
             grads[k] += wd * self.params[k]
