@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--tune", action="append", default=[], help="key=value passed to sgcn_tune")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true")
+    p.add_argument("--epoch-timeout", type=int, default=240, help="watchdog of the train-epoch leg, s")
     p.add_argument("--no-backward", action="store_true")
     p.add_argument("--kernel", default="cs", choices=["rows", "cs"],
                    help="rows = row-gather SpMM (sgcn_spmm.hip); cs = column-sweep (sgcn_spmm_cs.hip)")
@@ -252,6 +253,8 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    ev_ar = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(args.steps)] if world > 1 else []
 
     def step(i=None):
         if i is not None:
@@ -262,7 +265,11 @@ def main():
         if not args.no_backward:
             mm(A.transpose, dC, out=dX)
         if world > 1:
+            if i is not None:
+                ev_ar[i][0].record()
             dist.all_reduce(grad)
+            if i is not None:
+                ev_ar[i][1].record()
 
     for _ in range(args.warmup):
         step()
@@ -281,11 +288,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ar])) if ev_ar else None
     edges_per_step = nnz * (1 if args.no_backward else 2)
     value = edges_per_step * world * args.steps / el
     bytes_alg = nnz * 8 + (n + 1) * 4 + 2 * n * d * 4
@@ -299,7 +302,7 @@ def main():
             "" if args.no_backward else " + bwd A^T.dC", d, pitch,
             ", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else ""),
             "N": n, "nnz": nnz, "d": d, "per_gpu": "one S-Reddit vertex-range shard",
-            "kernel": args.kernel, "tune": args.tune,
+            "kernel": args.kernel, "tune": args.tune, "grad_allreduce_ms": ar_ms,
             # column sweep: ceil(d/320) passes (64 float4 + <= 64 extra floats per lane row) x rounds of 4096 tiles
             "kernel_launches_per_spmm": (-(-((d + 3) // 4 * 4) // 320) if (d + 3) // 4 > 64 else 1)
             * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
@@ -318,15 +321,46 @@ def main():
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
             tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
-    if not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
         if data10 is not None:
             out["cpu_baseline"]["sampler"] = sampler_baseline(data10)
-    if world == 1 and not args.no_epoch and data10 is not None:
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+    if not args.no_epoch and data10 is not None:
+        # the minibatch training epoch, on every rank (vertex-range shards, RCCL gradient
+        # all-reduce + history exchange when N > 1).  A watchdog bounds a wedged collective: the
+        # SpMM line above is still printed.
+        import threading
+
+        def bail():
+            out["train_epoch"] = {"error": "timed out after %d s" % args.epoch_timeout}
+            emit()
+            os._exit(0)
+        dog = threading.Timer(args.epoch_timeout, bail)
+        dog.daemon = True
+        dog.start()
         del A, Xp, dCp, X, dC, C, dX
         torch.cuda.empty_cache()
-        out["train_epoch"] = train_epoch_leg(data10, dev)
-    print(json.dumps(out), flush=True)
+        try:
+            if rank != 0:       # data parallelism needs ONE graph, replicated: rank 0's (seed 1)
+                data10 = make_graph(args, 0)[3]
+            te = train_epoch_leg(data10, dev)
+            if world > 1:
+                t = torch.tensor([te["epoch_time_s"]], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                te["epoch_time_s"] = float(t.item())
+                te["ms_per_step"] = te["epoch_time_s"] / te["steps"] * 1e3
+                te["agg_edges_per_s"] = None
+                te["sharding"] = "train ids by vertex range over %d ranks; global batch %d" % (world, 512 * world)
+            out["train_epoch"] = te
+        except Exception as e:      # the headline SpMM measurement must survive this leg
+            out["train_epoch"] = {"error": repr(e)}
+        dog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

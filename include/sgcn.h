@@ -156,7 +156,8 @@ int sgcn_vr_aggregate_f32(const int32_t* dev_a_rowptr, const int32_t* dev_a_col,
 int sgcn_gather_rows_f32(const float* dev_in, int64_t ldi, const int32_t* dev_r, int32_t n,
                          int32_t d, float* dev_out, int64_t ldo, void* stream);
 
-/* H[r[i], 0:d] = src[i, 0:d]   (r unique)       replaces tf.scatter_update gcn/models.py:165 */
+/* H[r[i], 0:d] = src[i, 0:d]   (r unique)       replaces tf.scatter_update gcn/models.py:165
+ * r[i] < 0 skips row i (padding of the fixed-capacity multi-GPU history exchange). */
 int sgcn_scatter_rows_f32(float* dev_H, int64_t ldh, const int32_t* dev_r, int32_t n,
                           int32_t d, const float* dev_src, int64_t lds, void* stream);
 

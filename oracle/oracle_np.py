@@ -96,8 +96,11 @@ def gather_rows(a, r):
 
 
 def scatter_rows(H, r, src):
-    """tf.scatter_update(H, ifield, new) (gcn/models.py:160-166); r unique. In place."""
-    H[_i32(r)] = _f32(src)
+    """tf.scatter_update(H, ifield, new) (gcn/models.py:160-166); r unique. In place.
+    Negative ids are padding and skipped (include/sgcn.h sgcn_scatter_rows_f32)."""
+    r = _i32(r)
+    keep = r >= 0
+    H[r[keep]] = _f32(src)[keep]
     return H
 
 

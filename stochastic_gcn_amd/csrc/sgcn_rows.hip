@@ -2,7 +2,8 @@
 //   gather  : out[i,:] = in[r[i],:]      replaces history.dense_slice (gcn/_history.pyx:53-62,
 //             gcn/history.cpp:74-88: single-thread scalar host loop, then a host->device feed
 //             every step) and tf.gather(history, field) (gcn/layers.py:304-305)
-//   scatter : H[r[i],:] = src[i,:]       replaces tf.scatter_update (gcn/models.py:160-166)
+//   scatter : H[r[i],:] = src[i,:]       replaces tf.scatter_update (gcn/models.py:160-166);
+//             r[i] < 0 skips row i (fixed-capacity multi-GPU history exchange pads with -1)
 //   slice   : CSR rows r -> CSR          replaces history.slice (gcn/_history.pyx:25-51,
 //             gcn/history.cpp:50-72)
 // All three are pure HBM copies: one G-lane group per row moving 16-byte vectors, so a
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const float* __restrict__ 
     const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
     if (i >= n) return;
     const int64_t ri = r[i];
+    if (SCATTER && ri < 0) return;          // negative row id: padding slot, nothing to write
     const float* src = in + (SCATTER ? i : ri) * ldi;
     float* dst = out + (SCATTER ? ri : i) * ldo;
     for (int vi = lig; vi < nvec; vi += G) {

@@ -25,11 +25,15 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
+    HISTORY_FIXED_LIMIT_BYTES = 16 << 20     # per-rank payload above which the bound is too loose
+
     def __init__(self, backend=None, device=None, init=True):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
+        self.history_cap = None          # upper bound of |fields[l]| per step (rows), or None
+        self._hist_bufs = {}
         if self.world > 1 and init and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -90,27 +94,43 @@ class DataParallel(object):
 
     def sync_history(self, history, idx, rows, scatter_fn):
         """All-gather this step's (idx[n], rows[n x d]) and apply every rank's update to the local
-        replica ``history`` in rank order.  One size exchange + one payload exchange: the int32
-        row ids travel bit-cast in an extra fp32 column."""
+        replica ``history`` in rank order.
+
+        Fixed-capacity path (``history_cap`` rows, set by the trainer from batch size and
+        degrees): ONE all-gather of a preallocated int32 buffer ``[cap ids | cap x d row bits]``
+        per rank, ids padded with -1 (the scatter kernel skips them) -- no size exchange, no
+        host synchronisation, so the step stays asynchronous.  Without a bound: a size exchange
+        (one host sync) followed by a padded all-gather."""
         if not self.active:
             scatter_fn(history, idx, rows)
             return
         dev = rows.device
-        n, d = rows.shape
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-        dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
-        sizes = [int(s.item()) for s in sizes]
-        cap = max(sizes)
-        payload = torch.zeros((cap, d + 1), dtype=torch.float32, device=dev)
-        payload[:n, :d] = rows
-        payload[:n, d] = idx.view(torch.float32)
-        gathered = [torch.empty_like(payload) for _ in range(self.world)]
-        dist.all_gather(gathered, payload)
+        n, d = int(rows.shape[0]), int(rows.shape[1])
+        cap = self.history_cap
+        if cap is not None and n > cap:      # a rank-local branch here would desynchronise the ranks
+            raise RuntimeError("history exchange: %d rows exceed history_cap=%d" % (n, cap))
+        if cap is None or cap * (d + 1) * 4 > self.HISTORY_FIXED_LIMIT_BYTES:
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+            dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
+            cap = max(int(s.item()) for s in sizes)
+            bufs = None
+        else:
+            bufs = self._hist_bufs.get((cap, d, dev))
+        if bufs is None:
+            send = torch.empty(cap * (d + 1), dtype=torch.int32, device=dev)
+            recv = torch.empty(self.world * cap * (d + 1), dtype=torch.int32, device=dev)
+            bufs = (send, recv)
+            if self.history_cap is not None and cap == self.history_cap:
+                self._hist_bufs[(cap, d, dev)] = bufs
+        send, recv = bufs
+        send[:n] = idx
+        send[n:cap] = -1
+        send[cap:].view(torch.float32).view(cap, d)[:n] = rows
+        per = cap * (d + 1)
+        dist.all_gather([recv[r * per:(r + 1) * per] for r in range(self.world)], send)
         for r in range(self.world):
-            m = sizes[r]
-            if m:
-                scatter_fn(history, gathered[r][:m, d].contiguous().view(torch.int32),
-                           gathered[r][:m, :d])
+            blk = recv[r * per:(r + 1) * per]
+            scatter_fn(history, blk[:cap], blk[cap:].view(torch.float32).view(cap, d))
 
     def shutdown(self):
         if self.active and dist.is_initialized():

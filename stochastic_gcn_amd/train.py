@@ -154,6 +154,12 @@ class Trainer(object):
         if par.active:
             par.attach(self.train_model)
             self.train_d = par.shard_ids(train_d, num_data).astype(np.int32)
+            # |fields[l]| <= batch * prod(1 + degree): lets the history exchange run without a
+            # size round-trip (parallel.DataParallel.sync_history)
+            bound = int(FLAGS.batch_size)
+            for _ in range(L):
+                bound = min(int(num_data), bound * (1 + int(FLAGS.degree)))
+            par.history_cap = bound
 
         train_degrees = np.array([FLAGS.degree] * L, dtype=np.int32)
         test_degrees = np.array([FLAGS.test_degree] * test_L, dtype=np.int32)

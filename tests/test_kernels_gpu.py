@@ -186,6 +186,14 @@ def test_gather_scatter_rows(dev, d, pad):
     want = a.copy()
     onp.scatter_rows(want[:, :d], r, src)
     np.testing.assert_array_equal(Hd.cpu().numpy(), want)      # padding columns untouched
+    # negative ids are padding slots of the fixed-capacity multi-GPU history exchange: skipped
+    r2 = r.copy()
+    r2[::3] = -1
+    Hd2 = T(a, dev)
+    ops.scatter_rows(Hd2[:, :d], T(r2, dev), T(src, dev))
+    want2 = a.copy()
+    onp.scatter_rows(want2[:, :d], r2, src)
+    np.testing.assert_array_equal(Hd2.cpu().numpy(), want2)
 
 
 def test_gather_rows_golden_dense_slice(dev):

@@ -67,12 +67,18 @@ def w_history(par):
 
     def scatter(h, i, r):
         onp.scatter_rows(h.numpy(), i.numpy(), r.numpy())
-    par.sync_history(H, torch.from_numpy(idx), torch.from_numpy(rows), scatter)
-    return dict(H=H.numpy(), idx=idx, rows=rows)
+    par.sync_history(H, torch.from_numpy(idx), torch.from_numpy(rows), scatter)    # size-exchange path
+    H2 = torch.zeros((N, d))
+    par.history_cap = 12                                   # fixed-capacity path (-1 padded ids)
+    par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows), scatter)
+    par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows), scatter)   # reuses its buffers
+    par.history_cap = None
+    return dict(H=H.numpy(), H2=H2.numpy(), idx=idx, rows=rows)
 
 
 def w_train_step(par):
     import model_cases as mc
+    from oracle import oracle_np as onp
     from stochastic_gcn_amd.scheduler import PyScheduler
     case = mc.build_case('reddit_cvd_pp')
     fl, c, ph = case['flags'], case['cfg'], case['ph']
@@ -97,7 +103,7 @@ def w_train_step(par):
         om.adam_step(grads)
         hist = torch.from_numpy(om.history[0])
         par.sync_history(hist, torch.from_numpy(feed[ph['fields'][0]]), torch.from_numpy(om._new_hist[0]),
-                         lambda h, i, r: h.numpy().__setitem__(i.numpy(), r.numpy()))
+                         lambda h, i, r: onp.scatter_rows(h.numpy(), i.numpy(), r.numpy()))
         out["avg_grad%d" % step] = flat.numpy().copy()
     out["theta"] = np.concatenate([om.params[k].ravel() for k in names])
     out["hist"] = om.history[0]
@@ -127,6 +133,8 @@ def test_history_sync_is_replica_consistent_and_rank_ordered(tmp_path):
         want[x["idx"]] = x["rows"]
     np.testing.assert_array_equal(r[0]["H"], want)
     np.testing.assert_array_equal(want[5], r[1]["rows"][0])         # higher rank wins the conflict
+    np.testing.assert_array_equal(r[0]["H2"], want)                 # fixed-capacity path, -1 padding
+    np.testing.assert_array_equal(r[1]["H2"], want)
 
 
 def test_two_rank_training_step_matches_mean_gradient(tmp_path):
