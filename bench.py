@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
+    p.add_argument("--shard", choices=["resident", "allgather"], default=None,
+                   help="STRONG scaling: ONE graph row-block sharded over the ranks (nnz-balanced), dense "
+                        "operand resident on every GPU or all-gathered per product (SURVEY.md 8e)")
     return p.parse_args()
 
 
@@ -217,7 +220,7 @@ def main():
         k, v = kv.split("=")
         _ffi.tune(k, int(v))
 
-    n, full_adj, wname, data10 = make_graph(args, rank)
+    n, full_adj, wname, data10 = make_graph(args, 0 if args.shard else rank)
     if args.colmod:
         import scipy.sparse as sp
         coo = full_adj.tocoo()
@@ -227,7 +230,13 @@ def main():
     d = args.d
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
-    if args.kernel == "cs":
+    sh = None
+    if args.shard:
+        from stochastic_gcn_amd.parallel import DataParallel, ShardedSpMM
+        sh = ShardedSpMM(DataParallel(device=dev, init=False), full_adj, dev, kernel=args.kernel,
+                         with_transpose=not args.no_backward)
+        A = sh.A
+    elif args.kernel == "cs":
         A = ops.ColumnSweepCSR(full_adj, dev, R=args.cs_r, T=args.cs_t)
         A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, R=args.cs_r, T=args.cs_t)
         mm = ops.spmm_cs
@@ -244,7 +253,15 @@ def main():
     C = torch.zeros((n, pitch), device=dev)[:, :d]
     dX = torch.zeros((n, pitch), device=dev)[:, :d]
     tuned = None
-    if args.kernel == "cs" and not any(kv.startswith("cs_pace") for kv in args.tune):
+    if sh is not None:
+        gen.manual_seed(1234)                      # one B / dC for the whole job
+        Xp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
+        dCp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
+        if args.kernel == "cs" and not any(kv.startswith("cs_pace") for kv in args.tune):
+            sh.autotune(X, None if args.no_backward else dC)
+        C, dX = C[sh.lo:sh.hi], dX[sh.lo:sh.hi]
+        Xl, dCl = X[sh.lo:sh.hi].contiguous(), dC[sh.lo:sh.hi].contiguous()
+    elif args.kernel == "cs" and not any(kv.startswith("cs_pace") for kv in args.tune):
         tuned = {"fwd": A.autotune(X)}                  # untimed setup, once per plan and width
         if not args.no_backward:
             tuned["bwd"] = A.transpose.autotune(dC)
@@ -254,9 +271,22 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     ev_ar = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-             for _ in range(args.steps)] if world > 1 else []
+             for _ in range(args.steps)] if (world > 1 and not args.shard) else []
+
+    def step_sharded(i=None):
+        gather = args.shard == "allgather"
+        Bf = sh.allgather_rows(Xl) if gather else X
+        if i is not None:
+            ev[i][0].record()
+        sh.forward(Bf, out=C)
+        if i is not None:
+            ev[i][1].record()
+        if not args.no_backward:
+            sh.backward(sh.allgather_rows(dCl) if gather else dC, out=dX)
 
     def step(i=None):
+        if sh is not None:
+            return step_sharded(i)
         if i is not None:
             ev[i][0].record()
         mm(A, X, out=C)
@@ -290,18 +320,26 @@ def main():
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ar])) if ev_ar else None
     edges_per_step = nnz * (1 if args.no_backward else 2)
-    value = edges_per_step * world * args.steps / el
+    value = edges_per_step * (1 if sh is not None else world) * args.steps / el
     bytes_alg = nnz * 8 + (n + 1) * 4 + 2 * n * d * 4
+    if sh is not None:      # this rank's row block: its nonzeros, its C rows, every referenced B row
+        nnz_l, m_l = sh.local_nnz, sh.hi - sh.lo
+        bytes_alg = nnz_l * 8 + (m_l + 1) * 4 + min(n, nnz_l) * d * 4 + m_l * d * 4
     achieved = bytes_alg / (fwd_ms * 1e-3)
     out = {
         "metric": "training edges/s (SpMM)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if sh is not None else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wname + ", fwd A.X%s, d=%d (pitch %d)%s" % (
             "" if args.no_backward else " + bwd A^T.dC", d, pitch,
-            ", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else ""),
-            "N": n, "nnz": nnz, "d": d, "per_gpu": "one S-Reddit vertex-range shard",
+            (", + all-gather of the dense operand per product" if args.shard == "allgather" else "") if sh is not None
+            else (", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else "")),
+            "N": n, "nnz": nnz, "d": d,
+            "per_gpu": ("nnz-balanced row block of ONE graph, dense operand %s; rank 0 rows [%d, %d), %d nnz"
+                        % (args.shard, sh.lo, sh.hi, sh.local_nnz)) if sh is not None
+            else "one S-Reddit vertex-range shard",
             "kernel": args.kernel, "tune": args.tune, "grad_allreduce_ms": ar_ms,
             # column sweep: ceil(d/320) passes (64 float4 + <= 64 extra floats per lane row) x rounds of 4096 tiles
             "kernel_launches_per_spmm": (-(-((d + 3) // 4 * 4) // 320) if (d + 3) // 4 > 64 else 1)
@@ -312,11 +350,13 @@ def main():
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
                      "traffic": None, "traffic_source": None, "bytes_alg_per_launch": bytes_alg,
-                     "ms_per_launch": fwd_ms, "edges_per_s_fwd": nnz / (fwd_ms * 1e-3),
-                     "gather_model_GBps": (nnz * (d * 4 + 8) + n * d * 4) / (fwd_ms * 1e-3) / 1e9},
+                     "ms_per_launch": fwd_ms,
+                     "edges_per_s_fwd": (sh.local_nnz if sh is not None else nnz) / (fwd_ms * 1e-3),
+                     "gather_model_GBps": (nnz * (d * 4 + 8) + n * d * 4) / (fwd_ms * 1e-3) / 1e9
+                     if sh is None else None},
     }
     tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
-        if not args.tune else None
+        if not (args.tune or sh is not None) else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
@@ -330,7 +370,7 @@ def main():
         if rank == 0:
             print(json.dumps(out), flush=True)
 
-    if not args.no_epoch and data10 is not None:
+    if not args.no_epoch and data10 is not None and sh is None:
         # the minibatch training epoch, on every rank (vertex-range shards, RCCL gradient
         # all-reduce + history exchange when N > 1).  A watchdog bounds a wedged collective: the
         # SpMM line above is still printed.

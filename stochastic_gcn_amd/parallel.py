@@ -135,3 +135,110 @@ class DataParallel(object):
     def shutdown(self):
         if self.active and dist.is_initialized():
             dist.destroy_process_group()
+
+
+# ---- row-block sharded full-graph SpMM (SURVEY.md §8e "Full-graph SpMM", BASELINE configs 4/5) ----
+def partition_rows_by_nnz(indptr, world):
+    """Row boundaries ``b[0..world]`` of contiguous vertex ranges with (nearly) equal nonzero
+    counts: power-law rows make equal-vertex ranges badly unbalanced, equal-nnz ranges are what
+    keeps the ranks' SpMM times equal.  Empty ranges are allowed (more ranks than rows)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    M = indptr.shape[0] - 1
+    nnz = int(indptr[-1])
+    b = np.zeros(world + 1, dtype=np.int64)
+    b[world] = M
+    for r in range(1, world):
+        # first row boundary whose prefix reaches r/world of the nonzeros
+        b[r] = min(M, max(b[r - 1], int(np.searchsorted(indptr, (nnz * r + world - 1) // world, side='left'))))
+    return b
+
+
+class ShardedSpMM(object):
+    """``C = A . B`` and ``dB = A^T . dC`` with the vertex set split into contiguous ranges, one
+    per GPU, balanced by nonzeros (of A and A^T together, so forward and backward are both
+    even).  Rank g owns rows ``[b[g], b[g+1])`` of A and C -- and the same rows of A^T and dB,
+    which keeps a layer's activations and their gradients sharded identically.
+
+    Both products are "row block of a static sparse matrix x full dense matrix" on the
+    single-GPU kernels, so the only data-path question is where the dense operand lives (§8e):
+      * ``forward(B)`` / ``backward(dC)``          -- operand replicated / resident: no collective;
+      * ``forward_allgather(B_local)`` / ``backward_allgather(dC_local)`` -- the operand is a
+        layer activation sharded like C: the ranks all-gather their row blocks first
+        (xGMI-bound for large operands; bench.py reports both variants)."""
+
+    def __init__(self, par, adj, device, kernel="cs", with_transpose=True):
+        from . import ops
+        adj = adj.tocsr()
+        if adj.shape[0] != adj.shape[1]:
+            raise ValueError("ShardedSpMM shards one vertex set: the matrix must be square")
+        self.par, self.device, self.kernel = par, device, kernel
+        self.shape = (int(adj.shape[0]), int(adj.shape[1]))
+        adj_t = adj.T.tocsr() if with_transpose else None
+        load = adj.indptr.astype(np.int64) + (adj_t.indptr.astype(np.int64) if with_transpose else 0)
+        self.bounds = partition_rows_by_nnz(load, par.world)
+        self.lo, self.hi = int(self.bounds[par.rank]), int(self.bounds[par.rank + 1])
+        self.row_counts = [int(self.bounds[r + 1] - self.bounds[r]) for r in range(par.world)]
+        blk = adj[self.lo:self.hi]
+        blk_t = adj_t[self.lo:self.hi] if with_transpose else None
+        self.local_nnz = int(blk.nnz)
+        self.A = self.AT = self._mm = None
+        if self.hi == self.lo:          # more ranks than row blocks: this rank only joins collectives
+            pass
+        elif kernel == "cs":
+            self.A = ops.ColumnSweepCSR(blk, device)
+            self.AT = ops.ColumnSweepCSR(blk_t, device) if with_transpose else None
+            self._mm = ops.spmm_cs
+        else:
+            self.A = ops.DeviceCSR.from_scipy(blk, device)
+            self.AT = ops.DeviceCSR.from_scipy(blk_t, device) if with_transpose else None
+            self._mm = ops.spmm
+
+    def autotune(self, B, dC=None):
+        if self.kernel == "cs" and self.A is not None:
+            self.A.autotune(B)
+            if self.AT is not None and dC is not None:
+                self.AT.autotune(dC)
+
+    def _local(self, A, X, out):
+        if A is None:
+            return torch.empty((0, X.shape[1]), dtype=torch.float32, device=X.device)
+        return self._mm(A, X, out=out)
+
+    def forward(self, B, out=None):
+        """C[lo:hi] = A[lo:hi, :] . B        (B: all rows, resident on this GPU)."""
+        return self._local(self.A, B, out)
+
+    def backward(self, dC, out=None):
+        """dB[lo:hi] = A^T[lo:hi, :] . dC    (dC: all rows, resident on this GPU)."""
+        return self._local(self.AT, dC, out)
+
+    def allgather_rows(self, X_local):
+        """All rows from the ranks' blocks (ragged blocks travel padded to the largest one).
+        The result keeps 16-byte aligned rows (pitch = d rounded up to 4 floats), which the
+        column-sweep kernel requires of its dense operand."""
+        par = self.par
+        d = int(X_local.shape[1])
+        pitch = (d + 3) // 4 * 4
+        if not par.active:
+            if X_local.stride(0) % 4 == 0 and X_local.stride(1) == 1:
+                return X_local
+            full = torch.zeros((X_local.shape[0], pitch), dtype=torch.float32, device=X_local.device)
+            full[:, :d] = X_local
+            return full[:, :d]
+        cap = max(self.row_counts)
+        send = torch.zeros((cap, pitch), dtype=torch.float32, device=X_local.device)
+        send[:X_local.shape[0], :d] = X_local
+        recv = torch.empty((par.world, cap, pitch), dtype=torch.float32, device=X_local.device)
+        dist.all_gather([recv[r] for r in range(par.world)], send)
+        if all(c == cap for c in self.row_counts):
+            return recv.view(par.world * cap, pitch)[:, :d]
+        full = torch.empty((self.shape[0], pitch), dtype=torch.float32, device=X_local.device)
+        for r in range(par.world):
+            full[int(self.bounds[r]):int(self.bounds[r + 1])] = recv[r, :self.row_counts[r]]
+        return full[:, :d]
+
+    def forward_allgather(self, B_local, out=None):
+        return self.forward(self.allgather_rows(B_local), out=out)
+
+    def backward_allgather(self, dC_local, out=None):
+        return self.backward(self.allgather_rows(dC_local), out=out)

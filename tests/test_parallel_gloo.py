@@ -147,3 +147,19 @@ def test_two_rank_training_step_matches_mean_gradient(tmp_path):
     np.testing.assert_array_equal(r[0]["theta"], r[1]["theta"])     # replicas stay in lock-step
     np.testing.assert_array_equal(r[0]["hist"], r[1]["hist"])
     assert np.abs(r[0]["hist"]).sum() > 0
+
+
+def test_partition_rows_by_nnz_balances_power_law_rows():
+    from stochastic_gcn_amd.parallel import partition_rows_by_nnz
+    from stochastic_gcn_amd import synthetic
+    a = synthetic.rmat_like(1 << 12, 40 << 12, seed=3)
+    for world in (1, 2, 3, 8):
+        b = partition_rows_by_nnz(a.indptr, world)
+        assert b[0] == 0 and b[-1] == a.shape[0] and np.all(np.diff(b) >= 0)
+        per = np.diff(a.indptr[b])
+        assert per.sum() == a.nnz
+        heaviest_row = int(np.diff(a.indptr).max())
+        assert per.max() <= a.nnz / world + heaviest_row          # within one row of the ideal
+    # more ranks than rows: empty ranges, still a partition
+    b = partition_rows_by_nnz(np.array([0, 3, 4]), 5)
+    assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
