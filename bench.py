@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="reddit", choices=["reddit", "reddit-small", "rmat"])
+    p.add_argument("--workload", default="reddit", choices=["reddit", "reddit-small", "reddit-114m", "rmat", "rmat-10m"])
     p.add_argument("--d", type=int, default=602)
     p.add_argument("--pitch", type=int, default=0, help="row pitch of X/C in floats (0: d rounded up to 32)")
     p.add_argument("--plan-t", type=int, default=0)
@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
+    p.add_argument("--emulate-shard", default=None, metavar="R/W",
+                   help="with --shard resident on ONE GPU: build and time rank R's block of a W-way sharding")
     p.add_argument("--shard", choices=["resident", "allgather"], default=None,
                    help="STRONG scaling: ONE graph row-block sharded over the ranks (nnz-balanced), dense "
                         "operand resident on every GPU or all-gathered per product (SURVEY.md 8e)")
@@ -74,6 +76,12 @@ def make_graph(args, rank):
         data = synthetic.reddit_like(n=23296, m=1160000, splits=(15241, 2369, 5533),
                                      seed=1 + rank, with_features=False)
         name = "S-Reddit/10 (N=23296)"
+    elif args.workload == "reddit-114m":    # the denser Reddit distribution (114.6 M nnz, avg deg 492)
+        data = synthetic.reddit_like(m=57_400_000, seed=1 + rank, with_features=False)
+        return data[0], data[2], "S-Reddit-114M full-graph CSR x dense (N=232965, avg degree ~490)", None
+    elif args.workload == "rmat-10m":       # BASELINE config 5 (SURVEY.md 8d S-RMAT); minutes of host time
+        n = 10_000_000
+        return n, synthetic.rmat_like(n, 200_000_000, seed=1), "S-RMAT 10 M vertices, 200 M edges", None
     else:
         n = 1 << 20
         return n, synthetic.rmat_like(n, 20 * n, seed=1 + rank), "S-RMAT 2^20 vertices, 20 M edges", None
@@ -233,8 +241,13 @@ def main():
     sh = None
     if args.shard:
         from stochastic_gcn_amd.parallel import DataParallel, ShardedSpMM
-        sh = ShardedSpMM(DataParallel(device=dev, init=False), full_adj, dev, kernel=args.kernel,
-                         with_transpose=not args.no_backward)
+        par = DataParallel(device=dev, init=False)
+        if args.emulate_shard:
+            assert world == 1 and args.shard == "resident", "--emulate-shard: one process, resident operand"
+            import types
+            r_, w_ = (int(x) for x in args.emulate_shard.split("/"))
+            par = types.SimpleNamespace(rank=r_, world=w_, active=False)    # no peers: no collectives
+        sh = ShardedSpMM(par, full_adj, dev, kernel=args.kernel, with_transpose=not args.no_backward)
         A = sh.A
     elif args.kernel == "cs":
         A = ops.ColumnSweepCSR(full_adj, dev, R=args.cs_r, T=args.cs_t)
@@ -320,11 +333,13 @@ def main():
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_ar])) if ev_ar else None
     edges_per_step = nnz * (1 if args.no_backward else 2)
+    if args.emulate_shard:
+        edges_per_step = sh.local_nnz * (1 if args.no_backward else 2)       # this block only
     value = edges_per_step * (1 if sh is not None else world) * args.steps / el
     bytes_alg = nnz * 8 + (n + 1) * 4 + 2 * n * d * 4
     if sh is not None:      # this rank's row block: its nonzeros, its C rows, every referenced B row
         nnz_l, m_l = sh.local_nnz, sh.hi - sh.lo
-        bytes_alg = nnz_l * 8 + (m_l + 1) * 4 + min(n, nnz_l) * d * 4 + m_l * d * 4
+        bytes_alg = nnz_l * 8 + (m_l + 1) * 4 + sh.distinct_cols * d * 4 + m_l * d * 4
     achieved = bytes_alg / (fwd_ms * 1e-3)
     out = {
         "metric": "training edges/s (SpMM)", "value": value, "unit": "edges/s",

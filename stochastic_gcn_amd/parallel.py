@@ -181,6 +181,7 @@ class ShardedSpMM(object):
         blk = adj[self.lo:self.hi]
         blk_t = adj_t[self.lo:self.hi] if with_transpose else None
         self.local_nnz = int(blk.nnz)
+        self.distinct_cols = int(np.unique(blk.indices).shape[0])     # rows of B this block touches
         self.A = self.AT = self._mm = None
         if self.hi == self.lo:          # more ranks than row blocks: this rank only joins collectives
             pass
