@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md:35)
+L2_PEAK = 34.5e12          # aggregate L2 bandwidth, MI355X_MICROARCH.md "L2 (per XCD)"
 HBM_COPY = 6.29e12         # measured float4-copy ceiling (ibid.)
 
 
@@ -368,7 +369,14 @@ def main():
                      "ms_per_launch": fwd_ms,
                      "edges_per_s_fwd": (sh.local_nnz if sh is not None else nnz) / (fwd_ms * 1e-3),
                      "gather_model_GBps": (nnz * (d * 4 + 8) + n * d * 4) / (fwd_ms * 1e-3) / 1e9
-                     if sh is None else None},
+                     if sh is None else None,
+                     # secondary view: every edge moves one d-float row of B from L2 to the VGPRs
+                     # whatever the cache hit rate, so the L2 (MI355X_MICROARCH.md: ~34.5 TB/s
+                     # aggregate) is the bound a gather-based SpMM on this graph actually meets
+                     "l2_gather": {"bytes_per_launch": (sh.local_nnz if sh is not None else nnz) * d * 4,
+                                   "achieved_GBps": (sh.local_nnz if sh is not None else nnz) * d * 4 / (fwd_ms * 1e-3) / 1e9,
+                                   "peak_GBps": L2_PEAK / 1e9,
+                                   "frac": (sh.local_nnz if sh is not None else nnz) * d * 4 / (fwd_ms * 1e-3) / L2_PEAK}},
     }
     tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
         if not (args.tune or sh is not None) else None
