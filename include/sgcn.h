@@ -189,18 +189,22 @@ int sgcn_ln_act_bwd_f32(const float* dev_dy, int64_t lddy, const float* dev_y, i
                         float* dev_doffset, float* dev_dscale, float* dev_ws, void* stream);
 /* fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact fp32) for the dense weight layers:
  *   C[M x N] = op(A) . op(B) (+ C when accumulate != 0);  trans_a: A is stored [K x M];
- *   trans_b: B is stored [N x K].        replaces tf.matmul gcn/layers.py:36 and its autodiff */
+ *   trans_b: B is stored [N x K].        replaces tf.matmul gcn/layers.py:36 and its autodiff
+ * dev_ws (nullable): sgcn_gemm_ws_floats(M, N, K) floats of scratch enable deterministic split-K --
+ * a weight-gradient GEMM has a 128 x 128 output and K ~ 1,000, i.e. four output tiles; its K
+ * range is cut across workgroups and the partial tiles are summed in a fixed order. */
+int64_t sgcn_gemm_ws_floats(int32_t M, int32_t N, int32_t K);
 int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K,
                   const float* dev_A, int64_t lda, const float* dev_B, int64_t ldb, float* dev_C,
-                  int64_t ldc, int32_t accumulate, void* stream);
+                  int64_t ldc, int32_t accumulate, float* dev_ws, void* stream);
 /* One launch per dense layer: Y = act(LN(X . W) * scale + offset)   (N <= 128 when LN / ReLU is
  * requested; offset/scale NULL -> no LayerNorm).   gcn/layers.py:120-138, :396-411 */
 int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int64_t ldx,
                        const float* dev_W, int64_t ldw, const float* dev_offset,
                        const float* dev_scale, float eps, int32_t relu, float* dev_Y, int64_t ldy,
                        float* dev_xhat, float* dev_rstd, void* stream);
-/* Softmax cross-entropy over n rows: stats[0] = sum_i CE_i, stats[1] = #rows whose arg-max
- * matches the label arg-max; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
+/* Softmax cross-entropy over n rows: stats[4] = {sum_i CE_i, #rows whose arg-max matches the label
+ * arg-max, mean CE (the loss), accuracy}; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
  * pred (nullable) = softmax; rowstat: 2*n floats of scratch (per-row CE and hit flag, summed
  * in a fixed order).                                           gcn/models.py:68-94,198-202 */
 int sgcn_softmax_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,

@@ -75,8 +75,9 @@ SIGNATURES = {
     "sgcn_ln_act_bwd_ws_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "sgcn_ln_act_bwd_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, P, P, P, C.c_int32, C.c_int32,
                                       C.c_int32, P, C.c_int64, P, P, P, P]),
+    "sgcn_gemm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "sgcn_gemm_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
-                                C.c_int64, P, C.c_int64, C.c_int32, P]),
+                                C.c_int64, P, C.c_int64, C.c_int32, P, P]),
     "sgcn_dense_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P,
                                      C.c_float, C.c_int32, P, C.c_int64, P, P, P]),
     "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     if (lane == 0) { rowstat[row] = l; rowstat[n + row] = (am == alm) ? 1.f : 0.f; }
 }
 
-// stats[0] = sum_i CE_i, stats[1] = #correct: one workgroup, fixed summation order
+// stats = {sum_i CE_i, #correct, mean CE, accuracy}: one workgroup, fixed summation order
 __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float* __restrict__ rowstat,
                                                                int32_t n, float* __restrict__ stats) {
     __shared__ float red[2][kBlock];
@@ -173,7 +173,10 @@ __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float* __re
         if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stats[0] = red[0][0]; stats[1] = red[1][0]; }
+    if (threadIdx.x == 0) {
+        stats[0] = red[0][0]; stats[1] = red[1][0];
+        stats[2] = red[0][0] / (float)n; stats[3] = red[1][0] / (float)n;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,

@@ -25,6 +25,8 @@ struct GemmArgs {
     float* C; int64_t ldc;
     int32_t M, N, K;
     int32_t accumulate;              // C += instead of C =
+    int32_t kchunk;                  // split-K: blockIdx.z covers k in [z*kchunk, (z+1)*kchunk); the
+    float* ws;                       // partial tiles go to ws[z][M][N] and splitk_reduce_kernel adds them
     // fused LN/act epilogue (N <= 128 only): Y = act(LN(C)*scale + offset)
     const float* offset; const float* scale; float eps; int32_t relu;
     float* xhat; float* rstd;        // [M x N], [M]   kept for the backward when LN is on
@@ -37,58 +39,90 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// The K loop is software-pipelined: the global loads of K-step s+1 are issued into registers
+// before the MFMAs of step s, so their latency hides behind the matrix work and the two
+// barriers (these GEMMs have 4..64 workgroups: nothing else would hide it).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
     __shared__ float As[kTM][kTK + 1];          // [i][kk]
     __shared__ float Bs[kTK][kTN + 4];          // [kk][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * kTM, n0 = blockIdx.y * kTN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
     f16acc acc = {};
+    float ra[4], rb[16];
 
-    for (int k0 = 0; k0 < g.K; k0 += kTK) {
-        // ---- A tile -> As[i][kk]
+    auto fetch = [&](int k0) {
         if (!TA) {          // A is [M x K]: thread reads 4 consecutive k of one row
-            const int i = tid >> 3, kq = (tid & 7) * 4;
-            const int row = m0 + i;
+            const int i = tid >> 3, kq = (tid & 7) * 4, row = m0 + i;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int k = k0 + kq + e;
-                As[i][kq + e] = (row < g.M && k < g.K) ? g.A[(int64_t)row * g.lda + k] : 0.f;
+                ra[e] = (row < g.M && k < kend) ? g.A[(int64_t)row * g.lda + k] : 0.f;
             }
         } else {            // A is [K x M]: thread reads 4 consecutive m of one k
-            const int kk = tid >> 3, iq = (tid & 7) * 4;
-            const int k = k0 + kk;
+            const int kk = tid >> 3, iq = (tid & 7) * 4, k = k0 + kk;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int row = m0 + iq + e;
-                As[iq + e][kk] = (row < g.M && k < g.K) ? g.A[(int64_t)k * g.lda + row] : 0.f;
+                ra[e] = (row < g.M && k < kend) ? g.A[(int64_t)k * g.lda + row] : 0.f;
             }
         }
-        // ---- B tile -> Bs[kk][j]
         if (!TB) {          // B is [K x N]
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4;
-                const int k = k0 + kk;
+                const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4, k = k0 + kk;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int col = n0 + jq + e;
-                    Bs[kk][jq + e] = (k < g.K && col < g.N) ? g.B[(int64_t)k * g.ldb + col] : 0.f;
+                    rb[r * 4 + e] = (k < kend && col < g.N) ? g.B[(int64_t)k * g.ldb + col] : 0.f;
                 }
             }
         } else {            // B is [N x K]
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int j = (tid >> 3) + 32 * r, kq = (tid & 7) * 4;
-                const int col = n0 + j;
+                const int j = (tid >> 3) + 32 * r, kq = (tid & 7) * 4, col = n0 + j;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int k = k0 + kq + e;
-                    Bs[kq + e][j] = (k < g.K && col < g.N) ? g.B[(int64_t)col * g.ldb + k] : 0.f;
+                    rb[r * 4 + e] = (k < kend && col < g.N) ? g.B[(int64_t)col * g.ldb + k] : 0.f;
                 }
             }
         }
+    };
+    auto stage = [&]() {
+        if (!TA) {
+            const int i = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) As[i][kq + e] = ra[e];
+        } else {
+            const int kk = tid >> 3, iq = (tid & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) As[iq + e][kk] = ra[e];
+        }
+        if (!TB) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) Bs[kk][jq + e] = rb[r * 4 + e];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = (tid >> 3) + 32 * r, kq = (tid & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) Bs[kq + e][j] = rb[r * 4 + e];
+            }
+        }
+    };
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += kTK) {
+        stage();
         __syncthreads();
+        if (k0 + kTK < kend) fetch(k0 + kTK);          // in flight during the MFMAs below
         // ---- 16 x (32x32x2) MFMAs: lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
         const int fi = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -103,12 +137,15 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int cj = wave * 32 + (lane & 31);
     if (g.epi == 0) {
+        float* base = g.ws ? g.ws + (int64_t)blockIdx.z * g.M * g.N : g.C;
+        const int64_t ld = g.ws ? g.N : g.ldc;
+        const bool add = !g.ws && g.accumulate;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + cj;
             if (row < g.M && col < g.N) {
-                float* p = g.C + (int64_t)row * g.ldc + col;
-                *p = g.accumulate ? *p + acc[r] : acc[r];
+                float* p = base + (int64_t)row * ld + col;
+                *p = add ? *p + acc[r] : acc[r];
             }
         }
         return;
@@ -143,30 +180,69 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// C (+)= sum_z ws[z]   in z order (deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int32_t S, int32_t M, int32_t N,
+                                     float* __restrict__ C, int64_t ldc, int32_t accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t mn = (int64_t)M * N;
+    if (i >= mn) return;
+    float s = 0.f;
+    for (int z = 0; z < S; z++) s += ws[(int64_t)z * mn + i];
+    float* p = C + (i / N) * ldc + (i % N);
+    *p = accumulate ? *p + s : s;
+}
+
 }  // namespace sgcn
 
 using namespace sgcn;
 
-static int launch_gemm(const GemmArgs& g, int ta, int tb, hipStream_t st) {
-    dim3 grid((unsigned)((g.M + kTM - 1) / kTM), (unsigned)((g.N + kTN - 1) / kTN));
+// Split-K factor: a weight-gradient GEMM (dW = X^T g) has a tiny output (128 x 128: FOUR tiles)
+// and a long K (the ~1,000 rows of the minibatch), so the K range is cut across blockIdx.z until
+// the grid has ~256 workgroups, every slice keeping at least three K-steps (so the K = 128 GEMMs
+// of the step are never split: the reduction is a second launch and must buy more than it costs).
+static int split_factor(int M, int N, int K) {
+    const int tiles = ((M + kTM - 1) / kTM) * ((N + kTN - 1) / kTN);
+    int s = 256 / std::max(tiles, 1);
+    s = std::min(s, K / (3 * kTK));
+    return std::max(s, 1);
+}
+
+static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st) {
+    int S = (ws && g.epi == 0) ? split_factor(g.M, g.N, g.K) : 1;
+    g.kchunk = ((g.K + S - 1) / S + kTK - 1) / kTK * kTK;
+    S = g.K > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+    if (g.K == 0) g.kchunk = kTK;
+    g.ws = S > 1 ? ws : nullptr;
+    dim3 grid((unsigned)((g.M + kTM - 1) / kTM), (unsigned)((g.N + kTN - 1) / kTN), (unsigned)S);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(kBlock), 0, st, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(kBlock), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(kBlock), 0, st, g);
     else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(kBlock), 0, st, g);
+    if (S > 1) {
+        const int64_t mn = (int64_t)g.M * g.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st,
+                           g.ws, S, g.M, g.N, g.C, g.ldc, g.accumulate);
+    }
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }
 
+extern "C" int64_t sgcn_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int S = split_factor(M, N, K);
+    return S > 1 ? (int64_t)S * M * N : 0;
+}
+
 extern "C" int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K,
                              const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-                             int64_t ldc, int32_t accumulate, void* stream) {
+                             int64_t ldc, int32_t accumulate, float* ws, void* stream) {
     SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
     if (M == 0 || N == 0) return SGCN_OK;
     SGCN_REQUIRE(A && B && C, "gemm: null operand");
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.accumulate = accumulate; g.epi = 0;
-    return launch_gemm(g, trans_a, trans_b, (hipStream_t)stream);
+    return launch_gemm(g, trans_a, trans_b, ws, (hipStream_t)stream);
 }
 
 extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
@@ -183,5 +259,5 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
     g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
     g.M = M; g.N = N; g.K = K; g.offset = offset; g.scale = scale; g.eps = eps; g.relu = relu;
     g.xhat = xhat; g.rstd = rstd; g.epi = norm ? 2 : (relu ? 1 : 0);
-    return launch_gemm(g, 0, 0, (hipStream_t)stream);
+    return launch_gemm(g, 0, 0, nullptr, (hipStream_t)stream);
 }

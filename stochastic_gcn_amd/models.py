@@ -113,12 +113,13 @@ class DevFeed(object):
         """Fast path: the sampler already laid the batch out (sgcn_sched_batch_packed); two H2D
         copies out of the (pinned) staging slot, then views."""
         self = cls.__new__(cls)
-        if pb.slot is not None:
-            it, ft = pb.slot.ibuf[:max(pb.n_i, 1)], pb.slot.fbuf[:max(pb.n_f, 1)]
+        if pb.slot is not None:           # one H2D copy: [int32 section | fp32 section]
+            n_i = max(pb.n_i, 1)
+            words = pb.slot.buf[:n_i + max(pb.n_f, 1)].to(device, non_blocking=True)
+            self.ibuf, self.fbuf = words[:n_i], words[n_i:].view(torch.float32)
         else:
-            it, ft = torch.from_numpy(pb.ibuf[:max(pb.n_i, 1)]), torch.from_numpy(pb.fbuf[:max(pb.n_f, 1)])
-        self.ibuf = it.to(device, non_blocking=True)
-        self.fbuf = ft.to(device, non_blocking=True)
+            self.ibuf = torch.from_numpy(pb.ibuf[:max(pb.n_i, 1)]).to(device, non_blocking=True)
+            self.fbuf = torch.from_numpy(pb.fbuf[:max(pb.n_f, 1)]).to(device, non_blocking=True)
         if pb.slot is not None and device.type == 'cuda':
             ev = torch.cuda.Event()
             ev.record()
@@ -483,8 +484,8 @@ class GCN(Model):
         else:
             stats, dlogits, pred = ops.softmax_ce(z, labels, want_grad=self.is_training or self._want_grad,
                                                   want_pred=not self.is_training or self._want_grad)
-            loss = wd + stats[0] / n
-            acc = stats[1] / n
+            loss = stats[2] + wd if FLAGS.weight_decay else stats[2]       # mean CE, computed in-kernel
+            acc = stats[3]
         return loss, acc, pred, dlogits
 
     def backward(self, dlogits):

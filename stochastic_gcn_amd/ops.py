@@ -273,16 +273,17 @@ def ln_act_bwd(dy, y, ctx, scale, relu, doffset=None, dscale=None):
 
 
 def softmax_ce(logits, labels, want_grad=True, want_pred=False):
-    """(stats[2] = {sum CE, #correct}, dlogits or None, pred or None)   (sgcn_softmax_ce_f32)."""
+    """(stats[4] = {sum CE, #correct, mean CE, accuracy}, dlogits or None, pred or None)
+    (sgcn_softmax_ce_f32)."""
     zp, ldz = _rows2d(logits, "logits")
     lp, ldl = _rows2d(labels, "labels")
     n, c = int(logits.shape[0]), int(logits.shape[1])
-    stats = torch.empty(2 + 2 * n, dtype=torch.float32, device=logits.device)   # [stats | per-row scratch]
+    stats = torch.empty(4 + 2 * n, dtype=torch.float32, device=logits.device)   # [stats | per-row scratch]
     dz = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
     pred = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_pred else None
     check(lib.sgcn_softmax_ce_f32(zp, ldz, lp, ldl, n, c, _ptr(dz), c, _ptr(pred), c, stats.data_ptr(),
-                                  stats.data_ptr() + 8, _stream()))
-    return stats[:2], dz, pred
+                                  stats.data_ptr() + 16, _stream()))
+    return stats, dz, pred
 
 
 def adam_step(theta, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
@@ -391,7 +392,20 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
 # Above this many multiply-adds a GEMM is no longer launch-latency-bound and the library GEMM
 # (rocBLAS via torch, "plain library GEMM") is the better tool; below it our one-launch kernels
 # (and the fused GEMM+LayerNorm+ReLU) win on launch count and dispatch cost.
-GEMM_LIBRARY_THRESHOLD = 96 * 1024 * 1024
+GEMM_LIBRARY_THRESHOLD = 512 * 1024 * 1024
+
+
+_GEMM_WS = {}
+
+
+def _gemm_ws(floats, device):
+    """Split-K scratch, one growing buffer per device (all launches share one stream, so the
+    next GEMM cannot overwrite partials the previous reduce has not consumed)."""
+    w = _GEMM_WS.get(device)
+    if w is None or w.numel() < floats:
+        w = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
+        _GEMM_WS[device] = w
+    return w
 
 
 def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False):
@@ -415,8 +429,10 @@ def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False):
             raise ValueError("accumulate needs an existing `out`")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     cp, ldc = _rows2d(out, "out")
+    need = int(lib.sgcn_gemm_ws_floats(int(M), int(N), int(K)))     # > 0: split-K pays (small M x N, long K)
+    ws = _gemm_ws(need, A.device) if need else None
     check(lib.sgcn_gemm_f32(int(trans_a), int(trans_b), int(M), int(N), int(K), ap, lda, bp, ldb, cp, ldc,
-                            int(accumulate), _stream()))
+                            int(accumulate), _ptr(ws), _stream()))
     return out
 
 

@@ -220,22 +220,26 @@ CSR_DESC = 11   # nrows ncols nnz rowptr col val seg nseg fix nfix nslots  (incl
 
 
 class StagingSlot(object):
-    """Reusable (pinned when CUDA is present) host staging buffers for one in-flight batch."""
+    """Reusable (pinned when CUDA is present) host staging buffer for one in-flight batch: the
+    int32 section and the fp32 section share ONE allocation ``[n_i ints | n_f floats]`` so the
+    batch crosses PCIe in a single copy."""
 
     def __init__(self, pin):
         self.pin = pin
-        self.ibuf = self.fbuf = None       # torch tensors
-        self.event = None                  # recorded by the consumer after its H2D copies
+        self.buf = None                    # torch int32 tensor (raw 4-byte words)
+        self.ibuf = self.fbuf = None       # views of the current batch
+        self.event = None                  # recorded by the consumer after its H2D copy
 
     def ensure(self, n_i, n_f):
         import torch
         if self.event is not None:         # the previous H2D copy out of this slot must be done
             self.event.synchronize()
             self.event = None
-        if self.ibuf is None or self.ibuf.numel() < n_i:
-            self.ibuf = torch.empty(max(int(n_i * 1.5), 1024), dtype=torch.int32, pin_memory=self.pin)
-        if self.fbuf is None or self.fbuf.numel() < n_f:
-            self.fbuf = torch.empty(max(int(n_f * 1.5), 1024), dtype=torch.float32, pin_memory=self.pin)
+        n_i, n_f = max(int(n_i), 1), max(int(n_f), 1)
+        if self.buf is None or self.buf.numel() < n_i + n_f:
+            self.buf = torch.empty(max(int((n_i + n_f) * 1.5), 2048), dtype=torch.int32, pin_memory=self.pin)
+        self.ibuf = self.buf[:n_i]
+        self.fbuf = self.buf[n_i:n_i + n_f].view(torch.float32)
 
 
 class PackedBatch(object):

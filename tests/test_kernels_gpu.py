@@ -307,10 +307,13 @@ def test_column_sweep_full_size_matches_row_gather(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 41, 70), (512, 128, 256), (1021, 128, 1204), (200, 300, 50),
-                                   (64, 128, 128), (31, 7, 33)])
-def test_gemm_all_transposes_vs_numpy(dev, M, N, K):
+                                   (64, 128, 128), (31, 7, 33),
+                                   # weight-gradient shapes of the Reddit step: split-K (4..8 output tiles, long K)
+                                   (128, 128, 1021), (256, 128, 512), (128, 41, 512), (1204, 128, 1021), (5, 3, 4000)])
+def test_gemm_all_transposes_vs_numpy(dev, M, N, K, monkeypatch):
     """fp32 MFMA GEMM vs float64 NumPy; asymmetric operands (a swapped row/col map must fail)."""
     from stochastic_gcn_amd import ops
+    monkeypatch.setattr(ops, "GEMM_LIBRARY_THRESHOLD", 1 << 62)        # always our kernel
     rng = np.random.RandomState(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     B = rng.standard_normal((K, N)).astype(np.float32)
@@ -325,6 +328,9 @@ def test_gemm_all_transposes_vs_numpy(dev, M, N, K):
     out = T(c0, dev)
     ops.gemm(T(A, dev), T(B, dev), out=out, accumulate=True)
     assert onp.rel_err(out.cpu().numpy(), ref + c0) <= 1e-5
+    out2 = T(c0, dev)
+    ops.gemm(T(A, dev), T(B, dev), out=out2, accumulate=True)
+    assert torch.equal(out, out2)                       # split-K partials are summed in a fixed order
     # identity check with an asymmetric B
     eye = T(np.eye(K, dtype=np.float32), dev)
     np.testing.assert_array_equal(ops.gemm(eye, T(B, dev)).cpu().numpy(), B)
