@@ -1,0 +1,62 @@
+"""Host-side batch pipelines of stochastic_gcn_amd/train.py (no GPU): the in-order multi-sampler
+prefetcher of the non-parity fast mode, and the wrap-around batch walk."""
+import numpy as np
+
+from stochastic_gcn_amd import synthetic
+from stochastic_gcn_amd.scheduler import PyScheduler, StagingSlot
+from stochastic_gcn_amd.train import ParallelPrefetcher, epoch_batches
+
+PH = {'adj': ['a0', 'a1'], 'madj': ['m0', 'm1'], 'fadj': ['f0', 'f1'], 'fields': ['x0', 'x1', 'x2'],
+      'ffields': ['ff0', 'ff1'], 'scales': ['s0', 's1'], 'labels': 'l'}
+
+
+def _graph(n=600):
+    a = synthetic.rmat_like(n, 12 * n, seed=2)
+    labels = np.eye(4, dtype=np.float32)[np.arange(n) % 4]
+    return a, labels
+
+
+def test_epoch_batches_wraps_like_minibatch():
+    data = np.arange(10, dtype=np.int32)
+    b = epoch_batches(data, 4, 5)
+    assert [x.tolist() for x in b] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9], [0, 1, 2, 3], [4, 5, 6, 7]]
+
+
+def test_parallel_prefetcher_delivers_valid_batches_in_order():
+    a, labels = _graph()
+    L, deg = 2, np.array([3, 3], dtype=np.int32)
+    schs = [PyScheduler(a, labels, L, deg, PH, 7 + 1000 * k, cv=True) for k in range(3)]
+    ids = np.random.RandomState(0).permutation(a.shape[0]).astype(np.int32)
+    batches = epoch_batches(ids, 32, 25)
+    slots = [StagingSlot(pin=False) for _ in range(2 * 3 + 3)]
+    pre = ParallelPrefetcher(schs, batches, 0, slots, depth=2)
+    indptr, indices = a.indptr, a.indices
+    for i, want in enumerate(batches):
+        pb = pre.next()
+        np.testing.assert_array_equal(pb.field(L), want)              # batch i, in order
+        fd = pb.feed_dict(PH)
+        for l in range(L):
+            idx, w, shape = fd[PH['adj'][l]]
+            f_in, f_out = fd[PH['fields'][l]], fd[PH['fields'][l + 1]]
+            assert shape[0] == len(f_out) and shape[1] == len(f_in)
+            # every sampled edge is a real edge of the graph
+            src, dst = f_out[idx[:, 0]], f_in[idx[:, 1]]
+            for s_, d_ in zip(src[:50], dst[:50]):
+                assert s_ == d_ or d_ in indices[indptr[s_]:indptr[s_ + 1]]
+    assert pre.next() is None
+
+
+def test_single_sampler_prefetcher_is_the_sequential_sequence():
+    a, labels = _graph()
+    deg = np.array([2], dtype=np.int32)
+    ids = np.arange(a.shape[0], dtype=np.int32)
+    batches = epoch_batches(ids, 50, 6)
+    seq = PyScheduler(a, labels, 1, deg, PH, 3, cv=True)
+    ref = [seq.batch_packed(b) for b in batches]
+    one = PyScheduler(a, labels, 1, deg, PH, 3, cv=True)
+    pre = ParallelPrefetcher([one], batches, 0, [StagingSlot(pin=False) for _ in range(5)], depth=2)
+    for r in ref:
+        pb = pre.next()
+        assert pb.n_i == r.n_i and pb.n_f == r.n_f
+        np.testing.assert_array_equal(np.asarray(pb.ibuf[:pb.n_i]), np.asarray(r.ibuf[:r.n_i]))
+        np.testing.assert_array_equal(np.asarray(pb.fbuf[:pb.n_f]), np.asarray(r.fbuf[:r.n_f]))
