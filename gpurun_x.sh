@@ -1,6 +1,2 @@
-COMMON="--dataset reddit --normalization graphsage --weight_decay 0 --dropout 0.2 --layer_norm --hidden1 128 --num_fc_layers 2 --batch_size=512 --test_batch_size=512 --epochs 2 --early_stopping 30"
-for T in 1 4 8 16; do
-echo "=== NS L=2 no PP degree 20, sampler_threads $T"; timeout 600 python -m stochastic_gcn_amd.train $COMMON --degree=20 --test_degree=20 --nopreprocess --notest_preprocess --max_steps 120 --sampler_threads $T 2>&1 | grep -E "Epoch: 0002|sgcn\] epoch" | tail -2 | cut -c1-250
-done
-echo "=== NS+PP degree 20 threads 8"; timeout 600 python -m stochastic_gcn_amd.train $COMMON --degree=20 --test_degree=20 --sampler_threads 8 2>&1 | grep -E "Epoch: 0002|sgcn\] epoch" | tail -2 | cut -c1-250
-echo "=== CVD+PP threads 4"; timeout 600 python -m stochastic_gcn_amd.train $COMMON --cv --cvd --test_cv --degree=1 --test_degree=1 --sampler_threads 4 2>&1 | grep -E "Epoch: 0002|sgcn\] epoch" | tail -2 | cut -c1-250
+python bench.py --steps 5 --no-cpu-baseline | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['train_epoch'])"
+python profiles/epoch_cprofile.py 2>&1 | grep -v amdgpu.ids | cut -c1-150 | sed -n 3,24p

@@ -187,22 +187,48 @@ int sgcn_ln_act_bwd_f32(const float* dev_dy, int64_t lddy, const float* dev_y, i
                         const float* dev_xhat, const float* dev_rstd, const float* dev_scale,
                         int32_t n, int32_t d, int32_t relu, float* dev_dx, int64_t lddx,
                         float* dev_doffset, float* dev_dscale, float* dev_ws, void* stream);
+/* Dropout with a counter-based hash instead of a stateful generator (tf.nn.dropout gcn/layers.py:396,
+ * 425-433: keep with probability `keep`, scale by 1/keep).  Element (row, col) of an [n x width]
+ * activation is kept iff  fmix32((row * width + col) * 0x9E3779B1 + key) < keep * 2^32  (fmix32 = the
+ * murmur3 finaliser); `key` is derived on the host from (seed, layer index, step).  Being a pure
+ * function of the element index, the mask is never stored: the forward GEMM applies it while loading
+ * its operand, the weight-gradient GEMM recomputes it, the input-gradient GEMM applies it in its
+ * epilogue -- and the CPU oracle replays exactly the same masks.  rows: only rows < rows are dropped
+ * (the clean CVD stream stacked below the dropout stream is not); rows < 0 = all rows. */
+typedef struct {
+    uint32_t key;
+    float keep;
+    int32_t rows;
+    int32_t width;   /* columns of the activation the mask is defined on */
+} sgcn_dropout_t;
+/* out[i, 0:d] = x[i, 0:d] * mask / keep   (the unfused form; also its own backward) */
+int sgcn_dropout_f32(const float* dev_x, int64_t ldx, int32_t n, int32_t d, const sgcn_dropout_t* drop,
+                     float* dev_out, int64_t ldo, void* stream);
+
 /* fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact fp32) for the dense weight layers:
  *   C[M x N] = op(A) . op(B) (+ C when accumulate != 0);  trans_a: A is stored [K x M];
  *   trans_b: B is stored [N x K].        replaces tf.matmul gcn/layers.py:36 and its autodiff
  * dev_ws (nullable): sgcn_gemm_ws_floats(M, N, K) floats of scratch enable deterministic split-K --
  * a weight-gradient GEMM has a 128 x 128 output and K ~ 1,000, i.e. four output tiles; its K
- * range is cut across workgroups and the partial tiles are summed in a fixed order. */
+ * range is cut across workgroups and the partial tiles are summed in a fixed order.
+ * drop_a (nullable): the STORED A matrix is a dropout input -- its elements are masked and scaled
+ *   while they are loaded (forward: A = x; weight gradient, trans_a: A = x stored [n x fin]);
+ * drop_c (nullable): mask and scale the OUTPUT (input gradient dx = (g . W^T) * mask / keep). */
 int64_t sgcn_gemm_ws_floats(int32_t M, int32_t N, int32_t K);
 int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K,
                   const float* dev_A, int64_t lda, const float* dev_B, int64_t ldb, float* dev_C,
-                  int64_t ldc, int32_t accumulate, float* dev_ws, void* stream);
+                  int64_t ldc, int32_t accumulate, float* dev_ws, const sgcn_dropout_t* drop_a,
+                  const sgcn_dropout_t* drop_c, void* stream);
 /* One launch per dense layer: Y = act(LN(X . W) * scale + offset)   (N <= 128 when LN / ReLU is
- * requested; offset/scale NULL -> no LayerNorm).   gcn/layers.py:120-138, :396-411 */
+ * requested; offset/scale NULL -> no LayerNorm).   gcn/layers.py:120-138, :396-411
+ * dev_X2 (nullable): rows >= split of the operand come from X2 (row - split): the CVD layer runs its
+ * dropout stream and its clean stream, which share W and the LayerNorm parameters, as ONE stacked
+ * GEMM without materialising [dropout(x) ; mu].  drop (nullable): dropout on the operand rows. */
 int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int64_t ldx,
+                       const float* dev_X2, int64_t ldx2, int32_t split,
                        const float* dev_W, int64_t ldw, const float* dev_offset,
                        const float* dev_scale, float eps, int32_t relu, float* dev_Y, int64_t ldy,
-                       float* dev_xhat, float* dev_rstd, void* stream);
+                       float* dev_xhat, float* dev_rstd, const sgcn_dropout_t* drop, void* stream);
 /* Softmax cross-entropy over n rows: stats[4] = {sum_i CE_i, #rows whose arg-max matches the label
  * arg-max, mean CE (the loss), accuracy}; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
  * pred (nullable) = softmax; rowstat: 2*n floats of scratch (per-row CE and hit flag, summed

@@ -115,6 +115,46 @@ def layer_norm_bwd(dy, ctx, scale):
     return dx.astype(f32), doffset, dscale
 
 
+# ---- the product's counter-based dropout masks, restated (include/sgcn.h sgcn_dropout_t) ---------
+def _fmix32(h):
+    """murmur3 finaliser on uint64 arrays holding 32-bit values."""
+    M = np.uint64(0xFFFFFFFF)
+    h = h & M
+    h = h ^ (h >> np.uint64(16))
+    h = (h * np.uint64(0x85EBCA6B)) & M
+    h = h ^ (h >> np.uint64(13))
+    h = (h * np.uint64(0xC2B2AE35)) & M
+    h = h ^ (h >> np.uint64(16))
+    return h
+
+
+def dropout_key(seed, layer_index, step):
+    f = lambda v: int(_fmix32(np.array([v & 0xFFFFFFFF], dtype=np.uint64))[0])      # noqa: E731
+    return f(f(int(seed) * 0x9E3779B1 + int(layer_index) * 0x85EBCA77 + 0x27D4EB2F) + int(step) * 0xC2B2AE3D)
+
+
+def hash_mask(key, shape, keep):
+    """{0,1} mask of an activation of `shape` (row-major element index) for one dropout site."""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    h = _fmix32((idx * np.uint64(0x9E3779B1) + np.uint64(key)) & np.uint64(0xFFFFFFFF))
+    t = float(np.float32(keep)) * 4294967296.0
+    thr = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    return (h < np.uint64(thr)).astype(f32).reshape(shape)
+
+
+class HashMasks(object):
+    """`masks(tag, shape)` callback for Model.forward that replays the product's masks: the key
+    of layer i at a given step is dropout_key(seed, i, step); tags are 'L<i>'."""
+
+    def __init__(self, seed, step, keep):
+        self.seed, self.step, self.keep, self.calls = seed, step, keep, 0
+
+    def __call__(self, tag, shape):
+        self.calls += 1
+        return hash_mask(dropout_key(self.seed, int(tag[1:]), self.step), tuple(shape), self.keep)
+
+
 def dropout_fwd(x, keep_prob, mask):
     """tf.nn.dropout: x * mask / keep_prob with mask in {0,1}."""
     if mask is None:

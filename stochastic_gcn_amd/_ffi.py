@@ -38,6 +38,11 @@ class CsPlan(C.Structure):
                 ("pace_ns_per_nnz", C.c_int32)]
 
 
+class Dropout(C.Structure):
+    """include/sgcn.h sgcn_dropout_t"""
+    _fields_ = [("key", C.c_uint32), ("keep", C.c_float), ("rows", C.c_int32), ("width", C.c_int32)]
+
+
 class Plan(C.Structure):
     _fields_ = [("dev_seg", C.c_void_p), ("nseg", C.c_int64),
                 ("dev_fix", C.c_void_p), ("nfix", C.c_int64),
@@ -77,9 +82,10 @@ SIGNATURES = {
                                       C.c_int32, P, C.c_int64, P, P, P, P]),
     "sgcn_gemm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "sgcn_gemm_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
-                                C.c_int64, P, C.c_int64, C.c_int32, P, P]),
-    "sgcn_dense_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P,
-                                     C.c_float, C.c_int32, P, C.c_int64, P, P, P]),
+                                C.c_int64, P, C.c_int64, C.c_int32, P, P, P, P]),
+    "sgcn_dense_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, C.c_int32,
+                                     P, C.c_int64, P, P, C.c_float, C.c_int32, P, C.c_int64, P, P, P, P]),
+    "sgcn_dropout_f32": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, C.c_int64, P]),
     "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
                                       P, C.c_int64, P, P, P]),
     "sgcn_adam_f32": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, P]),

@@ -193,6 +193,17 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
     }
 }
 
+// out = x * mask / keep with the hash mask of sgcn_dropout_t (unfused form and its own backward)
+__global__ __launch_bounds__(kBlock) void dropout_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         int32_t n, int32_t d, DropArgs a,
+                                                         float* __restrict__ out, int64_t ldo) {
+    const int64_t total = (int64_t)n * d;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int row = (int)(i / d), col = (int)(i % d);
+        out[row * ldo + col] = x[row * ldx + col] * drop_factor(a, row, col);
+    }
+}
+
 }  // namespace sgcn
 
 using namespace sgcn;
@@ -259,6 +270,22 @@ extern "C" int sgcn_adam_f32(float* theta, const float* grad, float* m, float* v
     const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m,
                        v, n, lr_t, beta1, beta2, eps);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_dropout_f32(const float* x, int64_t ldx, int32_t n, int32_t d,
+                                const sgcn_dropout_t* drop, float* out, int64_t ldo, void* stream) {
+    SGCN_REQUIRE(n >= 0 && d >= 0, "dropout: negative size");
+    if (n == 0 || d == 0) return SGCN_OK;
+    SGCN_REQUIRE(x && out && drop && ldx >= d && ldo >= d, "dropout: bad operand");
+    SGCN_REQUIRE(drop->keep > 0.f && drop->width >= d, "dropout: keep must be > 0 and width >= d");
+    DropArgs a = drop_args(drop);
+    if (!a.on) { a.on = 1; a.rows = 0; a.scale = 1.f; }      // keep >= 1: plain copy
+    const int64_t total = (int64_t)n * d;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, n, d, a,
+                       out, ldo);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }

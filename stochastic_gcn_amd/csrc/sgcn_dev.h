@@ -95,4 +95,33 @@ inline int pick_vw(int d, std::initializer_list<const void*> ptrs, std::initiali
 
 int tune_get(const char* key);  // sgcn_spmm.hip
 
+// ---- counter-based dropout (include/sgcn.h sgcn_dropout_t) ---------------------------------------
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {      // murmur3 finaliser
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+struct DropArgs {            // device-side form of sgcn_dropout_t
+    uint32_t key, thr;       // keep iff fmix32(idx * 0x9E3779B1 + key) < thr
+    float scale;             // 1 / keep
+    int32_t rows, width;
+    int32_t on;
+};
+
+inline DropArgs drop_args(const sgcn_dropout_t* d) {
+    DropArgs a{};
+    if (!d || d->keep >= 1.0f) return a;
+    a.on = 1; a.key = d->key; a.rows = d->rows < 0 ? 0x7fffffff : d->rows; a.width = d->width;
+    const double t = (double)d->keep * 4294967296.0;
+    a.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    a.scale = 1.0f / d->keep;
+    return a;
+}
+
+__device__ __forceinline__ float drop_factor(const DropArgs& a, int row, int col) {
+    if (row >= a.rows) return 1.0f;
+    const uint32_t idx = (uint32_t)row * (uint32_t)a.width + (uint32_t)col;
+    return fmix32(idx * 0x9E3779B1u + a.key) < a.thr ? a.scale : 0.0f;
+}
+
 }  // namespace sgcn

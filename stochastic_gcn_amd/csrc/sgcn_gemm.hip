@@ -31,6 +31,9 @@ struct GemmArgs {
     const float* offset; const float* scale; float eps; int32_t relu;
     float* xhat; float* rstd;        // [M x N], [M]   kept for the backward when LN is on
     int32_t epi;                     // 0 plain, 1 act only, 2 LN + act
+    const float* A2; int64_t lda2; int32_t a_split;   // rows >= a_split of A come from A2 (not TA)
+    DropArgs drop_a;                 // dropout on the stored A matrix, applied while loading
+    DropArgs drop_c;                 // dropout on the output (plain epilogue only)
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -56,17 +59,23 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
     auto fetch = [&](int k0) {
         if (!TA) {          // A is [M x K]: thread reads 4 consecutive k of one row
             const int i = tid >> 3, kq = (tid & 7) * 4, row = m0 + i;
+            const float* ar = (g.A2 && row >= g.a_split) ? g.A2 + (int64_t)(row - g.a_split) * g.lda2
+                                                         : g.A + (int64_t)row * g.lda;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int k = k0 + kq + e;
-                ra[e] = (row < g.M && k < kend) ? g.A[(int64_t)row * g.lda + k] : 0.f;
+                float v = (row < g.M && k < kend) ? ar[k] : 0.f;
+                if (g.drop_a.on) v *= drop_factor(g.drop_a, row, k);       // stored A = x[row][k]
+                ra[e] = v;
             }
         } else {            // A is [K x M]: thread reads 4 consecutive m of one k
             const int kk = tid >> 3, iq = (tid & 7) * 4, k = k0 + kk;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int row = m0 + iq + e;
-                ra[e] = (row < g.M && k < kend) ? g.A[(int64_t)k * g.lda + row] : 0.f;
+                float v = (row < g.M && k < kend) ? g.A[(int64_t)k * g.lda + row] : 0.f;
+                if (g.drop_a.on) v *= drop_factor(g.drop_a, k, row);       // stored A = x[k][row]
+                ra[e] = v;
             }
         }
         if (!TB) {          // B is [K x N]
@@ -145,7 +154,9 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + cj;
             if (row < g.M && col < g.N) {
                 float* p = base + (int64_t)row * ld + col;
-                *p = add ? *p + acc[r] : acc[r];
+                float v = acc[r];
+                if (g.drop_c.on) v *= drop_factor(g.drop_c, row, col);
+                *p = add ? *p + v : v;
             }
         }
         return;
@@ -235,20 +246,27 @@ extern "C" int64_t sgcn_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
 
 extern "C" int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K,
                              const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-                             int64_t ldc, int32_t accumulate, float* ws, void* stream) {
+                             int64_t ldc, int32_t accumulate, float* ws,
+                             const sgcn_dropout_t* drop_a, const sgcn_dropout_t* drop_c, void* stream) {
     SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
     if (M == 0 || N == 0) return SGCN_OK;
     SGCN_REQUIRE(A && B && C, "gemm: null operand");
     GemmArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.accumulate = accumulate; g.epi = 0;
+    g.drop_a = drop_args(drop_a);
+    g.drop_c = drop_args(drop_c);
+    SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == (trans_a ? M : K), "gemm: drop_a width must be the stored A's row length");
+    SGCN_REQUIRE(!g.drop_c.on || g.drop_c.width == N, "gemm: drop_c width must be N");
+    if (g.drop_c.on) ws = nullptr;           // the output mask is applied in the GEMM's own epilogue
     return launch_gemm(g, trans_a, trans_b, ws, (hipStream_t)stream);
 }
 
 extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
+                                  const float* X2, int64_t ldx2, int32_t split,
                                   const float* W, int64_t ldw, const float* offset,
                                   const float* scale, float eps, int32_t relu, float* Y, int64_t ldy,
-                                  float* xhat, float* rstd, void* stream) {
+                                  float* xhat, float* rstd, const sgcn_dropout_t* drop, void* stream) {
     SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "dense_fwd: negative size");
     if (M == 0 || N == 0) return SGCN_OK;
     SGCN_REQUIRE(X && W && Y, "dense_fwd: null operand");
@@ -259,5 +277,9 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
     g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
     g.M = M; g.N = N; g.K = K; g.offset = offset; g.scale = scale; g.eps = eps; g.relu = relu;
     g.xhat = xhat; g.rstd = rstd; g.epi = norm ? 2 : (relu ? 1 : 0);
+    SGCN_REQUIRE(!X2 || (split >= 0 && split <= M), "dense_fwd: bad split");
+    g.A2 = X2; g.lda2 = ldx2; g.a_split = split;
+    g.drop_a = drop_args(drop);
+    SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
     return launch_gemm(g, 0, 0, nullptr, (hipStream_t)stream);
 }

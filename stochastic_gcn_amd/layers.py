@@ -20,54 +20,30 @@ import torch
 from . import ops
 from .flags import FLAGS
 
-# Test hook: when set, dropout masks come from `MASK_HOOK(tag, shape) -> numpy {0,1}` so that the
-# device path and the CPU oracle can be fed identical randomness (tests/test_model_gpu.py).
-MASK_HOOK = None
-_GEN = {}
+class Dropped(object):
+    """A dense activation with a PENDING dropout (tf.nn.dropout, gcn/layers.py:396,425-433).
+
+    Dropout masks are a counter-based hash of (seed, layer index, step, element index)
+    (include/sgcn.h sgcn_dropout_t), so a mask never has to be stored or even produced: a Dense
+    layer consumes a Dropped as is -- its forward GEMM masks the operand while loading it, its
+    weight-gradient GEMM recomputes the mask, its input-gradient GEMM applies it in the epilogue.
+    Any other consumer calls ``materialize()``."""
+
+    def __init__(self, x, drop):
+        self.x, self.drop, self._m = x, drop, None
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+    def materialize(self):
+        if self._m is None:
+            self._m = ops.dropout(self.x, self.drop)
+        return self._m
 
 
-def _generator(device):
-    g = _GEN.get(device)
-    if g is None:
-        g = torch.Generator(device=device)
-        g.manual_seed(int(FLAGS.seed))
-        _GEN[device] = g
-    return g
-
-
-def seed_dropout(seed, device):
-    _generator(device).manual_seed(int(seed))
-
-
-def dropout_mask(tag, shape, keep_prob, device):
-    """{0,1} mask with P(1) = keep_prob (tf.nn.dropout's floor(keep_prob + U))."""
-    if MASK_HOOK is not None:
-        m = MASK_HOOK(tag, tuple(shape))
-        return None if m is None else torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(device)
-    return (torch.rand(shape, device=device, generator=_generator(device)) < keep_prob).to(torch.float32)
-
-
-def dropout_fwd(x, keep, tag):
-    """tf.nn.dropout.  Returns (out, ctx); ctx feeds dropout_bwd.  Native path: one fused
-    Philox kernel (mask + scale); hook path: explicit {0,1} masks shared with the oracle."""
-    if keep >= 1.0:
-        return x, None
-    if MASK_HOOK is not None:
-        m = dropout_mask(tag, x.shape, keep, x.device)
-        if m is None:
-            return x, None
-        m = m * (1.0 / keep)
-        return x * m, ('mul', m)
-    out, mask = torch.native_dropout(x, 1.0 - keep, True)
-    return out, ('native', mask, 1.0 / keep)
-
-
-def dropout_bwd(g, ctx):
-    if g is None or ctx is None:
-        return g
-    if ctx[0] == 'mul':
-        return g * ctx[1]
-    return torch.ops.aten.native_dropout_backward(g, ctx[1], ctx[2])
+def dense_of(x):
+    return x.materialize() if isinstance(x, Dropped) else x
 
 
 def dot(x, y, sparse=False):
@@ -127,6 +103,14 @@ class Layer(object):
         self.grads = {}     # name -> tensor view into the model's flat gradient buffer
         self.sparse_inputs = False
         self.need_dx = True  # models.py clears it on the first parametrised layer (no consumer)
+        self.index = 0       # position in the model's layer list (part of the dropout key)
+        self.key_fn = None   # () -> 32-bit dropout key of this layer at the current step
+
+    def drop_site(self, keep):
+        """The dropout site of this layer at the current step, or None when nothing is dropped."""
+        if keep >= 1.0:
+            return None
+        return ops.Drop(keep, self.key_fn() if self.key_fn else ops.dropout_key(FLAGS.seed, self.index, 0))
 
     def param_shapes(self):
         return []
@@ -141,30 +125,34 @@ class Dropout(Layer):
     def __init__(self, keep_prob_fn, cvd, **kw):
         super(Dropout, self).__init__(**kw)
         self.keep_prob_fn, self.cvd = keep_prob_fn, cvd
+        self.fuse_next = False      # models.py: the consumer is a Dense layer that applies the mask itself
 
     def forward(self, inputs):
         keep = self.keep_prob_fn()
-        self._mask, self._keep, self._sparse = None, keep, False
+        self._drop, self._sparse, self._fused = self.drop_site(keep), False, False
         if self.cvd and isinstance(inputs, tuple):
             inputs = inputs[0]                          # keeps only dropout(h), :423-425
         if isinstance(inputs, SparseInput):
             self._sparse = True
-            if keep >= 1.0:
-                return inputs
-            m = dropout_mask(self.name, (inputs.csr.nnz,), keep, inputs.csr.val.device)
-            if m is None:
+            if self._drop is None:
                 return inputs
             out = SparseInput(inputs.csr)
-            out.csr = inputs.with_values(inputs.csr.val * (m * (1.0 / keep)))
+            out.csr = inputs.with_values(ops.dropout(inputs.csr.val, self._drop))
             out.csr.coo_rows = inputs.csr.coo_rows
             return out
-        out, self._mask = dropout_fwd(inputs, keep, self.name)
-        return out
+        inputs = dense_of(inputs)
+        if self._drop is None:
+            return inputs
+        pending = Dropped(inputs, self._drop)
+        if self.fuse_next:
+            self._fused = True
+            return pending
+        return pending.materialize()
 
     def backward(self, g):
-        if g is None or self._sparse:
-            return g
-        return dropout_bwd(g, self._mask)
+        if g is None or self._sparse or self._drop is None or self._fused:
+            return g                  # fused: the consumer's dx GEMM already applied the mask
+        return ops.dropout(g, self._drop)
 
 
 class Dense(Layer):
@@ -187,6 +175,9 @@ class Dense(Layer):
 
     def forward(self, x):
         W = self.vars['weights']
+        self._drop = None
+        if isinstance(x, Dropped):         # pending dropout: applied by our own GEMMs
+            x, self._drop = x.x, x.drop
         self._x = x
         off = self.vars.get('offset') if self.norm else None
         sc = self.vars.get('scale') if self.norm else None
@@ -196,9 +187,10 @@ class Dense(Layer):
             if self.norm or self.act:      # fused LayerNorm + ReLU (one kernel)
                 y, self._ctx = ops.ln_act_fwd(y, off, sc, self.act)
         elif self.output_dim <= 128 or not (self.norm or self.act):
-            y, self._ctx = ops.dense_fwd(x, W, off, sc, self.act)      # GEMM + LN + ReLU, one launch
+            # dropout + GEMM + LN + ReLU, one launch
+            y, self._ctx = ops.dense_fwd(x, W, off, sc, self.act, drop=self._drop)
         else:
-            y, self._ctx = ops.ln_act_fwd(ops.gemm(x, W), off, sc, self.act)
+            y, self._ctx = ops.ln_act_fwd(ops.gemm(x, W, drop_a=self._drop), off, sc, self.act)
         self._out = y
         return y
 
@@ -210,10 +202,11 @@ class Dense(Layer):
             xt = self._x.transpose_of(self._x.csr.val)
             ops.spmm(xt, g, out=self.grads['weights'], beta=1.0)
             return None
-        ops.gemm(self._x, g, out=self.grads['weights'], trans_a=True, accumulate=True)   # dW += x^T g
+        ops.gemm(self._x, g, out=self.grads['weights'], trans_a=True, accumulate=True,
+                 drop_a=self._drop)                                                       # dW += dropout(x)^T g
         if not self.need_dx:
             return None
-        return ops.gemm(g, self.vars['weights'], trans_b=True)                            # dx = g W^T
+        return ops.gemm(g, self.vars['weights'], trans_b=True, drop_c=self._drop)         # dx = (g W^T) * mask
 
 
 class AugmentedDropoutDense(Layer):
@@ -239,44 +232,39 @@ class AugmentedDropoutDense(Layer):
         x, mu = inputs if isinstance(inputs, tuple) else (inputs, inputs)
         keep = self.keep_prob_fn()
         W = self.vars['weights']
-        self._mask, self._keep = None, keep
-        if self.sparse_inputs:
-            val = x.csr.val
-            if keep < 1.0:
-                m = dropout_mask(self.name, (x.csr.nnz,), keep, val.device)
-                if m is not None:
-                    val = val * (m * (1.0 / keep))
-            self._xd = (x, val)
-            xs = ops.spmm(x.with_values(val), W)
-            mus = ops.spmm(mu.csr, W)
-        else:
-            xd, self._mask = dropout_fwd(x, keep, self.name)
-            self._xd = xd
-            off = self.vars.get('offset') if self.norm else None
-            sc = self.vars.get('scale') if self.norm else None
-            fused = self.output_dim <= 128
-            if mu is x and xd is x:
-                # test models run with dropout 0 on a single stream: both streams coincide
-                hx, self._ctx = ops.dense_fwd(xd, W, off, sc, True) if fused else \
-                    ops.ln_act_fwd(ops.gemm(xd, W), off, sc, True)
-                self._out = hx
-                return hx, hx
-            # the dropout stream and the clean stream share W and the LayerNorm parameters: one
-            # stacked GEMM and one fused LN+ReLU launch over [x_dropped ; mu] (2n x d)
-            n = xd.shape[0]
-            stacked = torch.cat((xd, mu), dim=0)
-            h2, ctx2 = ops.dense_fwd(stacked, W, off, sc, True) if fused else \
-                ops.ln_act_fwd(ops.gemm(stacked, W), off, sc, True)
-            self._ctx = (ctx2[0][:n], ctx2[1][:n]) if ctx2 is not None else None
-            self._out = h2[:n]
-            return h2[:n], h2[n:]
-        same = mus is xs
+        self._drop = drop = self.drop_site(keep)
         off = self.vars.get('offset') if self.norm else None
         sc = self.vars.get('scale') if self.norm else None
-        hx, self._ctx = ops.ln_act_fwd(xs, off, sc, True)       # fused LN + ReLU
-        hmu = hx if same else ops.ln_act_fwd(mus, off, sc, True)[0]
-        self._out = hx
-        return hx, hmu
+        if self.sparse_inputs:
+            val = x.csr.val if drop is None else ops.dropout(x.csr.val, drop)
+            self._xd = (x, val)
+            xs = ops.spmm(x.with_values(val), W)
+            mus = xs if (mu is x and drop is None) else ops.spmm(mu.csr, W)
+            hx, self._ctx = ops.ln_act_fwd(xs, off, sc, True)       # fused LN + ReLU
+            hmu = hx if mus is xs else ops.ln_act_fwd(mus, off, sc, True)[0]
+            self._out = hx
+            return hx, hmu
+        x, mu = dense_of(x), dense_of(mu)
+        self._x = x
+        fused = self.output_dim <= 128
+        if mu is x and drop is None:
+            # test models run with dropout 0 on a single stream: both streams coincide
+            hx, self._ctx = ops.dense_fwd(x, W, off, sc, True) if fused else \
+                ops.ln_act_fwd(ops.gemm(x, W), off, sc, True)
+            self._out = hx
+            return hx, hx
+        # the dropout stream and the clean stream share W and the LayerNorm parameters: ONE stacked
+        # GEMM + LN + ReLU launch over [dropout(x) ; mu] (2n x d) -- the operand is never
+        # concatenated and the dropout mask never materialised (ops.dense_fwd x2 / drop)
+        n = x.shape[0]
+        if fused:
+            h2, ctx2 = ops.dense_fwd(x, W, off, sc, True, x2=mu, drop=drop)
+        else:
+            xd = x if drop is None else ops.dropout(x, drop)
+            h2, ctx2 = ops.ln_act_fwd(ops.gemm(torch.cat((xd, mu), dim=0), W), off, sc, True)
+        self._ctx = (ctx2[0][:n], ctx2[1][:n]) if ctx2 is not None else None
+        self._out = h2[:n]
+        return h2[:n], h2[n:]
 
     def backward(self, g):
         # only the x stream carries gradient: mu is stop_gradient (gcn/layers.py:412)
@@ -286,11 +274,10 @@ class AugmentedDropoutDense(Layer):
             x, val = self._xd
             ops.spmm(x.transpose_of(val), g, out=self.grads['weights'], beta=1.0)
             return None
-        ops.gemm(self._xd, g, out=self.grads['weights'], trans_a=True, accumulate=True)
+        ops.gemm(self._x, g, out=self.grads['weights'], trans_a=True, accumulate=True, drop_a=self._drop)
         if not self.need_dx:
             return None
-        g = ops.gemm(g, self.vars['weights'], trans_b=True)
-        return dropout_bwd(g, self._mask)
+        return ops.gemm(g, self.vars['weights'], trans_b=True, drop_c=self._drop)
 
 
 class PlainAggregator(Layer):
@@ -301,6 +288,7 @@ class PlainAggregator(Layer):
         self.model, self.l = model, l
 
     def forward(self, x):
+        x = dense_of(x)
         A = self.model.cur.adj[self.l]
         concat = FLAGS.normalization != 'gcn'
         n1, d = A.shape[0], x.shape[1]
@@ -336,13 +324,13 @@ class VRAggregator(Layer):
         concat = FLAGS.normalization != 'gcn'
         hist = self.model.history[l][0]
         if self.cvd:
-            h, mu = inputs
+            h, mu = (dense_of(t) for t in inputs)
             out_h, out_mu = ops.vr_aggregate(A, P, h, mu, hist, cur.fields[l], cur.ffields[l],
                                              cur.scales[l], True, concat)
             self.new_history = [mu]
             out = (out_h, out_mu)
         else:
-            x = inputs
+            x = inputs = dense_of(inputs)
             out_h, _ = ops.vr_aggregate(A, P, x, None, hist, cur.fields[l], cur.ffields[l],
                                         None, False, concat)
             self.new_history = [x]

@@ -310,6 +310,16 @@ class GCN(Model):
         self.history_vars = [h[0] for h in self.history]
         if self.is_training:
             self.adam_t = 0
+        # dropout sites: key = hash(seed, layer index, step); a Dropout feeding a dense-input Dense
+        # layer hands its mask over instead of applying it (layers.Dropped)
+        self.dropout_step = 0
+        from .layers import Dropout as _Dropout, Dense as _Dense
+        for i, layer in enumerate(self.layers):
+            layer.index = i
+            layer.key_fn = (lambda idx=i: ops.dropout_key(FLAGS.seed, idx, self.dropout_step))
+            if isinstance(layer, _Dropout) and i + 1 < len(self.layers):
+                nxt = self.layers[i + 1]
+                layer.fuse_next = isinstance(nxt, _Dense) and not nxt.sparse_inputs
         # nothing upstream of the first parametrised layer needs a gradient
         self._first_param = next((i for i, l in enumerate(self.layers) if l.param_shapes()), len(self.layers))
         if self._first_param < len(self.layers):
@@ -572,6 +582,7 @@ class GCN(Model):
             self.update_history(cur)
         finally:
             ops.unpin_stream()
+        self.dropout_step += 1          # the next step draws fresh masks at every dropout site
         if sync:
             loss, acc = float(loss), float(acc)
             outs = [None, loss, acc] if self.is_training else [loss, acc, pred.cpu().numpy()]
@@ -593,4 +604,5 @@ class GCN(Model):
             self._want_grad = False
         self.backward(dlogits)
         first = self.named_vars()[0][0]
+        self.dropout_step += 1
         return pred.cpu().numpy(), [self.get_grads()[first]]

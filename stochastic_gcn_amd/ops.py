@@ -408,9 +408,55 @@ def _gemm_ws(floats, device):
     return w
 
 
-def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False):
-    """out = op(A) @ op(B) (+ out)   (sgcn_gemm_f32; exact fp32 on the matrix cores)."""
-    if A.shape[0] * A.shape[1] * (B.shape[0] if trans_b else B.shape[1]) >= GEMM_LIBRARY_THRESHOLD:
+# ---- counter-based dropout (include/sgcn.h sgcn_dropout_t) ---------------------------------------
+def _fmix32(h):
+    h &= 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def dropout_key(seed, layer_index, step):
+    """The 32-bit key of one dropout site at one step: a hash of (seed, layer index, step)."""
+    return _fmix32(_fmix32(int(seed) * 0x9E3779B1 + int(layer_index) * 0x85EBCA77 + 0x27D4EB2F)
+                   + int(step) * 0xC2B2AE3D)
+
+
+class Drop(object):
+    """One dropout site: (keep, key) + the activation geometry the mask is defined on."""
+    __slots__ = ("keep", "key")
+
+    def __init__(self, keep, key):
+        self.keep, self.key = float(keep), int(key)
+
+    def struct(self, width, rows=-1):
+        return _ffi.Dropout(self.key, self.keep, int(rows), int(width))
+
+
+def dropout(x, drop, out=None):
+    """x * mask / keep with the hash mask (sgcn_dropout_f32): the unfused form, and -- the mask being
+    a function of the element index only -- also its own backward."""
+    if x.dim() == 1:
+        x2 = x.view(1, -1)
+        return dropout(x2, drop, None if out is None else out.view(1, -1)).view(-1)
+    xp, ldx = _rows2d(x, "x")
+    n, d = int(x.shape[0]), int(x.shape[1])
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    op, ldo = _rows2d(out, "out")
+    st = drop.struct(d)
+    check(lib.sgcn_dropout_f32(xp, ldx, n, d, C.byref(st), op, ldo, _stream()))
+    return out
+
+
+def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False, drop_a=None, drop_c=None):
+    """out = op(A) @ op(B) (+ out)   (sgcn_gemm_f32; exact fp32 on the matrix cores).
+    drop_a: the stored A is a dropout input (masked while loaded); drop_c: mask the output."""
+    if drop_a is None and drop_c is None and \
+            A.shape[0] * A.shape[1] * (B.shape[0] if trans_b else B.shape[1]) >= GEMM_LIBRARY_THRESHOLD:
         a = A.t() if trans_a else A
         b = B.t() if trans_b else B
         if out is None:
@@ -431,24 +477,32 @@ def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False):
     cp, ldc = _rows2d(out, "out")
     need = int(lib.sgcn_gemm_ws_floats(int(M), int(N), int(K)))     # > 0: split-K pays (small M x N, long K)
     ws = _gemm_ws(need, A.device) if need else None
+    da = C.byref(drop_a.struct(A.shape[1])) if drop_a is not None else None
+    dc = C.byref(drop_c.struct(N)) if drop_c is not None else None
     check(lib.sgcn_gemm_f32(int(trans_a), int(trans_b), int(M), int(N), int(K), ap, lda, bp, ldb, cp, ldc,
-                            int(accumulate), _ptr(ws), _stream()))
+                            int(accumulate), _ptr(ws), da, dc, _stream()))
     return out
 
 
-def dense_fwd(x, W, offset, scale, relu, eps=1e-9):
+def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
     """y = act(LN(x @ W) * scale + offset) in ONE launch (sgcn_dense_fwd_f32).
-    Returns (y, ctx) like ln_act_fwd; falls back to gemm for N > 128 without epilogue."""
-    M, K, N = int(x.shape[0]), int(x.shape[1]), int(W.shape[1])
-    if M * K * N >= GEMM_LIBRARY_THRESHOLD:
+    Returns (y, ctx) like ln_act_fwd.  x2: a second operand stacked below x ([x ; x2] @ W without
+    the concatenation); drop: dropout on the rows of x (never on x2), applied while the operand is
+    loaded.  Needs N <= 128 when LayerNorm / ReLU is requested."""
+    n1, K, N = int(x.shape[0]), int(x.shape[1]), int(W.shape[1])
+    M = n1 + (int(x2.shape[0]) if x2 is not None else 0)
+    if x2 is None and drop is None and M * K * N >= GEMM_LIBRARY_THRESHOLD:
         return ln_act_fwd(torch.mm(x, W), offset, scale, relu, eps) if (offset is not None or relu) \
             else (torch.mm(x, W), None)
     xp, ldx = _rows2d(x, "x")
+    x2p, ldx2 = _rows2d(x2, "x2") if x2 is not None else (None, 0)
     wp, ldw = _rows2d(W, "W")
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     norm = offset is not None
     xhat = torch.empty((M, N), dtype=torch.float32, device=x.device) if norm else None
     rstd = torch.empty((M,), dtype=torch.float32, device=x.device) if norm else None
-    check(lib.sgcn_dense_fwd_f32(M, N, K, xp, ldx, wp, ldw, _ptr(offset), _ptr(scale), float(eps),
-                                 int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), _stream()))
+    dr = C.byref(drop.struct(K, rows=n1)) if drop is not None else None
+    check(lib.sgcn_dense_fwd_f32(M, N, K, xp, ldx, x2p, ldx2, n1, wp, ldw, _ptr(offset), _ptr(scale),
+                                 float(eps), int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), dr,
+                                 _stream()))
     return y, ((xhat, rstd) if norm else None)

@@ -376,3 +376,61 @@ def test_column_sweep_extra_plane_widths(dev, d, pad):
     A.pace[d] = 300                                   # paced and unpaced sweeps agree bit for bit
     o2 = ops.spmm_cs(A, T(B, dev)[:, :d])
     assert torch.equal(o2, out_full[:, :d])
+
+
+# ---- counter-based dropout (sgcn_dropout_t): standalone and fused into the GEMMs -------------------
+@pytest.mark.parametrize("n,d,keep", [(1, 1, 0.5), (37, 19, 0.8), (1021, 1204, 0.8), (512, 256, 0.3), (64, 128, 1.0)])
+def test_dropout_is_the_oracles_hash_mask(dev, n, d, keep):
+    from stochastic_gcn_amd import ops
+    from oracle import model_np as mnp
+    rng = np.random.RandomState(n + d)
+    x = rng.standard_normal((n, d + 3)).astype(np.float32)
+    key = ops.dropout_key(1, 5, n)
+    assert key == mnp.dropout_key(1, 5, n)
+    m = mnp.hash_mask(key, (n, d), keep) if keep < 1 else np.ones((n, d), np.float32)
+    want = x[:, :d] * (m * np.float32(1.0 / keep))
+    got = ops.dropout(T(x, dev)[:, :d], ops.Drop(keep, key))
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    if keep < 1:
+        assert abs(m.mean() - keep) < 4 * np.sqrt(keep * (1 - keep) / m.size) + 1e-3     # P(keep) = keep
+    v = rng.standard_normal(777).astype(np.float32)                                       # 1-D (sparse values)
+    got = ops.dropout(T(v, dev), ops.Drop(0.6, key))
+    np.testing.assert_array_equal(got.cpu().numpy(), v * (mnp.hash_mask(key, (777,), 0.6) * np.float32(1 / 0.6)))
+
+
+@pytest.mark.parametrize("n,K,N,norm", [(300, 96, 128, True), (1021, 1204, 128, True), (77, 40, 41, False)])
+def test_fused_dropout_dense_layer_forward_and_backward(dev, n, K, N, norm):
+    """[dropout(x) ; mu] @ W -> LN -> ReLU in one launch (no concatenation, no mask tensor), the
+    weight gradient with the mask recomputed, the input gradient with the mask in the epilogue --
+    against the oracle's explicit-mask arithmetic."""
+    from stochastic_gcn_amd import ops
+    from oracle import model_np as mnp
+    rng = np.random.RandomState(K)
+    x = rng.standard_normal((n, K)).astype(np.float32)
+    mu = rng.standard_normal((n, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    off = (0.1 * rng.standard_normal((1, N))).astype(np.float32)
+    sc = (1 + 0.1 * rng.standard_normal((1, N))).astype(np.float32)
+    keep, key = 0.8, ops.dropout_key(3, 2, 11)
+    drop = ops.Drop(keep, key)
+    m = mnp.hash_mask(key, (n, K), keep) * np.float32(1.0 / keep)
+    xd = (x * m).astype(np.float32)
+    stacked = np.concatenate([xd, mu], 0)
+    pre = (stacked.astype(np.float64) @ W.astype(np.float64)).astype(np.float32)
+    if norm:
+        pre, _ = mnp.layer_norm_fwd(pre, off, sc)
+    want = np.maximum(pre, 0)
+    y, ctx = ops.dense_fwd(T(x, dev), T(W, dev), T(off, dev) if norm else None, T(sc, dev) if norm else None,
+                           True, x2=T(mu, dev), drop=drop)
+    assert onp.rel_err(y.cpu().numpy(), want) <= TOL
+    # the same without the second stream, and through the plain GEMM
+    y1 = ops.gemm(T(x, dev), T(W, dev), drop_a=drop)
+    assert onp.rel_err(y1.cpu().numpy(), xd.astype(np.float64) @ W.astype(np.float64)) <= 1e-5
+    # backward pieces
+    g = rng.standard_normal((n, N)).astype(np.float32)
+    dW = ops.gemm(T(x, dev), T(g, dev), trans_a=True, drop_a=drop)
+    assert onp.rel_err(dW.cpu().numpy(), xd.T.astype(np.float64) @ g.astype(np.float64)) <= 1e-5
+    dx = ops.gemm(T(g, dev), T(W, dev), trans_b=True, drop_c=drop)
+    want_dx = (g.astype(np.float64) @ W.T.astype(np.float64)) * m
+    assert onp.rel_err(dx.cpu().numpy(), want_dx) <= 1e-5
+    np.testing.assert_array_equal(dx.cpu().numpy() == 0, m == 0)           # exactly the dropped elements
