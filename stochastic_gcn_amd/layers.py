@@ -11,8 +11,10 @@ TF autodiff derives) keep every sparse product on our HIP kernels in both direct
   aggregator backward      -> ops.spmm on the transposed CSR the sampler emitted (K6)
   history rows             -> read in place by the fused kernel / ops.scatter_rows (models.py)
 
-Dense GEMMs / LayerNorm / ReLU / softmax are the "downstream dense" part (SURVEY.md §8a
-a-13): fp32 PyTorch-ROCm ops (rocBLAS GEMM on the matrix cores).
+Dense GEMMs / LayerNorm / ReLU / dropout are the "downstream dense" part:
+one fused fp32 MFMA launch per dense layer forward (dropout on the operand load + GEMM + LayerNorm
++ ReLU, ops.dense_fwd), two GEMM launches backward (ops.gemm with the dropout mask recomputed /
+applied in the epilogue); rocBLAS only above ops.GEMM_LIBRARY_THRESHOLD.
 """
 import numpy as np
 import torch
