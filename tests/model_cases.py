@@ -78,6 +78,16 @@ CASES = {
     'ns_nopp_L2': dict(n=900, avg=10, f=20, classes=4, sparse=False, model='plain', batch=40,
                        flags=dict(normalization='gcn', dropout=0.5, hidden1=16, degree=3,
                                   preprocess=False)),
+    # --reverse ("original models", gcn/models.py:323-333): Dense -> Dropout -> aggregator, i.e. a
+    # dropout whose consumer is NOT a Dense layer (the mask is materialised instead of fused)
+    'ns_nopp_L2_reverse': dict(n=900, avg=10, f=20, classes=4, sparse=False, model='plain', batch=40,
+                               flags=dict(normalization='graphsage', dropout=0.4, hidden1=16, degree=3,
+                                          preprocess=False, reverse=True, layer_norm=True)),
+    # wide hidden layer (> 128): LayerNorm cannot ride in the GEMM epilogue (unfused LN path)
+    'reddit_cvd_pp_wide': dict(n=700, avg=12, f=24, classes=5, sparse=False, model='vr', batch=48,
+                               flags=dict(normalization='graphsage', dropout=0.2, layer_norm=True,
+                                          hidden1=160, num_fc_layers=2, cv=True, cvd=True, degree=1,
+                                          preprocess=True)),
 }
 
 
