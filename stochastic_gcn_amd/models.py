@@ -124,13 +124,17 @@ class DevFeed(object):
             ev = torch.cuda.Event()
             ev.record()
             pb.slot.event = ev                       # the producer waits on it before reusing the slot
-        iv = lambda off, n: self.ibuf[off:off + n]   # noqa: E731
-        fv = lambda off, n: self.fbuf[off:off + n]   # noqa: E731
+        # windows into the two sections, not tensor views (ops.DevArray): address + length is all
+        # the kernels need
+        ibuf, fbuf, ip, fp = self.ibuf, self.fbuf, self.ibuf.data_ptr(), self.fbuf.data_ptr()
+        DA = ops.DevArray
+        iv = lambda off, n: DA(ibuf, ip, int(off), int(n))   # noqa: E731
+        fv = lambda off, n: DA(fbuf, fp, int(off), int(n))   # noqa: E731
         L = pb.L
         self.host_fields = [pb.field(l) for l in range(L + 1)]
         self.fields = [iv(*pb._fields[l]) for l in range(L + 1)]
         lo, lr, lc = (int(x) for x in pb._labels)
-        self.labels = fv(lo, lr * lc).view(lr, lc)
+        self.labels = fbuf[lo:lo + lr * lc].view(lr, lc)
         self.scales = [fv(*pb._scales[l]) for l in range(L)]
         self.ffields = [iv(*pb._ffields[l]) for l in range(L)] if pb.cv else []
 

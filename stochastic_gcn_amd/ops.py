@@ -65,6 +65,40 @@ def _rows2d(t, name):
     return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
 
 
+class DevArray(object):
+    """A typed window ``base[off : off + n]`` of a 1-D device buffer that is NOT a tensor: the ops
+    only need its address and length, and a torch slice costs ~2.5 us of host time -- a packed
+    minibatch has ~25 such windows, i.e. a tenth of the launch-bound training step.  ``tensor()``
+    materialises the view for the rare consumer that wants one."""
+    __slots__ = ("base", "off", "n", "dtype", "_ptr")
+    is_cuda = True
+
+    def __init__(self, base, base_ptr, off, n):
+        self.base, self.off, self.n, self.dtype = base, off, n, base.dtype
+        self._ptr = base_ptr + 4 * off          # int32 / fp32 elements
+
+    def data_ptr(self):
+        return self._ptr
+
+    @property
+    def shape(self):
+        return (self.n,)
+
+    @property
+    def device(self):
+        return self.base.device
+
+    def numel(self):
+        return self.n
+
+    def tensor(self):
+        return self.base[self.off:self.off + self.n]
+
+
+def as_tensor(x):
+    return x.tensor() if isinstance(x, DevArray) else x
+
+
 class DevicePlan(object):
     """Device copy of a host work plan + its partial-sum workspace."""
 
@@ -262,9 +296,7 @@ def ln_act_bwd(dy, y, ctx, scale, relu, doffset=None, dscale=None):
     n, d = int(dy.shape[0]), int(dy.shape[1])
     dx = torch.empty((n, d), dtype=torch.float32, device=dy.device)
     norm = ctx is not None
-    ws = None
-    if norm:
-        ws = torch.empty(int(lib.sgcn_ln_act_bwd_ws_floats(n, d)), dtype=torch.float32, device=dy.device)
+    ws = _gemm_ws(int(lib.sgcn_ln_act_bwd_ws_floats(n, d)), dy.device) if norm else None   # shared scratch
     check(lib.sgcn_ln_act_bwd_f32(gp, ldg, yp, ldy, _ptr(ctx[0]) if norm else None,
                                   _ptr(ctx[1]) if norm else None, _ptr(scale) if norm else None, n, d,
                                   int(bool(relu)), dx.data_ptr(), d, _ptr(doffset), _ptr(dscale),

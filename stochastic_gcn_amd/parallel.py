@@ -123,7 +123,7 @@ class DataParallel(object):
             if self.history_cap is not None and cap == self.history_cap:
                 self._hist_bufs[(cap, d, dev)] = bufs
         send, recv = bufs
-        send[:n] = idx
+        send[:n] = idx.tensor() if hasattr(idx, "tensor") and not torch.is_tensor(idx) else idx
         send[n:cap] = -1
         send[cap:].view(torch.float32).view(cap, d)[:n] = rows
         per = cap * (d + 1)
