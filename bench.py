@@ -89,7 +89,7 @@ def make_graph(args, rank):
     return data[0], data[2], name, data
 
 
-def train_epoch_leg(data, dev, epochs=3):
+def train_epoch_leg(data, dev, epochs=6):
     """The CVD+PP minibatch epoch of BASELINE config 3 on the same synthetic graph: reddit.config
     flags (gcn/config/reddit.config:2) + --cv --cvd --degree=1 (README.md:46-55), 298 steps of
     batch 512, the real training path (sampler thread -> packed H2D -> fused step -> Adam ->
