@@ -1,2 +1,1 @@
-for i in 1 2 3; do python bench.py --steps 3 --no-cpu-baseline | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['train_epoch']['epoch_times_s'], j['train_epoch']['sch_wait_s'])"; done
-lscpu | grep -E "Model name|MHz" | head -3
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4

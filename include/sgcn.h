@@ -228,7 +228,10 @@ int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int6
                        const float* dev_X2, int64_t ldx2, int32_t split,
                        const float* dev_W, int64_t ldw, const float* dev_offset,
                        const float* dev_scale, float eps, int32_t relu, float* dev_Y, int64_t ldy,
-                       float* dev_xhat, float* dev_rstd, const sgcn_dropout_t* drop, void* stream);
+                       float* dev_xhat, float* dev_rstd, const sgcn_dropout_t* drop,
+                       float* dev_ws /* nullable: sgcn_gemm_ws_floats(M, N, K) floats -> split-K, the
+                                        epilogue then runs in the reduction */,
+                       void* stream);
 /* Softmax cross-entropy over n rows: stats[4] = {sum_i CE_i, #rows whose arg-max matches the label
  * arg-max, mean CE (the loss), accuracy}; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
  * pred (nullable) = softmax; rowstat: 2*n floats of scratch (per-row CE and hit flag, summed

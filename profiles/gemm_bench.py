@@ -23,3 +23,24 @@ for name, ta, tb, M, N, K in shapes:
     ops.GEMM_LIBRARY_THRESHOLD = 0
     lib = timeit(lambda: ops.gemm(A, B, out=out, trans_a=bool(ta), trans_b=bool(tb), accumulate=bool(ta)))
     print("%-14s M=%5d N=%4d K=%5d  own %7.1f us   rocBLAS(torch) %7.1f us" % (name, M, N, K, own, lib))
+
+print("---- fused dense forward (stacked streams, dropout on the operand load)")
+for name, n, K, N in [("fwd0", 1021, 1204, 128), ("fwd1", 1021, 128, 128), ("fwd2 (single)", 512, 256, 128)]:
+    x = torch.randn((n, K), device=dev); mu = torch.randn((n, K), device=dev)
+    W = torch.randn((K, N), device=dev) * 0.05
+    off = torch.zeros((1, N), device=dev); sc = torch.ones((1, N), device=dev)
+    drop = ops.Drop(0.8, 12345)
+    ops.GEMM_LIBRARY_THRESHOLD = 1 << 62
+    def ev(f, reps=50):
+        for _ in range(5): f()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+    a = ev(lambda: ops.dense_fwd(x, W, off, sc, True))
+    b = ev(lambda: ops.dense_fwd(x, W, off, sc, True, x2=mu))
+    c = ev(lambda: ops.dense_fwd(x, W, off, sc, True, x2=mu, drop=drop))
+    d_ = ev(lambda: torch.mm(torch.cat((x, mu)), W))
+    print("%-14s n=%5d K=%5d N=%4d  single %6.1f us | stacked %6.1f | stacked+dropout %6.1f | cat+rocBLAS mm %6.1f" % (name, n, K, N, a, b, c, d_))

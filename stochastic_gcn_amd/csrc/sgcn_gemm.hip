@@ -34,6 +34,7 @@ struct GemmArgs {
     const float* A2; int64_t lda2; int32_t a_split;   // rows >= a_split of A come from A2 (not TA)
     DropArgs drop_a;                 // dropout on the stored A matrix, applied while loading
     DropArgs drop_c;                 // dropout on the output (plain epilogue only)
+    int32_t vec_a, vec_b;            // operand rows 16-byte aligned: 4-float runs load as one float4
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -45,58 +46,69 @@ __device__ __forceinline__ float wsum(float v) {
 // The K loop is software-pipelined: the global loads of K-step s+1 are issued into registers
 // before the MFMAs of step s, so their latency hides behind the matrix work and the two
 // barriers (these GEMMs have 4..64 workgroups: nothing else would hide it).
-template <bool TA, bool TB>
-__global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
-    __shared__ float As[kTM][kTK + 1];          // [i][kk]
-    __shared__ float Bs[kTK][kTN + 4];          // [kk][j]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+//
+// KG "K-groups": a workgroup is KG x 4 wavefronts; group kg takes the K-steps s = kg (mod KG)
+// with its own LDS tiles, and the groups' 32 x 128 partial tiles are added in group order through
+// LDS before the epilogue.  A forward GEMM of the step has M/32 = 16..64 workgroups and up to 38
+// dependent K-steps of ~1,000 MFMA cycles each: KG = 4 cuts that serial chain to a quarter and
+// still fits the fused LayerNorm epilogue (which needs whole rows in one workgroup, so split-K
+// across workgroups is not an option there).
+constexpr int kAsFloats = kTM * (kTK + 1), kBsFloats = kTK * (kTN + 4);
+constexpr int kGroupFloats = kAsFloats + kBsFloats;
+
+template <bool TA, bool TB, int KG>
+__global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
+    extern __shared__ float smem[];
+    const int kg = threadIdx.x / kBlock;                       // K-group of this thread
+    const int tid = threadIdx.x % kBlock, lane = tid & 63, wave = tid >> 6;
+    float (*As)[kTK + 1] = reinterpret_cast<float (*)[kTK + 1]>(smem + kg * kGroupFloats);            // [i][kk]
+    float (*Bs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + kg * kGroupFloats + kAsFloats); // [kk][j]
     const int m0 = blockIdx.x * kTM, n0 = blockIdx.y * kTN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     f16acc acc = {};
     float ra[4], rb[16];
 
+    // four consecutive floats at p (the run is contiguous in every operand layout): one 16-byte
+    // load when the host verified alignment and the run is fully in range, else guarded scalars
+    auto ld4 = [&](const float* p, bool vec, bool rowok, int first, int limit, float* out) {
+        if (vec && rowok && first + 3 < limit) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[e] = (rowok && first + e < limit) ? p[e] : 0.f;
+        }
+    };
     auto fetch = [&](int k0) {
         if (!TA) {          // A is [M x K]: thread reads 4 consecutive k of one row
             const int i = tid >> 3, kq = (tid & 7) * 4, row = m0 + i;
             const float* ar = (g.A2 && row >= g.a_split) ? g.A2 + (int64_t)(row - g.a_split) * g.lda2
                                                          : g.A + (int64_t)row * g.lda;
+            ld4(ar + k0 + kq, g.vec_a, row < g.M, k0 + kq, kend, ra);
+            if (g.drop_a.on) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int k = k0 + kq + e;
-                float v = (row < g.M && k < kend) ? ar[k] : 0.f;
-                if (g.drop_a.on) v *= drop_factor(g.drop_a, row, k);       // stored A = x[row][k]
-                ra[e] = v;
+                for (int e = 0; e < 4; e++) ra[e] *= drop_factor(g.drop_a, row, k0 + kq + e);   // stored A = x[row][k]
             }
         } else {            // A is [K x M]: thread reads 4 consecutive m of one k
             const int kk = tid >> 3, iq = (tid & 7) * 4, k = k0 + kk;
+            ld4(g.A + (int64_t)k * g.lda + m0 + iq, g.vec_a, k < kend, m0 + iq, g.M, ra);
+            if (g.drop_a.on) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int row = m0 + iq + e;
-                float v = (row < g.M && k < kend) ? g.A[(int64_t)k * g.lda + row] : 0.f;
-                if (g.drop_a.on) v *= drop_factor(g.drop_a, k, row);       // stored A = x[k][row]
-                ra[e] = v;
+                for (int e = 0; e < 4; e++) ra[e] *= drop_factor(g.drop_a, k, m0 + iq + e);     // stored A = x[k][row]
             }
         }
-        if (!TB) {          // B is [K x N]
+        if (!TB) {          // B is [K x N]: 4 consecutive columns of one k
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4, k = k0 + kk;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int col = n0 + jq + e;
-                    rb[r * 4 + e] = (k < kend && col < g.N) ? g.B[(int64_t)k * g.ldb + col] : 0.f;
-                }
+                ld4(g.B + (int64_t)k * g.ldb + n0 + jq, g.vec_b, k < kend, n0 + jq, g.N, rb + r * 4);
             }
-        } else {            // B is [N x K]
+        } else {            // B is [N x K]: 4 consecutive k of one column
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int j = (tid >> 3) + 32 * r, kq = (tid & 7) * 4, col = n0 + j;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int k = k0 + kq + e;
-                    rb[r * 4 + e] = (k < kend && col < g.N) ? g.B[(int64_t)col * g.ldb + k] : 0.f;
-                }
+                ld4(g.B + (int64_t)col * g.ldb + k0 + kq, g.vec_b, col < g.N, k0 + kq, kend, rb + r * 4);
             }
         }
     };
@@ -114,8 +126,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; e++) Bs[kk][jq + e] = rb[r * 4 + e];
+                *reinterpret_cast<float4*>(&Bs[kk][jq]) = make_float4(rb[r * 4], rb[r * 4 + 1], rb[r * 4 + 2], rb[r * 4 + 3]);
             }
         } else {
 #pragma unroll
@@ -127,11 +138,14 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
         }
     };
 
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += kTK) {
+    // every group runs the same number of iterations (uniform barriers); a step past kend loads zeros
+    const int iters = ((kend - kbeg + kTK - 1) / kTK + KG - 1) / KG;
+    if (iters > 0) fetch(kbeg + kg * kTK);
+    for (int it = 0; it < iters; it++) {
+        const int k0 = kbeg + (it * KG + kg) * kTK;
         stage();
         __syncthreads();
-        if (k0 + kTK < kend) fetch(k0 + kTK);          // in flight during the MFMAs below
+        if (it + 1 < iters) fetch(k0 + KG * kTK);      // in flight during the MFMAs below
         // ---- 16 x (32x32x2) MFMAs: lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
         const int fi = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -145,7 +159,22 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
 
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int cj = wave * 32 + (lane & 31);
+    if (KG > 1) {        // partial tiles of groups 1.. -> their own Bs region -> group 0 adds them in order
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) Bs[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][cj] = acc[r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            for (int o = 1; o < KG; o++) {
+                float (*P)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + o * kGroupFloats + kAsFloats);
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] += P[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][cj];
+            }
+        }
+    }
     if (g.epi == 0) {
+        if (kg != 0) return;
         float* base = g.ws ? g.ws + (int64_t)blockIdx.z * g.M * g.N : g.C;
         const int64_t ld = g.ws ? g.N : g.ldc;
         const bool add = !g.ws && g.accumulate;
@@ -162,11 +191,14 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(GemmArgs g) {
         return;
     }
     // ---- fused epilogue: tile -> LDS, then one wavefront per row (needs the whole row: N <= 128)
-    float (*Cs)[kTN + 4] = Bs;            // 32 x 132 floats fit in Bs
+    float (*Cs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + kAsFloats);   // group 0's Bs: 32 x 132 floats
+    if (KG > 1) __syncthreads();          // group 0 has finished reading the other groups' tiles
+    if (kg == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) Cs[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][cj] = acc[r];
+        for (int r = 0; r < 16; r++) Cs[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][cj] = acc[r];
+    }
     __syncthreads();
-    for (int rr = wave; rr < kTM; rr += kBlock / kWave) {
+    for (int rr = kg * (kBlock / kWave) + wave; rr < kTM; rr += KG * (kBlock / kWave)) {
         const int row = m0 + rr;
         if (row >= g.M) break;
         float* yr = g.C + (int64_t)row * g.ldc;
@@ -203,6 +235,51 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int32_t S, in
     *p = accumulate ? *p + s : s;
 }
 
+// Split-K with the dense layer's epilogue: Y = act(LN(sum_z ws[z]) * scale + offset), one wavefront
+// per output row (the forward GEMM of the first layer is 2,042 x 128 x 1,204: 64 tiles whose
+// MFMA work alone is ~16 us on 64 CUs -- cut 4-ways over K it runs on all 256).
+__global__ __launch_bounds__(kBlock) void splitk_ln_act_kernel(const float* __restrict__ ws, int32_t S,
+                                                               GemmArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (row >= g.M) return;
+    const int64_t mn = (int64_t)g.M * g.N;
+    float v[2];                                   // N <= 128: two columns per lane
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int c = lane + e * kWave;
+        float s = 0.f;
+        if (c < g.N)
+            for (int z = 0; z < S; z++) s += ws[(int64_t)z * mn + row * g.N + c];
+        v[e] = s;
+    }
+    float* yr = g.C + row * g.ldc;
+    if (g.epi == 2) {
+        const float mean = wsum(v[0] + v[1]) / (float)g.N;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) if (lane + e * kWave < g.N) { const float t = v[e] - mean; q += t * t; }
+        const float rs = rsqrtf(wsum(q) / (float)g.N + g.eps);
+        if (lane == 0) g.rstd[row] = rs;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            if (c < g.N) {
+                const float h = (v[e] - mean) * rs;
+                g.xhat[row * g.N + c] = h;
+                const float y = h * g.scale[c] + g.offset[c];
+                yr[c] = g.relu ? fmaxf(y, 0.f) : y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            if (c < g.N) yr[c] = (g.epi == 1 && g.relu) ? fmaxf(v[e], 0.f) : v[e];
+        }
+    }
+}
+
 }  // namespace sgcn
 
 using namespace sgcn;
@@ -218,18 +295,51 @@ static int split_factor(int M, int N, int K) {
     return std::max(s, 1);
 }
 
+template <bool TA, bool TB, int KG>
+static void launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    const size_t lds = (size_t)KG * kGroupFloats * sizeof(float);
+    static bool raised = false;          // > 64 KB of dynamic LDS needs the attribute once per kernel
+    if (lds > 64 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, KG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, KG>), grid, dim3(kBlock * KG), lds, st, g);
+}
+
+template <bool TA, bool TB>
+static void launch_kg(const GemmArgs& g, dim3 grid, int kgroups, hipStream_t st) {
+    if (kgroups >= 4) launch_one<TA, TB, 4>(g, grid, st);
+    else if (kgroups == 2) launch_one<TA, TB, 2>(g, grid, st);
+    else launch_one<TA, TB, 1>(g, grid, st);
+}
+
 static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st) {
-    int S = (ws && g.epi == 0) ? split_factor(g.M, g.N, g.K) : 1;
+    auto al = [](const void* p, int64_t ld) { return p && ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
+    g.vec_a = al(g.A, g.lda) && (!g.A2 || al(g.A2, g.lda2));
+    g.vec_b = al(g.B, g.ldb);
+    int S = ws ? split_factor(g.M, g.N, g.K) : 1;
     g.kchunk = ((g.K + S - 1) / S + kTK - 1) / kTK * kTK;
     S = g.K > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
     if (g.K == 0) g.kchunk = kTK;
     g.ws = S > 1 ? ws : nullptr;
+    const int epi = g.epi;
+    if (S > 1) g.epi = 0;                 // partial tiles are plain; the epilogue moves to the reduce
     dim3 grid((unsigned)((g.M + kTM - 1) / kTM), (unsigned)((g.N + kTN - 1) / kTN), (unsigned)S);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(kBlock), 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(kBlock), 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(kBlock), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(kBlock), 0, st, g);
-    if (S > 1) {
+    // K-groups inside the workgroup: worth it while the grid leaves most CUs idle and the
+    // per-workgroup K chain is long
+    const int steps = (std::min(g.kchunk, g.K) + kTK - 1) / kTK;
+    const int blocks = (int)(grid.x * grid.y * grid.z);
+    const int kgroups = (blocks <= 128 && steps >= 8) ? 4 : ((blocks <= 256 && steps >= 4) ? 2 : 1);
+    if (!ta && !tb) launch_kg<false, false>(g, grid, kgroups, st);
+    else if (ta && !tb) launch_kg<true, false>(g, grid, kgroups, st);
+    else if (!ta && tb) launch_kg<false, true>(g, grid, kgroups, st);
+    else launch_kg<true, true>(g, grid, kgroups, st);
+    if (S > 1 && epi != 0) {
+        g.epi = epi;
+        const unsigned rb = (unsigned)((g.M + (kBlock / kWave) - 1) / (kBlock / kWave));
+        hipLaunchKernelGGL(splitk_ln_act_kernel, dim3(rb), dim3(kBlock), 0, st, g.ws, S, g);
+    } else if (S > 1) {
         const int64_t mn = (int64_t)g.M * g.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st,
                            g.ws, S, g.M, g.N, g.C, g.ldc, g.accumulate);
@@ -266,7 +376,8 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
                                   const float* X2, int64_t ldx2, int32_t split,
                                   const float* W, int64_t ldw, const float* offset,
                                   const float* scale, float eps, int32_t relu, float* Y, int64_t ldy,
-                                  float* xhat, float* rstd, const sgcn_dropout_t* drop, void* stream) {
+                                  float* xhat, float* rstd, const sgcn_dropout_t* drop, float* ws,
+                                  void* stream) {
     SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "dense_fwd: negative size");
     if (M == 0 || N == 0) return SGCN_OK;
     SGCN_REQUIRE(X && W && Y, "dense_fwd: null operand");
@@ -281,5 +392,5 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
     g.A2 = X2; g.lda2 = ldx2; g.a_split = split;
     g.drop_a = drop_args(drop);
     SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
-    return launch_gemm(g, 0, 0, nullptr, (hipStream_t)stream);
+    return launch_gemm(g, 0, 0, N <= kTN ? ws : nullptr, (hipStream_t)stream);
 }

@@ -534,7 +534,9 @@ def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
     xhat = torch.empty((M, N), dtype=torch.float32, device=x.device) if norm else None
     rstd = torch.empty((M,), dtype=torch.float32, device=x.device) if norm else None
     dr = C.byref(drop.struct(K, rows=n1)) if drop is not None else None
+    need = int(lib.sgcn_gemm_ws_floats(M, N, K)) if N <= 128 else 0        # few tiles, long K: split-K
+    ws = _gemm_ws(need, x.device) if need else None
     check(lib.sgcn_dense_fwd_f32(M, N, K, xp, ldx, x2p, ldx2, n1, wp, ldw, _ptr(offset), _ptr(scale),
                                  float(eps), int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), dr,
-                                 _stream()))
+                                 _ptr(ws), _stream()))
     return y, ((xhat, rstd) if norm else None)
