@@ -394,3 +394,31 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
     SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
     return launch_gemm(g, 0, 0, N <= kTN ? ws : nullptr, (hipStream_t)stream);
 }
+
+// The whole backward of one dense layer in ONE call (three Python round trips are a quarter of
+// the launch-bound training step):  g = LN/ReLU-backward(dy)  ->  dW += dropout(x)^T . g  ->
+// dx = (g . W^T) * mask.   Same kernels, same order, same results as the three separate entries.
+extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy,
+                                  const float* y, int64_t ldy, const float* xhat, const float* rstd,
+                                  const float* scale, int32_t relu, const float* x, int64_t ldx,
+                                  const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
+                                  float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
+                                  float* g_tmp, float* ws, void* stream) {
+    SGCN_REQUIRE(n >= 0 && N >= 0 && K >= 0, "dense_bwd: negative size");
+    if (n == 0 || N == 0 || K == 0) return SGCN_OK;
+    SGCN_REQUIRE(dy && x && W && dW, "dense_bwd: null operand");
+    const float* g = dy;
+    int64_t ldg = lddy;
+    if (scale || relu) {
+        SGCN_REQUIRE(g_tmp && y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
+        const int rc = sgcn_ln_act_bwd_f32(dy, lddy, y, ldy, xhat, rstd, scale, n, N, relu, g_tmp, N, doffset,
+                                           dscale, ws, stream);
+        if (rc != SGCN_OK) return rc;
+        g = g_tmp; ldg = N;
+    }
+    // dW[K x N] += x^T[K x n] . g[n x N]      (x stored [n x K]: trans_a)
+    int rc = sgcn_gemm_f32(1, 0, K, N, n, x, ldx, g, ldg, dW, lddw, 1, ws, drop, nullptr, stream);
+    if (rc != SGCN_OK || !dx) return rc;
+    // dx[n x K] = g[n x N] . W^T              (W stored [K x N]: trans_b)
+    return sgcn_gemm_f32(0, 1, n, K, N, g, ldg, W, ldw, dx, lddx, 0, ws, nullptr, drop, stream);
+}

@@ -197,18 +197,17 @@ class Dense(Layer):
         return y
 
     def backward(self, g):
-        if self.norm or self.act:
-            g = ops.ln_act_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None,
-                               self.act, self.grads.get('offset'), self.grads.get('scale'))
         if self.sparse_inputs:
+            if self.norm or self.act:
+                g = ops.ln_act_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None,
+                                   self.act, self.grads.get('offset'), self.grads.get('scale'))
             xt = self._x.transpose_of(self._x.csr.val)
             ops.spmm(xt, g, out=self.grads['weights'], beta=1.0)
             return None
-        ops.gemm(self._x, g, out=self.grads['weights'], trans_a=True, accumulate=True,
-                 drop_a=self._drop)                                                       # dW += dropout(x)^T g
-        if not self.need_dx:
-            return None
-        return ops.gemm(g, self.vars['weights'], trans_b=True, drop_c=self._drop)         # dx = (g W^T) * mask
+        # LN/ReLU backward -> dW += dropout(x)^T g -> dx = (g W^T) * mask, one call
+        return ops.dense_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None, self.act,
+                             self._x, self.vars['weights'], self.grads['weights'], self.grads.get('offset'),
+                             self.grads.get('scale'), need_dx=self.need_dx, drop=self._drop)
 
 
 class AugmentedDropoutDense(Layer):
@@ -270,16 +269,15 @@ class AugmentedDropoutDense(Layer):
 
     def backward(self, g):
         # only the x stream carries gradient: mu is stop_gradient (gcn/layers.py:412)
-        g = ops.ln_act_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None, True,
-                           self.grads.get('offset'), self.grads.get('scale'))
         if self.sparse_inputs:
+            g = ops.ln_act_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None, True,
+                               self.grads.get('offset'), self.grads.get('scale'))
             x, val = self._xd
             ops.spmm(x.transpose_of(val), g, out=self.grads['weights'], beta=1.0)
             return None
-        ops.gemm(self._x, g, out=self.grads['weights'], trans_a=True, accumulate=True, drop_a=self._drop)
-        if not self.need_dx:
-            return None
-        return ops.gemm(g, self.vars['weights'], trans_b=True, drop_c=self._drop)
+        return ops.dense_bwd(g, self._out, self._ctx, self.vars.get('scale') if self.norm else None, True,
+                             self._x, self.vars['weights'], self.grads['weights'], self.grads.get('offset'),
+                             self.grads.get('scale'), need_dx=self.need_dx, drop=self._drop)
 
 
 class PlainAggregator(Layer):

@@ -440,6 +440,43 @@ def _gemm_ws(floats, device):
     return w
 
 
+def dense_bwd(dy, y, ctx, scale, relu, x, W, dW, doffset=None, dscale=None, need_dx=True, drop=None):
+    """Backward of ``dense_fwd`` in one call (sgcn_dense_bwd_f32): accumulates dW (and the LayerNorm
+    parameter gradients), returns dx or None.  ``x`` is the UNdropped layer input; ``drop`` the
+    dropout site that was applied to it in the forward."""
+    n, N, K = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
+    norm = ctx is not None
+    if drop is None and n * N * K >= GEMM_LIBRARY_THRESHOLD:       # library-sized: three steps
+        g = ln_act_bwd(dy, y, ctx, scale, relu, doffset, dscale) if (norm or relu) else dy
+        gemm(x, g, out=dW, trans_a=True, accumulate=True)
+        return gemm(g, W, trans_b=True) if need_dx else None
+    gp, ldg = _rows2d(dy, "dy")
+    xp, ldx = _rows2d(x, "x")
+    wp, ldw = _rows2d(W, "W")
+    dwp, lddw = _rows2d(dW, "dW")
+    pre = norm or bool(relu)
+    yp, ldy = _rows2d(y, "y") if pre else (None, 0)
+    g_tmp = torch.empty((n, N), dtype=torch.float32, device=dy.device) if pre else None
+    dx = torch.empty((n, K), dtype=torch.float32, device=dy.device) if need_dx else None
+    key = (n, N, K, norm)
+    need = _DENSE_BWD_WS.get(key)
+    if need is None:
+        need = max(int(lib.sgcn_ln_act_bwd_ws_floats(n, N)) if norm else 0,
+                   int(lib.sgcn_gemm_ws_floats(K, N, n)), int(lib.sgcn_gemm_ws_floats(n, K, N)))
+        if len(_DENSE_BWD_WS) < 4096:
+            _DENSE_BWD_WS[key] = need
+    ws = _gemm_ws(need, dy.device) if need else None
+    dr = C.byref(drop.struct(K)) if drop is not None else None
+    check(lib.sgcn_dense_bwd_f32(n, N, K, gp, ldg, yp, ldy, _ptr(ctx[0]) if norm else None,
+                                 _ptr(ctx[1]) if norm else None, _ptr(scale) if norm else None,
+                                 int(bool(relu)), xp, ldx, wp, ldw, dwp, lddw, _ptr(doffset), _ptr(dscale),
+                                 _ptr(dx), K, dr, _ptr(g_tmp), _ptr(ws), _stream()))
+    return dx
+
+
+_DENSE_BWD_WS = {}
+
+
 # ---- counter-based dropout (include/sgcn.h sgcn_dropout_t) ---------------------------------------
 def _fmix32(h):
     h &= 0xFFFFFFFF

@@ -434,3 +434,34 @@ def test_fused_dropout_dense_layer_forward_and_backward(dev, n, K, N, norm):
     want_dx = (g.astype(np.float64) @ W.T.astype(np.float64)) * m
     assert onp.rel_err(dx.cpu().numpy(), want_dx) <= 1e-5
     np.testing.assert_array_equal(dx.cpu().numpy() == 0, m == 0)           # exactly the dropped elements
+
+
+@pytest.mark.parametrize("n,K,N,norm,relu,with_drop", [(300, 96, 128, True, True, True), (512, 256, 128, True, True, False),
+                                                       (77, 40, 41, False, False, True), (1021, 128, 128, True, True, True),
+                                                       (50, 20, 160, True, True, True)])
+def test_dense_bwd_composite_matches_the_three_steps(dev, n, K, N, norm, relu, with_drop):
+    """sgcn_dense_bwd_f32 (one call) == ln_act_bwd -> gemm(dW) -> gemm(dx), bit for bit."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(n + K + N)
+    x = T(rng.standard_normal((n, K)).astype(np.float32), dev)
+    W = T((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32), dev)
+    off = T((0.1 * rng.standard_normal((1, N))).astype(np.float32), dev) if norm else None
+    sc = T((1 + 0.1 * rng.standard_normal((1, N))).astype(np.float32), dev) if norm else None
+    drop = ops.Drop(0.7, 999) if with_drop else None
+    if N <= 128 or not (norm or relu):
+        y, ctx = ops.dense_fwd(x, W, off, sc, relu, drop=drop)
+    else:
+        y, ctx = ops.ln_act_fwd(ops.gemm(x, W, drop_a=drop), off, sc, relu)
+    dy = T(rng.standard_normal((n, N)).astype(np.float32), dev)
+    # three steps
+    dW1 = torch.zeros((K, N), device=dev); do1 = torch.zeros((1, N), device=dev); ds1 = torch.zeros((1, N), device=dev)
+    g = ops.ln_act_bwd(dy, y, ctx, sc, relu, do1 if norm else None, ds1 if norm else None) if (norm or relu) else dy
+    ops.gemm(x, g, out=dW1, trans_a=True, accumulate=True, drop_a=drop)
+    dx1 = ops.gemm(g, W, trans_b=True, drop_c=drop)
+    # one call
+    dW2 = torch.zeros((K, N), device=dev); do2 = torch.zeros((1, N), device=dev); ds2 = torch.zeros((1, N), device=dev)
+    dx2 = ops.dense_bwd(dy, y, ctx, sc, relu, x, W, dW2, do2 if norm else None, ds2 if norm else None,
+                        need_dx=True, drop=drop)
+    assert torch.equal(dW1, dW2) and torch.equal(dx1, dx2) and torch.equal(do1, do2) and torch.equal(ds1, ds2)
+    assert ops.dense_bwd(dy, y, ctx, sc, relu, x, W, dW2, do2 if norm else None, ds2 if norm else None,
+                         need_dx=False, drop=drop) is None
