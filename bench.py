@@ -164,6 +164,19 @@ def cpu_baseline(full_adj, d, rows, seed=0):
            "kind": "port",
            "sample": "oracle_c.c OpenMP CSR SpMM, first %d rows (%d edges) of the same matrix, "
                      "d=%d, %d reps in %.1f s" % (rows, sub.nnz, d, reps, el)}
+    # B1 on ONE core ("1 and all cores"), on a smaller sample
+    try:
+        lib = onp.clib()
+        nthreads = int(lib.oracle_max_threads())
+        one = full_adj[:min(4000, n)].tocsr()
+        lib.oracle_set_threads(1)
+        t0 = time.time()
+        onp.spmm(one.indptr, one.indices, one.data, B)
+        out["single_thread_edges_per_s"] = one.nnz / (time.time() - t0)
+        lib.oracle_set_threads(nthreads)
+        out["cores"] = nthreads
+    except Exception:
+        pass
     # B2: scipy.sparse csr @ dense, single thread -- literally what the reference
     # uses for the PP product (gcn/utils.py:321-322)
     small = full_adj[:min(8000, n)].tocsr()

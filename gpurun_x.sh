@@ -1,1 +1,2 @@
-python profiles/epoch_cprofile.py 2>&1 | grep -v amdgpu.ids | cut -c1-160 | sed -n 3,45p
+python bench.py > gpurun_out/bench_default.json 2>gpurun_out/bench_default.err; python -c "
+import json; j=json.load(open('gpurun_out/bench_default.json')); print(j['value'], j['roofline']['frac'], j['cpu_baseline'], j['train_epoch']['epoch_time_s'])"

@@ -17,6 +17,25 @@
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* thread count of the row-parallel loops (bench.py times the baseline on all cores and on one) */
+void oracle_set_threads(int32_t n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int32_t oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* C[M x d] = A[M x K, CSR] * B[K x d]           (gcn/layers.py:31-37 dot(sparse=True) ->
  * tf.sparse_tensor_dense_matmul; K1/K11 in SURVEY §2.1).  beta==0 overwrites C. */
