@@ -129,26 +129,26 @@ def reddit_like(n=232965, m=11600000, f=602, classes=41, splits=(152410, 23699, 
     return n, train_adj, full_adj, feats, None, None, labels, tr, va, te
 
 
-def planetoid_like(n, m, f, per_row, classes, n_train, n_val, n_test, normalization, seed):
+def planetoid_like(n, m, f, per_row, classes, n_train, n_val, n_test, normalization, seed, planted=False):
     rng = np.random.RandomState(seed)
     a = er_edges(n, m, rng)
     adj = _gcn_normalize(a) if normalization == 'gcn' else _row_normalize(a)
     feats = _sparse_features(n, f, per_row, rng)
-    labels = _onehot(n, classes, rng)
+    labels = planted_labels(adj, feats, classes, rng) if planted else _onehot(n, classes, rng)
     tr = np.arange(n_train, dtype=np.int32)
     va = np.arange(n_train, n_train + n_val, dtype=np.int32)
     te = np.arange(n - n_test, n, dtype=np.int32)
     return n, adj, adj.copy(), feats, None, None, labels, tr, va, te
 
 
-def cora_like(normalization='gcn', seed=123):
+def cora_like(normalization='gcn', seed=123, planted=False):
     """S-Cora: N=2,708, 5,278 undirected edges, 1,433 sparse features (~18/row), 7 classes."""
-    return planetoid_like(2708, 5278, 1433, 18, 7, 140, 500, 1000, normalization, seed)
+    return planetoid_like(2708, 5278, 1433, 18, 7, 140, 500, 1000, normalization, seed, planted)
 
 
-def pubmed_like(normalization='gcn', seed=123):
+def pubmed_like(normalization='gcn', seed=123, planted=False):
     """S-PubMed: N=19,717, 44,324 undirected edges, 500 sparse features (~50/row), 3 classes."""
-    return planetoid_like(19717, 44324, 500, 50, 3, 60, 500, 1000, normalization, seed)
+    return planetoid_like(19717, 44324, 500, 50, 3, 60, 500, 1000, normalization, seed, planted)
 
 
 def rmat_edges(scale_log2, m, rng, abcd=(0.57, 0.19, 0.19, 0.05)):
@@ -181,14 +181,17 @@ def rmat_like(n, m, seed=1):
 
 def load_data(dataset, normalization='gcn', scale=1.0, seed=None):
     """Synthetic counterpart of gcn/utils.py:466-473 ``load_data(dataset)``."""
+    # the command-line datasets carry PLANTED labels (a random linear teacher on the 1-hop
+    # aggregate) so that a training run has something to learn; the generators' default is random
+    # labels, which is all the benchmarks and parity tests need
     if dataset in ('cora', 's-cora'):
-        return cora_like(normalization, 123 if seed is None else seed)
+        return cora_like(normalization, 123 if seed is None else seed, planted=True)
     if dataset in ('pubmed', 's-pubmed'):
-        return pubmed_like(normalization, 123 if seed is None else seed)
+        return pubmed_like(normalization, 123 if seed is None else seed, planted=True)
     if dataset in ('reddit', 's-reddit'):
         n = int(232965 * scale)
         m = int(11600000 * scale)
         sp_ = tuple(int(x * scale) for x in (152410, 23699, 55334))
-        return reddit_like(n, m, 602, 41, sp_, 1 if seed is None else seed)
+        return reddit_like(n, m, 602, 41, sp_, 1 if seed is None else seed, planted=True)
     raise ValueError("no synthetic generator for dataset '%s' (real datasets are not on this box)"
                      % dataset)
