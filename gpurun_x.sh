@@ -1,4 +1,4 @@
-echo "== cora exact"; timeout 300 python -m stochastic_gcn_amd.train --dataset cora --epochs 60 --early_stopping 100 2>&1 | grep -E "Epoch: 00(01|30|60)|Test set" | cut -c1-130
-echo "== pubmed cvd+pp"; timeout 300 python -m stochastic_gcn_amd.train --dataset pubmed --cv --cvd --test_cv --degree=1 --test_degree=1 --epochs 60 --early_stopping 100 2>&1 | grep -E "Epoch: 00(01|30|60)|Test set" | tail -3 | cut -c1-130
-echo "== reddit cvd+pp"; timeout 600 python -m stochastic_gcn_amd.train --dataset reddit --normalization graphsage --weight_decay 0 --dropout 0.2 --layer_norm --hidden1 128 --num_fc_layers 2 --epochs 4 --early_stopping 30 --batch_size=512 --test_batch_size=512 --cv --cvd --test_cv --degree=1 --test_degree=1 2>&1 | grep -E "Epoch|Test set" | cut -c1-170
-python -m pytest tests/test_train_gpu.py -m gpu -q 2>&1 | tail -2
+COMMON="--dataset reddit --normalization graphsage --weight_decay 0 --dropout 0.2 --layer_norm --hidden1 128 --num_fc_layers 2 --epochs 4 --early_stopping 30 --batch_size=512 --test_batch_size=512 --cv --cvd --test_cv --degree=1 --test_degree=1"
+for extra in "" "--prefetch 6" "--sampler_threads 2"; do
+echo "== $extra"; timeout 600 python -m stochastic_gcn_amd.train $COMMON $extra 2>&1 | grep -E "sgcn\] epoch|Epoch" | sed -E 's/.*(time= [0-9.]+ ttime= [0-9.]+ \(sch [0-9.]+ s\)).*/\1/' | tail -6
+done

@@ -317,10 +317,11 @@ class GCN(Model):
         # dropout sites: key = hash(seed, layer index, step); a Dropout feeding a dense-input Dense
         # layer hands its mask over instead of applying it (layers.Dropped)
         self.dropout_step = 0
+        self.dropout_seed = int(FLAGS.seed)       # parallel.DataParallel.attach adds the rank
         from .layers import Dropout as _Dropout, Dense as _Dense
         for i, layer in enumerate(self.layers):
             layer.index = i
-            layer.key_fn = (lambda idx=i: ops.dropout_key(FLAGS.seed, idx, self.dropout_step))
+            layer.key_fn = (lambda idx=i: ops.dropout_key(self.dropout_seed, idx, self.dropout_step))
             if isinstance(layer, _Dropout) and i + 1 < len(self.layers):
                 nxt = self.layers[i + 1]
                 layer.fuse_next = isinstance(nxt, _Dense) and not nxt.sparse_inputs

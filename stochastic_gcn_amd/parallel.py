@@ -90,6 +90,7 @@ class DataParallel(object):
         """Install the gradient all-reduce into a model's step and align the replicas' weights."""
         model.grad_hook = self.allreduce_mean_
         model.history_hook = self.sync_history
+        model.dropout_seed = int(getattr(model, "dropout_seed", 0)) + 7919 * self.rank   # independent masks per rank
         self.broadcast_(model.theta)
 
     def sync_history(self, history, idx, rows, scatter_fn):

@@ -43,7 +43,7 @@ def _masks(dmodel, keep):
     key of layer i at this step is dropout_key(seed, i, step) on both sides."""
     from oracle import model_np as mnp
     from stochastic_gcn_amd.flags import FLAGS
-    return mnp.HashMasks(FLAGS.seed, dmodel.dropout_step, keep)
+    return mnp.HashMasks(dmodel.dropout_seed, dmodel.dropout_step, keep)
 
 
 @pytest.mark.parametrize("name", sorted(mc.CASES))
