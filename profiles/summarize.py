@@ -17,7 +17,7 @@ import sys
 
 
 def db(path):
-    f = glob.glob(os.path.join(path, "*results.db"))
+    f = glob.glob(os.path.join(path, "**", "*results.db"), recursive=True)   # <dir>/<host>/<pid>_results.db
     return sqlite3.connect(f[0]) if f else None
 
 
@@ -26,8 +26,8 @@ def main(src, tag):
     lines = []
     t = db(os.path.join(src, "trace"))
     if t:
-        lines.append("== rocprofv3 --kernel-trace --stats : per-kernel totals (ns)")
-        lines.append("%-100s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        lines.append("== rocprofv3 --kernel-trace --stats : per-kernel totals (microseconds: the rocpd top_kernels view)")
+        lines.append("%-100s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for r in t.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 15"):
             lines.append("%-100s %8d %14d %12.0f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
     for sub, note in (("pmc_fetch", "FETCH_SIZE is in KiB; on gfx950 it reports 1/2 of a wide coalesced read "
