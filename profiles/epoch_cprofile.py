@@ -9,7 +9,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch          # noqa: E402
-import bench          # noqa: E402
 from stochastic_gcn_amd import synthetic          # noqa: E402
 from stochastic_gcn_amd.flags import FLAGS        # noqa: E402
 from stochastic_gcn_amd.train import Trainer      # noqa: E402

@@ -1,4 +1,4 @@
-import sys, torch, time
+import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stochastic_gcn_amd import ops
 dev = torch.device('cuda:0')

@@ -16,7 +16,6 @@ one fused fp32 MFMA launch per dense layer forward (dropout on the operand load 
 + ReLU, ops.dense_fwd), two GEMM launches backward (ops.gemm with the dropout mask recomputed /
 applied in the epilogue); rocBLAS only above ops.GEMM_LIBRARY_THRESHOLD.
 """
-import numpy as np
 import torch
 
 from . import ops

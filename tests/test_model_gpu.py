@@ -48,7 +48,6 @@ def _masks(dmodel, keep):
 
 @pytest.mark.parametrize("name", sorted(mc.CASES))
 def test_training_steps_match_oracle(name):
-    from stochastic_gcn_amd import layers
     from stochastic_gcn_amd.scheduler import PyScheduler
     case = mc.build_case(name)
     fl, c, ph = case['flags'], case['cfg'], case['ph']
@@ -159,7 +158,7 @@ def test_full_size_reddit_cvd_pp_steps_match_oracle():
     the device's gate for |pre| < KINK (and the test checks those elements really are that small);
     (2) Adam's first steps are sign-like (lr * g / |g|), so weights whose gradient is ~0 are
     compared only where |g| is well above the gradient noise."""
-    from stochastic_gcn_amd import layers, synthetic, ops
+    from stochastic_gcn_amd import synthetic, ops
     from stochastic_gcn_amd.scheduler import PyScheduler
     from oracle import model_np as mnp
     n, train_adj, full_adj, _, _, _, labels, tr, va, te = synthetic.reddit_like(with_features=False)
