@@ -10,9 +10,9 @@ history_vars`` (gcn/models.py:339-347) -- but executes eagerly on one MI355X:
     119 MB for Reddit; the box has 288 GB), so the per-step host gather + feed copy of the
     reference (gcn/vrgcn.py:39-47, 3.2 ms/step measured in SURVEY.md §6) becomes a device
     row gather;
-  * a minibatch arrives as ONE int32 and ONE fp32 pinned staging buffer (``DevFeed``) holding
-    fields / ffields / scales / labels and the CSR, transposed-CSR and row plan of each
-    layer, i.e. two H2D copies per step;
+  * a minibatch arrives as ONE pinned staging buffer ``[int32 section | fp32 section]``
+    (``DevFeed``) holding fields / ffields / scales / labels and the CSR, transposed-CSR and row
+    plan of each layer: one H2D copy per step, addressed through ``ops.DevArray`` windows;
   * parameters, gradients and Adam moments are single flat fp32 buffers (one fused update,
     and exactly one RCCL all-reduce per step in the multi-GPU driver, parallel.py);
   * history rows are scattered after the optimizer step, as the reference orders it

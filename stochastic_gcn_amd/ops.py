@@ -9,6 +9,9 @@ Reference seams replaced:
   gather_rows     history.dense_slice / tf.gather           gcn/_history.pyx:53-62, layers.py:304
   scatter_rows    tf.scatter_update                         gcn/models.py:165
   csr_slice       history.slice                             gcn/_history.pyx:25-51
+  dense_fwd / dense_bwd / gemm / dropout   the dense layers around the aggregators (dot + MyLayerNorm
+                  + relu + tf.nn.dropout and their autodiff) gcn/layers.py:87-138,365-433
+  spmm_cs         the same product as spmm for a STATIC graph (column sweep, ColumnSweepCSR)
 """
 import ctypes as C
 
