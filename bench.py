@@ -118,6 +118,7 @@ def train_epoch_leg(data, dev, epochs=6):
     # each aggregation edge is used by the forward aggregate; sampled edges again by the backward
     return {"epoch_time_s": best, "epoch_times_s": walls, "steps": le['steps'], "batch_size": 512,
             "ms_per_step": best / le['steps'] * 1e3, "sch_wait_s": le['sch_wait_s'],
+            "producer_busy_s": le.get('producer_s'),
             "agg_edges_per_epoch": edges, "agg_edges_per_s": edges / best,
             "recipe": "reddit.config + --cv --cvd --degree=1 (CVD+PP), validation excluded"}
 

@@ -76,6 +76,14 @@ int sgcn_spmm_csr_f32(const int32_t* dev_rowptr, const int32_t* dev_col, const f
                       const float* dev_rscale, const float* dev_cscale,
                       float* dev_C, int64_t ldc, float beta,
                       const sgcn_plan_t* plan, void* stream);
+/* The same with an addend in the epilogue: C[row, :] += add[row, :] for row < add_rows -- the
+ * backward of a concat aggregator, dX = A^T (s (.) g_nbr) + [g_self ; 0], in one launch
+ * (gcn/layers.py:311-319 autodiff). */
+int sgcn_spmm_csr_add_f32(const int32_t* dev_rowptr, const int32_t* dev_col, const float* dev_val,
+                          int32_t M, int32_t K, int32_t d, const float* dev_B, int64_t ldb,
+                          const int32_t* dev_gidx, const float* dev_rscale, const float* dev_cscale,
+                          float* dev_C, int64_t ldc, float beta, const sgcn_plan_t* plan,
+                          const float* dev_add, int64_t ldadd, int32_t add_rows, void* stream);
 
 /* ---- column-sweep plan for a STATIC graph (full-graph / PP products, K11) --------------------
  * A row-gather SpMM re-fetches a B row for every nonzero (measured on S-Reddit: 55.6 GB of
@@ -314,6 +322,16 @@ int sgcn_sched_batch_packed(sgcn_sched_t* s, int32_t n, const int32_t* host_ids,
                             const int32_t* host_degrees, const float* host_labels,
                             int32_t n_classes, int32_t plan_T, int64_t* meta, int64_t meta_cap,
                             int64_t* n_i32, int64_t* n_f32);
+/* sgcn_sched_batch_packed + sgcn_sched_packed_copy in one call when the caller's staging buffer
+ * (cap_words 4-byte words, laid out [max(n_i32,1) ints | max(n_f32,1) floats]) is large enough:
+ * returns 0 and the buffer is filled; returns 1 (not an error) when it is too small -- grow it
+ * and call sgcn_sched_packed_copy.  One foreign call per minibatch keeps the producer thread's
+ * interpreter-lock traffic away from the launching thread. */
+int sgcn_sched_batch_packed_into(sgcn_sched_t* s, int32_t n, const int32_t* host_ids, int32_t L,
+                                 const int32_t* host_degrees, const float* host_labels,
+                                 int32_t n_classes, int32_t plan_T, int64_t* host_meta,
+                                 int64_t meta_cap, void* host_words, int64_t cap_words,
+                                 int64_t* n_i32, int64_t* n_f32);
 int64_t sgcn_sched_packed_meta_len(int32_t L);
 int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32);
 

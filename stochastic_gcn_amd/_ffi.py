@@ -61,6 +61,8 @@ SIGNATURES = {
     "sgcn_plan_fill": (C.c_int, [P, C.c_int32, C.c_int32, P, P]),
     "sgcn_spmm_csr_f32": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
                                     P, P, P, C.c_int64, C.c_float, C.POINTER(Plan), P]),
+    "sgcn_spmm_csr_add_f32": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
+                                    P, P, P, C.c_int64, C.c_float, C.POINTER(Plan), P, C.c_int64, C.c_int32, P]),
     "sgcn_tune": (C.c_int, [C.c_char_p, C.c_int64]),
     "sgcn_tune_get": (C.c_int64, [C.c_char_p]),
     "sgcn_csplan_count": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
@@ -103,6 +105,9 @@ SIGNATURES = {
     "sgcn_sched_batch_packed": (C.c_int, [C.c_void_p, C.c_int32, P, C.c_int32, P, P, C.c_int32,
                                           C.c_int32, P, C.c_int64, C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int64)]),
+    "sgcn_sched_batch_packed_into": (C.c_int, [C.c_void_p, C.c_int32, P, C.c_int32, P, P, C.c_int32,
+                                               C.c_int32, P, C.c_int64, P, C.c_int64,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_sched_packed_meta_len": (C.c_int64, [C.c_int32]),
     "sgcn_sched_packed_copy": (C.c_int, [C.c_void_p, P, P]),
     "sgcn_mult_create": (C.c_int, [P, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -452,6 +452,18 @@ int sgcn_sched_batch_packed(sgcn_sched_t* s, int32_t n, const int32_t* ids, int3
         return sgcn::fail(SGCN_ERR_INVALID, "batch_packed: bad argument");
     return s->impl.pack_batch(n, ids, L, degrees, labels, n_classes, plan_T, meta, meta_cap, n_i32, n_f32);
 }
+int sgcn_sched_batch_packed_into(sgcn_sched_t* s, int32_t n, const int32_t* ids, int32_t L,
+                                 const int32_t* degrees, const float* labels, int32_t n_classes,
+                                 int32_t plan_T, int64_t* meta, int64_t meta_cap, void* words,
+                                 int64_t cap_words, int64_t* n_i32, int64_t* n_f32) {
+    const int rc = sgcn_sched_batch_packed(s, n, ids, L, degrees, labels, n_classes, plan_T, meta, meta_cap,
+                                           n_i32, n_f32);
+    if (rc != SGCN_OK) return rc;
+    const int64_t ni = *n_i32 > 0 ? *n_i32 : 1, nf = *n_f32 > 0 ? *n_f32 : 1;
+    if (!words || ni + nf > cap_words) return 1;          // too small: grow, then sgcn_sched_packed_copy
+    s->impl.packed_copy(static_cast<int32_t*>(words), reinterpret_cast<float*>(static_cast<int32_t*>(words) + ni));
+    return SGCN_OK;
+}
 int64_t sgcn_sched_packed_meta_len(int32_t L) { return sgcn::NeighbourSampler::meta_len(L); }
 int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32) {
     if (!s) return sgcn::fail(SGCN_ERR_INVALID, "null sampler");

@@ -71,6 +71,9 @@ struct SpmmArgs {
     float* ws;
     int64_t ldw;
     int32_t slabmajor;
+    const float* add;        // optional addend: C[row] += add[row] for row < add_rows
+    int64_t ldadd;
+    int32_t add_rows;
 };
 
 template <int VW>
@@ -86,6 +89,17 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs& a, int row, int v
             for (int e = 0; e < VW; e++)
                 if (e < left) {
                     if constexpr (VW == 1) r += a.beta * out[0]; else r[e] += a.beta * out[e];
+                }
+        }
+    }
+    if (a.add && row < a.add_rows) {     // e.g. the self term of a concat aggregator's backward
+        const float* ad = a.add + (int64_t)row * a.ldadd + (int64_t)vi * VW;
+        if (left >= VW) r += vload<VW>(ad);
+        else {
+#pragma unroll
+            for (int e = 0; e < VW; e++)
+                if (e < left) {
+                    if constexpr (VW == 1) r += ad[0]; else r[e] += ad[e];
                 }
         }
     }
@@ -267,11 +281,26 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     return fail(SGCN_ERR_INVALID, "sgcn_tune: unknown key '%s'", key);
 }
 
+extern "C" int sgcn_spmm_csr_add_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                     int32_t M, int32_t K, int32_t d, const float* B, int64_t ldb,
+                                     const int32_t* gidx, const float* rscale, const float* cscale,
+                                     float* C, int64_t ldc, float beta, const sgcn_plan_t* plan,
+                                     const float* add, int64_t ldadd, int32_t add_rows, void* stream);
+
 extern "C" int sgcn_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                  int32_t M, int32_t K, int32_t d, const float* B, int64_t ldb,
                                  const int32_t* gidx, const float* rscale, const float* cscale,
                                  float* C, int64_t ldc, float beta, const sgcn_plan_t* plan,
                                  void* stream) {
+    return sgcn_spmm_csr_add_f32(rowptr, col, val, M, K, d, B, ldb, gidx, rscale, cscale, C, ldc, beta, plan,
+                                 nullptr, 0, 0, stream);
+}
+
+extern "C" int sgcn_spmm_csr_add_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                     int32_t M, int32_t K, int32_t d, const float* B, int64_t ldb,
+                                     const int32_t* gidx, const float* rscale, const float* cscale,
+                                     float* C, int64_t ldc, float beta, const sgcn_plan_t* plan,
+                                     const float* add, int64_t ldadd, int32_t add_rows, void* stream) {
     SGCN_REQUIRE(M >= 0 && K >= 0 && d >= 0, "spmm: negative size");
     if (M == 0 || d == 0) return SGCN_OK;
     SGCN_REQUIRE(rowptr && C && (B || K == 0), "spmm: null operand");
@@ -284,6 +313,10 @@ extern "C" int sgcn_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d;
     a.nseg = M;
     a.slabmajor = g_tune_slabmajor;
+    if (add && add_rows > 0) {
+        SGCN_REQUIRE(ldadd >= d && add_rows <= M, "spmm: bad addend");
+        a.add = add; a.ldadd = ldadd; a.add_rows = add_rows;
+    }
     if (plan) {
         SGCN_REQUIRE(plan->dev_seg && plan->nseg >= M, "spmm: malformed plan");
         a.seg = plan->dev_seg; a.nseg = plan->nseg;
@@ -295,7 +328,7 @@ extern "C" int sgcn_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
                          (long long)(plan->nslots * a.ldw));
         }
     }
-    const int vw = pick_vw(d, {B, C, plan ? plan->dev_ws : nullptr}, {ldb, ldc});
+    const int vw = pick_vw(d, {B, C, plan ? plan->dev_ws : nullptr, a.add}, {ldb, ldc, a.add ? a.ldadd : ldc});
     a.nvec = (d + vw - 1) / vw;
     const int G = group_lanes(a.nvec);
     int NV = 1;

@@ -303,10 +303,8 @@ class PlainAggregator(Layer):
         A, d = self._A, self._d
         if not self._concat:
             return ops.spmm(A.transpose, g)
-        dx = torch.zeros((A.shape[1], d), dtype=torch.float32, device=g.device)
-        dx[:A.shape[0]] = g[:, :d]
-        ops.spmm(A.transpose, g[:, d:], out=dx, beta=1.0)
-        return dx
+        # dX = A^T g_nbr + [g_self ; 0]: the self term rides in the SpMM epilogue (one launch)
+        return ops.spmm(A.transpose, g[:, d:], add=g[:, :d], add_rows=A.shape[0])
 
 
 class VRAggregator(Layer):
@@ -344,7 +342,4 @@ class VRAggregator(Layer):
         A, d = self._A, self._d
         if not self._concat:
             return ops.spmm(A.transpose, g, cscale=self._s)
-        dx = torch.zeros((A.shape[1], d), dtype=torch.float32, device=g.device)
-        dx[:A.shape[0]] = g[:, :d]
-        ops.spmm(A.transpose, g[:, d:], out=dx, cscale=self._s, beta=1.0)
-        return dx
+        return ops.spmm(A.transpose, g[:, d:], cscale=self._s, add=g[:, :d], add_rows=A.shape[0])

@@ -31,6 +31,20 @@ from .layers import (AugmentedDropoutDense, Dense, Dropout, SparseInput)
 from .scheduler import PackedBatch, build_plan
 
 
+from .scheduler import CSR_DESC as _CSR_DESC          # noqa: E402
+
+
+class _LazyHostFields(object):
+    """``cur.host_fields[l]`` for a packed batch without touching NumPy unless somebody asks (only
+    the sparse-feature input slice does)."""
+
+    def __init__(self, pb):
+        self.pb = pb
+
+    def __getitem__(self, l):
+        return self.pb.field(l)
+
+
 class VariableStore(object):
     """What ``tf.make_template`` provides in the reference (gcn/train.py:115-119): the second
     model instance created through the same template reuses the first one's weights."""
@@ -125,37 +139,40 @@ class DevFeed(object):
             ev.record()
             pb.slot.event = ev                       # the producer waits on it before reusing the slot
         # windows into the two sections, not tensor views (ops.DevArray): address + length is all
-        # the kernels need
+        # the kernels need; offsets come from the descriptor table as plain Python ints (pb.m)
         ibuf, fbuf, ip, fp = self.ibuf, self.fbuf, self.ibuf.data_ptr(), self.fbuf.data_ptr()
-        DA = ops.DevArray
-        iv = lambda off, n: DA(ibuf, ip, int(off), int(n))   # noqa: E731
-        fv = lambda off, n: DA(fbuf, fp, int(off), int(n))   # noqa: E731
-        L = pb.L
-        self.host_fields = [pb.field(l) for l in range(L + 1)]
-        self.fields = [iv(*pb._fields[l]) for l in range(L + 1)]
-        lo, lr, lc = (int(x) for x in pb._labels)
+        DA, m, L = ops.DevArray, pb.m, pb.L
+        self.host_fields = _LazyHostFields(pb)
+        self.fields = [DA(ibuf, ip, m[4 + 2 * l], m[5 + 2 * l]) for l in range(L + 1)]
+        o = pb.o_labels
+        lo, lr, lc = m[o], m[o + 1], m[o + 2]
         self.labels = fbuf[lo:lo + lr * lc].view(lr, lc)
-        self.scales = [fv(*pb._scales[l]) for l in range(L)]
-        self.ffields = [iv(*pb._ffields[l]) for l in range(L)] if pb.cv else []
+        o = pb.o_scales
+        self.scales = [DA(fbuf, fp, m[o + 2 * l], m[o + 2 * l + 1]) for l in range(L)]
+        o = pb.o_ffields
+        self.ffields = [DA(ibuf, ip, m[o + 2 * l], m[o + 2 * l + 1]) for l in range(L)] if pb.cv else []
+        ND = _CSR_DESC
 
-        def csr(d):
-            d = [int(x) for x in d]
+        def csr(b):     # descriptor at m[b : b + ND]: rows, cols, nnz, rowptr, col, val, seg, nseg, fix, nfix, nslots
             plan = ops.DevicePlan.__new__(ops.DevicePlan)
-            plan.nseg, plan.nfix, plan.nslots = d[7], d[9], d[10]
-            plan.seg = iv(d[6], 4 * d[7])
-            plan.fix = iv(d[8], 3 * d[9]) if d[9] else None
+            plan.nseg, plan.nfix, plan.nslots = m[b + 7], m[b + 9], m[b + 10]
+            plan.seg = DA(ibuf, ip, m[b + 6], 4 * m[b + 7])
+            plan.fix = DA(ibuf, ip, m[b + 8], 3 * m[b + 9]) if m[b + 9] else None
             plan.ws, plan.device = None, device
-            return ops.DeviceCSR((d[0], d[1]), iv(d[3], d[0] + 1), iv(d[4], d[2]), fv(d[5], d[2]), plan)
+            return ops.DeviceCSR((m[b], m[b + 1]), DA(ibuf, ip, m[b + 3], m[b] + 1), DA(ibuf, ip, m[b + 4], m[b + 2]),
+                                 DA(fbuf, fp, m[b + 5], m[b + 2]), plan)
         self.adj, self.fadj = [], []
+        base = pb.o_csr
         for l in range(L):
-            a = csr(pb._csr[l, 0])
-            a.transpose = csr(pb._csr[l, 1])
+            b = base + 3 * l * ND
+            a = csr(b)
+            a.transpose = csr(b + ND)
             self.adj.append(a)
             if pb.cv:
-                self.fadj.append(csr(pb._csr[l, 2]))
-        self.sizes = dict(adj=[int(pb._csr[l, 0, 2]) for l in range(L)],
-                          fadj=[int(pb._csr[l, 2, 2]) for l in range(L)],
-                          fields=[int(pb._fields[l, 1]) for l in range(L + 1)])
+                self.fadj.append(csr(b + 2 * ND))
+        self.sizes = dict(adj=[m[base + 3 * l * ND + 2] for l in range(L)],
+                          fadj=[m[base + (3 * l + 2) * ND + 2] for l in range(L)],
+                          fields=[m[5 + 2 * l] for l in range(L + 1)])
         return self
 
     @staticmethod

@@ -167,8 +167,9 @@ class DeviceCSR(object):
         return m
 
 
-def spmm(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=None):
-    """out[M x d] = rscale (.) (A (cscale (.) B[gidx])) + beta * out   (sgcn_spmm_csr_f32)."""
+def spmm(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=None, add=None, add_rows=0):
+    """out[M x d] = rscale (.) (A (cscale (.) B[gidx])) + beta * out   (sgcn_spmm_csr_f32);
+    with ``add``: out[i] += add[i] for i < add_rows in the same launch (sgcn_spmm_csr_add_f32)."""
     M, K = A.shape
     bptr, ldb = _rows2d(B, "B")
     d = int(B.shape[1] if d is None else d)
@@ -183,6 +184,14 @@ def spmm(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=None):
     if rows_needed is not None and B.shape[0] < rows_needed:
         raise ValueError("B has %d rows, A has %d columns" % (B.shape[0], K))
     plan = A.plan.struct(d) if A.plan is not None else None
+    if add is not None:
+        aptr, ldadd = _rows2d(add, "add")
+        check(lib.sgcn_spmm_csr_add_f32(
+            A.rowptr.data_ptr(), _ptr(A.col), _ptr(A.val), M, K, d, bptr, ldb,
+            _ptr(_dev(gidx, torch.int32, "gidx")), _ptr(_dev(rscale, torch.float32, "rscale")),
+            _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),
+            C.byref(plan) if plan is not None else None, aptr, ldadd, int(add_rows), _stream()))
+        return out
     check(lib.sgcn_spmm_csr_f32(
         A.rowptr.data_ptr(), _ptr(A.col), _ptr(A.val), M, K, d, bptr, ldb,
         _ptr(_dev(gidx, torch.int32, "gidx")), _ptr(_dev(rscale, torch.float32, "rscale")),

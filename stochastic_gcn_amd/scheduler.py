@@ -222,41 +222,93 @@ CSR_DESC = 11   # nrows ncols nnz rowptr col val seg nseg fix nfix nslots  (incl
 class StagingSlot(object):
     """Reusable (pinned when CUDA is present) host staging buffer for one in-flight batch: the
     int32 section and the fp32 section share ONE allocation ``[n_i ints | n_f floats]`` so the
-    batch crosses PCIe in a single copy."""
+    batch crosses PCIe in a single copy.  Producers touch it through raw addresses only."""
 
-    def __init__(self, pin):
+    def __init__(self, pin, words=0):
         self.pin = pin
         self.buf = None                    # torch int32 tensor (raw 4-byte words)
-        self.ibuf = self.fbuf = None       # views of the current batch
+        self.np = None                     # the same memory as a NumPy int32 array
+        self.ptr, self.cap = 0, 0
         self.event = None                  # recorded by the consumer after its H2D copy
+        if words:
+            self._alloc(words)
 
-    def ensure(self, n_i, n_f):
+    def _alloc(self, words):
         import torch
-        if self.event is not None:         # the previous H2D copy out of this slot must be done
+        self.buf = torch.empty(int(words), dtype=torch.int32, pin_memory=self.pin)
+        self.np = self.buf.numpy()
+        self.ptr = self.buf.data_ptr()
+        self.cap = int(self.buf.numel())
+
+    def wait(self):
+        """The previous H2D copy out of this slot must be done before it is overwritten."""
+        if self.event is not None:
             self.event.synchronize()
             self.event = None
-        n_i, n_f = max(int(n_i), 1), max(int(n_f), 1)
-        if self.buf is None or self.buf.numel() < n_i + n_f:
-            self.buf = torch.empty(max(int((n_i + n_f) * 1.5), 2048), dtype=torch.int32, pin_memory=self.pin)
-        self.ibuf = self.buf[:n_i]
-        self.fbuf = self.buf[n_i:n_i + n_f].view(torch.float32)
+
+    def ensure(self, n_i, n_f):
+        """Make room for the batch; returns (address of the int32 section, of the fp32 section)."""
+        self.wait()
+        need = n_i + n_f
+        if self.buf is None or self.cap < need:
+            self._alloc(max(int(need * 1.5), 1 << 18))
+        return self.ptr, self.ptr + 4 * n_i
 
 
 class PackedBatch(object):
-    """One minibatch as two flat host arrays + a descriptor table (sgcn_sched_batch_packed)."""
+    """One minibatch as two flat host arrays + a descriptor table (sgcn_sched_batch_packed).
+    ``m`` is the descriptor table as a plain list of Python ints (what the launching thread
+    reads); the NumPy views of the sections are made on demand (tests, feed_dict())."""
 
     def __init__(self, L, cv, meta, ibuf, fbuf, n_i, n_f, slot=None):
         self.L, self.cv, self.meta = L, cv, meta
-        self.ibuf, self.fbuf, self.n_i, self.n_f = ibuf, fbuf, n_i, n_f
+        self._ibuf, self._fbuf, self.n_i, self.n_f = ibuf, fbuf, n_i, n_f
         self.slot = slot
-        m = meta
-        self._fields = m[4:4 + 2 * (L + 1)].reshape(L + 1, 2)
+        self.m = meta.tolist()
         o = 4 + 2 * (L + 1)
-        self._scales = m[o:o + 2 * L].reshape(L, 2); o += 2 * L
-        self._ffields = m[o:o + 2 * L].reshape(L, 2); o += 2 * L
-        self._labels = m[o:o + 3]; o += 3
-        self._medg = m[o:o + 2 * L].reshape(L, 2); o += 2 * L
-        self._csr = m[o:o + 3 * L * CSR_DESC].reshape(L, 3, CSR_DESC)
+        self.o_scales = o; o += 2 * L
+        self.o_ffields = o; o += 2 * L
+        self.o_labels = o; o += 3
+        self.o_medg = o; o += 2 * L
+        self.o_csr = o
+
+    # lazily built host views --------------------------------------------------------------------
+    @property
+    def ibuf(self):
+        if self._ibuf is None:
+            self._ibuf = self.slot.np[:max(self.n_i, 1)]
+        return self._ibuf
+
+    @property
+    def fbuf(self):
+        if self._fbuf is None:
+            n_i = max(self.n_i, 1)
+            self._fbuf = self.slot.np[n_i:n_i + max(self.n_f, 1)].view(np.float32)
+        return self._fbuf
+
+    @property
+    def _fields(self):
+        return self.meta[4:4 + 2 * (self.L + 1)].reshape(self.L + 1, 2)
+
+    @property
+    def _scales(self):
+        return self.meta[self.o_scales:self.o_scales + 2 * self.L].reshape(self.L, 2)
+
+    @property
+    def _ffields(self):
+        return self.meta[self.o_ffields:self.o_ffields + 2 * self.L].reshape(self.L, 2)
+
+    @property
+    def _labels(self):
+        return self.meta[self.o_labels:self.o_labels + 3]
+
+    @property
+    def _medg(self):
+        return self.meta[self.o_medg:self.o_medg + 2 * self.L].reshape(self.L, 2)
+
+    @property
+    def _csr(self):
+        return self.meta[self.o_csr:self.o_csr + 3 * self.L * CSR_DESC].reshape(self.L, 3, CSR_DESC)
 
     # numpy views (host) -------------------------------------------------------------------------
     def _i(self, off, n):
@@ -319,20 +371,31 @@ def _batch_packed(self, data, plan_T=0, slot=None):
         self._lab32 = lab if (isinstance(lab, np.ndarray) and lab.dtype == np.float32
                               and lab.flags['C_CONTIGUOUS']) else np.ascontiguousarray(lab, dtype=np.float32)
         self._meta_len = int(lib.sgcn_sched_packed_meta_len(L))
+        self._deg32_ptr, self._lab32_ptr = self._deg32.ctypes.data, self._lab32.ctypes.data
+        self._lab32_cols = int(self._lab32.shape[1])
     meta = np.zeros(self._meta_len, dtype=np.int64)
     n_i, n_f = C.c_int64(), C.c_int64()
-    check(lib.sgcn_sched_batch_packed(self.c_sch._h, int(data.shape[0]), data.ctypes.data, L,
-                                      self._deg32.ctypes.data, self._lab32.ctypes.data,
-                                      int(self._lab32.shape[1]), int(plan_T), meta.ctypes.data,
-                                      meta.shape[0], C.byref(n_i), C.byref(n_f)))
     if slot is not None:
-        slot.ensure(n_i.value, n_f.value)
-        ib, fb = slot.ibuf.numpy(), slot.fbuf.numpy()
-    else:
-        ib = np.empty(max(n_i.value, 1), dtype=np.int32)
-        fb = np.empty(max(n_f.value, 1), dtype=np.float32)
+        # ONE foreign call per minibatch: sampling + CSR/plan packing + copy into the pinned slot
+        slot.wait()
+        rc = lib.sgcn_sched_batch_packed_into(self.c_sch._h, int(data.shape[0]), data.ctypes.data, L,
+                                              self._deg32_ptr, self._lab32_ptr, self._lab32_cols, int(plan_T),
+                                              meta.ctypes.data, self._meta_len, slot.ptr, slot.cap,
+                                              C.byref(n_i), C.byref(n_f))
+        if rc < 0:
+            check(rc)
+        if rc == 1:         # first use / outgrown: grow the slot, then copy
+            pi, pf = slot.ensure(max(n_i.value, 1), max(n_f.value, 1))
+            check(lib.sgcn_sched_packed_copy(self.c_sch._h, pi, pf))
+        return PackedBatch(L, self.c_sch.cv, meta, None, None, n_i.value, n_f.value, slot)
+    check(lib.sgcn_sched_batch_packed(self.c_sch._h, int(data.shape[0]), data.ctypes.data, L,
+                                      self._deg32_ptr, self._lab32_ptr, self._lab32_cols, int(plan_T),
+                                      meta.ctypes.data, self._meta_len, C.byref(n_i), C.byref(n_f)))
+    n_i, n_f = n_i.value, n_f.value
+    ib = np.empty(max(n_i, 1), dtype=np.int32)
+    fb = np.empty(max(n_f, 1), dtype=np.float32)
     check(lib.sgcn_sched_packed_copy(self.c_sch._h, ib.ctypes.data, fb.ctypes.data))
-    return PackedBatch(L, self.c_sch.cv, meta, ib, fb, n_i.value, n_f.value, slot)
+    return PackedBatch(L, self.c_sch.cv, meta, ib, fb, n_i, n_f, None)
 
 
 def _minibatch_packed(self, batch_size, plan_T=0, slot=None):

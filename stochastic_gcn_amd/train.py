@@ -82,8 +82,13 @@ class Prefetcher(object):
         self.t.start()
 
     def _run(self, sch, batch_size, n_steps, slots):
+        t_make = 0.0
         for i in range(n_steps):
-            self.q.put(next_minibatch(sch, batch_size, slots[i % len(slots)] if slots else None))
+            t0 = time()
+            b = next_minibatch(sch, batch_size, slots[i % len(slots)] if slots else None)
+            t_make += time() - t0
+            self.q.put(b)
+        self.make_s = t_make          # producer time spent building batches (excludes queue waits)
         self.q.put(None)
 
     def next(self):
@@ -308,11 +313,13 @@ class Trainer(object):
             outs = train_model.run_one_step(self.sess, batch, sync=False)
         if pre:
             assert pre.next() is None
+            self.producer_s = getattr(pre, 'make_s', None)
         torch.cuda.synchronize()
         if outs is not None:      # Averager(1) of the reference = the last step's values
             self.avg_loss.add(float(outs[1]))
             self.avg_acc.add(float(outs[2]))
         self.last_epoch = dict(train_wall_s=time() - t, steps=n_steps, sch_wait_s=tsch,
+                               producer_s=getattr(self, 'producer_s', None),
                                sampled_edges=float(train_model.adj_sizes.sum()),
                                full_edges=float(train_model.fadj_sizes.sum()),
                                field0=float(train_model.field_sizes[0]))

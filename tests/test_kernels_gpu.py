@@ -465,3 +465,25 @@ def test_dense_bwd_composite_matches_the_three_steps(dev, n, K, N, norm, relu, w
     assert torch.equal(dW1, dW2) and torch.equal(dx1, dx2) and torch.equal(do1, do2) and torch.equal(ds1, ds2)
     assert ops.dense_bwd(dy, y, ctx, sc, relu, x, W, dW2, do2 if norm else None, ds2 if norm else None,
                          need_dx=False, drop=drop) is None
+
+
+@pytest.mark.parametrize("d", [16, 128, 37])
+def test_spmm_addend_epilogue(dev, d):
+    """C = A . B + [add ; 0] in one launch == the three-launch form (zeros, copy, beta = 1)."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(d)
+    M, K, n_add = 700, 300, 300
+    a = sp.random(M, K, density=0.05, format='csr', dtype=np.float32, random_state=rng)
+    a[5] = 0; a.eliminate_zeros()                      # an empty row inside and outside the addend range
+    a[650] = 0; a.eliminate_zeros()
+    B = rng.standard_normal((K, 2 * d)).astype(np.float32)
+    g = rng.standard_normal((n_add, 2 * d)).astype(np.float32)
+    A = ops.DeviceCSR.from_scipy(a, dev, plan_T=8)     # small T: split rows exercise the fix-up epilogue too
+    Bd, gd = T(B, dev), T(g, dev)
+    got = ops.spmm(A, Bd[:, d:], add=gd[:, :d], add_rows=n_add)
+    want = torch.zeros((M, d), device=dev)
+    want[:n_add] = gd[:, :d]
+    ops.spmm(A, Bd[:, d:], out=want, beta=1.0)
+    assert onp.rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+    ref = a.dot(B[:, d:].astype(np.float64)); ref[:n_add] += g[:, :d]
+    assert onp.rel_err(got.cpu().numpy(), ref) <= TOL
