@@ -333,6 +333,30 @@ int sgcn_sched_batch_packed_into(sgcn_sched_t* s, int32_t n, const int32_t* host
                                  int64_t meta_cap, void* host_words, int64_t cap_words,
                                  int64_t* n_i32, int64_t* n_f32);
 int64_t sgcn_sched_packed_meta_len(int32_t L);
+
+/* ---- native prefetch thread: the sampler of a whole epoch off the interpreter ------------------
+ * sgcn_prefetch_start copies the epoch's id slices (batch b = host_ids[offsets[b] : offsets[b+1]]) and
+ * starts ONE C++ thread that packs batch 0, 1, ... in order -- the same sample sequence as calling
+ * sgcn_sched_batch_packed in a loop -- each into a free staging slot (host_slot_words[i]: cap
+ * 4-byte words, pinned by the caller, laid out [max(n_i32,1) ints | max(n_f32,1) floats]).  The
+ * sampler handle must not be used by anyone else until sgcn_prefetch_stop.
+ * sgcn_prefetch_next blocks (holding no interpreter lock) for the next batch: 0 = filled *slot, sizes,
+ * meta[sgcn_sched_packed_meta_len(L)] (*spill != NULL: the batch outgrew the slot and lives in that
+ * heap buffer instead); 1 = epoch exhausted; < 0 = sampler error.  sgcn_prefetch_release hands a slot
+ * back once the consumer's copy out of it has completed.  Replaces the synchronous
+ * `feed_dict = sch.minibatch(batch_size)` of gcn/train.py:189-191. */
+typedef struct sgcn_prefetch sgcn_prefetch_t;
+int sgcn_prefetch_start(sgcn_sched_t* s, int32_t n_batches, const int32_t* host_ids,
+                        const int64_t* host_offsets, int32_t L, const int32_t* host_degrees,
+                        const float* host_labels, int32_t n_classes, int32_t plan_T, int32_t n_slots,
+                        void* const* host_slot_words, const int64_t* host_slot_caps,
+                        sgcn_prefetch_t** out);
+int sgcn_prefetch_next(sgcn_prefetch_t* p, int32_t* slot, int64_t* host_meta, int64_t* n_i32,
+                       int64_t* n_f32, const void** spill);
+int sgcn_prefetch_release(sgcn_prefetch_t* p, int32_t slot);
+/* producer-side seconds so far: [waiting for a free slot, sampling + packing, copying to slots] */
+int sgcn_prefetch_stats(sgcn_prefetch_t* p, double* out3);
+void sgcn_prefetch_stop(sgcn_prefetch_t* p);
 int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32);
 
 /* Fenwick-tree multinomial sampler without replacement (IS mode only)

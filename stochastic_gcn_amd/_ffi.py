@@ -109,6 +109,13 @@ SIGNATURES = {
                                                C.c_int32, P, C.c_int64, P, C.c_int64,
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_sched_packed_meta_len": (C.c_int64, [C.c_int32]),
+    "sgcn_prefetch_start": (C.c_int, [C.c_void_p, C.c_int32, P, P, C.c_int32, P, P, C.c_int32, C.c_int32,
+                                      C.c_int32, P, P, C.POINTER(C.c_void_p)]),
+    "sgcn_prefetch_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), P, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
+    "sgcn_prefetch_release": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sgcn_prefetch_stats": (C.c_int, [C.c_void_p, P]),
+    "sgcn_prefetch_stop": (None, [C.c_void_p]),
     "sgcn_sched_packed_copy": (C.c_int, [C.c_void_p, P, P]),
     "sgcn_mult_create": (C.c_int, [P, C.c_int32, C.POINTER(C.c_void_p)]),
     "sgcn_mult_destroy": (None, [C.c_void_p]),

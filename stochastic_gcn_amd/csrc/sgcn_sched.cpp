@@ -20,9 +20,16 @@
 #include "../../include/sgcn.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace sgcn {
@@ -395,6 +402,74 @@ private:
 
 // ---- C ABI --------------------------------------------------------------------------------------
 struct sgcn_sched { sgcn::NeighbourSampler impl; };
+
+// ---- native prefetch thread --------------------------------------------------------------------
+// The sampler of an epoch as a C++ thread: it walks the epoch's id slices in order (so the sample
+// sequence is the synchronous loop's, bit for bit), packs each minibatch and copies it into the
+// next free pinned staging slot.  No Python runs on this thread: a Python producer thread has to
+// re-take the interpreter lock after every foreign call, and against a launching thread that
+// releases and re-takes it every ~20 us that costs ~0.25 ms per batch (measured: 0.5 ms per batch
+// next to 0.26 ms alone) -- enough to make the sampler the bottleneck of the epoch.
+struct sgcn_prefetch {
+    struct Ready { int32_t batch, slot; int64_t n_i, n_f; std::vector<int64_t> meta; std::unique_ptr<std::vector<int32_t>> spill; };
+    sgcn_sched* s = nullptr;
+    std::vector<int32_t> ids; std::vector<int64_t> off;
+    int32_t L = 0, n_classes = 0, plan_T = 0;
+    std::vector<int32_t> degrees; const float* labels = nullptr;
+    std::vector<void*> slot_words; std::vector<int64_t> slot_caps;
+    int64_t meta_len = 0;
+    std::mutex mu; std::condition_variable cv_free, cv_ready;
+    std::deque<int32_t> free_slots; std::deque<Ready> ready;
+    std::vector<std::unique_ptr<std::vector<int32_t>>> spills;   // batches that outgrew their slot
+    bool stop = false, done = false; int error = 0; std::string error_msg;
+    double t_wait = 0, t_pack = 0, t_copy = 0;       // producer seconds: waiting for a slot / packing / copying
+    std::thread th;
+
+    void run() {
+        const int32_t nb = (int32_t)off.size() - 1;
+        for (int32_t b = 0; b < nb; b++) {
+            int32_t slot;
+            using clk = std::chrono::steady_clock;
+            const auto c0 = clk::now();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_free.wait(lk, [&] { return stop || !free_slots.empty(); });
+                if (stop) break;
+                slot = free_slots.front(); free_slots.pop_front();
+            }
+            const auto c1 = clk::now();
+            Ready r; r.batch = b; r.slot = slot; r.meta.assign((size_t)meta_len, 0);
+            const int rc = s->impl.pack_batch((int32_t)(off[b + 1] - off[b]), ids.data() + off[b], L, degrees.data(),
+                                              labels, n_classes, plan_T, r.meta.data(), meta_len, &r.n_i, &r.n_f);
+            if (rc != SGCN_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                error = rc; error_msg = sgcn::error_slot(); done = true; cv_ready.notify_all();
+                return;
+            }
+            const int64_t ni = std::max<int64_t>(r.n_i, 1), nf = std::max<int64_t>(r.n_f, 1);
+            int32_t* dst;
+            if (ni + nf <= slot_caps[slot]) dst = static_cast<int32_t*>(slot_words[slot]);
+            else {                       // rare: the batch outgrew the slot -> heap buffer, slot stays unused
+                r.spill.reset(new std::vector<int32_t>((size_t)(ni + nf)));
+                dst = r.spill->data();
+            }
+            const auto c2 = clk::now();
+            s->impl.packed_copy(dst, reinterpret_cast<float*>(dst + ni));
+            const auto c3 = clk::now();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready.push_back(std::move(r));
+                t_wait += std::chrono::duration<double>(c1 - c0).count();
+                t_pack += std::chrono::duration<double>(c2 - c1).count();
+                t_copy += std::chrono::duration<double>(c3 - c2).count();
+            }
+            cv_ready.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv_ready.notify_all();
+    }
+};
 struct sgcn_mult { sgcn::FenwickMultinomial impl; };
 
 extern "C" {
@@ -465,6 +540,95 @@ int sgcn_sched_batch_packed_into(sgcn_sched_t* s, int32_t n, const int32_t* ids,
     return SGCN_OK;
 }
 int64_t sgcn_sched_packed_meta_len(int32_t L) { return sgcn::NeighbourSampler::meta_len(L); }
+
+int sgcn_prefetch_start(sgcn_sched_t* s, int32_t n_batches, const int32_t* ids, const int64_t* offsets,
+                        int32_t L, const int32_t* degrees, const float* labels, int32_t n_classes,
+                        int32_t plan_T, int32_t n_slots, void* const* slot_words,
+                        const int64_t* slot_caps, sgcn_prefetch_t** out) {
+    if (!s || !out || n_batches < 0 || !offsets || (n_batches > 0 && !ids) || L < 0 || (L > 0 && !degrees) ||
+        n_slots < 1 || !slot_words || !slot_caps)
+        return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: bad argument");
+    try {
+        std::unique_ptr<sgcn_prefetch> p(new sgcn_prefetch);
+        p->s = s;
+        p->off.assign(offsets, offsets + n_batches + 1);
+        p->ids.assign(ids, ids + (n_batches ? offsets[n_batches] : 0));
+        p->L = L; p->n_classes = n_classes; p->plan_T = plan_T; p->labels = labels;
+        p->degrees.assign(degrees, degrees + L);
+        p->meta_len = sgcn::NeighbourSampler::meta_len(L);
+        for (int32_t i = 0; i < n_slots; i++) {
+            p->slot_words.push_back(slot_words[i]); p->slot_caps.push_back(slot_caps[i]);
+            p->free_slots.push_back(i);
+        }
+        sgcn_prefetch* raw = p.get();
+        p->th = std::thread([raw] { raw->run(); });
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: %s", e.what());
+    }
+    return SGCN_OK;
+}
+
+/* Blocks until the next batch (in order) is ready.  Returns 0 and fills slot / sizes / meta; 1 when
+ * the epoch is exhausted; < 0 on a sampler error.  *spill != NULL: the batch outgrew its slot and
+ * lives in that heap buffer (n_i + n_f words) until the slot index is released. */
+int sgcn_prefetch_next(sgcn_prefetch_t* p, int32_t* slot, int64_t* meta, int64_t* n_i, int64_t* n_f,
+                       const void** spill) {
+    if (!p || !slot || !meta || !n_i || !n_f || !spill) return sgcn::fail(SGCN_ERR_INVALID, "prefetch_next: bad argument");
+    sgcn_prefetch::Ready r;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_ready.wait(lk, [&] { return !p->ready.empty() || p->done; });
+        if (p->ready.empty()) {
+            if (p->error) return sgcn::fail(p->error, "%s", p->error_msg.c_str());
+            return 1;
+        }
+        r = std::move(p->ready.front());
+        p->ready.pop_front();
+    }
+    *slot = r.slot; *n_i = r.n_i; *n_f = r.n_f;
+    memcpy(meta, r.meta.data(), sizeof(int64_t) * (size_t)p->meta_len);
+    *spill = nullptr;
+    if (r.spill) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if ((size_t)r.slot >= p->spills.size()) p->spills.resize((size_t)r.slot + 1);
+        *spill = r.spill->data();
+        p->spills[(size_t)r.slot] = std::move(r.spill);
+    }
+    return SGCN_OK;
+}
+
+/* The consumer is done with the slot (its H2D copy has completed): the producer may overwrite it. */
+int sgcn_prefetch_release(sgcn_prefetch_t* p, int32_t slot) {
+    if (!p || slot < 0 || (size_t)slot >= p->slot_words.size()) return sgcn::fail(SGCN_ERR_INVALID, "prefetch_release: bad slot");
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if ((size_t)slot < p->spills.size()) p->spills[(size_t)slot].reset();
+        p->free_slots.push_back(slot);
+    }
+    p->cv_free.notify_one();
+    return SGCN_OK;
+}
+
+/* Producer-side seconds so far: out[0] waiting for a free slot, out[1] sampling + packing,
+ * out[2] copying into the staging slots. */
+int sgcn_prefetch_stats(sgcn_prefetch_t* p, double* out) {
+    if (!p || !out) return sgcn::fail(SGCN_ERR_INVALID, "prefetch_stats: bad argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    out[0] = p->t_wait; out[1] = p->t_pack; out[2] = p->t_copy;
+    return SGCN_OK;
+}
+
+void sgcn_prefetch_stop(sgcn_prefetch_t* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_free.notify_all();
+    if (p->th.joinable()) p->th.join();
+    delete p;
+}
 int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32) {
     if (!s) return sgcn::fail(SGCN_ERR_INVALID, "null sampler");
     s->impl.packed_copy(dst_i32, dst_f32);

@@ -365,14 +365,7 @@ def _batch_packed(self, data, plan_T=0, slot=None):
     """One C call for the whole minibatch (no per-array Python work, runs without the GIL)."""
     data = np.ascontiguousarray(data, dtype=np.int32)
     L = self.L
-    if getattr(self, "_deg32", None) is None:
-        self._deg32 = np.ascontiguousarray(self.degrees, dtype=np.int32)
-        lab = self.labels
-        self._lab32 = lab if (isinstance(lab, np.ndarray) and lab.dtype == np.float32
-                              and lab.flags['C_CONTIGUOUS']) else np.ascontiguousarray(lab, dtype=np.float32)
-        self._meta_len = int(lib.sgcn_sched_packed_meta_len(L))
-        self._deg32_ptr, self._lab32_ptr = self._deg32.ctypes.data, self._lab32.ctypes.data
-        self._lab32_cols = int(self._lab32.shape[1])
+    self._packed_setup()
     meta = np.zeros(self._meta_len, dtype=np.int64)
     n_i, n_f = C.c_int64(), C.c_int64()
     if slot is not None:
@@ -407,5 +400,92 @@ def _minibatch_packed(self, batch_size, plan_T=0, slot=None):
     return self.batch_packed(batch, plan_T, slot)
 
 
+class NativePrefetcher(object):
+    """An epoch's minibatches from the C++ sampler thread of libsgcn.so (sgcn_prefetch_*): same
+    sample sequence as calling ``batch_packed`` in a loop, but no Python runs on the producer, so
+    it never competes with the launching thread for the interpreter lock.  ``next()`` blocks in C
+    (lock released) and returns a PackedBatch living in one of ``n_slots`` pinned staging slots; a
+    slot goes back to the producer ``lag`` batches after it was handed out, once the H2D copy
+    the consumer recorded on it has completed."""
+
+    def __init__(self, sch, batches, plan_T=0, depth=2, pin=True, lag=2):
+        sch._packed_setup()
+        self.sch, self.L, self.lag = sch, sch.L, lag
+        self.n_batches = len(batches)
+        ids = np.ascontiguousarray(np.concatenate(batches) if batches else np.zeros(0), dtype=np.int32)
+        off = np.zeros(len(batches) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in batches], out=off[1:])
+        n_slots = max(1, depth) + 1 + lag
+        words = int(getattr(sch, "_slot_words", 0) or (1 << 20))
+        pool = getattr(sch, "_slot_pool", None)
+        if pool is None or len(pool) != n_slots or pool[0].cap < words or pool[0].pin != pin:
+            pool = [StagingSlot(pin, words) for _ in range(n_slots)]
+            sch._slot_pool = pool
+        self.slots = pool
+        for sl in pool:
+            sl.wait()
+        ptrs = (C.c_void_p * n_slots)(*[sl.ptr for sl in pool])
+        caps = (C.c_int64 * n_slots)(*[sl.cap for sl in pool])
+        self._h = C.c_void_p()
+        check(lib.sgcn_prefetch_start(sch.c_sch._h, len(batches), ids.ctypes.data, off.ctypes.data, self.L,
+                                      sch._deg32_ptr, sch._lab32_ptr, sch._lab32_cols, int(plan_T), n_slots,
+                                      ptrs, caps, C.byref(self._h)))
+        self.pending = []
+        self.max_words = 0
+
+    def next(self):
+        if self._h is None:
+            return None
+        while len(self.pending) > self.lag:            # hand old slots back to the producer
+            idx = self.pending.pop(0)
+            self.slots[idx].wait()
+            check(lib.sgcn_prefetch_release(self._h, idx))
+        meta = np.zeros(self.sch._meta_len, dtype=np.int64)
+        slot, n_i, n_f, spill = C.c_int32(), C.c_int64(), C.c_int64(), C.c_void_p()
+        rc = lib.sgcn_prefetch_next(self._h, C.byref(slot), meta.ctypes.data, C.byref(n_i), C.byref(n_f),
+                                    C.byref(spill))
+        if rc == 1:
+            self.close()
+            return None
+        check(rc)
+        n_i, n_f, idx = n_i.value, n_f.value, slot.value
+        self.max_words = max(self.max_words, max(n_i, 1) + max(n_f, 1))
+        if spill.value:      # outgrew the slot: copy out of the producer's heap buffer, free the slot at once
+            ni, nf = max(n_i, 1), max(n_f, 1)
+            raw = np.ctypeslib.as_array((C.c_int32 * (ni + nf)).from_address(spill.value)).copy()
+            check(lib.sgcn_prefetch_release(self._h, idx))
+            return PackedBatch(self.L, self.sch.c_sch.cv, meta, raw[:ni], raw[ni:].view(np.float32), n_i, n_f, None)
+        self.pending.append(idx)
+        return PackedBatch(self.L, self.sch.c_sch.cv, meta, None, None, n_i, n_f, self.slots[idx])
+
+    def close(self):
+        if self._h is not None:
+            st = (C.c_double * 3)()
+            lib.sgcn_prefetch_stats(self._h, st)
+            self.stats = dict(wait_slot_s=st[0], pack_s=st[1], copy_s=st[2])
+            lib.sgcn_prefetch_stop(self._h)
+            self._h = None
+            if self.max_words > self.slots[0].cap:      # size the next epoch's slots for what we saw
+                self.sch._slot_words = int(self.max_words * 1.5)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _packed_setup(self):
+    if getattr(self, "_deg32", None) is None:
+        self._deg32 = np.ascontiguousarray(self.degrees, dtype=np.int32)
+        lab = self.labels
+        self._lab32 = lab if (isinstance(lab, np.ndarray) and lab.dtype == np.float32
+                              and lab.flags['C_CONTIGUOUS']) else np.ascontiguousarray(lab, dtype=np.float32)
+        self._meta_len = int(lib.sgcn_sched_packed_meta_len(self.L))
+        self._deg32_ptr, self._lab32_ptr = self._deg32.ctypes.data, self._lab32.ctypes.data
+        self._lab32_cols = int(self._lab32.shape[1])
+
+
+PyScheduler._packed_setup = _packed_setup
 PyScheduler.batch_packed = _batch_packed
 PyScheduler.minibatch_packed = _minibatch_packed

@@ -27,7 +27,7 @@ from .flags import FLAGS
 from .models import make_template
 from .parallel import DataParallel
 from .plaingcn import PlainGCN
-from .scheduler import PyScheduler
+from .scheduler import NativePrefetcher, PyScheduler
 from .utils import Averager, calc_f1, load_data
 from .vrgcn import VRGCN
 
@@ -267,8 +267,12 @@ class Trainer(object):
         N = len(data)
         k = 0
         chunks = [data[st:min(st + FLAGS.test_batch_size, N)] for st in range(0, N, FLAGS.test_batch_size)]
-        pre = ParallelPrefetcher(self.eval_schs, chunks, FLAGS.plan_t, self.eval_slots, max(FLAGS.prefetch, 1)) \
-            if len(self.eval_schs) > 1 else None
+        if len(self.eval_schs) > 1:
+            pre = ParallelPrefetcher(self.eval_schs, chunks, FLAGS.plan_t, self.eval_slots, max(FLAGS.prefetch, 1))
+        elif FLAGS.prefetch > 0 and FLAGS.native_prefetch:
+            pre = NativePrefetcher(self.eval_sch, chunks, FLAGS.plan_t, depth=FLAGS.prefetch)
+        else:
+            pre = None
         for chunk in chunks:
             batch = pre.next() if pre else \
                 self.eval_sch.batch_packed(chunk, FLAGS.plan_t, self.eval_slots[k % len(self.eval_slots)])
@@ -277,6 +281,8 @@ class Trainer(object):
             stats.append(torch.stack([los, acc]) * prd.shape[0])
             total_pred.append(prd)
             total_labs.append(self.test_model.cur.labels)
+        if pre is not None and hasattr(pre, 'close'):
+            pre.close()
         if not stats:
             return 0.0, 0.0, 0.0, 0.0, time() - t_test
         tot = torch.stack(stats).sum(dim=0).cpu().numpy() / max(N, 1)      # the only host sync
@@ -300,6 +306,10 @@ class Trainer(object):
         if len(self.train_schs) > 1:
             pre = ParallelPrefetcher(self.train_schs, epoch_batches(train_sch.data, FLAGS.batch_size, n_steps),
                                      FLAGS.plan_t, slots, max(FLAGS.prefetch, 1))
+        elif FLAGS.prefetch > 0 and FLAGS.native_prefetch:
+            # the C++ sampler thread: same sample sequence, no interpreter lock on the producer
+            pre = NativePrefetcher(train_sch, epoch_batches(train_sch.data, FLAGS.batch_size, n_steps),
+                                   FLAGS.plan_t, depth=FLAGS.prefetch)
         else:
             pre = Prefetcher(train_sch, FLAGS.batch_size, FLAGS.prefetch, n_steps, slots) \
                 if FLAGS.prefetch > 0 else None
@@ -314,6 +324,9 @@ class Trainer(object):
         if pre:
             assert pre.next() is None
             self.producer_s = getattr(pre, 'make_s', None)
+            if hasattr(pre, 'close'):
+                pre.close()
+                self.producer_s = getattr(pre, 'stats', None)
         torch.cuda.synchronize()
         if outs is not None:      # Averager(1) of the reference = the last step's values
             self.avg_loss.add(float(outs[1]))

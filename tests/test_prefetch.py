@@ -60,3 +60,36 @@ def test_single_sampler_prefetcher_is_the_sequential_sequence():
         assert pb.n_i == r.n_i and pb.n_f == r.n_f
         np.testing.assert_array_equal(np.asarray(pb.ibuf[:pb.n_i]), np.asarray(r.ibuf[:r.n_i]))
         np.testing.assert_array_equal(np.asarray(pb.fbuf[:pb.n_f]), np.asarray(r.fbuf[:r.n_f]))
+
+
+def test_native_prefetcher_is_the_sequential_sequence_and_survives_small_slots():
+    """The C++ sampler thread (sgcn_prefetch_*) yields exactly the batches the synchronous loop
+    yields -- also when a batch outgrows its staging slot (spill path) and when the consumer
+    stops early."""
+    from stochastic_gcn_amd.scheduler import NativePrefetcher
+    a, labels = _graph()
+    deg = np.array([2, 3], dtype=np.int32)
+    ids = np.random.RandomState(3).permutation(a.shape[0]).astype(np.int32)
+    batches = epoch_batches(ids, 40, 17)
+    seq = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
+    ref = [seq.batch_packed(b) for b in batches]
+    for words in (1 << 20, 300):                          # roomy slots / every batch spills
+        sch = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
+        sch._slot_words = words
+        pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False)
+        for r in ref:
+            pb = pre.next()
+            assert (pb.n_i, pb.n_f) == (r.n_i, r.n_f)
+            np.testing.assert_array_equal(pb.meta, r.meta)
+            np.testing.assert_array_equal(np.asarray(pb.ibuf[:pb.n_i]), np.asarray(r.ibuf[:r.n_i]))
+            np.testing.assert_array_equal(np.asarray(pb.fbuf[:pb.n_f]), np.asarray(r.fbuf[:r.n_f]))
+        assert pre.next() is None and pre.next() is None
+        if words == 300:
+            assert sch._slot_words > 300                  # the next epoch gets bigger slots
+    # early stop: the thread is joined without draining the epoch
+    sch = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
+    pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False)
+    assert pre.next() is not None
+    pre.close()
+    # and the sampler is usable again afterwards
+    assert sch.batch_packed(batches[0]) is not None
