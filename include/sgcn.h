@@ -336,21 +336,24 @@ int64_t sgcn_sched_packed_meta_len(int32_t L);
 
 /* ---- native prefetch thread: the sampler of a whole epoch off the interpreter ------------------
  * sgcn_prefetch_start copies the epoch's id slices (batch b = host_ids[offsets[b] : offsets[b+1]]) and
- * starts ONE C++ thread that packs batch 0, 1, ... in order -- the same sample sequence as calling
- * sgcn_sched_batch_packed in a loop -- each into a free staging slot (host_slot_words[i]: cap
+ * starts one C++ thread per sampler.  With ONE sampler the thread packs batch 0, 1, ... in order --
+ * the same sample sequence as calling sgcn_sched_batch_packed in a loop; with N samplers (the
+ * NON-PARITY fast mode: independent RNG streams) thread k packs batches k, k + N, ... and the consumer
+ * still receives them in batch order.  Each batch goes into a free staging slot (host_slot_words[i]: cap
  * 4-byte words, pinned by the caller, laid out [max(n_i32,1) ints | max(n_f32,1) floats]).  The
  * sampler handle must not be used by anyone else until sgcn_prefetch_stop.
  * sgcn_prefetch_next blocks (holding no interpreter lock) for the next batch: 0 = filled *slot, sizes,
  * meta[sgcn_sched_packed_meta_len(L)] (*spill != NULL: the batch outgrew the slot and lives in that
  * heap buffer instead); 1 = epoch exhausted; < 0 = sampler error.  sgcn_prefetch_release hands a slot
- * back once the consumer's copy out of it has completed.  Replaces the synchronous
+ * back once the consumer's copy out of it has completed (`lag` = how many handed-out slots the
+ * consumer keeps besides the current one; it bounds the producers' look-ahead).  Replaces the synchronous
  * `feed_dict = sch.minibatch(batch_size)` of gcn/train.py:189-191. */
 typedef struct sgcn_prefetch sgcn_prefetch_t;
-int sgcn_prefetch_start(sgcn_sched_t* s, int32_t n_batches, const int32_t* host_ids,
-                        const int64_t* host_offsets, int32_t L, const int32_t* host_degrees,
-                        const float* host_labels, int32_t n_classes, int32_t plan_T, int32_t n_slots,
-                        void* const* host_slot_words, const int64_t* host_slot_caps,
-                        sgcn_prefetch_t** out);
+int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32_t n_batches,
+                        const int32_t* host_ids, const int64_t* host_offsets, int32_t L,
+                        const int32_t* host_degrees, const float* host_labels, int32_t n_classes,
+                        int32_t plan_T, int32_t n_slots, void* const* host_slot_words,
+                        const int64_t* host_slot_caps, int32_t lag, sgcn_prefetch_t** out);
 int sgcn_prefetch_next(sgcn_prefetch_t* p, int32_t* slot, int64_t* host_meta, int64_t* n_i32,
                        int64_t* n_f32, const void** spill);
 int sgcn_prefetch_release(sgcn_prefetch_t* p, int32_t slot);

@@ -109,8 +109,8 @@ SIGNATURES = {
                                                C.c_int32, P, C.c_int64, P, C.c_int64,
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_sched_packed_meta_len": (C.c_int64, [C.c_int32]),
-    "sgcn_prefetch_start": (C.c_int, [C.c_void_p, C.c_int32, P, P, C.c_int32, P, P, C.c_int32, C.c_int32,
-                                      C.c_int32, P, P, C.POINTER(C.c_void_p)]),
+    "sgcn_prefetch_start": (C.c_int, [P, C.c_int32, C.c_int32, P, P, C.c_int32, P, P, C.c_int32, C.c_int32,
+                                      C.c_int32, P, P, C.c_int32, C.POINTER(C.c_void_p)]),
     "sgcn_prefetch_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), P, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
     "sgcn_prefetch_release": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -411,65 +411,76 @@ struct sgcn_sched { sgcn::NeighbourSampler impl; };
 // releases and re-takes it every ~20 us that costs ~0.25 ms per batch (measured: 0.5 ms per batch
 // next to 0.26 ms alone) -- enough to make the sampler the bottleneck of the epoch.
 struct sgcn_prefetch {
-    struct Ready { int32_t batch, slot; int64_t n_i, n_f; std::vector<int64_t> meta; std::unique_ptr<std::vector<int32_t>> spill; };
-    sgcn_sched* s = nullptr;
+    struct Ready { int32_t batch = 0, slot = 0; int64_t n_i = 0, n_f = 0; std::vector<int64_t> meta; std::unique_ptr<std::vector<int32_t>> spill; };
+    std::vector<sgcn_sched*> ss;                   // one sampler per producer thread
     std::vector<int32_t> ids; std::vector<int64_t> off;
-    int32_t L = 0, n_classes = 0, plan_T = 0;
+    int32_t L = 0, n_classes = 0, plan_T = 0, lag = 2;
     std::vector<int32_t> degrees; const float* labels = nullptr;
     std::vector<void*> slot_words; std::vector<int64_t> slot_caps;
     int64_t meta_len = 0;
     std::mutex mu; std::condition_variable cv_free, cv_ready;
-    std::deque<int32_t> free_slots; std::deque<Ready> ready;
+    std::deque<int32_t> free_slots;
+    std::vector<Ready> ready; std::vector<char> is_ready;       // indexed by batch
+    int32_t next_batch = 0;                                      // the batch the consumer takes next
     std::vector<std::unique_ptr<std::vector<int32_t>>> spills;   // batches that outgrew their slot
-    bool stop = false, done = false; int error = 0; std::string error_msg;
+    bool stop = false; int32_t running = 0; int error = 0; std::string error_msg;
     double t_wait = 0, t_pack = 0, t_copy = 0;       // producer seconds: waiting for a slot / packing / copying
-    std::thread th;
+    std::vector<std::thread> ths;
 
-    void run() {
-        const int32_t nb = (int32_t)off.size() - 1;
-        for (int32_t b = 0; b < nb; b++) {
+    // Thread k builds batches k, k + N, k + 2N, ...  A batch may take a slot only inside the window
+    // of batches the consumer will ask for next: with `window` = slots the consumer never holds,
+    // the batches in the window can all be staged at once, so the one the consumer is waiting for
+    // can never be starved of a slot by later ones.
+    void run(int32_t k) {
+        const int32_t nb = (int32_t)off.size() - 1, N = (int32_t)ss.size();
+        const int32_t window = std::max<int32_t>(1, (int32_t)slot_words.size() - lag - 1);
+        using clk = std::chrono::steady_clock;
+        for (int32_t b = k; b < nb; b += N) {
             int32_t slot;
-            using clk = std::chrono::steady_clock;
             const auto c0 = clk::now();
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_free.wait(lk, [&] { return stop || !free_slots.empty(); });
-                if (stop) break;
+                cv_free.wait(lk, [&] { return stop || error || (b < next_batch + window && !free_slots.empty()); });
+                if (stop || error) break;
                 slot = free_slots.front(); free_slots.pop_front();
             }
             const auto c1 = clk::now();
             Ready r; r.batch = b; r.slot = slot; r.meta.assign((size_t)meta_len, 0);
-            const int rc = s->impl.pack_batch((int32_t)(off[b + 1] - off[b]), ids.data() + off[b], L, degrees.data(),
-                                              labels, n_classes, plan_T, r.meta.data(), meta_len, &r.n_i, &r.n_f);
+            const int rc = ss[(size_t)k]->impl.pack_batch((int32_t)(off[b + 1] - off[b]), ids.data() + off[b], L,
+                                                          degrees.data(), labels, n_classes, plan_T, r.meta.data(),
+                                                          meta_len, &r.n_i, &r.n_f);
             if (rc != SGCN_OK) {
                 std::lock_guard<std::mutex> lk(mu);
-                error = rc; error_msg = sgcn::error_slot(); done = true; cv_ready.notify_all();
-                return;
+                error = rc; error_msg = sgcn::error_slot();
+                break;
             }
             const int64_t ni = std::max<int64_t>(r.n_i, 1), nf = std::max<int64_t>(r.n_f, 1);
             int32_t* dst;
-            if (ni + nf <= slot_caps[slot]) dst = static_cast<int32_t*>(slot_words[slot]);
+            if (ni + nf <= slot_caps[(size_t)slot]) dst = static_cast<int32_t*>(slot_words[(size_t)slot]);
             else {                       // rare: the batch outgrew the slot -> heap buffer, slot stays unused
                 r.spill.reset(new std::vector<int32_t>((size_t)(ni + nf)));
                 dst = r.spill->data();
             }
             const auto c2 = clk::now();
-            s->impl.packed_copy(dst, reinterpret_cast<float*>(dst + ni));
+            ss[(size_t)k]->impl.packed_copy(dst, reinterpret_cast<float*>(dst + ni));
             const auto c3 = clk::now();
             {
                 std::lock_guard<std::mutex> lk(mu);
-                ready.push_back(std::move(r));
+                ready[(size_t)b] = std::move(r);
+                is_ready[(size_t)b] = 1;
                 t_wait += std::chrono::duration<double>(c1 - c0).count();
                 t_pack += std::chrono::duration<double>(c2 - c1).count();
                 t_copy += std::chrono::duration<double>(c3 - c2).count();
             }
-            cv_ready.notify_one();
+            cv_ready.notify_all();
         }
         std::lock_guard<std::mutex> lk(mu);
-        done = true;
+        running--;
         cv_ready.notify_all();
+        cv_free.notify_all();
     }
 };
+
 struct sgcn_mult { sgcn::FenwickMultinomial impl; };
 
 extern "C" {
@@ -541,27 +552,33 @@ int sgcn_sched_batch_packed_into(sgcn_sched_t* s, int32_t n, const int32_t* ids,
 }
 int64_t sgcn_sched_packed_meta_len(int32_t L) { return sgcn::NeighbourSampler::meta_len(L); }
 
-int sgcn_prefetch_start(sgcn_sched_t* s, int32_t n_batches, const int32_t* ids, const int64_t* offsets,
-                        int32_t L, const int32_t* degrees, const float* labels, int32_t n_classes,
-                        int32_t plan_T, int32_t n_slots, void* const* slot_words,
-                        const int64_t* slot_caps, sgcn_prefetch_t** out) {
-    if (!s || !out || n_batches < 0 || !offsets || (n_batches > 0 && !ids) || L < 0 || (L > 0 && !degrees) ||
-        n_slots < 1 || !slot_words || !slot_caps)
+int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32_t n_batches,
+                        const int32_t* ids, const int64_t* offsets, int32_t L, const int32_t* degrees,
+                        const float* labels, int32_t n_classes, int32_t plan_T, int32_t n_slots,
+                        void* const* slot_words, const int64_t* slot_caps, int32_t lag,
+                        sgcn_prefetch_t** out) {
+    if (!samplers || n_samplers < 1 || !out || n_batches < 0 || !offsets || (n_batches > 0 && !ids) || L < 0 ||
+        (L > 0 && !degrees) || n_slots < 1 || !slot_words || !slot_caps || lag < 0 || lag + 1 >= n_slots)
         return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: bad argument");
+    for (int32_t i = 0; i < n_samplers; i++)
+        if (!samplers[i]) return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: null sampler");
     try {
         std::unique_ptr<sgcn_prefetch> p(new sgcn_prefetch);
-        p->s = s;
+        p->ss.assign(samplers, samplers + n_samplers);
         p->off.assign(offsets, offsets + n_batches + 1);
         p->ids.assign(ids, ids + (n_batches ? offsets[n_batches] : 0));
-        p->L = L; p->n_classes = n_classes; p->plan_T = plan_T; p->labels = labels;
+        p->L = L; p->n_classes = n_classes; p->plan_T = plan_T; p->labels = labels; p->lag = lag;
         p->degrees.assign(degrees, degrees + L);
         p->meta_len = sgcn::NeighbourSampler::meta_len(L);
+        p->ready.resize((size_t)n_batches);
+        p->is_ready.assign((size_t)n_batches, 0);
         for (int32_t i = 0; i < n_slots; i++) {
             p->slot_words.push_back(slot_words[i]); p->slot_caps.push_back(slot_caps[i]);
             p->free_slots.push_back(i);
         }
         sgcn_prefetch* raw = p.get();
-        p->th = std::thread([raw] { raw->run(); });
+        p->running = n_samplers;
+        for (int32_t k = 0; k < n_samplers; k++) p->ths.emplace_back([raw, k] { raw->run(k); });
         *out = p.release();
     } catch (const std::exception& e) {
         return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: %s", e.what());
@@ -578,14 +595,17 @@ int sgcn_prefetch_next(sgcn_prefetch_t* p, int32_t* slot, int64_t* meta, int64_t
     sgcn_prefetch::Ready r;
     {
         std::unique_lock<std::mutex> lk(p->mu);
-        p->cv_ready.wait(lk, [&] { return !p->ready.empty() || p->done; });
-        if (p->ready.empty()) {
+        const int32_t b = p->next_batch;
+        if (b >= (int32_t)p->ready.size()) return 1;
+        p->cv_ready.wait(lk, [&] { return p->is_ready[(size_t)b] || p->error || p->running == 0; });
+        if (!p->is_ready[(size_t)b]) {
             if (p->error) return sgcn::fail(p->error, "%s", p->error_msg.c_str());
-            return 1;
+            return sgcn::fail(SGCN_ERR_INVALID, "prefetch_next: producers exited before batch %d", (int)b);
         }
-        r = std::move(p->ready.front());
-        p->ready.pop_front();
+        r = std::move(p->ready[(size_t)b]);
+        p->next_batch = b + 1;
     }
+    p->cv_free.notify_all();           // the window moved
     *slot = r.slot; *n_i = r.n_i; *n_f = r.n_f;
     memcpy(meta, r.meta.data(), sizeof(int64_t) * (size_t)p->meta_len);
     *spill = nullptr;
@@ -606,7 +626,7 @@ int sgcn_prefetch_release(sgcn_prefetch_t* p, int32_t slot) {
         if ((size_t)slot < p->spills.size()) p->spills[(size_t)slot].reset();
         p->free_slots.push_back(slot);
     }
-    p->cv_free.notify_one();
+    p->cv_free.notify_all();
     return SGCN_OK;
 }
 
@@ -626,7 +646,8 @@ void sgcn_prefetch_stop(sgcn_prefetch_t* p) {
         p->stop = true;
     }
     p->cv_free.notify_all();
-    if (p->th.joinable()) p->th.join();
+    for (auto& t : p->ths)
+        if (t.joinable()) t.join();
     delete p;
 }
 int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32) {

@@ -401,21 +401,29 @@ def _minibatch_packed(self, batch_size, plan_T=0, slot=None):
 
 
 class NativePrefetcher(object):
-    """An epoch's minibatches from the C++ sampler thread of libsgcn.so (sgcn_prefetch_*): same
-    sample sequence as calling ``batch_packed`` in a loop, but no Python runs on the producer, so
-    it never competes with the launching thread for the interpreter lock.  ``next()`` blocks in C
-    (lock released) and returns a PackedBatch living in one of ``n_slots`` pinned staging slots; a
-    slot goes back to the producer ``lag`` batches after it was handed out, once the H2D copy
-    the consumer recorded on it has completed."""
+    """An epoch's minibatches from the C++ sampler thread(s) of libsgcn.so (sgcn_prefetch_*).
+
+    One scheduler: the same sample sequence as calling ``batch_packed`` in a loop, but no Python
+    runs on the producer, so it never competes with the launching thread for the interpreter lock.
+    A list of N schedulers (independent private CSR copies and RNG streams): thread k builds batches
+    k, k + N, ... concurrently and the consumer still receives them in order -- the NON-PARITY fast
+    mode (``--sampler_threads N``) for sampler-bound runs (non-PP / NS / Exact).
+
+    ``next()`` blocks in C (lock released) and returns a PackedBatch living in one of the pinned
+    staging slots; a slot goes back to the producers ``lag`` batches after it was handed out, once
+    the H2D copy the consumer recorded on it has completed."""
 
     def __init__(self, sch, batches, plan_T=0, depth=2, pin=True, lag=2):
-        sch._packed_setup()
+        schs = list(sch) if isinstance(sch, (list, tuple)) else [sch]
+        for s_ in schs:
+            s_._packed_setup()
+        sch = schs[0]
         self.sch, self.L, self.lag = sch, sch.L, lag
         self.n_batches = len(batches)
         ids = np.ascontiguousarray(np.concatenate(batches) if batches else np.zeros(0), dtype=np.int32)
         off = np.zeros(len(batches) + 1, dtype=np.int64)
         np.cumsum([len(b) for b in batches], out=off[1:])
-        n_slots = max(1, depth) + 1 + lag
+        n_slots = max(1, depth) * len(schs) + 1 + lag
         words = int(getattr(sch, "_slot_words", 0) or (1 << 20))
         pool = getattr(sch, "_slot_pool", None)
         if pool is None or len(pool) != n_slots or pool[0].cap < words or pool[0].pin != pin:
@@ -426,10 +434,12 @@ class NativePrefetcher(object):
             sl.wait()
         ptrs = (C.c_void_p * n_slots)(*[sl.ptr for sl in pool])
         caps = (C.c_int64 * n_slots)(*[sl.cap for sl in pool])
+        handles = (C.c_void_p * len(schs))(*[s_.c_sch._h for s_ in schs])
         self._h = C.c_void_p()
-        check(lib.sgcn_prefetch_start(sch.c_sch._h, len(batches), ids.ctypes.data, off.ctypes.data, self.L,
+        check(lib.sgcn_prefetch_start(handles, len(schs), len(batches), ids.ctypes.data, off.ctypes.data, self.L,
                                       sch._deg32_ptr, sch._lab32_ptr, sch._lab32_cols, int(plan_T), n_slots,
-                                      ptrs, caps, C.byref(self._h)))
+                                      ptrs, caps, int(lag), C.byref(self._h)))
+        self._keep = schs
         self.pending = []
         self.max_words = 0
 

@@ -267,10 +267,11 @@ class Trainer(object):
         N = len(data)
         k = 0
         chunks = [data[st:min(st + FLAGS.test_batch_size, N)] for st in range(0, N, FLAGS.test_batch_size)]
-        if len(self.eval_schs) > 1:
+        if FLAGS.native_prefetch and (FLAGS.prefetch > 0 or len(self.eval_schs) > 1):
+            pre = NativePrefetcher(self.eval_schs if len(self.eval_schs) > 1 else self.eval_sch, chunks,
+                                   FLAGS.plan_t, depth=max(FLAGS.prefetch, 1))
+        elif len(self.eval_schs) > 1:
             pre = ParallelPrefetcher(self.eval_schs, chunks, FLAGS.plan_t, self.eval_slots, max(FLAGS.prefetch, 1))
-        elif FLAGS.prefetch > 0 and FLAGS.native_prefetch:
-            pre = NativePrefetcher(self.eval_sch, chunks, FLAGS.plan_t, depth=FLAGS.prefetch)
         else:
             pre = None
         for chunk in chunks:
@@ -303,13 +304,14 @@ class Trainer(object):
             n_steps = min(n_steps, FLAGS.max_steps)
         n_steps = int(par.max_scalar(n_steps))       # same step count on every rank
         slots = self.slots
-        if len(self.train_schs) > 1:
+        if FLAGS.native_prefetch and (FLAGS.prefetch > 0 or len(self.train_schs) > 1):
+            # C++ sampler thread(s): one = the reference's sample sequence, N = the non-parity fast mode
+            pre = NativePrefetcher(self.train_schs if len(self.train_schs) > 1 else train_sch,
+                                   epoch_batches(train_sch.data, FLAGS.batch_size, n_steps),
+                                   FLAGS.plan_t, depth=max(FLAGS.prefetch, 1))
+        elif len(self.train_schs) > 1:
             pre = ParallelPrefetcher(self.train_schs, epoch_batches(train_sch.data, FLAGS.batch_size, n_steps),
                                      FLAGS.plan_t, slots, max(FLAGS.prefetch, 1))
-        elif FLAGS.prefetch > 0 and FLAGS.native_prefetch:
-            # the C++ sampler thread: same sample sequence, no interpreter lock on the producer
-            pre = NativePrefetcher(train_sch, epoch_batches(train_sch.data, FLAGS.batch_size, n_steps),
-                                   FLAGS.plan_t, depth=FLAGS.prefetch)
         else:
             pre = Prefetcher(train_sch, FLAGS.batch_size, FLAGS.prefetch, n_steps, slots) \
                 if FLAGS.prefetch > 0 else None

@@ -93,3 +93,29 @@ def test_native_prefetcher_is_the_sequential_sequence_and_survives_small_slots()
     pre.close()
     # and the sampler is usable again afterwards
     assert sch.batch_packed(batches[0]) is not None
+
+
+def test_native_multi_sampler_delivers_valid_batches_in_order():
+    """N sampler threads in C++ (the non-parity fast mode): batch i is the i-th id slice, each
+    batch equals what the sampler that built it yields when run alone on its own slices."""
+    from stochastic_gcn_amd.scheduler import NativePrefetcher
+    a, labels = _graph()
+    deg = np.array([3], dtype=np.int32)
+    ids = np.random.RandomState(9).permutation(a.shape[0]).astype(np.int32)
+    batches = epoch_batches(ids, 32, 23)
+    N = 3
+    mk = lambda: [PyScheduler(a, labels, 1, deg, PH, 11 + 1000 * k, cv=True) for k in range(N)]   # noqa: E731
+    solo = mk()
+    want = {}
+    for k in range(N):                                   # sampler k alone on batches k, k+N, ...
+        for i in range(k, len(batches), N):
+            want[i] = solo[k].batch_packed(batches[i])
+    pre = NativePrefetcher(mk(), batches, 0, depth=2, pin=False)
+    for i in range(len(batches)):
+        pb = pre.next()
+        np.testing.assert_array_equal(pb.field(1), batches[i])
+        r = want[i]
+        assert (pb.n_i, pb.n_f) == (r.n_i, r.n_f)
+        np.testing.assert_array_equal(np.asarray(pb.ibuf[:pb.n_i]), np.asarray(r.ibuf[:r.n_i]))
+        np.testing.assert_array_equal(np.asarray(pb.fbuf[:pb.n_f]), np.asarray(r.fbuf[:r.n_f]))
+    assert pre.next() is None
