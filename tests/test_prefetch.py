@@ -119,3 +119,28 @@ def test_native_multi_sampler_delivers_valid_batches_in_order():
         np.testing.assert_array_equal(np.asarray(pb.ibuf[:pb.n_i]), np.asarray(r.ibuf[:r.n_i]))
         np.testing.assert_array_equal(np.asarray(pb.fbuf[:pb.n_f]), np.asarray(r.fbuf[:r.n_f]))
     assert pre.next() is None
+
+
+def test_native_prefetcher_stress_no_deadlock():
+    """Many short epochs with random early stops, sampler counts and depths: every epoch either
+    drains or closes cleanly (pytest-timeout guards against a hang)."""
+    from stochastic_gcn_amd.scheduler import NativePrefetcher
+    a, labels = _graph(300)
+    deg = np.array([2], dtype=np.int32)
+    rng = np.random.RandomState(0)
+    schs = [PyScheduler(a, labels, 1, deg, PH, 5 + k, cv=True) for k in range(4)]
+    ids = np.arange(a.shape[0], dtype=np.int32)
+    for it in range(60):
+        nb = int(rng.randint(0, 25))
+        batches = epoch_batches(ids, int(rng.randint(1, 40)), nb)
+        n = int(rng.randint(1, 5))
+        pre = NativePrefetcher(schs[:n] if n > 1 else schs[0], batches, 0, depth=int(rng.randint(1, 4)), pin=False,
+                               lag=int(rng.randint(0, 3)))
+        take = nb if rng.rand() < 0.5 else int(rng.randint(0, nb + 1))
+        for i in range(take):
+            pb = pre.next()
+            assert pb is not None
+            np.testing.assert_array_equal(pb.field(1), batches[i])
+        if take == nb:
+            assert pre.next() is None
+        pre.close()
