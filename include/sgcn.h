@@ -242,8 +242,8 @@ int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int6
                        void* stream);
 /* The backward of one dense layer in one call: g = LN/ReLU-backward(dy) (skipped when scale == NULL
  * and relu == 0), dW[K x N] += dropout(x)^T . g, dx[n x K] = (g . W^T) * mask (dx nullable).
- * g_tmp: n * N floats; ws: max(sgcn_ln_act_bwd_ws_floats(n, N), sgcn_gemm_ws_floats(K, N, n),
- * sgcn_gemm_ws_floats(n, K, N)) floats.       autodiff of gcn/layers.py:120-138,396-411 */
+ * g_tmp: n * N floats; ws: sgcn_ln_act_bwd_ws_floats(n, N) (rounded up to 4) + max(
+ * sgcn_gemm_ws_floats(K, N, n), sgcn_gemm_ws_floats(n, K, N)) floats.       autodiff of gcn/layers.py:120-138,396-411 */
 int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dev_dy, int64_t lddy,
                        const float* dev_y, int64_t ldy, const float* dev_xhat, const float* dev_rstd,
                        const float* dev_scale, int32_t relu, const float* dev_x, int64_t ldx,

@@ -104,18 +104,7 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
                                        float* __restrict__ doffset, float* __restrict__ dscale) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= 2 * d) return;
-    // four independent chains keep several loads in flight; combined in a fixed order
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        s0 += partial[(size_t)(b + 0) * 2 * d + c];
-        s1 += partial[(size_t)(b + 1) * 2 * d + c];
-        s2 += partial[(size_t)(b + 2) * 2 * d + c];
-        s3 += partial[(size_t)(b + 3) * 2 * d + c];
-    }
-    for (; b < nblk; b++) s0 += partial[(size_t)b * 2 * d + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (c < d) doffset[c] += s; else dscale[c - d] += s;
+    ln_param_reduce_col(partial, nblk, d, doffset, dscale, c);
 }
 
 // One wavefront per row, as many workgroups as rows need (a single-workgroup version spent
@@ -228,11 +217,12 @@ extern "C" int64_t sgcn_ln_act_bwd_ws_floats(int32_t n, int32_t d) {
     return blocks * 2 * d;
 }
 
-extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy,
-                                   const float* xhat, const float* rstd, const float* scale,
-                                   int32_t n, int32_t d, int32_t relu, float* dx, int64_t lddx,
-                                   float* doffset, float* dscale, float* ws, void* stream) {
+int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xhat,
+                            const float* rstd, const float* scale, int32_t n, int32_t d, int32_t relu,
+                            float* dx, int64_t lddx, float* doffset, float* dscale, float* ws,
+                            bool reduce_params, int32_t* nblk, hipStream_t st) {
     SGCN_REQUIRE(n >= 0 && d >= 0, "ln_act_bwd: negative size");
+    if (nblk) *nblk = 0;
     if (n == 0 || d == 0) return SGCN_OK;
     const int norm = scale ? 1 : 0;
     SGCN_REQUIRE(dy && y && dx && (!norm || (xhat && rstd && doffset && dscale && ws)),
@@ -240,14 +230,22 @@ extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y
     SGCN_REQUIRE(!norm || (size_t)d * 8 * sizeof(float) <= 64 * 1024, "ln_act_bwd: d too large for LDS");
     const int rows_per_block = 4 * kBwdRowsPerWave;
     const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ln_act_bwd_kernel, dim3(blocks), dim3(kBlock), norm ? (size_t)d * 8 * sizeof(float) : 0,
                        st, dy, lddy, y, ldy, xhat, rstd, scale, n, d, norm, relu, dx, lddx, ws);
-    if (norm)
+    if (nblk) *nblk = norm ? (int32_t)blocks : 0;
+    if (norm && reduce_params)
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, ws,
                            (int32_t)blocks, d, doffset, dscale);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
+}
+
+extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                                   const float* xhat, const float* rstd, const float* scale,
+                                   int32_t n, int32_t d, int32_t relu, float* dx, int64_t lddx,
+                                   float* doffset, float* dscale, float* ws, void* stream) {
+    return sgcn::ln_act_bwd_launch(dy, lddy, y, ldy, xhat, rstd, scale, n, d, relu, dx, lddx, doffset, dscale, ws,
+                                   true, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float* labels,

@@ -124,4 +124,30 @@ __device__ __forceinline__ float drop_factor(const DropArgs& a, int row, int col
     return fmix32(idx * 0x9E3779B1u + a.key) < a.thr ? a.scale : 0.0f;
 }
 
+// ---- LayerNorm parameter gradients: column c of the [d(offset) | d(scale)] vector from the
+// per-workgroup partials of ln_act_bwd_kernel, summed in a fixed order (four independent chains
+// keep several loads in flight).  Shared by the standalone reduce and the dense-layer backward's
+// combined reduce (sgcn_gemm.hip).
+__device__ __forceinline__ void ln_param_reduce_col(const float* __restrict__ partial, int nblk, int d,
+                                                    float* __restrict__ doffset, float* __restrict__ dscale, int c) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        s0 += partial[(size_t)(b + 0) * 2 * d + c];
+        s1 += partial[(size_t)(b + 1) * 2 * d + c];
+        s2 += partial[(size_t)(b + 2) * 2 * d + c];
+        s3 += partial[(size_t)(b + 3) * 2 * d + c];
+    }
+    for (; b < nblk; b++) s0 += partial[(size_t)b * 2 * d + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (c < d) doffset[c] += s; else dscale[c - d] += s;
+}
+
+// sgcn_dense.hip: LN/ReLU backward; with reduce_params == false the parameter-gradient partials stay
+// in ws ([*nblk][2][d]) for the caller to reduce.
+int ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xhat,
+                      const float* rstd, const float* scale, int32_t n, int32_t d, int32_t relu, float* dx,
+                      int64_t lddx, float* doffset, float* dscale, float* ws, bool reduce_params, int32_t* nblk,
+                      hipStream_t st);
+
 }  // namespace sgcn

@@ -235,6 +235,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int32_t S, in
     *p = accumulate ? *p + s : s;
 }
 
+struct ReduceJob {                // a split-K reduction the caller wants to launch itself
+    const float* ws; int32_t S, M, N; float* C; int64_t ldc; int32_t accumulate; int32_t pending;
+};
+
+// The two small reductions of a dense layer's backward in ONE launch: the split-K partial tiles of
+// dW (workgroups [0, gemm_blocks)) and the LayerNorm parameter-gradient partials (the rest).
+__global__ void dense_bwd_reduce_kernel(ReduceJob j, int32_t gemm_blocks, const float* __restrict__ ln_partial,
+                                        int32_t nblk, int32_t d, float* __restrict__ doffset,
+                                        float* __restrict__ dscale) {
+    if ((int)blockIdx.x < gemm_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int64_t mn = (int64_t)j.M * j.N;
+        if (i >= mn) return;
+        float s = 0.f;
+        for (int z = 0; z < j.S; z++) s += j.ws[(int64_t)z * mn + i];
+        float* p = j.C + (i / j.N) * j.ldc + (i % j.N);
+        *p = j.accumulate ? *p + s : s;
+    } else {
+        const int c = ((int)blockIdx.x - gemm_blocks) * blockDim.x + threadIdx.x;
+        if (c < 2 * d) ln_param_reduce_col(ln_partial, nblk, d, doffset, dscale, c);
+    }
+}
+
 // Split-K with the dense layer's epilogue: Y = act(LN(sum_z ws[z]) * scale + offset), one wavefront
 // per output row (the forward GEMM of the first layer is 2,042 x 128 x 1,204: 64 tiles whose
 // MFMA work alone is ~16 us on 64 CUs -- cut 4-ways over K it runs on all 256).
@@ -314,7 +337,8 @@ static void launch_kg(const GemmArgs& g, dim3 grid, int kgroups, hipStream_t st)
     else launch_one<TA, TB, 1>(g, grid, st);
 }
 
-static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st) {
+static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st, ReduceJob* defer = nullptr) {
+    if (defer) defer->pending = 0;
     auto al = [](const void* p, int64_t ld) { return p && ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
     g.vec_a = al(g.A, g.lda) && (!g.A2 || al(g.A2, g.lda2));
     g.vec_b = al(g.B, g.ldb);
@@ -339,6 +363,8 @@ static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st) {
         g.epi = epi;
         const unsigned rb = (unsigned)((g.M + (kBlock / kWave) - 1) / (kBlock / kWave));
         hipLaunchKernelGGL(splitk_ln_act_kernel, dim3(rb), dim3(kBlock), 0, st, g.ws, S, g);
+    } else if (S > 1 && defer) {           // the caller folds this reduction into its own launch
+        *defer = ReduceJob{g.ws, S, g.M, g.N, g.C, g.ldc, g.accumulate, 1};
     } else if (S > 1) {
         const int64_t mn = (int64_t)g.M * g.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st,
@@ -407,18 +433,39 @@ extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* 
     SGCN_REQUIRE(n >= 0 && N >= 0 && K >= 0, "dense_bwd: negative size");
     if (n == 0 || N == 0 || K == 0) return SGCN_OK;
     SGCN_REQUIRE(dy && x && W && dW, "dense_bwd: null operand");
+    hipStream_t st = (hipStream_t)stream;
     const float* g = dy;
     int64_t ldg = lddy;
+    int32_t nblk = 0;
+    // ws = [LayerNorm partials | split-K partials]: both live until the combined reduction
+    const int64_t ln_floats = scale ? (sgcn_ln_act_bwd_ws_floats(n, N) + 3) / 4 * 4 : 0;
+    float* ws_gemm = ws ? ws + ln_floats : nullptr;
     if (scale || relu) {
         SGCN_REQUIRE(g_tmp && y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
-        const int rc = sgcn_ln_act_bwd_f32(dy, lddy, y, ldy, xhat, rstd, scale, n, N, relu, g_tmp, N, doffset,
-                                           dscale, ws, stream);
+        SGCN_REQUIRE(!scale || ws, "dense_bwd: LayerNorm backward needs the workspace");
+        const int rc = ln_act_bwd_launch(dy, lddy, y, ldy, xhat, rstd, scale, n, N, relu, g_tmp, N, doffset, dscale,
+                                         ws, /*reduce_params=*/false, &nblk, st);
         if (rc != SGCN_OK) return rc;
         g = g_tmp; ldg = N;
     }
-    // dW[K x N] += x^T[K x n] . g[n x N]      (x stored [n x K]: trans_a)
-    int rc = sgcn_gemm_f32(1, 0, K, N, n, x, ldx, g, ldg, dW, lddw, 1, ws, drop, nullptr, stream);
-    if (rc != SGCN_OK || !dx) return rc;
+    // dW[K x N] += x^T[K x n] . g[n x N]      (x stored [n x K]: trans_a); its split-K reduction and the
+    // LayerNorm parameter reduction share one launch
+    GemmArgs a{};
+    a.A = x; a.lda = ldx; a.B = g; a.ldb = ldg; a.C = dW; a.ldc = lddw;
+    a.M = K; a.N = N; a.K = n; a.accumulate = 1; a.epi = 0;
+    a.drop_a = drop_args(drop);
+    SGCN_REQUIRE(!a.drop_a.on || a.drop_a.width == K, "dense_bwd: dropout width must be K");
+    ReduceJob job{};
+    int rc = launch_gemm(a, 1, 0, ws_gemm, st, &job);
+    if (rc != SGCN_OK) return rc;
+    if (job.pending || nblk > 0) {
+        const int gb = job.pending ? (int)(((int64_t)job.M * job.N + 255) / 256) : 0;
+        const int lb = nblk > 0 ? (2 * N + 255) / 256 : 0;
+        hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, st, job, gb, ws, nblk, N,
+                           doffset, dscale);
+        SGCN_HIP_TRY(hipGetLastError());
+    }
+    if (!dx) return SGCN_OK;
     // dx[n x K] = g[n x N] . W^T              (W stored [K x N]: trans_b)
-    return sgcn_gemm_f32(0, 1, n, K, N, g, ldg, W, ldw, dx, lddx, 0, ws, nullptr, drop, stream);
+    return sgcn_gemm_f32(0, 1, n, K, N, g, ldg, W, ldw, dx, lddx, 0, ws_gemm, nullptr, drop, stream);
 }

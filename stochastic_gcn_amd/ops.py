@@ -473,8 +473,8 @@ def dense_bwd(dy, y, ctx, scale, relu, x, W, dW, doffset=None, dscale=None, need
     key = (n, N, K, norm)
     need = _DENSE_BWD_WS.get(key)
     if need is None:
-        need = max(int(lib.sgcn_ln_act_bwd_ws_floats(n, N)) if norm else 0,
-                   int(lib.sgcn_gemm_ws_floats(K, N, n)), int(lib.sgcn_gemm_ws_floats(n, K, N)))
+        need = ((int(lib.sgcn_ln_act_bwd_ws_floats(n, N)) + 3) // 4 * 4 if norm else 0) + \
+            max(int(lib.sgcn_gemm_ws_floats(K, N, n)), int(lib.sgcn_gemm_ws_floats(n, K, N)))
         if len(_DENSE_BWD_WS) < 4096:
             _DENSE_BWD_WS[key] = need
     ws = _gemm_ws(need, dy.device) if need else None
