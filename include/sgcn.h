@@ -239,7 +239,10 @@ int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int6
                        float* dev_xhat, float* dev_rstd, const sgcn_dropout_t* drop,
                        float* dev_ws /* nullable: sgcn_gemm_ws_floats(M, N, K) floats -> split-K, the
                                         epilogue then runs in the reduction */,
-                       void* stream);
+                       const int32_t* dev_gidx /* nullable: operand row r is X[gidx[r]] -- the gather of
+                                                  the minibatch's feature rows (history.dense_slice,
+                                                  gcn/vrgcn.py:43-45) happens inside the GEMM */,
+                       const int32_t* dev_gidx2 /* the same for X2 */, void* stream);
 /* The backward of one dense layer in one call: g = LN/ReLU-backward(dy) (skipped when scale == NULL
  * and relu == 0), dW[K x N] += dropout(x)^T . g, dx[n x K] = (g . W^T) * mask (dx nullable).
  * g_tmp: n * N floats; ws: sgcn_ln_act_bwd_ws_floats(n, N) (rounded up to 4) + max(
@@ -249,7 +252,8 @@ int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dev_dy, int
                        const float* dev_scale, int32_t relu, const float* dev_x, int64_t ldx,
                        const float* dev_W, int64_t ldw, float* dev_dW, int64_t lddw,
                        float* dev_doffset, float* dev_dscale, float* dev_dx, int64_t lddx,
-                       const sgcn_dropout_t* drop, float* dev_g_tmp, float* dev_ws, void* stream);
+                       const sgcn_dropout_t* drop, float* dev_g_tmp, float* dev_ws,
+                       const int32_t* dev_gidx /* nullable: layer input row r is x[gidx[r]] */, void* stream);
 /* Softmax cross-entropy over n rows: stats[4] = {sum_i CE_i, #rows whose arg-max matches the label
  * arg-max, mean CE (the loss), accuracy}; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
  * pred (nullable) = softmax; rowstat: 2*n floats of scratch (per-row CE and hit flag, summed

@@ -86,10 +86,10 @@ SIGNATURES = {
     "sgcn_gemm_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
                                 C.c_int64, P, C.c_int64, C.c_int32, P, P, P, P]),
     "sgcn_dense_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, C.c_int32,
-                                     P, C.c_int64, P, P, C.c_float, C.c_int32, P, C.c_int64, P, P, P, P, P]),
+                                     P, C.c_int64, P, P, C.c_float, C.c_int32, P, C.c_int64, P, P, P, P, P, P, P]),
     "sgcn_dense_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P, P,
                                      C.c_int32, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, P, P, C.c_int64,
-                                     P, P, P, P]),
+                                     P, P, P, P, P]),
     "sgcn_dropout_f32": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, C.c_int64, P]),
     "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
                                       P, C.c_int64, P, P, P]),

@@ -35,6 +35,8 @@ struct GemmArgs {
     DropArgs drop_a;                 // dropout on the stored A matrix, applied while loading
     DropArgs drop_c;                 // dropout on the output (plain epilogue only)
     int32_t vec_a, vec_b;            // operand rows 16-byte aligned: 4-float runs load as one float4
+    const int32_t* a_gidx;           // row indirection of the stored A (and of A2): row r reads A[gidx[r]]
+    const int32_t* a_gidx2;          //   -- the minibatch's feature rows are gathered by the GEMM itself
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -83,8 +85,13 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
     auto fetch = [&](int k0) {
         if (!TA) {          // A is [M x K]: thread reads 4 consecutive k of one row
             const int i = tid >> 3, kq = (tid & 7) * 4, row = m0 + i;
-            const float* ar = (g.A2 && row >= g.a_split) ? g.A2 + (int64_t)(row - g.a_split) * g.lda2
-                                                         : g.A + (int64_t)row * g.lda;
+            const float* ar;
+            if (g.A2 && row >= g.a_split) {
+                const int r2 = row - g.a_split;
+                ar = g.A2 + (int64_t)((g.a_gidx2 && row < g.M) ? g.a_gidx2[r2] : r2) * g.lda2;
+            } else {
+                ar = g.A + (int64_t)((g.a_gidx && row < g.M) ? g.a_gidx[row] : row) * g.lda;
+            }
             ld4(ar + k0 + kq, g.vec_a, row < g.M, k0 + kq, kend, ra);
             if (g.drop_a.on) {
 #pragma unroll
@@ -92,7 +99,8 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
             }
         } else {            // A is [K x M]: thread reads 4 consecutive m of one k
             const int kk = tid >> 3, iq = (tid & 7) * 4, k = k0 + kk;
-            ld4(g.A + (int64_t)k * g.lda + m0 + iq, g.vec_a, k < kend, m0 + iq, g.M, ra);
+            const int64_t ak = (g.a_gidx && k < kend) ? g.a_gidx[k] : k;         // stored row k of x
+            ld4(g.A + ak * g.lda + m0 + iq, g.vec_a, k < kend, m0 + iq, g.M, ra);
             if (g.drop_a.on) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) ra[e] *= drop_factor(g.drop_a, k, m0 + iq + e);     // stored A = x[k][row]
@@ -403,7 +411,7 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
                                   const float* W, int64_t ldw, const float* offset,
                                   const float* scale, float eps, int32_t relu, float* Y, int64_t ldy,
                                   float* xhat, float* rstd, const sgcn_dropout_t* drop, float* ws,
-                                  void* stream) {
+                                  const int32_t* gidx, const int32_t* gidx2, void* stream) {
     SGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "dense_fwd: negative size");
     if (M == 0 || N == 0) return SGCN_OK;
     SGCN_REQUIRE(X && W && Y, "dense_fwd: null operand");
@@ -416,6 +424,7 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
     g.xhat = xhat; g.rstd = rstd; g.epi = norm ? 2 : (relu ? 1 : 0);
     SGCN_REQUIRE(!X2 || (split >= 0 && split <= M), "dense_fwd: bad split");
     g.A2 = X2; g.lda2 = ldx2; g.a_split = split;
+    g.a_gidx = gidx; g.a_gidx2 = gidx2;
     g.drop_a = drop_args(drop);
     SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
     return launch_gemm(g, 0, 0, N <= kTN ? ws : nullptr, (hipStream_t)stream);
@@ -429,7 +438,7 @@ extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* 
                                   const float* scale, int32_t relu, const float* x, int64_t ldx,
                                   const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
                                   float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
-                                  float* g_tmp, float* ws, void* stream) {
+                                  float* g_tmp, float* ws, const int32_t* gidx, void* stream) {
     SGCN_REQUIRE(n >= 0 && N >= 0 && K >= 0, "dense_bwd: negative size");
     if (n == 0 || N == 0 || K == 0) return SGCN_OK;
     SGCN_REQUIRE(dy && x && W && dW, "dense_bwd: null operand");
@@ -453,6 +462,7 @@ extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* 
     GemmArgs a{};
     a.A = x; a.lda = ldx; a.B = g; a.ldb = ldg; a.C = dW; a.ldc = lddw;
     a.M = K; a.N = N; a.K = n; a.accumulate = 1; a.epi = 0;
+    a.a_gidx = gidx;                       // x rows gathered on the fly (x = features, gidx = the field)
     a.drop_a = drop_args(drop);
     SGCN_REQUIRE(!a.drop_a.on || a.drop_a.width == K, "dense_bwd: dropout width must be K");
     ReduceJob job{};

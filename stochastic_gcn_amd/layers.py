@@ -44,7 +44,8 @@ class Dropped(object):
 
 
 def dense_of(x):
-    return x.materialize() if isinstance(x, Dropped) else x
+    """A plain tensor from a pending dropout (Dropped) or a pending row gather (ops.GatheredRows)."""
+    return x.materialize() if isinstance(x, (Dropped, ops.GatheredRows)) else x
 
 
 def dot(x, y, sparse=False):
@@ -179,6 +180,8 @@ class Dense(Layer):
         self._drop = None
         if isinstance(x, Dropped):         # pending dropout: applied by our own GEMMs
             x, self._drop = x.x, x.drop
+        if isinstance(x, ops.GatheredRows) and not (self.output_dim <= 128 or not (self.norm or self.act)):
+            x = x.materialize()            # only the fused launch reads rows through an index
         self._x = x
         off = self.vars.get('offset') if self.norm else None
         sc = self.vars.get('scale') if self.norm else None
@@ -244,9 +247,14 @@ class AugmentedDropoutDense(Layer):
             hmu = hx if mus is xs else ops.ln_act_fwd(mus, off, sc, True)[0]
             self._out = hx
             return hx, hmu
-        x, mu = dense_of(x), dense_of(mu)
-        self._x = x
         fused = self.output_dim <= 128
+        if not fused:
+            x, mu = dense_of(x), dense_of(mu)
+        else:       # a pending dropout is materialised; a pending row gather rides into the GEMMs
+            same = mu is x
+            x = x.materialize() if isinstance(x, Dropped) else x
+            mu = x if same else (mu.materialize() if isinstance(mu, Dropped) else mu)
+        self._x = x
         if mu is x and drop is None:
             # test models run with dropout 0 on a single stream: both streams coincide
             hx, self._ctx = ops.dense_fwd(x, W, off, sc, True) if fused else \

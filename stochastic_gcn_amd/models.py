@@ -489,8 +489,8 @@ class GCN(Model):
         if self.sparse_input and self.sparse_mm:
             sl = ops.csr_slice(self.features_dev, cur.host_fields[0], rows_dev=f0, with_coo_rows=True)
             cur.inputs = SparseInput(sl)
-        else:
-            cur.inputs = ops.gather_rows(self.features_dev, f0)
+        else:       # gathered by the first dense layer's GEMMs, or on demand (ops.GatheredRows)
+            cur.inputs = ops.GatheredRows(self.features_dev, f0)
         return cur
 
     def forward(self, cur):

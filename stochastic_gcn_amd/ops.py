@@ -456,9 +456,12 @@ def dense_bwd(dy, y, ctx, scale, relu, x, W, dW, doffset=None, dscale=None, need
     """Backward of ``dense_fwd`` in one call (sgcn_dense_bwd_f32): accumulates dW (and the LayerNorm
     parameter gradients), returns dx or None.  ``x`` is the UNdropped layer input; ``drop`` the
     dropout site that was applied to it in the forward."""
+    gidx = None
+    if isinstance(x, GatheredRows):
+        x, gidx = x.src, x.idx
     n, N, K = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
     norm = ctx is not None
-    if drop is None and n * N * K >= GEMM_LIBRARY_THRESHOLD:       # library-sized: three steps
+    if drop is None and gidx is None and n * N * K >= GEMM_LIBRARY_THRESHOLD:       # library-sized: three steps
         g = ln_act_bwd(dy, y, ctx, scale, relu, doffset, dscale) if (norm or relu) else dy
         gemm(x, g, out=dW, trans_a=True, accumulate=True)
         return gemm(g, W, trans_b=True) if need_dx else None
@@ -482,7 +485,7 @@ def dense_bwd(dy, y, ctx, scale, relu, x, W, dW, doffset=None, dscale=None, need
     check(lib.sgcn_dense_bwd_f32(n, N, K, gp, ldg, yp, ldy, _ptr(ctx[0]) if norm else None,
                                  _ptr(ctx[1]) if norm else None, _ptr(scale) if norm else None,
                                  int(bool(relu)), xp, ldx, wp, ldw, dwp, lddw, _ptr(doffset), _ptr(dscale),
-                                 _ptr(dx), K, dr, _ptr(g_tmp), _ptr(ws), _stream()))
+                                 _ptr(dx), K, dr, _ptr(g_tmp), _ptr(ws), _ptr(gidx), _stream()))
     return dx
 
 
@@ -565,14 +568,39 @@ def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False, drop_a=
     return out
 
 
+class GatheredRows(object):
+    """``src[idx]`` that has not been gathered (tf.gather / history.dense_slice of the minibatch's
+    input rows, gcn/vrgcn.py:43-45): the first dense layer's GEMMs read the rows through the index
+    (dense_fwd / dense_bwd ``gidx``), so the n x F copy is never made.  Any other consumer calls
+    ``materialize()``."""
+
+    def __init__(self, src, idx):
+        self.src, self.idx, self._m = src, idx, None
+
+    @property
+    def shape(self):
+        return (int(self.idx.shape[0]), int(self.src.shape[1]))
+
+    def materialize(self):
+        if self._m is None:
+            self._m = gather_rows(self.src, self.idx)
+        return self._m
+
+
 def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
     """y = act(LN(x @ W) * scale + offset) in ONE launch (sgcn_dense_fwd_f32).
     Returns (y, ctx) like ln_act_fwd.  x2: a second operand stacked below x ([x ; x2] @ W without
     the concatenation); drop: dropout on the rows of x (never on x2), applied while the operand is
     loaded.  Needs N <= 128 when LayerNorm / ReLU is requested."""
-    n1, K, N = int(x.shape[0]), int(x.shape[1]), int(W.shape[1])
-    M = n1 + (int(x2.shape[0]) if x2 is not None else 0)
-    if x2 is None and drop is None and M * K * N >= GEMM_LIBRARY_THRESHOLD:
+    gidx = gidx2 = None
+    if isinstance(x2, GatheredRows):
+        x2, gidx2 = x2.src, x2.idx
+    if isinstance(x, GatheredRows):
+        x, gidx = x.src, x.idx
+    n1 = int(x.shape[0] if gidx is None else gidx.shape[0])
+    K, N = int(x.shape[1]), int(W.shape[1])
+    M = n1 + (0 if x2 is None else int(x2.shape[0] if gidx2 is None else gidx2.shape[0]))
+    if x2 is None and drop is None and gidx is None and M * K * N >= GEMM_LIBRARY_THRESHOLD:
         return ln_act_fwd(torch.mm(x, W), offset, scale, relu, eps) if (offset is not None or relu) \
             else (torch.mm(x, W), None)
     xp, ldx = _rows2d(x, "x")
@@ -587,5 +615,5 @@ def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
     ws = _gemm_ws(need, x.device) if need else None
     check(lib.sgcn_dense_fwd_f32(M, N, K, xp, ldx, x2p, ldx2, n1, wp, ldw, _ptr(offset), _ptr(scale),
                                  float(eps), int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), dr,
-                                 _ptr(ws), _stream()))
+                                 _ptr(ws), _ptr(gidx), _ptr(gidx2), _stream()))
     return y, ((xhat, rstd) if norm else None)

@@ -473,9 +473,11 @@ def test_spmm_addend_epilogue(dev, d):
     from stochastic_gcn_amd import ops
     rng = np.random.RandomState(d)
     M, K, n_add = 700, 300, 300
-    a = sp.random(M, K, density=0.05, format='csr', dtype=np.float32, random_state=rng)
-    a[5] = 0; a.eliminate_zeros()                      # an empty row inside and outside the addend range
-    a[650] = 0; a.eliminate_zeros()
+    a = sp.random(M, K, density=0.05, format='lil', dtype=np.float32, random_state=rng)
+    a[5] = 0                                           # an empty row inside and outside the addend range
+    a[650] = 0
+    a = a.tocsr()
+    a.eliminate_zeros()
     B = rng.standard_normal((K, 2 * d)).astype(np.float32)
     g = rng.standard_normal((n_add, 2 * d)).astype(np.float32)
     A = ops.DeviceCSR.from_scipy(a, dev, plan_T=8)     # small T: split rows exercise the fix-up epilogue too
@@ -487,3 +489,31 @@ def test_spmm_addend_epilogue(dev, d):
     assert onp.rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-6
     ref = a.dot(B[:, d:].astype(np.float64)); ref[:n_add] += g[:, :d]
     assert onp.rel_err(got.cpu().numpy(), ref) <= TOL
+
+
+def test_dense_layer_reads_its_rows_through_an_index(dev):
+    """ops.GatheredRows: [dropout(F[idx]) ; F[idx]] @ W -> LN -> ReLU and its backward without ever
+    materialising F[idx] == the same on the gathered copy, bit for bit."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(4)
+    Nf, K, N, n = 5000, 96, 128, 777
+    F = T(rng.standard_normal((Nf, K)).astype(np.float32), dev)
+    idx = T(rng.choice(Nf, n, replace=False).astype(np.int32), dev)
+    W = T((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32), dev)
+    off = T((0.1 * rng.standard_normal((1, N))).astype(np.float32), dev)
+    sc = T((1 + 0.1 * rng.standard_normal((1, N))).astype(np.float32), dev)
+    drop = ops.Drop(0.8, 4242)
+    lazy = ops.GatheredRows(F, idx)
+    x = ops.gather_rows(F, idx)
+    y1, c1 = ops.dense_fwd(x, W, off, sc, True, x2=x, drop=drop)
+    y2, c2 = ops.dense_fwd(lazy, W, off, sc, True, x2=lazy, drop=drop)
+    assert torch.equal(y1, y2) and torch.equal(c1[0], c2[0]) and torch.equal(c1[1], c2[1])
+    dy = T(rng.standard_normal((n, N)).astype(np.float32), dev)
+    out = []
+    for xin in (x, lazy):
+        dW = torch.zeros((K, N), device=dev); do = torch.zeros((1, N), device=dev); ds = torch.zeros((1, N), device=dev)
+        dx = ops.dense_bwd(dy, y1[:n], (c1[0][:n], c1[1][:n]), sc, True, xin, W, dW, do, ds, need_dx=True, drop=drop)
+        out.append((dW, do, ds, dx))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert torch.equal(lazy.materialize(), x)
