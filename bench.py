@@ -101,7 +101,8 @@ def train_epoch_leg(data, dev, epochs=6):
     FLAGS.update(dataset='reddit', normalization='graphsage', weight_decay=0.0, dropout=0.2,
                  layer_norm=True, hidden1=128, num_fc_layers=2, batch_size=512, test_batch_size=512,
                  cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, seed=1,
-                 native_prefetch=os.environ.get("SGCN_NATIVE_PREFETCH", "1") == "1")
+                 native_prefetch=os.environ.get("SGCN_NATIVE_PREFETCH", "1") == "1",
+                 plan_t=int(os.environ.get("SGCN_PLAN_T", FLAGS.plan_t)))
     n, train_adj, full_adj, _, _, _, labels, tr, va, te = data
     g = torch.Generator(device=dev)
     g.manual_seed(7)

@@ -19,8 +19,13 @@
 #include "sgcn_host.h"
 #include "../../include/sgcn.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -409,6 +414,39 @@ private:
 // ---- C ABI --------------------------------------------------------------------------------------
 struct sgcn_sched { sgcn::NeighbourSampler impl; };
 
+// The CPUs of the NUMA node the calling thread runs on (Linux sysfs).  The sampler walks a private
+// ~200 MB CSR copy that the creating thread first-touched; a producer thread scheduled on the other
+// socket of a two-socket host measured 0.40 ms per batch instead of 0.28.
+static bool numa_cpus_of_caller(cpu_set_t* set) {
+    if (getenv("SGCN_NO_AFFINITY")) return false;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return false;
+    for (int node = 0; node < 64; node++) {
+        char path[96];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = fopen(path, "r");
+        if (!f) { if (node == 0) return false; break; }
+        char buf[4096];
+        const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+        fclose(f);
+        if (!ok) continue;
+        CPU_ZERO(set);
+        bool mine = false;
+        for (char* p = buf; *p;) {                      // "0-63,128-191"
+            char* e;
+            const long lo = strtol(p, &e, 10);
+            if (e == p) break;
+            long hi = lo;
+            if (*e == '-') { p = e + 1; hi = strtol(p, &e, 10); }
+            for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET((int)c, set); if (c == cpu) mine = true; }
+            p = (*e == ',') ? e + 1 : e;
+            if (*e != ',' ) break;
+        }
+        if (mine) return true;
+    }
+    return false;
+}
+
 // ---- native prefetch thread --------------------------------------------------------------------
 // The sampler of an epoch as a C++ thread: it walks the epoch's id slices in order (so the sample
 // sequence is the synchronous loop's, bit for bit), packs each minibatch and copies it into the
@@ -584,7 +622,13 @@ int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32
         }
         sgcn_prefetch* raw = p.get();
         p->running = n_samplers;
-        for (int32_t k = 0; k < n_samplers; k++) p->ths.emplace_back([raw, k] { raw->run(k); });
+        cpu_set_t node_cpus;
+        const bool pin = numa_cpus_of_caller(&node_cpus);      // keep the producers next to the CSR copy
+        for (int32_t k = 0; k < n_samplers; k++)
+            p->ths.emplace_back([raw, k, pin, node_cpus] {
+                if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_cpus);
+                raw->run(k);
+            });
         *out = p.release();
     } catch (const std::exception& e) {
         return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: %s", e.what());
