@@ -398,6 +398,9 @@ def main():
         if not (args.tune or sh is not None) else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
+        # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model
+        out["roofline"]["traffic_GBps"] = tr[0]["hbm_bytes_per_spmm"] / (fwd_ms * 1e-3) / 1e9
+        out["roofline"]["traffic_frac_of_peak"] = tr[0]["hbm_bytes_per_spmm"] / (fwd_ms * 1e-3) / HBM_PEAK
         out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
             tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
