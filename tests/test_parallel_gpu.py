@@ -64,3 +64,34 @@ def test_sharded_spmm_two_ranks(tmp_path, kernel):
         got = np.concatenate([r[0][key], r[1][key]], axis=0)      # rank order = vertex order
         assert got.shape == want.shape
         assert onp.rel_err(got, want) <= TOL, key
+
+
+def test_sharded_spmm_blocks_tile_the_full_product(dev=None):
+    """Four nnz-balanced row blocks of S-Reddit/10 (built one after the other on this GPU, no
+    collectives: the operand is resident) reproduce the unsharded product, forward and backward."""
+    import types
+    from stochastic_gcn_amd import ops, synthetic
+    from stochastic_gcn_amd.parallel import ShardedSpMM
+    from oracle import oracle_np as onp
+    dev = torch.device("cuda:0")
+    n, _, full_adj, *_ = synthetic.reddit_like(n=23296, m=1160000, splits=(15241, 2369, 5533), seed=3,
+                                               with_features=False)
+    d = 96
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    B = torch.randn((n, d), device=dev, generator=g)
+    dC = torch.randn((n, d), device=dev, generator=g)
+    whole = ops.DeviceCSR.from_scipy(full_adj, dev, with_transpose=True)
+    want_c, want_db = ops.spmm(whole, B), ops.spmm(whole.transpose, dC)
+    world, rows, nnz = 4, 0, []
+    cs, dbs = [], []
+    for r in range(world):
+        sh = ShardedSpMM(types.SimpleNamespace(rank=r, world=world, active=False), full_adj, dev)
+        assert sh.lo == rows
+        rows = sh.hi
+        nnz.append(sh.local_nnz)
+        cs.append(sh.forward(B))
+        dbs.append(sh.backward(dC))
+    assert rows == n and sum(nnz) == full_adj.nnz
+    assert max(nnz) - min(nnz) <= 2 * int(np.diff(full_adj.indptr).max())           # balanced by nonzeros
+    assert onp.rel_err(torch.cat(cs).cpu().numpy(), want_c.cpu().numpy()) <= TOL
+    assert onp.rel_err(torch.cat(dbs).cpu().numpy(), want_db.cpu().numpy()) <= TOL
