@@ -10,11 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` via gpurun)")
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _built():
-    """Tests call through the C-ABI: make sure libsgcn.so and the oracle's C file are built
-    (a no-op when the in-tree .so files travelled with the snapshot)."""
+    # Tests call through the C-ABI and some import the package at collection time: build
+    # libsgcn.so and the oracle's C file BEFORE collection (a no-op when the in-tree .so files are
+    # current, e.g. when they travelled with the gpurun snapshot).
     import __graft_entry__ as g
     g.build(quiet=True)
