@@ -17,6 +17,8 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
+ABI_VERSION = 2          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
 
@@ -145,6 +147,10 @@ def _load():
             raise ImportError("libsgcn.so does not export %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
+    if lib.sgcn_abi_version() != ABI_VERSION:      # same symbols, different signatures: never call into it
+        raise ImportError("libsgcn.so has ABI version %d, this binding needs %d (stale build: run "
+                          "`python -c 'import __graft_entry__ as g; g.build()'`)"
+                          % (lib.sgcn_abi_version(), ABI_VERSION))
     return lib
 
 
