@@ -25,7 +25,7 @@ def _train(flags, epochs):
     FLAGS.reset()
     FLAGS.update(dataset='reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1,
                  layer_norm=True, hidden1=64, num_fc_layers=1, batch_size=256, test_batch_size=512,
-                 learning_rate=0.01, seed=1, prefetch=2, **flags)
+                 learning_rate=0.01, seed=1, **dict(dict(prefetch=2), **flags))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         tr = Trainer(data=_data(), verbose=False)
@@ -72,3 +72,20 @@ def test_driver_log_lines_and_counters():
     assert m.amt_data == 3600 and m.adj_sizes[0] == 3600          # degree 1: one sampled edge per train id
     assert m.fadj_sizes[0] > m.adj_sizes[0] and m.field_sizes[1] == 3600
     assert m.g_ops > 0 and m.nn_ops > 0
+
+
+def test_training_is_bit_reproducible_and_prefetch_modes_agree():
+    """Same seed -> bit-identical weights and history: the sampler is a deterministic stream, the
+    dropout masks are a hash of (seed, layer, step, element), and no kernel uses float atomics
+    (split rows, split-K and LayerNorm-parameter partials are all added in a fixed order).  The
+    C++ prefetch thread, the Python prefetch thread and the synchronous loop are the same
+    computation."""
+    import torch
+    runs = []
+    for extra in (dict(prefetch=2, native_prefetch=True), dict(prefetch=2, native_prefetch=True),
+                  dict(prefetch=2, native_prefetch=False), dict(prefetch=0)):
+        tr, _ = _train(dict(cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, **extra), 2)
+        runs.append((tr.train_model.theta.clone(), tr.train_model.history[0][0].clone()))
+    for theta, hist in runs[1:]:
+        assert torch.equal(theta, runs[0][0])
+        assert torch.equal(hist, runs[0][1])
