@@ -28,7 +28,7 @@ from .models import make_template
 from .parallel import DataParallel
 from .plaingcn import PlainGCN
 from .scheduler import NativePrefetcher, PyScheduler
-from .utils import Averager, calc_f1, load_data
+from .utils import Averager, RunningStat, calc_f1, load_data
 from .vrgcn import VRGCN
 
 
@@ -380,6 +380,42 @@ class Trainer(object):
         if par.rank == 0:
             train_model.save(self.sess)
 
+    def GradientVariance(self, times=1000):
+        """--gradvar (gcn/train.py:241-276): bias and standard deviation of the prediction and of
+        the first layer's gradient under the training sampler, against the test sampler
+        (``--gradvar`` makes the test graph the training graph, so with ``--test_degree`` large
+        that is the exact aggregate), on the first batch of training vertices."""
+        log, ph = self.log, self.placeholders
+        batch = np.ascontiguousarray(self.train_d[:FLAGS.batch_size], dtype=np.int32)
+
+        def sweep(sch, model):
+            preds, grads = RunningStat(), RunningStat()
+            for _ in range(times):
+                feed = sch.batch(batch)
+                feed[ph['dropout']] = FLAGS.dropout
+                pred, grad = model.get_pred_and_grad(self.sess, feed)
+                preds.add(pred)
+                grads.add(grad)
+            return preds, grads
+        full_preds, full_grads = sweep(self.eval_sch, self.test_model)
+        full_preds_m = np.mean(np.abs(full_preds.mean()))
+        full_grads_m = np.mean(np.abs(full_grads.mean()))
+        log('Full pred stdev = {}'.format(np.mean(full_preds.std()) / full_preds_m))
+        log('Full grad stdev = {}'.format(np.mean(full_grads.std()) / full_grads_m))
+        part_preds, part_grads = sweep(self.train_sch, self.train_model)
+        out = dict(full_pred_std=np.mean(full_preds.std()) / full_preds_m,
+                   full_grad_std=np.mean(full_grads.std()) / full_grads_m,
+                   part_pred_bias=np.mean(np.abs(part_preds.mean() - full_preds.mean())) / full_preds_m,
+                   part_pred_std=np.mean(part_preds.std()) / full_preds_m,
+                   part_grad_bias=np.mean(np.abs(full_grads.mean() - part_grads.mean())) / full_grads_m,
+                   part_grad_std=np.mean(part_grads.std()) / full_grads_m)
+        log('Part pred bias = {}'.format(out['part_pred_bias']))
+        log('Part pred stdev = {}'.format(out['part_pred_std']))
+        log('Part grad bias = {}'.format(out['part_grad_bias']))
+        log('Part grad stdev = {}'.format(out['part_grad_std']))
+        log(full_grads_m, np.mean(part_grads.std()), np.mean(np.abs(part_grads.mean())))
+        return out
+
     def Test(self):
         test_cost, test_acc, micro, macro, test_duration = self.evaluate(self.test_d)
         self.log("Test set results:", "cost=", "{:.5f}".format(test_cost),
@@ -395,6 +431,8 @@ def main(argv=None):
     FLAGS.parse(argv)
     tr = Trainer()
     tr.SGDTrain()
+    if FLAGS.gradvar:
+        tr.GradientVariance()
     num_runs = FLAGS.num_layers + 1 if FLAGS.test_cv else 1
     for _ in range(num_runs):
         tr.Test()
