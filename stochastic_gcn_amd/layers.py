@@ -39,7 +39,8 @@ class Dropped(object):
 
     def materialize(self):
         if self._m is None:
-            self._m = ops.dropout(self.x, self.drop)
+            x = self.x.materialize() if isinstance(self.x, ops.GatheredRows) else self.x
+            self._m = ops.dropout(x, self.drop)
         return self._m
 
 
@@ -142,7 +143,8 @@ class Dropout(Layer):
             out.csr = inputs.with_values(ops.dropout(inputs.csr.val, self._drop))
             out.csr.coo_rows = inputs.csr.coo_rows
             return out
-        inputs = dense_of(inputs)
+        if not (self.fuse_next and isinstance(inputs, ops.GatheredRows)):
+            inputs = dense_of(inputs)      # (a pending row gather rides on into a fusing Dense layer)
         if self._drop is None:
             return inputs
         pending = Dropped(inputs, self._drop)
