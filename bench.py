@@ -377,7 +377,7 @@ def main():
             "kernel_launches_per_spmm": (-(-((d + 3) // 4 * 4) // 320) if (d + 3) // 4 > 64 else 1)
             * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
             "cs_autotune_ms_pace": tuned},
-        "roofline": {"bound": "hbm", "kernel": ("cs_spmm_kernel (column sweep, all slabs/rounds + fix-up)" if args.kernel == "cs"
+        "roofline": {"bound": "hbm", "kernel": ("sgcn::cs_spmm16_kernel<4, true> (column sweep: all slab/round launches of one SpMM + cs_fix_kernel)" if args.kernel == "cs"
                                 else "spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
