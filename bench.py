@@ -36,7 +36,7 @@ L2_PEAK = 34.5e12          # aggregate L2 bandwidth, MI355X_MICROARCH.md "L2 (pe
 HBM_COPY = 6.29e12         # measured float4-copy ceiling (ibid.)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
@@ -63,7 +63,49 @@ def parse():
     p.add_argument("--shard", choices=["resident", "allgather"], default=None,
                    help="STRONG scaling: ONE graph row-block sharded over the ranks (nnz-balanced), dense "
                         "operand resident on every GPU or all-gathered per product (SURVEY.md 8e)")
-    return p.parse_args()
+    p.add_argument("--dry-run", action="store_true",
+                   help="[test hook] no GPU work: only the launch / rendezvous / collective skeleton of "
+                        "the run (what the CPU test of `--gpus N` exercises under SGCN_DIST_BACKEND=gloo); "
+                        "the JSON line carries \"dry_run\": true and no throughput")
+    return p.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec under
+    torch.distributed.run, one rank per GPU (the driver's own invocation goes through
+    torch.distributed.run already and never reaches this).  Fails loudly when the box has fewer
+    than N GPUs -- a line with n_gpus != --gpus is never printed."""
+    import subprocess
+    backend = os.environ.get("SGCN_DIST_BACKEND", "nccl")
+    if backend == "nccl" and not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; RCCL needs one "
+                             "device per rank (SGCN_DIST_BACKEND=gloo shares a device for smoke tests)\n"
+                             % (args.gpus, have))
+            return 2, None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    rc = proc.wait()
+    return rc, (json.loads(line) if line else None)
 
 
 def make_graph(args, rank):
@@ -215,15 +257,64 @@ def sampler_baseline(data10):
     return res
 
 
-def main():
-    args = parse()
+def dry_run(args, world, rank):
+    """The distributed skeleton of a run without any GPU work (CPU test of `--gpus N`): rendezvous,
+    an all-gather of the ranks, the timed loop's barrier / all-reduce pattern, one JSON line."""
     import torch
     import torch.distributed as dist
-    import __graft_entry__ as g
+    ranks, total = [0], 1.0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("SGCN_DIST_BACKEND", "gloo"))
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        ranks = [int(x.item()) for x in got]
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+        total = float(t.item())
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        dist.destroy_process_group()
+    out = {"metric": "training edges/s (SpMM)", "value": None, "unit": "edges/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / max(args.steps, 1) * 1e3,
+           "dry_run": True, "ranks": ranks, "allreduce_of_rank_plus_1": total}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return out
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        rc, line = launch(args, argv)
+        if rc != 0:
+            raise SystemExit(rc)
+        return line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to "
+                         "print a line whose n_gpus differs from --gpus" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if os.environ.get("SGCN_DIST_BACKEND", "nccl") == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible; RCCL needs one device per rank"
+                         % (world, torch.cuda.device_count()))
     # one process per GPU.  (SGCN_DIST_BACKEND=gloo lets a 1-GPU box smoke-test the N>1 code
     # path with several ranks sharing cuda:0; RCCL itself refuses duplicate devices.)
     backend = os.environ.get("SGCN_DIST_BACKEND", "nccl")
@@ -445,6 +536,7 @@ def main():
     emit()
     if world > 1:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -82,6 +82,21 @@ class DataParallel(object):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def sum_scalar(self, x):
+        if not self.active:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def broadcast_scalar(self, x, src=0):
+        """Rank ``src``'s value on every rank (control decisions must be taken once per job)."""
+        if not self.active:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device or "cpu")
+        dist.broadcast(t, src=src)
+        return float(t.item())
+
     def barrier(self):
         if self.active:
             dist.barrier()

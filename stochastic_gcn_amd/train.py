@@ -174,6 +174,18 @@ def next_minibatch(sch, batch_size, slot=None):
     return fd
 
 
+def stop_verdict(par, epoch, cost_val, amt_data):
+    """0 = go on, 1 = early stopping, 2 = epoch / data budget reached (gcn/train.py:231-235), the
+    same value on every rank: rank 0's validation history and the job-wide amount of data decide."""
+    amt = par.sum_scalar(amt_data)
+    stop = 0
+    if epoch > FLAGS.early_stopping and cost_val[-1] > np.mean(cost_val[-(FLAGS.early_stopping + 1):-1]):
+        stop = 1
+    elif amt >= FLAGS.data and epoch > FLAGS.epochs:
+        stop = 2
+    return int(par.broadcast_scalar(stop))
+
+
 class Trainer(object):
     """Everything gcn/train.py does between flag parsing and the end of training, as an object
     (so bench.py can time epochs of the real training path).  FLAGS must be set before."""
@@ -226,6 +238,14 @@ class Trainer(object):
         if par.active:
             par.attach(self.train_model)
             self.train_d = par.shard_ids(train_d, num_data).astype(np.int32)
+            # a vertex range without a single train id (tiny or skewed sets, many ranks) would feed
+            # empty batches into kernels that reject n == 0 while the peers wait in the all-reduce:
+            # every rank falls back to round-robin id sharding when ANY range is empty
+            if par.max_scalar(1.0 if len(self.train_d) == 0 else 0.0) > 0:
+                self.train_d = np.ascontiguousarray(np.asarray(train_d)[par.rank::par.world], dtype=np.int32)
+                if len(self.train_d) == 0:
+                    raise RuntimeError("data-parallel training: %d train ids cannot be sharded over %d ranks"
+                                       % (len(train_d), par.world))
             # |fields[l]| <= batch * prod(1 + degree): lets the history exchange run without a
             # size round-trip (parallel.DataParallel.sync_history)
             bound = int(FLAGS.batch_size)
@@ -238,8 +258,11 @@ class Trainer(object):
         self.train_sch = PyScheduler(train_adj, labels, L, train_degrees, placeholders,
                                      par.sampler_seed(FLAGS.seed), self.train_d, cv=FLAGS.cv,
                                      importance=FLAGS.importance)
+        # the evaluation sampler is seeded IDENTICALLY on every rank: all ranks evaluate the same
+        # vertices with the same (all-reduced) weights, so validation cost -- and with it the
+        # early-stopping decision -- agrees across the job
         self.eval_sch = PyScheduler(full_adj, labels, test_L, test_degrees, placeholders,
-                                    par.sampler_seed(FLAGS.seed), cv=FLAGS.test_cv,
+                                    int(FLAGS.seed), cv=FLAGS.test_cv,
                                     importance=FLAGS.test_importance)
         self.sess = None   # API compatibility: run_one_step(sess, feed_dict)
         from .scheduler import StagingSlot
@@ -250,7 +273,7 @@ class Trainer(object):
                                                par.sampler_seed(FLAGS.seed) + 1000 * k, cv=FLAGS.cv,
                                                importance=FLAGS.importance))
             self.eval_schs.append(PyScheduler(full_adj, labels, test_L, test_degrees, placeholders,
-                                              par.sampler_seed(FLAGS.seed) + 1000 * k, cv=FLAGS.test_cv,
+                                              int(FLAGS.seed) + 1000 * k, cv=FLAGS.test_cv,
                                               importance=FLAGS.test_importance))
         ring = max(FLAGS.prefetch, 1) * nthr + 3
         self.slots = [StagingSlot(pin=True) for _ in range(ring)]
@@ -371,10 +394,15 @@ class Trainer(object):
                 train_model.field_sizes, train_model.adj_sizes, train_model.fadj_sizes))
             log('[sgcn] epoch train wall = {:.5f} s over {} steps ({} GPU(s))'.format(
                 self.last_epoch['train_wall_s'], self.last_epoch['steps'], par.world))
-            if epoch > FLAGS.early_stopping and cost_val[-1] > np.mean(cost_val[-(FLAGS.early_stopping + 1):-1]):
+            # the two exits of gcn/train.py:231-235, verbatim conditions (`epoch > FLAGS.epochs`:
+            # the reference trains epochs + 2 epochs).  In a multi-GPU job the decision is COLLECTIVE:
+            # rank 0 decides on its validation cost and the job-wide amount of data, and broadcasts
+            # the verdict -- a rank-local `break` would leave the peers blocked in the next epoch's
+            # all-reduce.
+            stop = stop_verdict(par, epoch, cost_val, train_model.amt_data)
+            if stop == 1:
                 log("Early stopping...")
-                break
-            if train_model.amt_data >= FLAGS.data and epoch + 1 >= FLAGS.epochs:
+            if stop:
                 break
         log("Optimization Finished!")
         if par.rank == 0:

@@ -1,12 +1,13 @@
 """Data loading / metrics helpers the training driver needs (subset of gcn/utils.py).
 
 ``load_data(dataset)`` returns the reference's 10-tuple (gcn/utils.py:183,335).  It reads the
-reference's ``.npz`` dataset cache when one is present -- same file name and key schema
-(``data/<name>.npz`` for GraphSAGE sets, gcn/utils.py:325-333; ``data/<name>.<normalization>.npz``
--style for the Planetoid sets, gcn/utils.py:172-181) -- so a cache produced by the reference
-drops in; otherwise it falls back to the deterministic synthetic stand-ins of synthetic.py
-(no datasets and no network on the box).  Raw-format parsers (networkx-1.11 JSON, Planetoid
-pickles) are out of scope.
+reference's ``.npz`` dataset cache -- same file names (``data/<name>.npz`` /
+``data/<name>_deg<max_degree>.npz`` for GraphSAGE sets, gcn/utils.py:193-196;
+``data/<name>_<normalization>.npz`` for the Planetoid sets, gcn/utils.py:34) and key schema
+(gcn/utils.py:172-181, :325-333) -- so a cache produced by the reference drops in.  The
+deterministic synthetic stand-ins of synthetic.py (no datasets and no network on the box) are
+selected explicitly: ``--dataset s-reddit`` / ``s-cora`` / ``s-pubmed`` or ``--synthetic``.
+Raw-format parsers (networkx-1.11 JSON, Planetoid pickles) are out of scope.
 """
 import os
 
@@ -58,13 +59,37 @@ def save_npz_cache(path, tup):
         np.savez(f, **blob)
 
 
+GCN_DATASETS = ('cora', 'citeseer', 'pubmed', 'nell')     # gcn/utils.py:467
+
+
+def cache_path(dataset):
+    """The reference's cache file name for ``dataset`` under the current flags:
+    ``data/{name}_{normalization}.npz`` for the Planetoid sets (gcn/utils.py:34),
+    ``data/{name}.npz`` or ``data/{name}_deg{max_degree}.npz`` for GraphSAGE-format sets
+    (gcn/utils.py:193-196)."""
+    if dataset in GCN_DATASETS:
+        return 'data/{}_{}.npz'.format(dataset, FLAGS.normalization)
+    if FLAGS.max_degree == -1:
+        return 'data/{}.npz'.format(dataset)
+    return 'data/{}_deg{}.npz'.format(dataset, FLAGS.max_degree)
+
+
 def load_data(dataset):
-    for cand in ('data/{}.npz'.format(dataset), 'data/{}.{}.npz'.format(dataset, FLAGS.normalization)):
-        if os.path.exists(cand):
-            print('Found preprocessed dataset {}, loading...'.format(cand))
-            return load_npz_cache(cand)
-    print('No dataset cache for "{}": using the synthetic stand-in (scale={})'.format(dataset, FLAGS.scale))
-    return synthetic.load_data(dataset, FLAGS.normalization, FLAGS.scale)
+    """gcn/utils.py:466-473.  ``s-cora`` / ``s-pubmed`` / ``s-reddit`` (or any name with
+    ``--synthetic``) select the deterministic synthetic stand-ins of synthetic.py; a real dataset
+    name loads the reference's ``.npz`` cache and FAILS when it is absent -- a training run never
+    silently reports numbers on stand-in data."""
+    if dataset.startswith('s-') or FLAGS.synthetic:
+        print('Synthetic stand-in for "{}" (scale={})'.format(dataset, FLAGS.scale))
+        return synthetic.load_data(dataset, FLAGS.normalization, FLAGS.scale)
+    cand = cache_path(dataset)
+    if os.path.exists(cand):
+        print('Found preprocessed dataset {}, loading...'.format(cand))
+        return load_npz_cache(cand)
+    raise FileNotFoundError(
+        'no dataset cache {} for "{}" (the reference writes it on its first run; the raw-format '
+        'parsers are out of scope here).  Use --dataset s-{} or --synthetic for the synthetic '
+        'stand-in.'.format(cand, dataset, dataset))
 
 
 class Averager(object):

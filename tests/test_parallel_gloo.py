@@ -111,6 +111,25 @@ def w_train_step(par):
     return out
 
 
+def w_stop_verdict(par):
+    """Ranks whose validation histories disagree (rank 1's plateaued, rank 0's did not) must still
+    leave the epoch loop together (a rank-local `break` deadlocks the peers)."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import stop_verdict
+    FLAGS.reset()
+    FLAGS.update(early_stopping=2, epochs=100, data=0)
+    falling = [1.0, 0.9, 0.8, 0.7, 0.6]
+    rising = [1.0, 0.9, 0.8, 0.9, 1.0]
+    mine = rising if par.rank == 1 else falling
+    v1 = stop_verdict(par, 4, mine, 10)                     # rank 0 says go on -> everybody goes on
+    mine = rising if par.rank == 0 else falling
+    v2 = stop_verdict(par, 4, mine, 10)                     # rank 0 says stop -> everybody stops
+    FLAGS.update(epochs=3, data=25)
+    v3 = stop_verdict(par, 4, falling, 10)                  # job-wide data 20 < 25: go on
+    v4 = stop_verdict(par, 4, falling, 13)                  # job-wide data 26 >= 25 and epoch > epochs
+    return dict(v=np.array([v1, v2, v3, v4]))
+
+
 # ---- tests -----------------------------------------------------------------------------------
 def test_sharding_allreduce_broadcast(tmp_path):
     r = _run("w_shard_and_allreduce", tmp_path)
@@ -147,6 +166,12 @@ def test_two_rank_training_step_matches_mean_gradient(tmp_path):
     np.testing.assert_array_equal(r[0]["theta"], r[1]["theta"])     # replicas stay in lock-step
     np.testing.assert_array_equal(r[0]["hist"], r[1]["hist"])
     assert np.abs(r[0]["hist"]).sum() > 0
+
+
+def test_stop_decision_is_collective(tmp_path):
+    r = _run("w_stop_verdict", tmp_path)
+    for x in r:
+        assert x["v"].tolist() == [0, 1, 0, 2]
 
 
 def test_partition_rows_by_nnz_balances_power_law_rows():
