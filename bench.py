@@ -41,7 +41,11 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="reddit", choices=["reddit", "reddit-small", "reddit-114m", "rmat", "rmat-10m"])
+    p.add_argument("--workload", default="reddit", choices=["reddit", "reddit-small", "reddit-114m", "reddit-sbm", "rmat", "rmat-10m"])
+    p.add_argument("--reorder", default=None, choices=["none", "lp", "labels"],
+                   help="locality-preserving column-sweep plan: communities from label propagation on the graph "
+                        "(lp) or from the dataset's labels; default: lp for reddit-sbm, none otherwise")
+    p.add_argument("--p-in", type=float, default=0.8, help="reddit-sbm: fraction of a vertex's edges inside its community")
     p.add_argument("--d", type=int, default=602)
     p.add_argument("--pitch", type=int, default=0, help="row pitch of X/C in floats (0: d rounded up to 32)")
     p.add_argument("--plan-t", type=int, default=0)
@@ -119,6 +123,9 @@ def make_graph(args, rank):
         data = synthetic.reddit_like(n=23296, m=1160000, splits=(15241, 2369, 5533),
                                      seed=1 + rank, with_features=False)
         name = "S-Reddit/10 (N=23296)"
+    elif args.workload == "reddit-sbm":     # S-Reddit degree law + 41 planted communities (locality-bearing)
+        data = synthetic.reddit_sbm(seed=1 + rank, p_in=args.p_in)
+        name = "S-Reddit-SBM full-graph CSR x dense (N=232965, Zipf(0.6) sources, 41 communities, p_in=%.2f)" % args.p_in
     elif args.workload == "reddit-114m":    # the denser Reddit distribution (114.6 M nnz, avg deg 492)
         data = synthetic.reddit_like(m=57_400_000, seed=1 + rank, with_features=False)
         return data[0], data[2], "S-Reddit-114M full-graph CSR x dense (N=232965, avg degree ~490)", None
@@ -140,7 +147,7 @@ def train_epoch_leg(data, dev, epochs=6):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.train import Trainer
     FLAGS.reset()
-    FLAGS.update(dataset='reddit', normalization='graphsage', weight_decay=0.0, dropout=0.2,
+    FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.2,
                  layer_norm=True, hidden1=128, num_fc_layers=2, batch_size=512, test_batch_size=512,
                  cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, seed=1,
                  native_prefetch=os.environ.get("SGCN_NATIVE_PREFETCH", "1") == "1",
@@ -182,6 +189,16 @@ def profiled_traffic(kernel_prefix, nnz, d):
         if j.get("kernel", "").startswith(kernel_prefix) and j.get("nnz") == nnz and j.get("d") == d:
             best = (j, os.path.basename(f))
     return best
+
+
+def gather_ceiling():
+    """{'hit': TB/s, 'miss': TB/s} of the pure-gather microbenchmark (profiles/gather_ceiling.json), or None."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))
+        b = j["best_1216B"]
+        return {"hit": b["hit"]["TBps"], "miss": b["miss"]["TBps"]}
+    except Exception:
+        return None
 
 
 def reddit_grad_floats(d_in=602, hidden=128, classes=41):
@@ -347,6 +364,8 @@ def main(argv=None):
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
     sh = None
+    reorder = args.reorder or ("lp" if args.workload == "reddit-sbm" else "none")
+    reorder_info = None
     if args.shard:
         from stochastic_gcn_amd.parallel import DataParallel, ShardedSpMM
         par = DataParallel(device=dev, init=False)
@@ -358,8 +377,18 @@ def main(argv=None):
         sh = ShardedSpMM(par, full_adj, dev, kernel=args.kernel, with_transpose=not args.no_backward)
         A = sh.A
     elif args.kernel == "cs":
-        A = ops.ColumnSweepCSR(full_adj, dev, R=args.cs_r, T=args.cs_t)
-        A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, R=args.cs_r, T=args.cs_t)
+        comm = None
+        if reorder == "lp":
+            t_lp = time.time()
+            comm, ncomm = ops.reorder_labels(full_adj)
+            reorder_info = {"method": "label propagation on the graph (sgcn_reorder_lp)", "communities": ncomm,
+                            "host_s": round(time.time() - t_lp, 2)}
+        elif reorder == "labels":
+            comm = np.ascontiguousarray(data10[6].argmax(1), dtype=np.int32)
+            reorder_info = {"method": "dataset labels", "communities": int(comm.max()) + 1}
+        A = ops.ColumnSweepCSR(full_adj, dev, R=args.cs_r, T=args.cs_t, col_labels=comm, row_labels=comm)
+        A.transpose = None if args.no_backward else ops.ColumnSweepCSR(
+            full_adj.T.tocsr(), dev, R=args.cs_r, T=args.cs_t, col_labels=comm, row_labels=comm)
         mm = ops.spmm_cs
     else:
         A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)
@@ -468,8 +497,8 @@ def main(argv=None):
             "kernel_launches_per_spmm": (-(-((d + 3) // 4 * 4) // 320) if (d + 3) // 4 > 64 else 1)
             * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
             "cs_autotune_ms_pace": tuned},
-        "roofline": {"bound": "hbm", "kernel": ("sgcn::cs_spmm16_kernel<4, true> (column sweep: all slab/round launches of one SpMM + cs_fix_kernel)" if args.kernel == "cs"
-                                else "spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
+        "roofline": {"bound": "hbm", "kernel": ((A.variant(d) + " + cs_fix_kernel: one SpMM") if args.kernel == "cs"
+                                else "sgcn::spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
                      "traffic": None, "traffic_source": None, "bytes_alg_per_launch": bytes_alg,
@@ -485,8 +514,23 @@ def main(argv=None):
                                    "peak_GBps": L2_PEAK / 1e9,
                                    "frac": (sh.local_nnz if sh is not None else nnz) * d * 4 / (fwd_ms * 1e-3) / L2_PEAK}},
     }
+    if reorder_info:
+        out["config"]["reorder"] = reorder_info
+    gc = gather_ceiling()
+    if gc is not None and args.kernel == "cs":
+        # every edge moves one d-float row of B from an L2 into VGPRs whatever else happens; the pure
+        # gather microbenchmark (profiles/gather_ceiling.hip) gives the rate of that alone
+        nn = sh.local_nnz if sh is not None else nnz
+        t_floor = nn * d * 4 / (gc["hit"] * 1e12)
+        out["roofline"]["gather_ceiling"] = {
+            "source": "profiles/gather_ceiling.json (pure row gather, no FMA; 1,216 B pieces)",
+            "l2_hit_TBps": gc["hit"], "fabric_miss_TBps": gc["miss"],
+            "ms_all_hit_floor": t_floor * 1e3,
+            "note": "hits and misses do not overlap in the vector memory path (mixed launch = sum of the two): "
+                    "T_model = miss_bytes/miss_rate + hit_bytes/hit_rate"}
+        out["roofline"]["frac_of_gather_ceiling"] = t_floor / (fwd_ms * 1e-3)
     tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
-        if not (args.tune or sh is not None) else None
+        if not (args.tune or sh is not None or reorder != "none") else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model
@@ -494,6 +538,12 @@ def main(argv=None):
         out["roofline"]["traffic_frac_of_peak"] = tr[0]["hbm_bytes_per_spmm"] / (fwd_ms * 1e-3) / HBM_PEAK
         out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
             tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
+        if gc is not None:      # the two-rate model of this kernel's own traffic
+            miss_b = tr[0]["fetch_bytes_corrected"] * tr[0]["kernel_launches_per_spmm"]
+            hit_b = max(nnz * (d * 4 + 8) - miss_b, 0)
+            t_model = miss_b / (gc["miss"] * 1e12) + hit_b / (gc["hit"] * 1e12)
+            out["roofline"]["gather_ceiling"]["ms_model_for_profiled_traffic"] = t_model * 1e3
+            out["roofline"]["frac_of_traffic_model"] = t_model / (fwd_ms * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
         if data10 is not None:

@@ -111,18 +111,34 @@ typedef struct {
     int32_t pace_ns_per_nnz;        /* sweep clock: a launch lasts (heaviest tile nnz) x this many
                                        ns; found by timing a few values once per plan+width.
                                        0 = library default knob, < 0 = unpaced                  */
+    int32_t xcd_map;                /* != 0: consecutive tiles of a launch go to the SAME XCD (the
+                                       dispatcher deals workgroups round-robin over the 8 XCDs):
+                                       with a grouped plan the tiles that share B rows share an L2.
+                                       Placement only -- results do not depend on it.            */
 } sgcn_csplan_t;
+/* row_group (nullable, [M], labels >= 0): tiles are formed inside groups, groups in label order
+ * (locality-preserving reordering of a graph that has communities, e.g. from sgcn_reorder_lp);
+ * NULL = one group = tiles balanced over all rows (the uniform-graph default). */
 int sgcn_csplan_count(const int32_t* host_rowptr, int32_t M, int32_t R, int32_t T,
-                      int64_t* ntiles, int64_t* nfix, int64_t* nslots);
+                      const int32_t* host_row_group, int64_t* ntiles, int64_t* nfix, int64_t* nslots);
 int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val,
-                     int32_t M, int32_t R, int32_t T, int64_t* host_tile_ptr,
-                     int32_t* host_colrow, float* host_valout, int32_t* host_tile_rows,
-                     int32_t* host_tile_slots, sgcn_fix_t* host_fix);
+                     int32_t M, int32_t R, int32_t T, const int32_t* host_row_group,
+                     int64_t* host_tile_ptr, int32_t* host_colrow, float* host_valout,
+                     int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
+/* Community labels of a square CSR pattern by seeded asynchronous label propagation (host, graph
+ * only; new -- the reference has no reordering).  comm[n] in [0, *ncomm), numbered by decreasing
+ * size; communities smaller than min_size share the last label.  max_iters <= 0: 12 sweeps. */
+int sgcn_reorder_lp(const int32_t* host_rowptr, const int32_t* host_col, int32_t n, int32_t max_iters,
+                    uint32_t seed, int32_t min_size, int32_t* host_comm, int32_t* ncomm);
 /* Same contract as sgcn_spmm_csr_f32 (C = rscale (.) (A (cscale (.) B[g])) + beta C). */
 int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K, int32_t d,
                      const float* dev_B, int64_t ldb, const int32_t* dev_gidx,
                      const float* dev_rscale, const float* dev_cscale,
                      float* dev_C, int64_t ldc, float beta, void* stream);
+
+/* The kernel variant and launch geometry sgcn_spmm_cs_f32 dispatches for (plan, d) under the
+ * current knobs, as text (bench.py reports it as roofline.kernel). */
+int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_t buflen);
 
 /* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)

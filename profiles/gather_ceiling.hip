@@ -129,6 +129,62 @@ __global__ __launch_bounds__(256) void gather_kernel(const char* __restrict__ B,
     if (sink && lane == 9999) sink[0] = 1.f;
 }
 
+// Do L2 hits flow past outstanding misses?  Two wave populations in ONE launch: waves with an even
+// index in their workgroup gather nA rows each from the L2-resident set, odd waves nB rows each from
+// the whole operand (all-miss).  Run (nA, 0), (0, nB) and (nA, nB): if hits and misses overlap, the
+// mixed launch takes ~max of the two; if they serialise in the CU's vector-memory path, ~the sum.
+template <int U>
+__global__ __launch_bounds__(256) void mixed_kernel(const char* __restrict__ B, int64_t ldb_bytes,
+                                                    const int32_t* __restrict__ idxA, int nA,
+                                                    const int32_t* __restrict__ idxB, int nB, int stride,
+                                                    int by_cu) {
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
+    // by_cu: the role is a property of the CU (HW_REG_HW_ID bits 11:8 = cu_id), so a CU's vector
+    // memory path only ever sees one kind of traffic
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const bool roleB = by_cu ? ((hwid >> 8) & 1) : (wib & 1);
+    const int32_t* my = (roleB ? idxB : idxA) + wave * stride;
+    const int n = roleB ? nB : nA;
+    const uint32_t off16 = lane * 16u, off4 = lane * 4u;
+    for (int k = 0; k < n; k += 64) {
+        const int myidx = my[k + lane];
+#pragma unroll 1
+        for (int j = 0; j < 64; j += U) {
+            f4 a[U];
+            float e[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int r = __builtin_amdgcn_readlane(myidx, j + u);
+                const char* base = B + (int64_t)r * ldb_bytes;
+                a[u] = ld16<PLAIN>(base, off16);
+                e[u] = ld4<PLAIN>(base, 1024u + (lane < 48 ? off4 : 0u));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < U; u++) { asm volatile("" :: "v"(a[u])); asm volatile("" :: "v"(e[u])); }
+        }
+    }
+}
+
+template <int U>
+static float run_mixed(const char* B, int64_t ldb, const int32_t* ia, int nA, const int32_t* ib, int nB, int stride, int blocks, int by_cu = 0) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 4; r++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((mixed_kernel<U>), dim3(blocks), dim3(256), 0, 0, B, ldb, ia, nA, ib, nB, stride, by_cu);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms < best) best = ms;
+    }
+    return best;
+}
+
 struct Cfg { const char* name; int U, pol, shape; };
 
 template <int U, int POL, int SHAPE>
@@ -225,5 +281,30 @@ int main(int argc, char** argv) {
     RUN(4, PLAIN, 6, 4)
     RUN(8, PLAIN, 6, 4)
     RUN(8, PLAIN, 6, 8)
+    // hit-under-miss: 2 hit waves + 2 miss waves per SIMD-group (4 waves per workgroup, 4 workgroups per CU)
+    {
+        const int blocks = 256 * 4;
+        const int nA = 4096, nB = 1024;
+        const float ta = run_mixed<8>(B, pitch, idx_hit, nA, idx_miss, 0, npw, blocks);
+        const float tb = run_mixed<8>(B, pitch, idx_hit, 0, idx_miss, nB, npw, blocks);
+        const float tm = run_mixed<8>(B, pitch, idx_hit, nA, idx_miss, nB, npw, blocks);
+        const double ba = (double)blocks * 2 * nA * 1216, bb = (double)blocks * 2 * nB * 1216;
+        printf("{\"regime\": \"mixed\", \"shape\": \"x4+x1\", \"bytes_per_row\": 1216, \"U\": 8, \"policy\": \"plain\", "
+               "\"waves_per_simd\": 4, \"ms_hit_only\": %.4f, \"ms_miss_only\": %.4f, \"ms\": %.4f, "
+               "\"TBps_hit_only\": %.3f, \"TBps_miss_only\": %.3f, \"TBps\": %.3f, \"B_per_clk_per_CU\": %.2f}\n",
+               ta, tb, tm, ba / ta / 1e9, bb / tb / 1e9, (ba + bb) / tm / 1e9, (ba + bb) / (tm * 1e-3) / 256.0 / 2.4e9);
+    }
+    {   // the same with the role tied to the CU: half the CUs only hit, the other half only miss
+        const int blocks = 256 * 4;
+        const int nA = 4096, nB = 1024;
+        const float ta = run_mixed<8>(B, pitch, idx_hit, nA, idx_miss, 0, npw, blocks, 1);
+        const float tb = run_mixed<8>(B, pitch, idx_hit, 0, idx_miss, nB, npw, blocks, 1);
+        const float tm = run_mixed<8>(B, pitch, idx_hit, nA, idx_miss, nB, npw, blocks, 1);
+        const double ba = (double)blocks * 2 * nA * 1216, bb = (double)blocks * 2 * nB * 1216;   // ~half the waves per role
+        printf("{\"regime\": \"mixed_by_cu\", \"shape\": \"x4+x1\", \"bytes_per_row\": 1216, \"U\": 8, \"policy\": \"plain\", "
+               "\"waves_per_simd\": 4, \"ms_hit_only\": %.4f, \"ms_miss_only\": %.4f, \"ms\": %.4f, "
+               "\"TBps_hit_only\": %.3f, \"TBps_miss_only\": %.3f, \"TBps\": %.3f, \"B_per_clk_per_CU\": %.2f}\n",
+               ta, tb, tm, ba / ta / 1e9, bb / tb / 1e9, (ba + bb) / tm / 1e9, (ba + bb) / (tm * 1e-3) / 256.0 / 2.4e9);
+    }
     return 0;
 }

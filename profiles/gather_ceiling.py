@@ -36,6 +36,11 @@ def main():
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     for r in rows:
+        if r["regime"].startswith("mixed"):
+            print(r["regime"] + ": hit-only %.3f ms (%.1f TB/s), miss-only %.3f ms (%.1f TB/s), both in one launch %.3f ms "
+                  "(sum %.3f, max %.3f)" % (r["ms_hit_only"], r["TBps_hit_only"], r["ms_miss_only"], r["TBps_miss_only"],
+                                            r["ms"], r["ms_hit_only"] + r["ms_miss_only"], max(r["ms_hit_only"], r["ms_miss_only"])))
+            continue
         print("%-7s %-13s %5d B  U=%-2d %-7s wps=%d  %8.3f ms  %7.2f TB/s  %6.1f B/clk/CU" % (
             r["regime"], r["shape"], r["bytes_per_row"], r["U"], r["policy"], r["waves_per_simd"], r["ms"], r["TBps"],
             r["B_per_clk_per_CU"]))

@@ -10,9 +10,17 @@
 // slow leaders down, which keeps the pack together.  B is fetched ~once per XCD per launch
 // instead of once per nonzero.
 //
-// The accumulator row is selected by a wave-uniform switch (the local row id travels in the top
-// 4 bits of the column word), i.e. scalar compare/branch -- no dynamic VGPR indexing, no LDS.
+// The local row id travels in the top 4 bits of the column word and selects the accumulator
+// through the gfx9 VGPR-indexing mode (s_set_gpr_idx_on lr; v_fma v<plane>...; s_set_gpr_idx_off):
+// the accumulators are PINNED to fixed registers, so a nonzero costs one indexed FMA group -- no
+// branches, no LDS, no register copies.  The sweep is clock-paced (s_memrealtime) so that all
+// waves of an XCD stay inside one L2-sized window of B.
 // Split rows / ordered fix-up exactly as in sgcn_spmm.hip (deterministic, no atomics).
+//
+// Where its time goes (profiles/gather_ceiling.*): L2 hits and fabric misses do
+// not overlap in the vector memory path -- T ~ miss_bytes / 7.2 TB/s + hit_bytes / 30 TB/s -- and
+// the kernel sits on that line; the levers left are fewer fabric bytes (rows resident per XCD) and
+// graphs with locality (grouped plans, xcd_map).
 #include "sgcn_dev.h"
 
 namespace sgcn {
@@ -34,7 +42,20 @@ struct CsArgs {
     float* ws; int64_t ldw;
     float cols_per_tick;   // pacing: columns the sweep may advance per 100 MHz tick (0 = unpaced)
     float slack_cols;      // how far ahead of the clock a wave may run
+    int32_t xcd_map;       // consecutive tiles of the launch on the same XCD (grouped plans)
 };
+
+// Workgroup -> first tile of the launch.  The dispatcher deals workgroups round-robin over the 8
+// XCDs (workgroup b runs on XCD b % 8); with xcd_map the launch's tile range is cut into 8
+// contiguous pieces, one per XCD, so tiles that are adjacent in the plan -- same row group, same B
+// rows -- share an L2.  Pure placement: any dispatch order gives the same result.
+__device__ __forceinline__ int64_t cs_first_tile(const CsArgs& a) {
+    const unsigned b = blockIdx.x, nb = gridDim.x;
+    if (!a.xcd_map || nb < 8) return a.tile_base + (int64_t)b * (kBlock / kWave);
+    const unsigned x = b & 7u, q = nb >> 3, r = nb & 7u;
+    const unsigned start = x * q + (x < r ? x : r);            // workgroups of XCDs 0..x-1
+    return a.tile_base + (int64_t)(start + (b >> 3)) * (kBlock / kWave);
+}
 
 #define SGCN_CS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
@@ -55,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     constexpr int kShift = 28;
     constexpr uint32_t kColMask = (1u << kShift) - 1u;
     const int lane = threadIdx.x & 63;
-    const int64_t tile = a.tile_base + (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
     if (tile >= a.tile_end) return;
     const int fbase = a.slab * a.slab_floats;                    // first column of this pass
     const int f4 = fbase + lane * 4;                             // my float4
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
     constexpr int kShift = (R <= 16) ? 28 : 27;                 // local row id lives above the column
     constexpr uint32_t kColMask = (1u << kShift) - 1u;
     const int lane = threadIdx.x & 63;
-    const int64_t tile = a.tile_base + (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
     if (tile >= a.tile_end) return;
     const int vi = a.slab * kWave + lane;
     const bool act = vi < a.nvec;
@@ -330,6 +351,56 @@ __global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix
 
 using namespace sgcn;
 
+namespace {
+// What sgcn_spmm_cs_f32 dispatches for (plan, d) under the current knobs: passes over the feature
+// dimension, columns per pass, the fifth plane, gathers in flight -- and the kernel's name.
+struct CsVariant { int nslab, slab_floats, U; bool pinned, extra; const char* name; };
+
+CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
+    CsVariant v{};
+    const int VW = plan->R <= 16 ? 4 : 2;
+    const int nvec = (d + VW - 1) / VW;
+    v.U = tune_get("cs_unroll") > 0 ? tune_get("cs_unroll") : 8;
+    v.nslab = (nvec + kWave - 1) / kWave;
+    v.pinned = plan->R == 16 && tune_get("cs_generic") <= 0;
+    v.slab_floats = 256;
+    if (v.pinned) {
+        // a pass costs the same whatever its width: cover d in ceil(d / 320) passes of
+        // (64 float4 + extra floats) instead of ceil(d / 256) passes of 64 float4
+        const int dp = (d + 3) / 4 * 4;
+        const int np = (dp + 319) / 320;
+        if (np < v.nslab && tune_get("cs_noextra") <= 0) {
+            v.nslab = np;
+            v.slab_floats = ((dp + np - 1) / np + 3) / 4 * 4;
+            v.extra = v.slab_floats > 256;
+        }
+        // EXTRA at U = 8 needs 142 VGPRs (3 waves/SIMD, breaks the 4096-tile residency): U = 4
+        if (v.extra) v.U = tune_get("cs_unroll") == 8 ? 8 : 4;
+        else v.U = v.U == 4 ? 4 : 8;
+        v.name = v.extra ? (v.U == 8 ? "sgcn::cs_spmm16_kernel<8, true>" : "sgcn::cs_spmm16_kernel<4, true>")
+                         : (v.U == 8 ? "sgcn::cs_spmm16_kernel<8, false>" : "sgcn::cs_spmm16_kernel<4, false>");
+    } else if (plan->R == 16) {
+        v.U = v.U == 4 ? 4 : 8;
+        v.name = v.U == 4 ? "sgcn::cs_spmm_kernel<16, 4, 4>" : "sgcn::cs_spmm_kernel<16, 4, 8>";
+    } else {
+        v.U = v.U == 4 ? 4 : 8;
+        v.name = v.U == 4 ? "sgcn::cs_spmm_kernel<32, 2, 4>" : "sgcn::cs_spmm_kernel<32, 2, 8>";
+    }
+    return v;
+}
+}  // namespace
+
+extern "C" int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_t buflen) {
+    SGCN_REQUIRE(plan && buf && buflen > 0 && d > 0, "spmm_cs_variant: bad argument");
+    SGCN_REQUIRE(plan->R == 16 || plan->R == 32, "spmm_cs_variant: R must be 16 or 32");
+    const CsVariant v = cs_variant(plan, d);
+    int64_t round = plan->round_tiles > 0 ? plan->round_tiles : (tune_get("cs_round") > 0 ? tune_get("cs_round") : 4096);
+    snprintf(buf, (size_t)buflen, "%s x %d launches (%d passes of %d columns x %lld rounds of %lld tiles)", v.name,
+             (int)(v.nslab * ((plan->ntiles + round - 1) / round)), v.nslab, v.slab_floats,
+             (long long)((plan->ntiles + round - 1) / round), (long long)round);
+    return SGCN_OK;
+}
+
 extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K, int32_t d,
                                 const float* B, int64_t ldb, const int32_t* gidx,
                                 const float* rscale, const float* cscale, float* C, int64_t ldc,
@@ -352,6 +423,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     a.B = B; a.ldb = ldb; a.gidx = gidx; a.rscale = rscale; a.cscale = cscale;
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
+    a.xcd_map = plan->xcd_map;
     if (plan->nfix > 0) {
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
                      "spmm_cs: workspace missing or too small");
@@ -361,26 +433,14 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
         const int tuned = tune_get("cs_round");
         round = tuned > 0 ? tuned : 4096;       // 256 CUs x 4 SIMDs x 4 waves of 64 acc VGPRs
     }
-    const int U = tune_get("cs_unroll") > 0 ? tune_get("cs_unroll") : 8;
     // pace: plan value wins (set by the autotuner); 0 -> global knob; < 0 -> unpaced
     const int pace_ns_per_nnz = plan->pace_ns_per_nnz != 0 ? (plan->pace_ns_per_nnz < 0 ? 0 : plan->pace_ns_per_nnz)
                                                            : tune_get("cs_pace");
     const int slack = tune_get("cs_slack") > 0 ? tune_get("cs_slack") : 512;
-    int nslab = (a.nvec + kWave - 1) / kWave;
-    const bool pinned = plan->R == 16 && tune_get("cs_generic") <= 0;
-    bool extra = false;
-    a.slab_floats = 256;
-    if (pinned) {
-        // a pass costs the same whatever its width: cover d in ceil(d / 320) passes of
-        // (64 float4 + extra floats) instead of ceil(d / 256) passes of 64 float4
-        const int dp = (d + 3) / 4 * 4;
-        const int np = (dp + 319) / 320;
-        if (np < nslab && tune_get("cs_noextra") <= 0) {
-            nslab = np;
-            a.slab_floats = ((dp + np - 1) / np + 3) / 4 * 4;
-            extra = a.slab_floats > 256;
-        }
-    }
+    const CsVariant var = cs_variant(plan, d);
+    const int nslab = var.nslab, U = var.U;
+    const bool pinned = var.pinned, extra = var.extra;
+    a.slab_floats = var.slab_floats;
     for (int slab = 0; slab < nslab; slab++) {
         a.slab = slab;
         for (int64_t t0 = 0; t0 < plan->ntiles; t0 += round) {
@@ -396,8 +456,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
 #define SGCN_CS_LAUNCH(RR, VV, UU) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU>), dim3(blocks), dim3(kBlock), 0, st, a)
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
             if (pinned) {
-                // EXTRA at U = 8 needs 142 VGPRs (3 waves/SIMD, breaks the 4096-tile residency): U = 4
-                if (extra) { if (tune_get("cs_unroll") == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
+                if (extra) { if (U == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }
             } else if (plan->R == 16) {         // generic (hipcc-lowered indexing) reference path
                 if (U == 4) SGCN_CS_LAUNCH(16, 4, 4); else SGCN_CS_LAUNCH(16, 4, 8);

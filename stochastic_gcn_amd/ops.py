@@ -337,25 +337,66 @@ def adam_step(theta, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
 
 
 # ---- column-sweep SpMM for static graphs (sgcn_spmm_cs.hip) --------------------------------------
+def reorder_labels(a, max_iters=0, seed=1, min_size=64):
+    """Community label per vertex of a square sparse matrix's pattern (sgcn_reorder_lp: seeded
+    asynchronous label propagation on the host, graph only).  Returns (comm int32[n], ncomm)."""
+    a = a.tocsr()
+    if a.shape[0] != a.shape[1]:
+        raise ValueError("reorder_labels needs a square (vertex x vertex) matrix")
+    rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+    col = np.ascontiguousarray(a.indices, dtype=np.int32)
+    comm = np.empty(a.shape[0], dtype=np.int32)
+    nc = C.c_int32()
+    check(lib.sgcn_reorder_lp(rowptr.ctypes.data, col.ctypes.data, int(a.shape[0]), int(max_iters), int(seed),
+                              int(min_size), comm.ctypes.data, C.byref(nc)))
+    return comm, int(nc.value)
+
+
 class ColumnSweepCSR(object):
     """A static CSR re-laid for the column sweep (include/sgcn.h sgcn_csplan_t): built once on the
-    host (full-graph / PP products), then multiplied many times."""
+    host (full-graph / PP products), then multiplied many times.
 
-    def __init__(self, a, device, R=16, T=0, round_tiles=0):
+    ``col_labels`` / ``row_labels`` (community label per column vertex / per row, e.g. from
+    ``reorder_labels``): a locality-preserving plan for graphs that HAVE communities.  Columns are
+    renumbered so that a community's vertices are contiguous (the sweep order; B itself is not
+    moved -- the kernel reads B rows through the position -> vertex map), tiles are formed inside
+    row communities in community order, a launch's consecutive tiles go to the same XCD, and the
+    sweep runs unpaced (the waves of an XCD then work on the same few communities' B rows, which is
+    what the clock pacing provides on a graph without structure).  Results equal the unlabelled
+    plan's up to fp32 summation order."""
+
+    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None):
         a = a.tocsr()
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
         val = np.ascontiguousarray(a.data, dtype=np.float32)
         M = rowptr.shape[0] - 1
+        self.grouped = col_labels is not None or row_labels is not None
+        self.pos2col = None
+        if col_labels is not None:
+            col_labels = np.ascontiguousarray(col_labels, dtype=np.int32)
+            if col_labels.shape[0] != a.shape[1]:
+                raise ValueError("col_labels must have one label per column")
+            pos2col = np.argsort(col_labels, kind='stable').astype(np.int32)     # sweep position -> vertex
+            col2pos = np.empty_like(pos2col)
+            col2pos[pos2col] = np.arange(pos2col.shape[0], dtype=np.int32)
+            col = np.ascontiguousarray(col2pos[col])                              # the plan lives in positions
+            self.pos2col = torch.from_numpy(pos2col).to(device)
+        rg = None
+        if row_labels is not None:
+            rg = np.ascontiguousarray(row_labels, dtype=np.int32)
+            if rg.shape[0] != M:
+                raise ValueError("row_labels must have one label per row")
+        rgp = rg.ctypes.data if rg is not None else None
         nt, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplan_count(rowptr.ctypes.data, M, R, T, C.byref(nt), C.byref(nfix), C.byref(nslots)))
+        check(lib.sgcn_csplan_count(rowptr.ctypes.data, M, R, T, rgp, C.byref(nt), C.byref(nfix), C.byref(nslots)))
         tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
         colrow = np.empty(col.shape[0], dtype=np.int32)
         valout = np.empty(col.shape[0], dtype=np.float32)
         tile_rows = np.empty(nt.value * R, dtype=np.int32)
         tile_slots = np.empty(nt.value * R, dtype=np.int32)
         fix = np.empty((nfix.value, 3), dtype=np.int32)
-        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, R, T,
+        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, R, T, rgp,
                                    tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data,
                                    tile_rows.ctypes.data, tile_slots.ctypes.data,
                                    fix.ctypes.data if nfix.value else None))
@@ -371,6 +412,83 @@ class ColumnSweepCSR(object):
         self.fix = to(fix) if nfix.value else None
         self.ws, self.device = None, device
         self.nnz = int(col.shape[0])
+
+    # ---- on-disk plan cache (beside the dataset's .npz) -------------------------
+    @staticmethod
+    def matrix_key(a):
+        """Cheap identity of a CSR (shape, nnz, CRC of its three arrays): a cached plan is reused only
+        for the matrix it was built from."""
+        import zlib
+        a = a.tocsr()
+        crc = 0
+        for x in (a.indptr, a.indices, a.data):
+            crc = zlib.crc32(np.ascontiguousarray(x).view(np.uint8), crc)
+        return "%dx%d:%d:%08x" % (a.shape[0], a.shape[1], a.nnz, crc)
+
+    def save(self, path, key):
+        if self.grouped:
+            raise ValueError("grouped plans are not cached (they are cheap to rebuild from the labels)")
+        t = lambda x: x.cpu().numpy()          # noqa: E731
+        blob = dict(key=np.array(key), R=self.R, shape=np.array(self.shape, np.int64), nslots=self.nslots,
+                    round_tiles=self.round_tiles, tile_ptr=t(self.tile_ptr), colrow=t(self.colrow), val=t(self.val),
+                    tile_rows=t(self.tile_rows), tile_slots=t(self.tile_slots),
+                    fix=t(self.fix) if self.fix is not None else np.zeros((0, 3), np.int32),
+                    pace=np.array([[d, p] for d, p in sorted(self.pace.items())], np.int64).reshape(-1, 2))
+        import os
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        tmp = path + ".tmp.npz"
+        with open(tmp, "wb") as f:
+            np.savez(f, **blob)
+        os.replace(tmp, path)
+
+    @classmethod
+    def load(cls, path, device, key):
+        """The plan cached at ``path`` if it was built from the matrix ``key`` identifies, else None."""
+        import os
+        if not os.path.exists(path):
+            return None
+        z = np.load(path)
+        if str(z["key"]) != key:
+            return None
+        self = cls.__new__(cls)
+        self.grouped, self.pos2col = False, None
+        self.shape = tuple(int(x) for x in z["shape"])
+        self.R, self.nslots, self.round_tiles = int(z["R"]), int(z["nslots"]), int(z["round_tiles"])
+        tile_ptr = z["tile_ptr"]
+        self.ntiles, self.nfix = int(tile_ptr.shape[0] - 1), int(z["fix"].shape[0])
+        self._tile_nnz = np.diff(tile_ptr).astype(np.int64)
+        self._hint, self._hint_round = None, None
+        self.pace = {int(d): int(p) for d, p in z["pace"]}
+        to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)          # noqa: E731
+        self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(z["colrow"]), to(z["val"])
+        self.tile_rows, self.tile_slots = to(z["tile_rows"]), to(z["tile_slots"])
+        self.fix = to(z["fix"]) if self.nfix else None
+        self.ws, self.device = None, device
+        self.nnz = int(z["colrow"].shape[0])
+        return self
+
+    @classmethod
+    def cached(cls, a, device, path=None):
+        """Plan of ``a``: loaded from ``path`` when that file holds the plan of this very matrix,
+        otherwise built (and written to ``path``).  Returns (plan, came_from_cache)."""
+        if path is None:
+            return cls(a, device), False
+        key = cls.matrix_key(a)
+        hit = cls.load(path, device, key)
+        if hit is not None:
+            return hit, True
+        plan = cls(a, device)
+        plan._cache = (path, key)
+        return plan, False
+
+    def store_if_cached(self):
+        """Write the plan (with the paces autotuned so far) to the path ``cached`` was given."""
+        c = getattr(self, "_cache", None)
+        if c is not None:
+            try:
+                self.save(*c)
+            except OSError:           # read-only dataset directory: the cache is an optimisation only
+                pass
 
     def struct(self, d):
         ldw = (d + 3) // 4 * 4
@@ -388,13 +506,23 @@ class ColumnSweepCSR(object):
                            self.val.data_ptr(), self.tile_rows.data_ptr(), self.tile_slots.data_ptr(),
                            _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
                            0 if self.ws is None else self.ws.numel(), rnd, self._hint.ctypes.data,
-                           int(self.pace.get(d, 0)))
+                           -1 if self.grouped else int(self.pace.get(d, 0)), 1 if self.grouped else 0)
+
+    def variant(self, d):
+        """The kernel variant / launch geometry sgcn_spmm_cs_f32 uses for this plan and width."""
+        buf = C.create_string_buffer(256)
+        plan = self.struct(d)
+        check(lib.sgcn_spmm_cs_variant(C.byref(plan), int(d), buf, 256))
+        return buf.value.decode()
 
     def autotune(self, B, d=None, candidates=(-1, 200, 220, 240, 260, 280, 320, 380), reps=2):
         """Pick the sweep clock for this plan and row width by timing a few candidates (the
         sustainable pace depends on the graph, d and the chip's clocks; too fast loses the
         lock-step and with it the L2 hits, too slow leaves the memory system idle)."""
         d = int(B.shape[1] if d is None else d)
+        if self.grouped:                 # grouped plans run unpaced (see the class docstring)
+            self.pace[d] = -1
+            return (None, -1)
         out = torch.empty((self.shape[0], (d + 3) // 4 * 4), dtype=torch.float32, device=B.device)[:, :d]
         best = None
         for p in candidates:
@@ -425,6 +553,10 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
         out = torch.empty((M, pitch), dtype=torch.float32, device=B.device)[:, :d]
     cptr, ldc = _rows2d(out, "out")
     plan = A.struct(d)
+    if A.pos2col is not None:        # the plan's columns are sweep positions: B row = pos2col[position]
+        if cscale is not None:
+            raise ValueError("a grouped column-sweep plan does not take cscale (scale B instead)")
+        gidx = A.pos2col if gidx is None else _dev(gidx, torch.int32, "gidx")[A.pos2col.long()]
     check(lib.sgcn_spmm_cs_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(gidx, torch.int32, "gidx")),
                                _ptr(_dev(rscale, torch.float32, "rscale")),
                                _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),

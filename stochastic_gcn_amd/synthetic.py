@@ -56,6 +56,33 @@ def zipf_uniform_edges(n, m, s, rng):
     return a
 
 
+def sbm_zipf_edges(n, m, s, comm, p_in, rng):
+    """m undirected edges with planted communities: source ~ bounded Zipf(s) as in
+    ``zipf_uniform_edges``; the destination is uniform INSIDE the source's community with
+    probability p_in, uniform over all vertices otherwise.  Same degree law as S-Reddit, plus the
+    block structure real Reddit has (posts of one subreddit are mostly linked to each other)."""
+    w = np.arange(1, n + 1, dtype=np.float64) ** (-s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    rank = np.searchsorted(cdf, rng.random_sample(m)).astype(np.int64)
+    np.minimum(rank, n - 1, out=rank)
+    perm = rng.permutation(n)
+    src = perm[rank]
+    members = np.argsort(comm, kind='stable')                 # vertices grouped by community
+    start = np.concatenate([[0], np.cumsum(np.bincount(comm))])
+    cs = comm[src]
+    inside = rng.random_sample(m) < p_in
+    pick = start[cs] + (rng.random_sample(m) * (start[cs + 1] - start[cs])).astype(np.int64)
+    dst = np.where(inside, members[np.minimum(pick, start[cs + 1] - 1)], rng.randint(0, n, m))
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    a = sp.coo_matrix((np.ones(src.shape[0], dtype=np.float32), (src, dst)), shape=(n, n)).tocsr()
+    a = a + a.T
+    a.data[:] = 1.0
+    a.sort_indices()
+    return a
+
+
 def er_edges(n, m, rng):
     src = rng.randint(0, n, m)
     dst = rng.randint(0, n, m)
@@ -126,6 +153,33 @@ def reddit_like(n=232965, m=11600000, f=602, classes=41, splits=(152410, 23699, 
     feats = rng.standard_normal((n, f)).astype(np.float32) if with_features else None
     if planted and with_features:
         labels = planted_labels(full_adj, feats, classes, rng)
+    return n, train_adj, full_adj, feats, None, None, labels, tr, va, te
+
+
+def reddit_sbm(n=232965, m=11600000, f=602, classes=41, splits=(152410, 23699, 55334), p_in=0.8,
+               seed=1, with_features=False):
+    """S-Reddit-SBM: the S-Reddit degree law with ``classes`` planted communities (sizes ~
+    rank^-0.5, vertex ids scattered at random -- the raw matrix shows no block structure), a
+    fraction p_in of every vertex's edges inside its community, labels = the community.  The
+    locality-bearing companion of ``reddit_like`` (whose destinations are uniform, i.e. which has
+    no structure any reordering could find).  Same 10-tuple."""
+    rng = np.random.RandomState(seed)
+    w = np.arange(1, classes + 1, dtype=np.float64) ** (-0.5)
+    comm = np.searchsorted(np.cumsum(w) / w.sum(), rng.random_sample(n)).astype(np.int64)
+    np.minimum(comm, classes - 1, out=comm)
+    a = sbm_zipf_edges(n, m, 0.6, comm, p_in, rng)
+    full_adj = _row_normalize(a)
+    tr, va, te = _splits(n, splits[0], splits[1], splits[2], rng)
+    is_train = np.ones(n, dtype=bool)
+    is_train[va] = False
+    is_train[te] = False
+    dm = sp.diags(is_train.astype(np.float32), 0)
+    at = dm.dot(a).dot(dm).tocsr()
+    at.eliminate_zeros()
+    train_adj = _row_normalize(at)
+    labels = np.zeros((n, classes), dtype=np.float32)
+    labels[np.arange(n), comm] = 1.0
+    feats = rng.standard_normal((n, f)).astype(np.float32) if with_features else None
     return n, train_adj, full_adj, feats, None, None, labels, tr, va, te
 
 

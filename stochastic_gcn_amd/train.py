@@ -56,18 +56,45 @@ def make_placeholders(L, num_classes):
     }
 
 
-def pp_products(train_adj, full_adj, features, device):
+def plan_cache_paths(dataset):
+    """Where the column-sweep plans of a dataset's two adjacency matrices are cached: beside the
+    reference-schema ``.npz`` dataset cache (utils.cache_path), or under $SGCN_PLAN_CACHE_DIR; None when
+    neither exists (synthetic stand-ins without a cache directory rebuild their plans, ~1 s)."""
+    import os
+    from .utils import cache_path
+    root = os.environ.get("SGCN_PLAN_CACHE_DIR")
+    if root:
+        base = os.path.join(root, os.path.basename(cache_path(dataset))[:-4])
+    elif os.path.exists(cache_path(dataset)):
+        base = cache_path(dataset)[:-4]
+    else:
+        return None, None
+    return base + ".csplan.train.npz", base + ".csplan.full.npz"
+
+
+def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats=None):
     """train_feats = train_adj . feats, test_feats = full_adj . feats (gcn/utils.py:169-170,
-    321-322).  Dense features: the SpMM kernel on the GPU (K11).  Sparse features: a
+    321-322).  Dense features: the column-sweep SpMM kernel on the GPU (K11; sgcn_spmm_cs_f32 -- the
+    kernel bench.py times), its host plan cached beside the dataset.  Sparse features: a
     sparse x sparse product, done once on the host with SciPy exactly like the reference."""
     if sp.issparse(features):
         return train_adj.dot(features).tocsr(), full_adj.dot(features).tocsr()
     X = features.to(device) if isinstance(features, torch.Tensor) else \
         torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(device)
+    d = int(X.shape[1])
+    if X.stride(0) % 4 != 0:            # the sweep reads 16-byte vectors: pad the row pitch once
+        Xp = torch.zeros((X.shape[0], (d + 3) // 4 * 4), dtype=torch.float32, device=device)
+        Xp[:, :d] = X
+        X = Xp[:, :d]
     out = []
-    for a in (train_adj, full_adj):
-        A = ops.DeviceCSR.from_scipy(a, device)
-        out.append(ops.spmm(A, X))
+    for a, path in zip((train_adj, full_adj), cache):
+        A, hit = ops.ColumnSweepCSR.cached(a, device, path)
+        if d not in A.pace:
+            A.autotune(X)               # once per plan and width; stored with the cached plan
+        A.store_if_cached()
+        if stats is not None:
+            stats.append(dict(plan_from_cache=hit, pace=A.pace.get(d), kernel=A.variant(d)))
+        out.append(ops.spmm_cs(A, X).contiguous())
     return out[0], out[1]
 
 
@@ -204,8 +231,10 @@ class Trainer(object):
 
         (num_data, train_adj, full_adj, features, train_features, test_features, labels,
          train_d, val_d, test_d) = data if data is not None else load_data(FLAGS.dataset)
+        self.pp_stats = []
         if train_features is None:
-            train_features, test_features = pp_products(train_adj, full_adj, features, device)
+            train_features, test_features = pp_products(train_adj, full_adj, features, device,
+                                                        cache=plan_cache_paths(FLAGS.dataset), stats=self.pp_stats)
         if FLAGS.gradvar:
             log('Analyze mode...')
             full_adj = train_adj.copy()

@@ -1,0 +1,100 @@
+"""Host-side column-sweep plan and graph reordering (csrc/sgcn_csplan.cpp): every nonzero lands in
+exactly one tile slot with its row and value, grouped plans keep tiles inside their row group,
+and label propagation finds planted communities (and nothing in a graph without structure)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from stochastic_gcn_amd import synthetic
+from stochastic_gcn_amd._ffi import check, lib
+
+
+def _plan(a, R=16, T=0, row_group=None):
+    a = a.tocsr()
+    rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+    col = np.ascontiguousarray(a.indices, dtype=np.int32)
+    val = np.ascontiguousarray(a.data, dtype=np.float32)
+    M = a.shape[0]
+    rg = None if row_group is None else np.ascontiguousarray(row_group, dtype=np.int32)
+    rgp = None if rg is None else rg.ctypes.data
+    nt, nf, ns = C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib.sgcn_csplan_count(rowptr.ctypes.data, M, R, T, rgp, C.byref(nt), C.byref(nf), C.byref(ns)))
+    tp = np.empty(nt.value + 1, np.int64)
+    cr = np.empty(a.nnz, np.int32)
+    vo = np.empty(a.nnz, np.float32)
+    tr = np.empty(nt.value * R, np.int32)
+    ts = np.empty(nt.value * R, np.int32)
+    fx = np.empty((nf.value, 3), np.int32)
+    check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, R, T, rgp, tp.ctypes.data,
+                               cr.ctypes.data, vo.ctypes.data, tr.ctypes.data, ts.ctypes.data,
+                               fx.ctypes.data if nf.value else None))
+    return dict(nt=nt.value, nfix=nf.value, nslots=ns.value, tile_ptr=tp, colrow=cr, val=vo, rows=tr.reshape(-1, R),
+                slots=ts.reshape(-1, R), fix=fx, R=R)
+
+
+def _rebuild(p, shape):
+    """The matrix a plan encodes (rows summed over their virtual pieces)."""
+    shift = 28 if p['R'] <= 16 else 27
+    cr = p['colrow'].view(np.uint32)
+    col = (cr & ((1 << shift) - 1)).astype(np.int64)
+    lr = (cr >> shift).astype(np.int64)
+    tile = np.repeat(np.arange(p['nt']), np.diff(p['tile_ptr']))
+    row = p['rows'][tile, lr]
+    assert (row >= 0).all()
+    return sp.coo_matrix((p['val'], (row, col)), shape=shape).tocsr()
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_plan_encodes_the_matrix_exactly(grouped):
+    rng = np.random.RandomState(3)
+    a = sp.random(700, 500, density=0.05, random_state=rng, format='csr', dtype=np.float32)
+    a = sp.vstack([a, sp.csr_matrix(np.ones((1, 500), np.float32))]).tocsr()     # one very long row -> split
+    a.sort_indices()
+    g = rng.randint(0, 7, a.shape[0]) if grouped else None
+    p = _plan(a, T=64, row_group=g)
+    assert p['nfix'] >= 1 and p['tile_ptr'][-1] == a.nnz
+    b = _rebuild(p, a.shape)
+    assert (abs(a - b)).nnz == 0
+    # column-sorted inside every tile
+    shift = 28
+    for t in range(p['nt']):
+        c = p['colrow'].view(np.uint32)[p['tile_ptr'][t]:p['tile_ptr'][t + 1]] & ((1 << shift) - 1)
+        assert (np.diff(c.astype(np.int64)) >= 0).all()
+    if grouped:     # a tile's rows belong to ONE group, groups appear in label order
+        tg = []
+        for t in range(p['nt']):
+            rows = p['rows'][t][p['rows'][t] >= 0]
+            assert len(set(g[rows].tolist())) == 1
+            tg.append(int(g[rows[0]]))
+        assert tg == sorted(tg)
+    # split rows: slots are consecutive per row, in row order
+    for r, first, cnt in p['fix']:
+        got = sorted(p['slots'][p['rows'] == r].tolist())
+        assert got == list(range(first, first + cnt))
+
+
+def test_negative_group_label_is_rejected():
+    a = sp.identity(8, format='csr', dtype=np.float32)
+    g = np.array([0, 1, -1, 0, 0, 0, 0, 0], np.int32)
+    nt, nf, ns = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib.sgcn_csplan_count(np.ascontiguousarray(a.indptr, np.int32).ctypes.data, 8, 16, 0, g.ctypes.data,
+                               C.byref(nt), C.byref(nf), C.byref(ns))
+    assert rc == -1 and b"negative group" in lib.sgcn_last_error()
+
+
+def test_label_propagation_finds_planted_communities_and_nothing_else():
+    from stochastic_gcn_amd import ops
+    d = synthetic.reddit_sbm(n=12000, m=500000, classes=12, splits=(8000, 1000, 3000), p_in=0.85, seed=4)
+    truth = d[6].argmax(1)
+    comm, nc = ops.reorder_labels(d[2], seed=1)
+    assert 6 <= nc <= 40
+    agree = sum(np.bincount(truth[comm == c]).max() for c in range(nc) if (comm == c).any())
+    assert agree / len(truth) > 0.8, agree / len(truth)
+    assert (np.diff(np.bincount(comm, minlength=nc)[:nc - 1]) <= 0).all()      # numbered by decreasing size
+    comm2, nc2 = ops.reorder_labels(d[2], seed=1)
+    assert nc2 == nc and np.array_equal(comm, comm2)                            # deterministic
+    u = synthetic.reddit_like(n=12000, m=500000, splits=(8000, 1000, 3000), seed=4, with_features=False)
+    _, ncu = ops.reorder_labels(u[2])
+    assert ncu == 1          # uniform destinations: no structure, the reordering degenerates to a no-op

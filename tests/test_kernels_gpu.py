@@ -306,6 +306,67 @@ def test_column_sweep_full_size_matches_row_gather(dev):
     assert torch.equal(ops.spmm_cs(Acs, Bfull[:, :602]), c2)       # deterministic
 
 
+def test_column_sweep_paced_full_size_vs_oracle_rows(dev):
+    """The configuration bench.py times -- full-size S-Reddit, d = 602 (pitch 608), the AUTOTUNED clock
+    pace -- against the CPU oracle on sampled rows (incl. the longest), not against another HIP kernel."""
+    from stochastic_gcn_amd import ops, synthetic
+    n, _, full_adj, *_ = synthetic.reddit_like(with_features=False)
+    Acs = ops.ColumnSweepCSR(full_adj, dev)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    Bfull = torch.zeros((n, 608), device=dev)
+    Bfull[:, :602] = torch.randn((n, 602), device=dev, generator=g)
+    B = Bfull[:, :602]
+    best = Acs.autotune(B)
+    assert Acs.pace[602] == best[1]
+    c = ops.spmm_cs(Acs, B)
+    deg = np.diff(full_adj.indptr)
+    rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.argsort(deg)[:20],
+                                     np.random.RandomState(0).choice(n, 1500, replace=False)]))
+    sub = full_adj[rows].tocsr()
+    ref = onp.spmm(sub.indptr, sub.indices, sub.data, B.cpu().numpy())
+    assert onp.rel_err(c[torch.from_numpy(rows).to(dev)].cpu().numpy(), ref) <= TOL
+    # a second pace (and the unpaced sweep) give bit-identical results: pacing is timing only
+    for p in (-1, 380):
+        Acs.pace[602] = p
+        assert torch.equal(ops.spmm_cs(Acs, B), c)
+
+
+@pytest.mark.parametrize("d,pad", [(64, 0), (602, 6), (256, 0)])
+def test_grouped_column_sweep_equals_plain_plan_and_oracle(dev, d, pad):
+    """Locality-preserving plan (community-ordered columns read through the position map, tiles inside
+    row communities, XCD-aware placement, unpaced) == the plain plan == the oracle."""
+    from stochastic_gcn_amd import ops, synthetic
+    data = synthetic.reddit_sbm(n=9000, m=300000, classes=9, splits=(6000, 1000, 2000), p_in=0.8, seed=2)
+    a = data[2]
+    comm, nc = ops.reorder_labels(a)
+    assert nc > 3
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((a.shape[1], d + pad)).astype(np.float32)
+    Bd = T(B, dev)[:, :d]
+    plain = ops.ColumnSweepCSR(a, dev, T=48)
+    grouped = ops.ColumnSweepCSR(a, dev, T=48, col_labels=comm, row_labels=comm)
+    assert grouped.grouped and grouped.ntiles >= plain.ntiles
+    c0 = ops.spmm_cs(plain, Bd)
+    c1 = ops.spmm_cs(grouped, Bd)
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    assert onp.rel_err(c1.cpu().numpy(), ref) <= TOL
+    assert float((c0 - c1).abs().max() / c0.abs().max()) <= 1e-5          # same product, other summation order
+    assert torch.equal(ops.spmm_cs(grouped, Bd), c1)                       # deterministic
+    # fusions through the position map: history gather (gidx), row scale, beta
+    H = rng.standard_normal((20000, d + pad)).astype(np.float32)
+    gi = rng.choice(20000, a.shape[1], replace=False).astype(np.int32)
+    rs = rng.rand(a.shape[0]).astype(np.float32)
+    cin = rng.standard_normal((a.shape[0], d + pad)).astype(np.float32)
+    o2 = T(cin, dev)
+    ops.spmm_cs(grouped, T(H, dev)[:, :d], out=o2[:, :d], gidx=T(gi, dev), rscale=T(rs, dev), beta=0.25)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, H[:, :d], gidx=gi, rscale=rs, C_in=cin[:, :d], beta=0.25)
+    assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
+    # labels for rows only (row block of a sharded matrix): still the same product
+    rows_only = ops.ColumnSweepCSR(a[:4000], dev, T=48, col_labels=comm, row_labels=comm[:4000])
+    c2 = ops.spmm_cs(rows_only, Bd)
+    assert onp.rel_err(c2.cpu().numpy(), ref[:4000]) <= TOL
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 41, 70), (512, 128, 256), (1021, 128, 1204), (200, 300, 50),
                                    (64, 128, 128), (31, 7, 33),
                                    # weight-gradient shapes of the Reddit step: split-K (4..8 output tiles, long K)

@@ -11,7 +11,10 @@ import model_cases as mc
 from oracle import oracle_np as onp
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = 1e-4          # activations, loss, history (BASELINE.json north_star)
+GRAD_TOL = 1e-4     # gradients, max-norm relative per tensor
+PARAM_TOL = 5e-4    # Adam-updated weights on well-conditioned entries: lr * g / (|g| + 3e-7) amplifies the
+                    # gradient's fp32 summation noise where |g| is small (tests/test_model_golden.py)
 
 
 def _make_device_model(case, params, is_training=True):
@@ -83,7 +86,7 @@ def test_training_steps_match_oracle(name):
         d_grads = dmodel.get_grads()
         for k, g in o_grads.items():
             e = onp.rel_err(d_grads[k], g)
-            assert e <= 5e-4, (name, step, 'grad', k, e)
+            assert e <= GRAD_TOL, (name, step, 'grad', k, e)
         # Adam's first steps are sign-like (lr * g / (|g| + 1e-8)): a weight whose gradient is ~1e-8
         # amplifies fp32 summation-order noise, so weights are compared where |g| is above it
         d_params = dmodel.get_params()
@@ -95,6 +98,68 @@ def test_training_steps_match_oracle(name):
             e = onp.rel_err(dmodel.history[l][0].cpu().numpy(), h)
             assert e <= TOL, (name, step, 'history', l, e)
     print("%s: worst activation rel err %.2e" % (name, worst))
+
+
+GOLD = None
+
+
+def _gold():
+    global GOLD
+    if GOLD is None:
+        import os
+        GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_steps.npz"))
+    return GOLD
+
+
+@pytest.mark.parametrize("name", sorted(mc.CASES))
+def test_training_steps_match_independent_golden(name):
+    """The HIP training step against golden vectors from an INDEPENDENT fp32 implementation (PyTorch-CPU
+    ops + autograd, tests/golden/make_model_golden.py) -- not against this repo's own oracle: logits,
+    aggregator outputs, loss, accuracy, every gradient, Adam-updated weights over 3 consecutive
+    unsynchronised steps, and the final history."""
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    from stochastic_gcn_amd.layers import PlainAggregator, VRAggregator
+    gold = _gold()
+    case = mc.build_case(name)
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    params = mc.make_oracle_model(case, seed=3).params
+    dmodel = _make_device_model(case, {k: v.copy() for k, v in params.items()})
+    assert dmodel.dropout_seed == 1
+    sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'],
+                      ph, 1, data=case['train'].copy(), cv=fl['cv'])
+    agg_index = [i for i, l in enumerate(dmodel.layers) if isinstance(l, (PlainAggregator, VRAggregator))]
+    well, worst = {}, dict(act=0.0, grad=0.0, param=0.0)
+    for step in range(3):
+        feed = sch.minibatch(c['batch'])
+        feed[ph['dropout']] = fl['dropout']
+        key = "%s/s%d/" % (name, step)
+        assert np.array_equal(feed[ph['fields'][0]], gold[key + "field0"])
+        outs = dmodel.run_one_step(None, feed)
+        acts = dmodel.activations[1:]
+        e = onp.rel_err(_np(acts[-1]), gold[key + "logits"]); worst['act'] = max(worst['act'], e)
+        assert e <= TOL, (name, step, 'logits', e)
+        for l, li in enumerate(agg_index):
+            a = _np(acts[li])
+            a = a[0] if isinstance(a, tuple) else a
+            e = onp.rel_err(a, gold[key + "agg%d" % l]); worst['act'] = max(worst['act'], e)
+            assert e <= TOL, (name, step, 'agg', l, e)
+        assert abs(outs[1] - float(gold[key + "loss"])) <= 1e-4 * max(1.0, abs(float(gold[key + "loss"])))
+        assert abs(outs[2] - float(gold[key + "acc"])) <= 1e-6
+        dg = dmodel.get_grads()
+        for k in params:
+            g = gold[key + "grad/" + k]
+            e = onp.rel_err(dg[k], g); worst['grad'] = max(worst['grad'], e)
+            assert e <= GRAD_TOL, (name, step, 'grad', k, e)
+            well[k] = well.get(k, True) & (np.abs(g) > 1e-6)
+        dp = dmodel.get_params()
+        for k in params:
+            gv = gold[key + "param/" + k]
+            e = np.abs(dp[k] - gv)[well[k]].max() / np.abs(gv).max(); worst['param'] = max(worst['param'], e)
+            assert e <= PARAM_TOL, (name, step, 'param', k, e)
+    for l in range(len(dmodel.history)):
+        assert onp.rel_err(dmodel.history[l][0].cpu().numpy(), gold["%s/history%d" % (name, l)]) <= TOL
+    print("%s vs independent golden: worst rel err  activations %.1e  grads %.1e  params %.1e"
+          % (name, worst['act'], worst['grad'], worst['param']))
 
 
 def test_eval_model_shares_weights_and_keeps_own_history():

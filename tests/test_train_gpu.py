@@ -23,7 +23,7 @@ def _train(flags, epochs):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.train import Trainer
     FLAGS.reset()
-    base = dict(dataset='reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+    base = dict(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
                 hidden1=64, num_fc_layers=1, batch_size=256, test_batch_size=512, learning_rate=0.01, seed=1,
                 prefetch=2)
     base.update(flags)
@@ -53,7 +53,7 @@ def test_driver_log_lines_and_counters():
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.train import Trainer
     FLAGS.reset()
-    FLAGS.update(dataset='reddit', normalization='graphsage', weight_decay=0.0, dropout=0.2, layer_norm=True,
+    FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.2, layer_norm=True,
                  hidden1=32, num_fc_layers=2, batch_size=128, test_batch_size=256, cv=True, cvd=True,
                  test_cv=True, degree=1, test_degree=1, epochs=0, early_stopping=30, prefetch=0)
     buf = io.StringIO()
@@ -109,3 +109,36 @@ def test_gradient_variance_analysis_cv_beats_ns():
         assert all(np.isfinite(v) for v in r.values())
     assert res["cv"]["part_pred_std"] < 0.5 * res["ns"]["part_pred_std"]
     assert res["cv"]["part_pred_bias"] < res["ns"]["part_pred_bias"]
+
+
+def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monkeypatch):
+    """The PP products of the training driver (gcn/utils.py:321-322) go through sgcn_spmm_cs_f32 --
+    the kernel bench.py times -- with the host plan cached beside the dataset; the result equals
+    SciPy's (the reference's own library for this product) within 1e-4."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+    from oracle import oracle_np as onp
+    monkeypatch.setenv("SGCN_PLAN_CACHE_DIR", str(tmp_path))
+    data = _data()
+    n, train_adj, full_adj, feats = data[0], data[1], data[2], data[3]
+    stats = []
+    for _ in range(2):
+        FLAGS.reset()
+        FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+                     hidden1=32, num_fc_layers=1, batch_size=256, test_batch_size=512, cv=True, cvd=True,
+                     test_cv=True, degree=1, test_degree=1)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            tr = Trainer(data=data, verbose=False)
+        stats.append(tr.pp_stats)
+        f = feats.shape[1]
+        for model, adj in ((tr.train_model, train_adj), (tr.test_model, full_adj)):
+            got = model.features_dev[:, f:].cpu().numpy()
+            want = adj.dot(feats).astype(np.float32)
+            assert onp.rel_err(got, want) <= 1e-4
+            assert np.array_equal(model.features_dev[:, :f].cpu().numpy(), feats)
+    assert len(stats[0]) == 2 and all("cs_spmm" in s["kernel"] for s in stats[0] + stats[1])
+    assert [s["plan_from_cache"] for s in stats[0]] == [False, False]
+    assert [s["plan_from_cache"] for s in stats[1]] == [True, True]          # second run: plans (and paces) from disk
+    assert [s["pace"] for s in stats[0]] == [s["pace"] for s in stats[1]]
+    assert len(list(tmp_path.glob("*.csplan.*.npz"))) == 2
