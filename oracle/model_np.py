@@ -339,9 +339,9 @@ class Model(object):
 
     # ---- backward -------------------------------------------------------------------------
     def _gate(self, name, pre):
-        """ReLU gate.  `relu_gate_hook(name, pre) -> bool array` lets a test take the gate of the
-        implementation under test where `pre` sits within fp32 rounding of the kink (there the
-        sign, and with it the whole gradient column, is decided by summation order)."""
+        """ReLU gate.  `relu_gate_hook(name, pre) -> bool array` lets a test enumerate the assignments of
+        the gates whose input sits within fp32 rounding of the kink (there the sign, and with it a whole
+        gradient contribution, is decided by summation order): tests/test_model_gpu.py _gate_interval."""
         hook = getattr(self, 'relu_gate_hook', None)
         return (pre > 0) if hook is None else hook(name, pre)
 
