@@ -196,6 +196,18 @@ int sgcn_csr_slice_f32(int32_t n, const int32_t* dev_r, const float* dev_a_d,
                        const int32_t* dev_a_i, const int32_t* dev_a_p,
                        const int32_t* dev_o_p, float* dev_o_d, int32_t* dev_o_col,
                        int32_t* dev_o_row, void* stream);
+/* Transpose index of a row-sliced sparse block (stable device counting sort): for the n x ncols CSR
+ * with column ids col[nnz] and COO row ids coo_row[nnz] (sgcn_csr_slice_f32's o_row), t_rowptr[ncols+1],
+ * t_row[nnz] (row of every transposed entry, ascending inside a column) and t_src[nnz] (its position in
+ * the source arrays, so values -- e.g. after sparse dropout -- follow with sgcn_gather_f32).  ws:
+ * sgcn_csr_transpose_ws_ints(ncols, nnz) int32.  New: TF derives dW = X^T g inside its autodiff of
+ * dot(x, W, sparse=True), gcn/layers.py:125,401-402. */
+int64_t sgcn_csr_transpose_ws_ints(int32_t ncols, int64_t nnz);
+int sgcn_csr_transpose_index(int32_t ncols, int64_t nnz, const int32_t* dev_col, const int32_t* dev_coo_row,
+                             int32_t* dev_t_rowptr, int32_t* dev_t_row, int32_t* dev_t_src, int32_t* dev_ws,
+                             void* stream);
+/* out[i] = src[idx[i]] */
+int sgcn_gather_f32(const float* dev_src, const int32_t* dev_idx, int64_t n, float* dev_out, void* stream);
 
 /* ---- fused row-wise kernels of the dense part of the step --------
  * y = act(LN(x) * scale + offset), eps as MyLayerNorm2 (1e-9)     gcn/layers.py:95-97,134-137
@@ -277,6 +289,17 @@ int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dev_dy, int
 int sgcn_softmax_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,
                         int32_t n, int32_t c, float* dev_dlogits, int64_t lddz, float* dev_pred,
                         int64_t ldp, float* dev_stats, float* dev_rowstat, void* stream);
+/* Multitask (ppi) loss: mean sigmoid cross-entropy with logits over all n*c elements, element
+ * accuracy, pred = sigmoid(z), dlogits = (pred - y)/(n*c).  stats/rowstat as sgcn_softmax_ce_f32.
+ * Replaces tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean   gcn/models.py:77-79,86-90,198-200 */
+int sgcn_sigmoid_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,
+                        int32_t n, int32_t c, float* dev_dlogits, int64_t lddz, float* dev_pred, int64_t ldp,
+                        float* dev_stats, float* dev_rowstat, void* stream);
+/* Weight decay on the flat-buffer range [lo, hi) (the vars of the first parametrised layer):
+ * grad[i] += wd * theta[i] (grad nullable) and loss[0] += 0.5 * wd * sum theta[i]^2 (loss nullable),
+ * deterministic.  Replaces FLAGS.weight_decay * tf.nn.l2_loss(var) and its gradient  gcn/models.py:68-75 */
+int sgcn_l2_penalty_f32(const float* dev_theta, int64_t lo, int64_t hi, float wd, float* dev_grad,
+                        float* dev_loss, void* stream);
 /* tf.train.AdamOptimizer step on flat buffers: m,v updated in place,
  * theta -= lr_t * m / (sqrt(v) + eps)  with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
  * caller.                                                       gcn/models.py:50-51 */

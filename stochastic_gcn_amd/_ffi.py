@@ -97,6 +97,12 @@ SIGNATURES = {
     "sgcn_dropout_f32": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, C.c_int64, P]),
     "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
                                       P, C.c_int64, P, P, P]),
+    "sgcn_sigmoid_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
+                                      P, C.c_int64, P, P, P]),
+    "sgcn_l2_penalty_f32": (C.c_int, [P, C.c_int64, C.c_int64, C.c_float, P, P, P]),
+    "sgcn_csr_transpose_ws_ints": (C.c_int64, [C.c_int32, C.c_int64]),
+    "sgcn_csr_transpose_index": (C.c_int, [C.c_int32, C.c_int64, P, P, P, P, P, P, P]),
+    "sgcn_gather_f32": (C.c_int, [P, P, C.c_int64, P, P]),
     "sgcn_adam_f32": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "sgcn_sched_create": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.POINTER(C.c_void_p)]),

@@ -168,6 +168,73 @@ __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float* __re
     }
 }
 
+// Multitask loss (ppi): mean over all n*c elements of sigmoid cross-entropy with logits,
+// max(z,0) - z*y + log1p(exp(-|z|)) (tf.nn.sigmoid_cross_entropy_with_logits, gcn/models.py:77-79);
+// accuracy = mean((z > 0) == (y > 0.5)) (gcn/models.py:86-90); pred = sigmoid(z) (:198-200);
+// dlogits = (sigmoid(z) - y) / (n*c).  One wave per row; per-row sums -> sigmoid_stats_kernel.
+__global__ __launch_bounds__(kBlock) void sigmoid_ce_kernel(
+    const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
+    int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
+    float* __restrict__ rowstat /* [2][n] */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (row >= n) return;
+    const float inv = 1.0f / ((float)n * (float)c);
+    float l = 0.f, hit = 0.f;
+    for (int k = lane; k < c; k += kWave) {
+        const float x = z[row * ldz + k], y = lab[row * ldl + k];
+        const float e = __expf(-fabsf(x));
+        l += fmaxf(x, 0.f) - x * y + log1pf(e);
+        const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        hit += ((x > 0.f) == (y > 0.5f)) ? 1.f : 0.f;
+        if (dz) dz[row * lddz + k] = (p - y) * inv;
+        if (pred) pred[row * ldp + k] = p;
+    }
+    l = wave_sum(l); hit = wave_sum(hit);
+    if (lane == 0) { rowstat[row] = l; rowstat[n + row] = hit; }
+}
+
+// stats = {sum CE, #correct elements, mean CE, accuracy} over n*c elements, fixed summation order
+__global__ __launch_bounds__(kBlock) void sigmoid_stats_kernel(const float* __restrict__ rowstat, int32_t n,
+                                                               int32_t c, float* __restrict__ stats) {
+    __shared__ float red[2][kBlock];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += kBlock) { a += rowstat[i]; b += rowstat[n + i]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float cnt = (float)n * (float)c;
+        stats[0] = red[0][0]; stats[1] = red[1][0];
+        stats[2] = red[0][0] / cnt; stats[3] = red[1][0] / cnt;
+    }
+}
+
+// Weight decay of the first parametrised layer (gcn/models.py:68-75: loss += wd * l2_loss(var),
+// l2_loss = sum(v^2)/2): ONE workgroup over the flat-buffer range [lo, hi) adds wd*theta to the
+// gradient and 0.5*wd*sum(theta^2) to the loss slot, partials combined in a fixed order.
+__global__ __launch_bounds__(kBlock) void l2_penalty_kernel(const float* __restrict__ theta, int64_t lo, int64_t hi,
+                                                            float wd, float* __restrict__ grad,
+                                                            float* __restrict__ loss) {
+    __shared__ float red[kBlock];
+    float a = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const float t = theta[i];
+        a += t * t;
+        if (grad) grad[i] += wd * t;
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] += 0.5f * wd * red[0];
+}
+
 __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
                                                       const float* __restrict__ grad,
                                                       float* __restrict__ m, float* __restrict__ v,
@@ -256,6 +323,27 @@ extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0,
                        (hipStream_t)stream, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, rowstat);
     hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, rowstat, n, stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_sigmoid_ce_f32(const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n,
+                                   int32_t c, float* dlogits, int64_t lddz, float* pred, int64_t ldp,
+                                   float* stats, float* rowstat, void* stream) {
+    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "sigmoid_ce: bad operand");
+    hipLaunchKernelGGL(sigmoid_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0,
+                       (hipStream_t)stream, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, rowstat);
+    hipLaunchKernelGGL(sigmoid_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, rowstat, n, c, stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_l2_penalty_f32(const float* theta, int64_t lo, int64_t hi, float wd, float* grad,
+                                   float* loss, void* stream) {
+    SGCN_REQUIRE(lo >= 0 && hi >= lo, "l2_penalty: bad range");
+    if (hi == lo || wd == 0.f || (!grad && !loss)) return SGCN_OK;
+    SGCN_REQUIRE(theta, "l2_penalty: null operand");
+    hipLaunchKernelGGL(l2_penalty_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, theta, lo, hi, wd, grad, loss);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }

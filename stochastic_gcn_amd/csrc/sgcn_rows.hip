@@ -76,9 +76,130 @@ __global__ __launch_bounds__(kBlock) void csr_slice_kernel(int32_t n, const int3
     }
 }
 
+// ---- stable CSR -> transposed-CSR index (device counting sort, deterministic) -------------------
+// The sparse first layer's weight gradient is dW = X[f0]^T g (autodiff of gcn/layers.py:125,401-402
+// with sparse_inputs): X[f0] is the minibatch's row slice, so its transpose is needed once per
+// minibatch.  Nonzeros are cut into chunks of kTChunk in storage (row-major) order:
+//   t_hist   per-chunk column histogram H[b][c]                       (integer LDS atomics)
+//   t_scan   column totals -> exclusive scan = t_rowptr; H[b][c] <- first output slot of chunk b in column c
+//   t_place  one lane per chunk walks its nonzeros IN ORDER: slot = H[b][c]++   -> rows ascending inside
+//            every column, whatever the schedule (the float sums that consume the transpose are ordered)
+constexpr int kTChunk = 512;
+constexpr int kTLdsCols = 16384;     // counters of a chunk live in LDS up to this many columns
+
+__global__ __launch_bounds__(kBlock) void t_hist_kernel(const int32_t* __restrict__ col, int64_t nnz, int32_t ncols,
+                                                        int32_t* __restrict__ H) {
+    int32_t* h = H + (int64_t)blockIdx.x * ncols;
+    for (int c = threadIdx.x; c < ncols; c += kBlock) h[c] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * kTChunk;
+    for (int64_t p = p0 + threadIdx.x; p < min(nnz, p0 + kTChunk); p += kBlock) atomicAdd(&h[col[p]], 1);
+}
+
+__global__ __launch_bounds__(kBlock) void t_scan_kernel(int32_t* __restrict__ H, int32_t nchunks, int32_t ncols,
+                                                        int32_t* __restrict__ t_rowptr) {
+    __shared__ int32_t part[kBlock];
+    // column totals into t_rowptr[c + 1]
+    for (int c = threadIdx.x; c < ncols; c += kBlock) {
+        int32_t s = 0;
+        for (int b = 0; b < nchunks; b++) s += H[(int64_t)b * ncols + c];
+        t_rowptr[c + 1] = s;
+    }
+    __syncthreads();
+    // exclusive scan over the columns: each thread owns a contiguous span
+    const int span = (ncols + kBlock - 1) / kBlock;
+    const int lo = min(ncols, (int)threadIdx.x * span), hi = min(ncols, lo + span);
+    int32_t s = 0;
+    for (int c = lo; c < hi; c++) s += t_rowptr[c + 1];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int t = 0; t < kBlock; t++) { const int32_t v = part[t]; part[t] = run; run += v; }
+        t_rowptr[0] = 0;
+    }
+    __syncthreads();
+    int32_t run = part[threadIdx.x];
+    for (int c = lo; c < hi; c++) { run += t_rowptr[c + 1]; t_rowptr[c + 1] = run; }
+    __syncthreads();
+    // first slot of every (chunk, column)
+    for (int c = threadIdx.x; c < ncols; c += kBlock) {
+        int32_t r = t_rowptr[c];
+        for (int b = 0; b < nchunks; b++) {
+            const int64_t k = (int64_t)b * ncols + c;
+            const int32_t v = H[k];
+            H[k] = r;
+            r += v;
+        }
+    }
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kWave) void t_place_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ coo_row,
+                                                        int64_t nnz, int32_t ncols, int32_t* __restrict__ H,
+                                                        int32_t* __restrict__ t_row, int32_t* __restrict__ t_src) {
+    extern __shared__ int32_t lds_cnt[];
+    int32_t* h = H + (int64_t)blockIdx.x * ncols;
+    if constexpr (LDS) {
+        for (int c = threadIdx.x; c < ncols; c += kWave) lds_cnt[c] = h[c];
+        __syncthreads();
+        h = lds_cnt;
+    }
+    if (threadIdx.x != 0) return;
+    const int64_t p0 = (int64_t)blockIdx.x * kTChunk, p1 = min(nnz, p0 + kTChunk);
+    for (int64_t p = p0; p < p1; p++) {
+        const int32_t slot = h[col[p]]++;
+        t_row[slot] = coo_row[p];
+        t_src[slot] = (int32_t)p;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                            int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = src[idx[i]];
+}
+
 }  // namespace sgcn
 
 using namespace sgcn;
+
+extern "C" int64_t sgcn_csr_transpose_ws_ints(int32_t ncols, int64_t nnz) {
+    if (ncols <= 0 || nnz <= 0) return 0;
+    return ((nnz + kTChunk - 1) / kTChunk) * (int64_t)ncols;
+}
+
+extern "C" int sgcn_csr_transpose_index(int32_t ncols, int64_t nnz, const int32_t* col, const int32_t* coo_row,
+                                        int32_t* t_rowptr, int32_t* t_row, int32_t* t_src, int32_t* ws, void* stream) {
+    SGCN_REQUIRE(ncols >= 0 && nnz >= 0 && nnz < (1ll << 31), "csr_transpose_index: bad size");
+    SGCN_REQUIRE(t_rowptr || ncols == 0, "csr_transpose_index: null t_rowptr");
+    hipStream_t st = (hipStream_t)stream;
+    if (nnz == 0) {
+        if (ncols > 0) SGCN_HIP_TRY(hipMemsetAsync(t_rowptr, 0, (size_t)(ncols + 1) * 4, st));
+        return SGCN_OK;
+    }
+    SGCN_REQUIRE(col && coo_row && t_row && t_src && ws, "csr_transpose_index: null operand");
+    const int64_t nchunks = (nnz + kTChunk - 1) / kTChunk;
+    hipLaunchKernelGGL(t_hist_kernel, dim3((unsigned)nchunks), dim3(kBlock), 0, st, col, nnz, ncols, ws);
+    hipLaunchKernelGGL(t_scan_kernel, dim3(1), dim3(kBlock), 0, st, ws, (int32_t)nchunks, ncols, t_rowptr);
+    if (ncols <= kTLdsCols)
+        hipLaunchKernelGGL(t_place_kernel<true>, dim3((unsigned)nchunks), dim3(kWave), (size_t)ncols * 4, st, col, coo_row,
+                           nnz, ncols, ws, t_row, t_src);
+    else
+        hipLaunchKernelGGL(t_place_kernel<false>, dim3((unsigned)nchunks), dim3(kWave), 0, st, col, coo_row, nnz, ncols,
+                           ws, t_row, t_src);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out, void* stream) {
+    SGCN_REQUIRE(n >= 0, "gather: negative size");
+    if (n == 0) return SGCN_OK;
+    SGCN_REQUIRE(src && idx && out, "gather: null operand");
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, src, idx, n, out);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
 
 extern "C" int sgcn_gather_rows_f32(const float* in, int64_t ldi, const int32_t* r, int32_t n,
                                     int32_t d, float* out, int64_t ldo, void* stream) {

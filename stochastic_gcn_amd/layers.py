@@ -56,30 +56,12 @@ def dot(x, y, sparse=False):
     return torch.mm(x, y)
 
 
-def layer_norm_fwd(x, offset, scale, eps=1e-9):
-    """MyLayerNorm2 (gcn/layers.py:95-97): moments over features + batch_normalization."""
-    mean = x.mean(dim=1, keepdim=True)
-    xc = x - mean
-    var = (xc * xc).mean(dim=1, keepdim=True)
-    rstd = torch.rsqrt(var + eps)
-    xhat = xc * rstd
-    return xhat * scale + offset, (xhat, rstd)
-
-
-def layer_norm_bwd(dy, ctx, scale):
-    xhat, rstd = ctx
-    dscale = (dy * xhat).sum(dim=0, keepdim=True)
-    doffset = dy.sum(dim=0, keepdim=True)
-    dxhat = dy * scale
-    dx = rstd * (dxhat - dxhat.mean(dim=1, keepdim=True) - xhat * (dxhat * xhat).mean(dim=1, keepdim=True))
-    return dx, doffset, dscale
-
-
 class SparseInput(object):
     """A row-sliced sparse feature block on device: CSR + COO row ids (for its transpose)."""
 
-    def __init__(self, csr):
+    def __init__(self, csr, t=None):
         self.csr = csr
+        self._t = t         # transpose index, shared by the views of one minibatch slice
 
     @property
     def shape(self):
@@ -89,14 +71,14 @@ class SparseInput(object):
         return ops.DeviceCSR(self.csr.shape, self.csr.rowptr, self.csr.col, val)
 
     def transpose_of(self, val):
-        """CSR of X^T for dW = X^T g, built on device (stable sort keeps row order)."""
+        """CSR of X^T for dW = X^T g.  The index is a device counting sort (ops.csr_transpose_index, rows
+        ascending inside a column -> ordered float sums), built once per minibatch; the values -- they
+        change with every dropout mask -- follow through one gather."""
         c = self.csr
-        order = torch.argsort(c.col.to(torch.int64), stable=True)
-        counts = torch.bincount(c.col.to(torch.int64), minlength=c.shape[1])
-        rowptr = torch.zeros(c.shape[1] + 1, dtype=torch.int32, device=c.col.device)
-        rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        return ops.DeviceCSR((c.shape[1], c.shape[0]), rowptr, c.coo_rows[order].contiguous(),
-                             val[order].contiguous())
+        if self._t is None:
+            self._t = ops.csr_transpose_index(c)
+        t_rowptr, t_row, t_src = self._t
+        return ops.DeviceCSR((c.shape[1], c.shape[0]), t_rowptr, t_row, ops.gather_f32(val, t_src))
 
 
 class Layer(object):
@@ -139,7 +121,9 @@ class Dropout(Layer):
             self._sparse = True
             if self._drop is None:
                 return inputs
-            out = SparseInput(inputs.csr)
+            if inputs._t is None:
+                inputs._t = ops.csr_transpose_index(inputs.csr)
+            out = SparseInput(inputs.csr, inputs._t)            # same structure, dropped values
             out.csr = inputs.with_values(ops.dropout(inputs.csr.val, self._drop))
             out.csr.coo_rows = inputs.csr.coo_rows
             return out

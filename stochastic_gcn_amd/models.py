@@ -435,14 +435,18 @@ class GCN(Model):
         if self.is_training:
             self.adam_m = torch.zeros_like(self.theta)
             self.adam_v = torch.zeros_like(self.theta)
-        # weight-decay mask: vars of the first parametrised layer (gcn/models.py:68-75)
-        self._wd_mask = torch.zeros_like(self.theta)
+        # weight decay: the vars of the first parametrised layer (gcn/models.py:68-75) are one contiguous
+        # range of the flat buffer (a layer's parameters are laid out back to back, wd_vars() first)
+        self._wd_range = (0, 0)
         for layer in self.layers:
             if layer.param_shapes():
-                for name, shape, _, off, n in layout:
-                    lname, pname = name.rsplit('/', 1)
-                    if lname == layer.name and pname in layer.wd_vars():
-                        self._wd_mask[off:off + n] = 1.0
+                spans = [(off, off + n) for name, shape, _, off, n in layout
+                         if name.rsplit('/', 1)[0] == layer.name and name.rsplit('/', 1)[1] in layer.wd_vars()]
+                lo, hi = min(a for a, _ in spans), max(b for _, b in spans)
+                # padding floats between parameters are zero and stay zero (zero gradient), so they add nothing
+                assert all(name.rsplit('/', 1)[0] == layer.name and name.rsplit('/', 1)[1] in layer.wd_vars()
+                           for name, shape, _, off, n in layout if lo <= off < hi), "wd vars must be contiguous"
+                self._wd_range = (lo, hi)
                 break
         self.vars = [v for _, v in self.named_vars()]
 
@@ -502,31 +506,24 @@ class GCN(Model):
         return self.outputs
 
     def loss_and_grad(self, labels):
-        """gcn/models.py:68-94.  Returns (loss, accuracy, pred, dlogits) as device tensors."""
+        """gcn/models.py:68-94.  Returns (loss, accuracy, pred, dlogits) as device tensors; the weight-decay
+        term of the first parametrised layer is added to the loss slot by sgcn_l2_penalty_f32."""
         z = self.outputs
-        n = z.shape[0]
-        wd = 0.5 * FLAGS.weight_decay * (self.theta * self.theta * self._wd_mask).sum() \
-            if FLAGS.weight_decay else 0.0
-        if self.multitask:
-            ce = torch.clamp(z, min=0) - z * labels + torch.log1p(torch.exp(-z.abs()))
-            loss = wd + ce.mean()
-            pred = torch.sigmoid(z)
-            dlogits = (pred - labels) / ce.numel()
-            acc = ((z > 0) == (labels > 0.5)).to(torch.float32).mean()
-        else:
-            stats, dlogits, pred = ops.softmax_ce(z, labels, want_grad=self.is_training or self._want_grad,
-                                                  want_pred=not self.is_training or self._want_grad)
-            loss = stats[2] + wd if FLAGS.weight_decay else stats[2]       # mean CE, computed in-kernel
-            acc = stats[3]
-        return loss, acc, pred, dlogits
+        want_grad = self.is_training or self._want_grad
+        want_pred = not self.is_training or self._want_grad
+        ce = ops.sigmoid_ce if self.multitask else ops.softmax_ce
+        stats, dlogits, pred = ce(z, labels, want_grad=want_grad, want_pred=want_pred)
+        if FLAGS.weight_decay and self._wd_range[1] > self._wd_range[0]:
+            ops.l2_penalty(self.theta, self._wd_range[0], self._wd_range[1], FLAGS.weight_decay, loss=stats[2:3])
+        return stats[2], stats[3], pred, dlogits
 
     def backward(self, dlogits):
         self.grad.zero_()
         g = dlogits
         for layer in reversed(self.layers[self._first_param:]):
             g = layer.backward(g)
-        if FLAGS.weight_decay:
-            self.grad.add_(self.theta * self._wd_mask, alpha=float(FLAGS.weight_decay))
+        if FLAGS.weight_decay and self._wd_range[1] > self._wd_range[0]:
+            ops.l2_penalty(self.theta, self._wd_range[0], self._wd_range[1], FLAGS.weight_decay, grad=self.grad)
         return self.grad
 
     def adam_step(self):

@@ -330,6 +330,53 @@ def softmax_ce(logits, labels, want_grad=True, want_pred=False):
     return stats, dz, pred
 
 
+def sigmoid_ce(logits, labels, want_grad=True, want_pred=False):
+    """Multitask (ppi) loss: (stats[4] = {sum CE, #correct elements, mean CE, element accuracy}, dlogits
+    or None, pred = sigmoid(logits) or None)   (sgcn_sigmoid_ce_f32)."""
+    zp, ldz = _rows2d(logits, "logits")
+    lp, ldl = _rows2d(labels, "labels")
+    n, c = int(logits.shape[0]), int(logits.shape[1])
+    stats = torch.empty(4 + 2 * n, dtype=torch.float32, device=logits.device)
+    dz = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
+    pred = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_pred else None
+    check(lib.sgcn_sigmoid_ce_f32(zp, ldz, lp, ldl, n, c, _ptr(dz), c, _ptr(pred), c, stats.data_ptr(),
+                                  stats.data_ptr() + 16, _stream()))
+    return stats, dz, pred
+
+
+def l2_penalty(theta, lo, hi, wd, grad=None, loss=None):
+    """Weight decay over the flat-buffer range [lo, hi): grad += wd * theta, loss[0] += 0.5 * wd * |theta|^2
+    (either may be None)   (sgcn_l2_penalty_f32)."""
+    _dev(theta, torch.float32, "theta")
+    check(lib.sgcn_l2_penalty_f32(theta.data_ptr(), int(lo), int(hi), float(wd), _ptr(grad), _ptr(loss), _stream()))
+
+
+def csr_transpose_index(A):
+    """(t_rowptr, t_row, t_src) of a row-sliced DeviceCSR with ``coo_rows`` (sgcn_csr_transpose_index):
+    the structure of A^T, rows ascending inside every column, + the source position of each entry."""
+    if getattr(A, "coo_rows", None) is None:
+        raise ValueError("csr_transpose_index needs the COO row ids (csr_slice(..., with_coo_rows=True))")
+    dev = A.col.device
+    ncols, nnz = int(A.shape[1]), int(A.col.shape[0])
+    t_rowptr = torch.empty(ncols + 1, dtype=torch.int32, device=dev)
+    t_row = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_src = torch.empty(nnz, dtype=torch.int32, device=dev)
+    need = int(lib.sgcn_csr_transpose_ws_ints(ncols, nnz))
+    ws = torch.empty(max(need, 1), dtype=torch.int32, device=dev)
+    check(lib.sgcn_csr_transpose_index(ncols, nnz, _ptr(A.col), _ptr(A.coo_rows), t_rowptr.data_ptr(),
+                                       t_row.data_ptr(), t_src.data_ptr(), ws.data_ptr(), _stream()))
+    return t_rowptr, t_row, t_src
+
+
+def gather_f32(src, idx):
+    """out[i] = src[idx[i]]   (sgcn_gather_f32)."""
+    _dev(src, torch.float32, "src")
+    _dev(idx, torch.int32, "idx")
+    out = torch.empty(idx.shape[0], dtype=torch.float32, device=src.device)
+    check(lib.sgcn_gather_f32(src.data_ptr(), idx.data_ptr(), int(idx.shape[0]), out.data_ptr(), _stream()))
+    return out
+
+
 def adam_step(theta, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
     check(lib.sgcn_adam_f32(theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
                             int(theta.numel()), float(lr_t), float(beta1), float(beta2), float(eps),

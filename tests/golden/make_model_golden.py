@@ -245,7 +245,6 @@ class TorchRef(object):
 
 
 def generate():
-    from stochastic_gcn_amd.scheduler import PyScheduler
     torch.manual_seed(0)
     torch.set_num_threads(1)          # fixed reduction order -> reproducible file
     blob = {}
@@ -254,8 +253,7 @@ def generate():
         fl, c, ph = case['flags'], case['cfg'], case['ph']
         params = mnp.init_params(mc.make_oracle_model(case, seed=3).specs, 3)
         ref = TorchRef(case, params)
-        sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'], ph,
-                          SAMPLER_SEED, data=case['train'].copy(), cv=fl['cv'])
+        sch = mc.make_scheduler(case, SAMPLER_SEED)
         for step in range(STEPS):
             feed = sch.minibatch(c['batch'])
             out = ref.step(feed, ph, fl['dropout'], step)

@@ -88,7 +88,44 @@ CASES = {
                                flags=dict(normalization='graphsage', dropout=0.2, layer_norm=True,
                                           hidden1=160, num_fc_layers=2, cv=True, cvd=True, degree=1,
                                           preprocess=True)),
+    # f-4: importance-sampling baseline (IS+PP; gcn/scheduler.cpp:63-123, --importance gcn/train.py:61-62):
+    # the sampler draws the layer's joint neighbourhood through the Fenwick multinomial and emits
+    # importance-weighted edges; the model side is PlainGCN on those weights
+    'is_pp': dict(n=900, avg=10, f=20, classes=4, sparse=False, model='plain', batch=40,
+                  flags=dict(normalization='gcn', dropout=0.3, hidden1=16, degree=4, preprocess=True,
+                             importance=True)),
 }
+
+
+def make_scheduler(case, seed=1, data=None):
+    """The product's sampler for a case (bit-exact against the reference C++, tests/test_sampler.py)."""
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    fl = case['flags']
+    return PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'], case['ph'],
+                       seed, data=(case['train'] if data is None else data).copy(), cv=fl['cv'],
+                       importance=bool(fl.get('importance', False)))
+
+
+def planetoid_case(which):
+    """BASELINE configs 1 / 2 at their SURVEY.md 8d sizes: S-Cora (N = 2,708, F = 1,433 sparse, 7 classes,
+    exact PlainGCN, degree 20, one 140-id batch) and S-PubMed (N = 19,717, F = 500 sparse, 3 classes, CVD+PP
+    degree 1, one 60-id batch) -- gcn/config/{cora,pubmed}.config flags with the README's CV switches."""
+    from stochastic_gcn_amd import synthetic
+    if which == 'cora':
+        data = synthetic.cora_like('gcn', 123)
+        flags = dict(normalization='gcn', hidden1=32, degree=20, preprocess=True, dropout=0.5, weight_decay=5e-4)
+        cfg = dict(n=2708, classes=7, model='plain', batch=140, sparse=True)
+    else:
+        data = synthetic.pubmed_like('gcn', 123)
+        flags = dict(normalization='gcn', hidden1=32, cv=True, cvd=True, degree=1, preprocess=True, dropout=0.5,
+                     weight_decay=5e-4)
+        cfg = dict(n=19717, classes=3, model='vr', batch=60, sparse=True)
+    n, adj, _, feats, _, _, labels, tr, _, _ = data
+    fl = mnp.make_flags(**flags)
+    nbr = adj.dot(feats).tocsr().astype(np.float32)             # PP product (gcn/utils.py:169-170)
+    nbr.sort_indices()
+    return dict(cfg=cfg, flags=fl, adj=adj, feats=feats, nbr=nbr, labels=labels, train=tr.astype(np.int32),
+                L_sched=1, ph=placeholders(1, cfg['classes']))
 
 
 def build_case(name, seed=0):

@@ -578,3 +578,72 @@ def test_dense_layer_reads_its_rows_through_an_index(dev):
     for a, b in zip(*out):
         assert torch.equal(a, b)
     assert torch.equal(lazy.materialize(), x)
+
+
+@pytest.mark.parametrize("n,c", [(1, 1), (37, 121), (512, 41), (300, 3)])
+def test_sigmoid_ce_vs_numpy(dev, n, c):
+    """Multitask loss (gcn/models.py:77-79,86-90,198-200) in float64 NumPy."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(n + c)
+    z = (rng.standard_normal((n, c)) * 3).astype(np.float32)
+    y = (rng.rand(n, c) < 0.3).astype(np.float32)
+    stats, dz, pred = ops.sigmoid_ce(T(z, dev), T(y, dev), want_grad=True, want_pred=True)
+    z64 = z.astype(np.float64)
+    ce = np.maximum(z64, 0) - z64 * y + np.log1p(np.exp(-np.abs(z64)))
+    p = 1.0 / (1.0 + np.exp(-z64))
+    st = stats[:4].cpu().numpy()
+    assert abs(st[2] - ce.mean()) <= 1e-5 * max(1.0, ce.mean()) and abs(st[0] - ce.sum()) <= 1e-4 * ce.sum()
+    assert st[1] == ((z > 0) == (y > 0.5)).sum() and abs(st[3] - ((z > 0) == (y > 0.5)).mean()) <= 1e-6
+    assert onp.rel_err(pred.cpu().numpy(), p.astype(np.float32)) <= 1e-5
+    assert onp.rel_err(dz.cpu().numpy(), ((p - y) / (n * c)).astype(np.float32)) <= 1e-5
+    s2, dz2, pr2 = ops.sigmoid_ce(T(z, dev), T(y, dev), want_grad=False, want_pred=False)
+    assert dz2 is None and pr2 is None and torch.equal(s2[:4], stats[:4])            # deterministic
+
+
+def test_l2_penalty_range_only(dev):
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(0)
+    th = rng.standard_normal(5000).astype(np.float32)
+    g0 = rng.standard_normal(5000).astype(np.float32)
+    theta, grad = T(th, dev), T(g0, dev)
+    loss = torch.tensor([0.0, 0.0, 1.25, 0.0], device=dev)
+    ops.l2_penalty(theta, 1000, 3333, 5e-4, grad=grad, loss=loss[2:3])
+    want_g = g0.copy()
+    want_g[1000:3333] += np.float32(5e-4) * th[1000:3333]
+    np.testing.assert_allclose(grad.cpu().numpy(), want_g, rtol=1e-6, atol=1e-9)
+    want_l = 1.25 + 0.5 * 5e-4 * (th[1000:3333].astype(np.float64) ** 2).sum()
+    got = loss.cpu().numpy()
+    assert abs(got[2] - want_l) <= 1e-5 * want_l and got[0] == 0 and got[1] == 0 and got[3] == 0
+    ops.l2_penalty(theta, 10, 10, 5e-4, grad=grad, loss=loss[2:3])                # empty range: no-op
+    assert abs(loss.cpu().numpy()[2] - got[2]) == 0
+
+
+@pytest.mark.parametrize("n,f,per", [(1, 5, 2), (616, 1433, 18), (107, 500, 50), (4000, 300, 40), (50, 20000, 7)])
+def test_csr_transpose_index_is_the_stable_transpose(dev, n, f, per):
+    """Device counting sort == SciPy's CSR transpose (rows ascending inside every column), bit-exact; the
+    > 16,384-column case takes the global-memory counter path."""
+    import scipy.sparse as sp
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(n)
+    rows = np.repeat(np.arange(n), per)
+    cols = np.concatenate([rng.choice(f, per, replace=False) for _ in range(n)])
+    a = sp.csr_matrix((rng.rand(n * per).astype(np.float32) + 0.1, (rows, cols)), shape=(n, f))
+    a.sort_indices()
+    A = ops.DeviceCSR.from_scipy(a, dev, with_plan=False)
+    A.coo_rows = T(np.repeat(np.arange(n, dtype=np.int32), np.diff(a.indptr)), dev)
+    t_rowptr, t_row, t_src = ops.csr_transpose_index(A)
+    at = a.T.tocsr()            # SciPy's transpose conversion is stable: ascending rows per column
+    at.sort_indices()
+    np.testing.assert_array_equal(t_rowptr.cpu().numpy(), at.indptr)
+    np.testing.assert_array_equal(t_row.cpu().numpy(), at.indices)
+    val_t = ops.gather_f32(A.val, t_src)
+    np.testing.assert_array_equal(val_t.cpu().numpy(), at.data)
+    # twice the same (no atomics decide an order)
+    r2 = ops.csr_transpose_index(A)
+    assert all(torch.equal(x, y) for x, y in zip((t_rowptr, t_row, t_src), r2))
+    # empty matrix
+    e = sp.csr_matrix((3, 7), dtype=np.float32)
+    E = ops.DeviceCSR.from_scipy(e, dev, with_plan=False)
+    E.coo_rows = torch.zeros(0, dtype=torch.int32, device=dev)
+    tp, tr_, ts = ops.csr_transpose_index(E)
+    assert tp.cpu().numpy().tolist() == [0] * 8 and tr_.numel() == 0

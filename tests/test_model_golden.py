@@ -36,8 +36,7 @@ def test_oracle_matches_independent_golden(gold, name):
     case = mc.build_case(name)
     fl, c, ph = case['flags'], case['cfg'], case['ph']
     om = mc.make_oracle_model(case, seed=3)
-    sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'], ph, 1,
-                      data=case['train'].copy(), cv=fl['cv'])
+    sch = mc.make_scheduler(case, 1)
     well, worst = {}, dict(act=0.0, grad=0.0, param=0.0)
     agg_index = [i for i, s in enumerate(om.specs) if s[0] == 'agg']
     for step in range(3):

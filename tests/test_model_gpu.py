@@ -57,8 +57,7 @@ def test_training_steps_match_oracle(name):
     omodel = mc.make_oracle_model(case, seed=3)
     dmodel = _make_device_model(case, {k: v.copy() for k, v in omodel.params.items()})
     assert len(dmodel.layers) == len(omodel.specs)          # layer index i keys the same dropout site
-    sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'],
-                      ph, 1, data=case['train'].copy(), cv=fl['cv'])
+    sch = mc.make_scheduler(case, 1)
     worst, well = 0.0, {}
     for step in range(3):
         feed = sch.minibatch(c['batch'])
@@ -125,8 +124,7 @@ def test_training_steps_match_independent_golden(name):
     params = mc.make_oracle_model(case, seed=3).params
     dmodel = _make_device_model(case, {k: v.copy() for k, v in params.items()})
     assert dmodel.dropout_seed == 1
-    sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'],
-                      ph, 1, data=case['train'].copy(), cv=fl['cv'])
+    sch = mc.make_scheduler(case, 1)
     agg_index = [i for i, l in enumerate(dmodel.layers) if isinstance(l, (PlainAggregator, VRAggregator))]
     well, worst = {}, dict(act=0.0, grad=0.0, param=0.0)
     for step in range(3):
@@ -160,6 +158,47 @@ def test_training_steps_match_independent_golden(name):
         assert onp.rel_err(dmodel.history[l][0].cpu().numpy(), gold["%s/history%d" % (name, l)]) <= TOL
     print("%s vs independent golden: worst rel err  activations %.1e  grads %.1e  params %.1e"
           % (name, worst['act'], worst['grad'], worst['param']))
+
+
+@pytest.mark.parametrize("which", ["cora", "pubmed"])
+def test_planetoid_configs_at_full_size_match_oracle(which):
+    """BASELINE configs 1 and 2 at their SURVEY.md 8d sizes (S-Cora: N = 2,708, 1,433 sparse features,
+    exact PlainGCN degree 20; S-PubMed: N = 19,717, 500 sparse features, CVD+PP degree 1): sparse first
+    layer (K9) with sparse dropout (K12), 3 consecutive unsynchronised steps vs the oracle."""
+    case = mc.planetoid_case(which)
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    omodel = mc.make_oracle_model(case, seed=3)
+    dmodel = _make_device_model(case, {k: v.copy() for k, v in omodel.params.items()})
+    sch = mc.make_scheduler(case, 1)
+    well, worst = {}, dict(act=0.0, grad=0.0)
+    for step in range(3):
+        sch.start = 0                       # one batch = the whole train set, every epoch
+        feed = sch.minibatch(1000)
+        assert feed[ph['fields'][-1]].shape[0] == c['batch']
+        feed[ph['dropout']] = fl['dropout']
+        masks = _masks(dmodel, 1.0 - fl['dropout'])
+        o_loss, o_acc, _, o_acts, o_grads = omodel.run_one_step(feed, ph, fl['dropout'], masks)
+        outs = dmodel.run_one_step(None, feed)
+        for da, oa in zip(dmodel.activations[1:], o_acts):
+            da = _np(da)
+            if da is None or hasattr(oa, 'tocsr'):
+                continue
+            for dd, oo in (zip(da, oa) if isinstance(oa, tuple) else [(da, oa)]):
+                e = onp.rel_err(dd, oo); worst['act'] = max(worst['act'], e)
+                assert e <= TOL, (which, step, e)
+        assert abs(outs[1] - float(o_loss)) <= 1e-4 * max(1.0, abs(float(o_loss)))
+        assert abs(outs[2] - float(o_acc)) <= 1e-6
+        dg = dmodel.get_grads()
+        for k, g in o_grads.items():
+            e = onp.rel_err(dg[k], g); worst['grad'] = max(worst['grad'], e)
+            assert e <= GRAD_TOL, (which, step, k, e)
+            well[k] = well.get(k, True) & (np.abs(g) > 1e-6)
+        dp = dmodel.get_params()
+        for k, v in omodel.params.items():
+            assert np.abs(dp[k] - v)[well[k]].max() <= PARAM_TOL * np.abs(v).max(), (which, step, k)
+        for l, h in enumerate(omodel.history):
+            assert onp.rel_err(dmodel.history[l][0].cpu().numpy(), h) <= TOL
+    print("S-%s at full size: worst rel err activations %.1e grads %.1e" % (which, worst['act'], worst['grad']))
 
 
 def test_eval_model_shares_weights_and_keeps_own_history():

@@ -108,8 +108,7 @@ def test_oracle_backward_matches_autograd(name):
             om.params[k] = (1 + 0.1 * rng.standard_normal(om.params[k].shape)).astype(np.float32)
     for h in om.history:
         h[:] = rng.uniform(-1, 1, h.shape)
-    sch = PyScheduler(case['adj'], case['labels'], case['L_sched'], [fl['degree']] * case['L_sched'],
-                      ph, 1, data=case['train'].copy(), cv=fl['cv'])
+    sch = mc.make_scheduler(case, 1)
     feed = sch.minibatch(c['batch'])
     masks = mc.MaskSource(7, 1.0 - fl['dropout'])
     logits, _ = om.forward(feed, ph, fl['dropout'], masks)

@@ -241,11 +241,11 @@ def test_csplan_covers_matrix_and_balances_tiles():
     rowptr, col, val = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float32)
     for R, T in ((16, 16), (32, 40), (16, 0)):
         nt, nf, ns = C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplan_count(rowptr.ctypes.data, n, R, T, C.byref(nt), C.byref(nf), C.byref(ns)))
+        check(lib.sgcn_csplan_count(rowptr.ctypes.data, n, R, T, None, C.byref(nt), C.byref(nf), C.byref(ns)))
         tp = np.empty(nt.value + 1, np.int64); cr = np.empty(a.nnz, np.int32); vo = np.empty(a.nnz, np.float32)
         tr = np.empty(nt.value * R, np.int32); ts = np.empty(nt.value * R, np.int32)
         fx = np.empty((max(nf.value, 1), 3), np.int32)
-        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, R, T,
+        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, R, T, None,
                                    tp.ctypes.data, cr.ctypes.data, vo.ctypes.data, tr.ctypes.data,
                                    ts.ctypes.data, fx.ctypes.data))
         shift = 28 if R <= 16 else 27
