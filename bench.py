@@ -207,40 +207,53 @@ def reddit_grad_floats(d_in=602, hidden=128, classes=41):
     return 2 * d_in * hidden + hidden * hidden + 2 * hidden * hidden + hidden * classes + 6 * hidden
 
 
-def cpu_baseline(full_adj, d, rows, seed=0):
-    from oracle import oracle_np as onp
+def cpu_baseline(full_adj, d, rows, seed=0, budget_s=3.0):
+    """The oracle's OpenMP C restatement of the same product on a bounded row sample, as an honest CPU
+    number: one subprocess per thread count (oracle/cpu_baseline.py) with the threads PINNED and spread
+    over the sockets, the dense operand page-interleaved over the NUMA nodes, at 1 / 16 / 64 / all cores
+    -- `value` is the best of them (on a two-socket host the all-core figure is usually the best, but
+    the scaling is printed so that it can be judged); plus scipy.sparse single-threaded, which is
+    literally what the reference runs for this product (gcn/utils.py:321-322)."""
+    import subprocess
+    import tempfile
     n = full_adj.shape[0]
     rows = min(rows, n)
     sub = full_adj[:rows].tocsr()
-    B = np.random.RandomState(seed).standard_normal((n, d)).astype(np.float32)
-    onp.spmm(sub.indptr[:65], sub.indices, sub.data, B)          # warm the library / threads
-    t0 = time.time()
-    reps = 0
-    while True:
-        onp.spmm(sub.indptr, sub.indices, sub.data, B)
-        reps += 1
-        el = time.time() - t0
-        if el > 10.0 or reps >= 50:
-            break
-    out = {"value": sub.nnz * reps / el, "unit": "edges/s", "cores": os.cpu_count(),
-           "kind": "port",
-           "sample": "oracle_c.c OpenMP CSR SpMM, first %d rows (%d edges) of the same matrix, "
-                     "d=%d, %d reps in %.1f s" % (rows, sub.nnz, d, reps, el)}
-    # B1 on ONE core ("1 and all cores"), on a smaller sample
-    try:
-        lib = onp.clib()
-        nthreads = int(lib.oracle_max_threads())
+    ncores = os.cpu_count() or 1
+    counts = sorted({c for c in (1, 16, 64, ncores) if c <= ncores})
+    script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
+    scaling, note = [], None
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "sample.npz")
+        np.savez(path, indptr=sub.indptr, indices=sub.indices, data=sub.data, K=n)
+        small = os.path.join(tmp, "small.npz")                   # one core gets a smaller sample (same matrix)
         one = full_adj[:min(4000, n)].tocsr()
-        lib.oracle_set_threads(1)
-        t0 = time.time()
-        onp.spmm(one.indptr, one.indices, one.data, B)
-        out["single_thread_edges_per_s"] = one.nnz / (time.time() - t0)
-        lib.oracle_set_threads(nthreads)
-        out["cores"] = nthreads
-    except Exception:
-        pass
+        np.savez(small, indptr=one.indptr, indices=one.indices, data=one.data, K=n)
+        for c in counts:
+            env = dict(os.environ, OMP_NUM_THREADS=str(c), OMP_PROC_BIND="spread", OMP_PLACES="cores",
+                       OMP_DYNAMIC="false")
+            try:
+                res = subprocess.run([sys.executable, script, small if c == 1 else path, str(d), str(budget_s), str(c)],
+                                     env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+                scaling.append(json.loads(res.stdout.strip().splitlines()[-1]))
+            except Exception as e:      # the checker is optional: keep the bench line
+                note = "thread count %d failed: %r" % (c, e)
+    best = max(scaling, key=lambda r: r["edges_per_s"]) if scaling else None
+    out = {"value": best["edges_per_s"] if best else None, "unit": "edges/s", "cores": best["threads"] if best else 0,
+           "kind": "port",
+           "sample": "oracle_c.c OpenMP CSR SpMM (loop order of gcn/history.cpp:10-48), first %d rows (%d edges) of the "
+                     "same matrix, d=%d, ~%.0f s per thread count, threads pinned (OMP_PROC_BIND=spread, OMP_PLACES=cores), "
+                     "B page-interleaved over the NUMA nodes; one core: first %d rows" % (rows, sub.nnz, d, budget_s, one.shape[0]),
+           "host_cores": ncores,
+           "scaling": [{"threads": r["threads"], "edges_per_s": r["edges_per_s"], "reps": r["reps"]} for r in scaling]}
+    if note:
+        out["note"] = note
+    for r in scaling:
+        if r["threads"] == 1:
+            out["single_thread_edges_per_s"] = r["edges_per_s"]
     # B2 (BASELINE.md §3): scipy.sparse csr @ dense, single thread -- literally what the reference
     # uses for the PP product (gcn/utils.py:321-322)
+    B = np.random.RandomState(seed).standard_normal((n, d)).astype(np.float32)
     small = full_adj[:min(8000, n)].tocsr()
     t0 = time.time()
     small.dot(B)

@@ -37,6 +37,19 @@ int32_t oracle_max_threads(void) {
 #endif
 }
 
+/* Touch a freshly allocated buffer page by page from all threads (static round-robin): with the
+ * threads spread over the sockets (OMP_PROC_BIND=spread) first-touch placement interleaves the pages
+ * over the NUMA nodes -- what a gather-bound SpMM wants of its dense operand (bench.py cpu_baseline). */
+void oracle_first_touch_interleaved(float* p, int64_t n) {
+    const int64_t page = 4096 / (int64_t)sizeof(float);
+    const int64_t npages = (n + page - 1) / page;
+#pragma omp parallel for schedule(static, 1)
+    for (int64_t g = 0; g < npages; g++) {
+        const int64_t lo = g * page, hi = lo + page < n ? lo + page : n;
+        for (int64_t i = lo; i < hi; i++) p[i] = 0.0f;
+    }
+}
+
 /* C[M x d] = A[M x K, CSR] * B[K x d]           (gcn/layers.py:31-37 dot(sparse=True) ->
  * tf.sparse_tensor_dense_matmul; K1/K11 in SURVEY §2.1).  beta==0 overwrites C. */
 void oracle_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,

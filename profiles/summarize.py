@@ -30,10 +30,16 @@ def main(src, tag):
         lines.append("%-100s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for r in t.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 15"):
             lines.append("%-100s %8d %14d %12.0f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
-    for sub, note in (("pmc_fetch", "FETCH_SIZE is in KiB; on gfx950 it reports 1/2 of a wide coalesced read "
-                                    "stream (x2 correction, calibrate on the copy kernel in the same trace)"),
-                      ("pmc_write", "WRITE_SIZE is in KiB"),
-                      ("pmc_l2", "L2 hit rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)")):
+    notes = {"pmc_fetch": "FETCH_SIZE is in KiB; on gfx950 it reports 1/2 of a wide coalesced read "
+                          "stream (x2 correction, calibrate on the copy kernel in the same trace)",
+             "pmc_write": "WRITE_SIZE is in KiB",
+             "pmc_l2": "L2 hit rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)"}
+    subs = ["pmc_fetch", "pmc_write", "pmc_l2"] + sorted(
+        os.path.basename(x) for x in glob.glob(os.path.join(src, "pmc_*"))
+        if os.path.isdir(x) and os.path.basename(x) not in notes)
+    counters = {}
+    for sub in subs:
+        note = notes.get(sub, "separate run")
         d = db(os.path.join(src, sub))
         if not d:
             continue
@@ -44,6 +50,8 @@ def main(src, tag):
              "group by name, counter_name order by avg(duration) desc limit 12")
         for r in d.execute(q):
             lines.append("%-100s %-14s %6d %16.1f %12.0f" % (r[0][:100], r[1], r[2], r[3], r[4]))
+            if "sgcn::cs_spmm" in r[0] or "sgcn::spmm_seg" in r[0]:
+                counters.setdefault(r[0], {})[r[1]] = {"mean_per_dispatch": r[3], "mean_ns": r[4], "dispatches": r[2]}
     # machine-readable traffic record of the dominant (longest) sgcn kernel, read by bench.py
     try:
         import json
@@ -74,6 +82,51 @@ def main(src, tag):
                         rec["kernel_launches_per_spmm"], rec["hbm_bytes_per_spmm"] / 1e9))
     except Exception as e:   # partial profile directories are fine
         lines.append("(no traffic record: %s)" % e)
+    if counters:
+        import json as _json
+        _json.dump(counters, open(os.path.join(out_dir, "%s_counters.json" % tag), "w"), indent=1)
+        for k, c in counters.items():
+            g = lambda n: c.get(n, {}).get("mean_per_dispatch")       # noqa: E731
+            lines.append("")
+            lines.append("== derived, %s" % k[:90])
+            ns = next(iter(c.values()))["mean_ns"]
+            lines.append("   mean dispatch %.1f us" % (ns / 1e3))
+            cyc = g("GRBM_GUI_ACTIVE")             # shader-clock cycles of the dispatch (per XCD instance)
+            if cyc:
+                lines.append("   %.0f shader cycles (%.2f GHz)" % (cyc, cyc / ns))
+            if g("TCC_BUSY_avr") is not None and cyc:
+                lines.append("   L2 (TCC) busy %.1f %% of the dispatch  [TCC_BUSY_avr = %.0f cycles, mean over the L2 channels]"
+                             % (100.0 * g("TCC_BUSY_avr") / cyc, g("TCC_BUSY_avr")))
+            if g("TA_BUSY_avr") is not None and cyc:
+                lines.append("   texture-address units (TA) busy %.1f %%  [TA_BUSY_avr = %.0f cycles]; of that stalled by the cache on "
+                             "addresses %.1f %%, on data %.1f %% of the dispatch"
+                             % (100.0 * g("TA_BUSY_avr") / cyc, g("TA_BUSY_avr"),
+                                100.0 * (g("TA_ADDR_STALLED_BY_TC_CYCLES_sum") or 0) / 256 / cyc,
+                                100.0 * (g("TA_DATA_STALLED_BY_TC_CYCLES_sum") or 0) / 256 / cyc))
+            if g("TCP_PENDING_STALL_CYCLES_sum") is not None and cyc:
+                lines.append("   vector L1 (TCP) stalled on pending misses %.1f %% of the dispatch (mean over 256 CUs)"
+                             % (100.0 * g("TCP_PENDING_STALL_CYCLES_sum") / 256 / cyc))
+            if g("TCC_EA0_RDREQ_LEVEL_sum") and g("TCC_EA0_RDREQ_sum"):
+                lines.append("   mean fabric read latency seen by the L2: %.0f cycles"
+                             % (g("TCC_EA0_RDREQ_LEVEL_sum") / g("TCC_EA0_RDREQ_sum")))
+            if g("TCP_UTCL1_TRANSLATION_MISS_sum") is not None:
+                lines.append("   L1 TLB misses per dispatch: %.0f (negligible)" % g("TCP_UTCL1_TRANSLATION_MISS_sum"))
+            if g("TCP_TCC_READ_REQ_sum") and g("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                lines.append("   vector L1: %.3g tag lookups, %.3g read requests to L2 (x 128 B = %.2f GB per dispatch)"
+                             % (g("TCP_TOTAL_CACHE_ACCESSES_sum"), g("TCP_TCC_READ_REQ_sum"),
+                                g("TCP_TCC_READ_REQ_sum") * 128 / 1e9))
+            if g("TCP_TCC_READ_REQ_LATENCY_sum") and g("TCP_TCC_READ_REQ_sum"):
+                lines.append("   mean L1->L2 read latency %.0f cycles" % (g("TCP_TCC_READ_REQ_LATENCY_sum") / g("TCP_TCC_READ_REQ_sum")))
+            if g("SQ_WAIT_INST_ANY") and g("SQ_WAVE_CYCLES"):
+                lines.append("   waves waiting on an instruction dependency %.1f %% of wave-cycles; issuing VMEM %.1f %%, VALU %.1f %%, scalar %.1f %%"
+                             % (100.0 * g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+                                100.0 * (g("SQ_ACTIVE_INST_VMEM") or 0) / g("SQ_WAVE_CYCLES"),
+                                100.0 * (g("SQ_ACTIVE_INST_VALU") or 0) / g("SQ_WAVE_CYCLES"),
+                                100.0 * (g("SQ_ACTIVE_INST_SCA") or 0) / g("SQ_WAVE_CYCLES")))
+            if g("TCC_EA0_RDREQ_sum") and g("TCC_REQ_sum"):
+                lines.append("   L2: %.3g requests, %.3g fabric read requests, tag stalls %.3g, DRAM-credit stalls %.3g"
+                             % (g("TCC_REQ_sum"), g("TCC_EA0_RDREQ_sum"), g("TCC_TAG_STALL_sum") or 0,
+                                g("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum") or 0))
     path = os.path.join(out_dir, "%s_rocprof_summary.txt" % tag)
     open(path, "w").write("\n".join(lines) + "\n")
     print(path)
