@@ -207,20 +207,34 @@ def reddit_grad_floats(d_in=602, hidden=128, classes=41):
     return 2 * d_in * hidden + hidden * hidden + 2 * hidden * hidden + hidden * classes + 6 * hidden
 
 
-def cpu_baseline(full_adj, d, rows, seed=0, budget_s=3.0):
+def usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(full_adj, d, rows, seed=0, budget_s=2.5):
     """The oracle's OpenMP C restatement of the same product on a bounded row sample, as an honest CPU
     number: one subprocess per thread count (oracle/cpu_baseline.py) with the threads PINNED and spread
-    over the sockets, the dense operand page-interleaved over the NUMA nodes, at 1 / 16 / 64 / all cores
-    -- `value` is the best of them (on a two-socket host the all-core figure is usually the best, but
-    the scaling is printed so that it can be judged); plus scipy.sparse single-threaded, which is
-    literally what the reference runs for this product (gcn/utils.py:321-322)."""
+    over the sockets, the dense operand page-interleaved over the NUMA nodes, at 1 / 8 / 16 / 32 / 64 /
+    all usable cores -- `value` is the BEST of them and the whole scaling curve is printed (on the GPU
+    box the container's CPU quota makes counts beyond it slower, not faster); plus scipy.sparse
+    single-threaded, which is literally what the reference runs for this product
+    (gcn/utils.py:321-322)."""
     import subprocess
     import tempfile
     n = full_adj.shape[0]
     rows = min(rows, n)
     sub = full_adj[:rows].tocsr()
     ncores = os.cpu_count() or 1
-    counts = sorted({c for c in (1, 16, 64, ncores) if c <= ncores})
+    usable = usable_cores()
+    counts = sorted({c for c in (1, 8, 16, 32, 64, usable) if c <= ncores})
     script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
     scaling, note = [], None
     with tempfile.TemporaryDirectory() as tmp:
@@ -244,7 +258,7 @@ def cpu_baseline(full_adj, d, rows, seed=0, budget_s=3.0):
            "sample": "oracle_c.c OpenMP CSR SpMM (loop order of gcn/history.cpp:10-48), first %d rows (%d edges) of the "
                      "same matrix, d=%d, ~%.0f s per thread count, threads pinned (OMP_PROC_BIND=spread, OMP_PLACES=cores), "
                      "B page-interleaved over the NUMA nodes; one core: first %d rows" % (rows, sub.nnz, d, budget_s, one.shape[0]),
-           "host_cores": ncores,
+           "host_cores": ncores, "usable_cores": usable,
            "scaling": [{"threads": r["threads"], "edges_per_s": r["edges_per_s"], "reps": r["reps"]} for r in scaling]}
     if note:
         out["note"] = note

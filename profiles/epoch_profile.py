@@ -36,8 +36,44 @@ def summarize(src, steps):
         print("%-92s %8d %10.2f %12.1f %10.2f %6.2f" % (r[0][:92], r[1], r[1] / steps, r[2] / 1e3, r[3], r[4]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--gaps"):
     if len(sys.argv) > 1 and sys.argv[1] == "--summarize":
         summarize(sys.argv[2], int(sys.argv[3]))
     else:
         run(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+
+
+def gaps(src):
+    """Idle time between consecutive kernels of the training steps (rocpd kernel dispatch timestamps):
+    ~1.5 us back to back means the GPU is the bound, several us means it waits for the launching host."""
+    f = glob.glob(os.path.join(src, "**", "*results.db"), recursive=True)
+    t = sqlite3.connect(f[0])
+    tabs = [r[0] for r in t.execute("select name from sqlite_master where type in ('table','view')")]
+    view = "kernels" if "kernels" in tabs else None
+    if view is None:
+        print("tables:", tabs)
+        return
+    cols = [r[1] for r in t.execute("pragma table_info(%s)" % view)]
+    rows = list(t.execute("select name, start, end from %s order by start" % view))
+    import numpy as np
+    st = np.array([r[1] for r in rows], dtype=np.int64)
+    en = np.array([r[2] for r in rows], dtype=np.int64)
+    names = [r[0] for r in rows]
+    # steady state: the last third of the trace, only sgcn kernels' neighbours
+    lo = len(rows) * 2 // 3
+    gap = (st[lo + 1:] - en[lo:-1]) / 1e3
+    dur = (en[lo:] - st[lo:]) / 1e3
+    span = (en[-1] - st[lo]) / 1e3
+    print("steady-state window: %d kernels over %.1f ms: busy %.1f ms (%.1f %%), idle between kernels %.1f ms"
+          % (len(dur), span / 1e3, dur.sum() / 1e3, 100 * dur.sum() / span, gap.sum() / 1e3))
+    print("gap between consecutive kernels: median %.2f us, mean %.2f us, p90 %.2f us, share of gaps > 4 us: %.1f %%"
+          % (np.median(gap), gap.mean(), np.percentile(gap, 90), 100 * (gap > 4).mean()))
+    adam = [i for i in range(lo, len(rows)) if "adam_kernel" in names[i]]
+    if len(adam) > 2:
+        per = np.diff(st[adam]) / 1e3
+        print("step period (adam to adam): median %.1f us; kernels per step %.1f"
+              % (np.median(per), (adam[-1] - adam[0]) / (len(adam) - 1)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--gaps":
+    gaps(sys.argv[2])
