@@ -144,7 +144,8 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)
  *   cs_round (tiles per launch), cs_unroll (4|8), cs_pace (ns per nonzero of the heaviest tile,
  *   0 = unpaced), cs_slack (columns), cs_generic (compiler-lowered indexing instead of the pinned
- *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane) : column-sweep kernel */
+ *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane) : column-sweep kernel
+ *   step_overlap (default 1): in sgcn_step_run, weight-gradient GEMMs + reductions on an auxiliary stream */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */
 
@@ -173,6 +174,19 @@ int sgcn_vr_aggregate_f32(const int32_t* dev_a_rowptr, const int32_t* dev_a_col,
                           int32_t cvd, int32_t concat_self,
                           const sgcn_plan_t* f_plan /* plan over f_rowptr, nullable */,
                           void* stream);
+
+/* The same aggregate in two phases that are bit-identical to the fused call: _pre computes the
+ * history-only part  accP[n1 x ldw] = P . Hbar[ffield]  (ldw = 4*ceil(d/4); it depends on nothing the
+ * step computes, so the step program runs it beside the dense layers), _post the rest. */
+int sgcn_vr_aggregate_pre_f32(const int32_t* dev_f_rowptr, const int32_t* dev_f_col, const float* dev_f_val,
+                              int32_t n1, int32_t nf, int32_t d, const float* dev_Hbar, int64_t ldh,
+                              const int32_t* dev_ffield, float* dev_accP, const sgcn_plan_t* f_plan,
+                              void* stream);
+int sgcn_vr_aggregate_post_f32(const int32_t* dev_a_rowptr, const int32_t* dev_a_col, const float* dev_a_val,
+                               int32_t n1, int32_t n0, int32_t d, const float* dev_h, const float* dev_mu,
+                               int64_t ldx, const float* dev_Hbar, int64_t ldh, const int32_t* dev_ifield,
+                               const float* dev_s, float* dev_out_h, float* dev_out_mu, int64_t ldo,
+                               int32_t cvd, int32_t concat_self, const float* dev_accP, void* stream);
 
 /* out[i, 0:d] = in[r[i], 0:d]                  replaces history.dense_slice / c_dense_slice
  *                                              gcn/_history.pyx:53-62, gcn/history.cpp:74-88
@@ -413,6 +427,46 @@ void sgcn_mult_destroy(sgcn_mult_t* m);
 int sgcn_mult_tree(sgcn_mult_t* m, const float** bit, int64_t* len); /* bit[0..N] */
 int sgcn_mult_query_u(sgcn_mult_t* m, float u, int32_t* result);     /* mult.cpp:38-51 */
 int sgcn_mult_query(sgcn_mult_t* m, int32_t* result);                /* mult.cpp:29-36 */
+
+
+/* ---- one step as ONE call: the native launch loop (csrc/sgcn_step.cpp) --------------------------
+ * The reference runs a training step as one sess.run of a static graph (gcn/vrgcn.py:72-82,
+ * gcn/train.py:187-209).  A step PROGRAM is a flat list of calls to this library's own entry points;
+ * argument j of an op evaluates to  mul[j] * slots[slot[j]] + add[j]  (slot[j] < 0: the constant
+ * add[j]), pointers and integers as int64, floats as their bit pattern in the low 32 bits, the
+ * sgcn_dropout_t / sgcn_plan_t arguments flattened to {on, fields...}.  The slot table is what changes
+ * from minibatch to minibatch (row counts, addresses inside the staging buffer, dropout keys, the Adam
+ * step size); the program is compiled once per model (stochastic_gcn_amd/step_program.py).  Ops are
+ * executed in order on `stream` with exactly the arguments the eager path passes: same results, bit
+ * for bit.  Argument order of every op = the parameter order of the entry point it names. */
+#define SGCN_STEP_MAX_ARGS 48
+enum {
+    SGCN_OP_DENSE_FWD = 1,    /* sgcn_dense_fwd_f32 (ws, ws_capacity: split-K scratch used iff the library asks) */
+    SGCN_OP_DENSE_BWD = 2,    /* sgcn_dense_bwd_f32 (g_tmp, ws, ws_capacity) */
+    SGCN_OP_VR_AGG = 3,       /* sgcn_vr_aggregate_f32 */
+    SGCN_OP_SPMM = 4,         /* sgcn_spmm_csr_f32, or sgcn_spmm_csr_add_f32 when add != NULL */
+    SGCN_OP_SOFTMAX_CE = 5,   /* sgcn_softmax_ce_f32 */
+    SGCN_OP_ADAM = 6,         /* sgcn_adam_f32 */
+    SGCN_OP_SCATTER_ROWS = 7, /* sgcn_scatter_rows_f32 */
+    SGCN_OP_MEMSET0 = 8,      /* hipMemsetAsync(ptr, 0, bytes) */
+    SGCN_OP_DROPOUT = 9,      /* sgcn_dropout_f32 */
+    SGCN_OP_L2_PENALTY = 10,  /* sgcn_l2_penalty_f32 */
+    SGCN_OP_GATHER_ROWS = 11, /* sgcn_gather_rows_f32 */
+    SGCN_OP_COPY2D = 12,      /* hipMemcpy2DAsync(dst, ldd, src, lds, rows, cols) in floats */
+    SGCN_OP_SIGMOID_CE = 13,  /* sgcn_sigmoid_ce_f32 */
+    SGCN_OP_VR_AGG_PRE = 14,  /* sgcn_vr_aggregate_pre_f32, issued on the auxiliary stream (forked from `stream`) */
+    SGCN_OP_VR_AGG_POST = 15, /* `stream` waits for the auxiliary stream, then sgcn_vr_aggregate_post_f32 */
+    SGCN_OP_AUX_SCATTER_ROWS = 16, /* sgcn_scatter_rows_f32 on the auxiliary stream (forked from `stream`) */
+    SGCN_OP_AUX_MEMSET0 = 17  /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
+};
+typedef struct {
+    int32_t op, nargs;
+    int64_t mul[SGCN_STEP_MAX_ARGS];
+    int32_t slot[SGCN_STEP_MAX_ARGS];
+    int64_t add[SGCN_STEP_MAX_ARGS];
+} sgcn_step_op_t;
+int sgcn_step_run(const sgcn_step_op_t* host_ops, int32_t nops, const int64_t* host_slots, int32_t nslots,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ def summarize(src, steps):
         print("%-92s %8d %10.2f %12.1f %10.2f %6.2f" % (r[0][:92], r[1], r[1] / steps, r[2] / 1e3, r[3], r[4]))
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--gaps"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("--gaps", "--timeline")):
     if len(sys.argv) > 1 and sys.argv[1] == "--summarize":
         summarize(sys.argv[2], int(sys.argv[3]))
     else:
@@ -77,3 +77,22 @@ def gaps(src):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--gaps":
     gaps(sys.argv[2])
+
+
+def timeline(src, n=70):
+    """One steady-state step as a kernel timeline (start offset, duration, queue): shows what overlaps."""
+    f = glob.glob(os.path.join(src, "**", "*results.db"), recursive=True)
+    t = sqlite3.connect(f[0])
+    cols = [r[1] for r in t.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    rows = list(t.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")))
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+    a, b = adam[len(adam) // 2], adam[len(adam) // 2 + 1]
+    t0 = rows[a][2]
+    print("columns:", cols)
+    for r in rows[a:b + 1][:n]:
+        print("%9.2f us  +%7.2f us  q=%s  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else "-", r[0][:70]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--timeline":
+    timeline(sys.argv[2])

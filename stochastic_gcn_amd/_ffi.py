@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 3          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 4          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -38,6 +38,15 @@ class CsPlan(C.Structure):
                 ("nslots", C.c_int64), ("dev_ws", C.c_void_p), ("ws_elems", C.c_int64),
                 ("round_tiles", C.c_int64), ("host_tile_nnz_hint", C.c_void_p),
                 ("pace_ns_per_nnz", C.c_int32), ("xcd_map", C.c_int32)]
+
+
+STEP_MAX_ARGS = 48
+
+
+class StepOp(C.Structure):
+    """include/sgcn.h sgcn_step_op_t"""
+    _fields_ = [("op", C.c_int32), ("nargs", C.c_int32), ("mul", C.c_int64 * STEP_MAX_ARGS),
+                ("slot", C.c_int32 * STEP_MAX_ARGS), ("add", C.c_int64 * STEP_MAX_ARGS)]
 
 
 class Dropout(C.Structure):
@@ -77,6 +86,10 @@ SIGNATURES = {
     "sgcn_vr_aggregate_f32": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, P, P, C.c_int64, P, C.c_int64, P, P, P, P, P,
                                         C.c_int64, C.c_int32, C.c_int32, C.POINTER(Plan), P]),
+    "sgcn_vr_aggregate_pre_f32": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, P,
+                                            C.POINTER(Plan), P]),
+    "sgcn_vr_aggregate_post_f32": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_int64, P, C.c_int64,
+                                             P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
     "sgcn_gather_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_scatter_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),
@@ -103,6 +116,7 @@ SIGNATURES = {
     "sgcn_csr_transpose_ws_ints": (C.c_int64, [C.c_int32, C.c_int64]),
     "sgcn_csr_transpose_index": (C.c_int, [C.c_int32, C.c_int64, P, P, P, P, P, P, P]),
     "sgcn_gather_f32": (C.c_int, [P, P, C.c_int64, P, P]),
+    "sgcn_step_run": (C.c_int, [C.POINTER(StepOp), C.c_int32, P, C.c_int32, P]),
     "sgcn_adam_f32": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "sgcn_sched_create": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.POINTER(C.c_void_p)]),

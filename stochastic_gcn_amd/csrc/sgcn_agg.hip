@@ -32,6 +32,9 @@ struct AggArgs {
     float* out_h; float* out_mu; int64_t ldo;
     int32_t d, nvec, cvd, off, concat;
     float* ws; int64_t ldw;
+    // two-phase form (sgcn_vr_aggregate_pre/post_f32): the P-sum of every row goes to / comes from
+    // accP[row * ldw ...] instead of living in registers across the two halves of the fused pass
+    float* accP_out; const float* accP_in;
 };
 
 template <int VW>
@@ -143,8 +146,9 @@ __global__ __launch_bounds__(kBlock) void agg_seg_kernel(AggArgs a) {
             if (act) accP += v * vload<VW>(Hl + (int64_t)c * a.ldh);
         }
     }
-    if (slot < 0) agg_finish<G, VW>(a, row, vi, lig, act, accP);
-    else if (act) vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accP);
+    if (slot >= 0) { if (act) vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accP); }
+    else if (a.accP_out) { if (act) vstore<VW>(a.accP_out + (int64_t)row * a.ldw + (int64_t)vi * VW, accP); }
+    else agg_finish<G, VW>(a, row, vi, lig, act, accP);
 }
 
 template <int G, int VW>
@@ -164,7 +168,45 @@ __global__ __launch_bounds__(kBlock) void agg_fix_kernel(AggArgs a, const sgcn_f
         const float* w = a.ws + (int64_t)fx.first_slot * a.ldw + (int64_t)vi * VW;
         for (int q = 0; q < fx.nslots; q++) accP += vload<VW>(w + (int64_t)q * a.ldw);
     }
-    agg_finish<G, VW>(a, uniform_i<G>(fx.row), vi, lig, act, accP);
+    if (a.accP_out) { if (act) vstore<VW>(a.accP_out + (int64_t)fx.row * a.ldw + (int64_t)vi * VW, accP); }
+    else agg_finish<G, VW>(a, uniform_i<G>(fx.row), vi, lig, act, accP);
+}
+
+// second phase of the two-phase form: one group per output row, P-sum read back from accP_in
+template <int G, int VW>
+__global__ __launch_bounds__(kBlock) void agg_post_kernel(AggArgs a, int32_t n1) {
+    typedef typename Vec<VW>::type VT;
+    constexpr int GPB = kBlock / G;
+    const int lig = threadIdx.x & (G - 1);
+    const int64_t nrblk = ((int64_t)n1 + GPB - 1) / GPB;
+    const int slab = (int)(blockIdx.x / nrblk);
+    const int64_t row = (blockIdx.x % nrblk) * GPB + threadIdx.x / G;
+    if (row >= n1) return;
+    const int vi = slab * G + lig;
+    const bool act = vi < a.nvec;
+    const VT accP = act ? vload<VW>(a.accP_in + row * a.ldw + (int64_t)vi * VW) : vzero<VW>();
+    agg_finish<G, VW>(a, uniform_i<G>((int)row), vi, lig, act, accP);
+}
+
+template <int VW>
+static int launch_agg_post(int G, const AggArgs& a, int32_t n1, hipStream_t st) {
+    const int nslab = (a.nvec + G - 1) / G;
+#define SGCN_AGGP_CASE(GG)                                                                               \
+    case GG: {                                                                                           \
+        const int64_t nrblk = ((int64_t)n1 + (kBlock / GG) - 1) / (kBlock / GG);                          \
+        hipLaunchKernelGGL((agg_post_kernel<GG, VW>), dim3((unsigned)(nrblk * nslab)), dim3(kBlock), 0, st, a, n1); \
+        break;                                                                                           \
+    }
+    switch (G) {
+        SGCN_AGGP_CASE(8)
+        SGCN_AGGP_CASE(16)
+        SGCN_AGGP_CASE(32)
+        SGCN_AGGP_CASE(64)
+        default: return fail(SGCN_ERR_INVALID, "vr_aggregate_post: bad group %d", G);
+    }
+#undef SGCN_AGGP_CASE
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
 }
 
 template <int VW>
@@ -243,4 +285,73 @@ extern "C" int sgcn_vr_aggregate_f32(const int32_t* a_rowptr, const int32_t* a_c
     if (vw == 4) return launch_agg<4>(G, a, f_plan, st);
     if (vw == 2) return launch_agg<2>(G, a, f_plan, st);
     return launch_agg<1>(G, a, f_plan, st);
+}
+
+// ---- the same aggregate in two phases -------------------------------------------------------------
+// P . Hbar[ffield] -- the dominant gather of the step (Reddit CVD+PP: 50.8 k history rows of 512 B) --
+// depends on nothing the step computes: only on the history and the minibatch.  _pre computes it for
+// every output row into accP (n1 x ldw, ldw = 4*ceil(d/4)), so that it can run BESIDE the dense layers
+// that produce h / mu (the step program issues it on the auxiliary stream); _post is the rest of the
+// fused pass.  Per element the two phases perform exactly the fused kernel's operations in the fused
+// kernel's order -- accP only takes a round trip through memory -- so pre + post == sgcn_vr_aggregate_f32
+// bit for bit (tests/test_kernels_gpu.py).
+extern "C" int sgcn_vr_aggregate_pre_f32(const int32_t* f_rowptr, const int32_t* f_col, const float* f_val,
+                                         int32_t n1, int32_t nf, int32_t d, const float* Hbar, int64_t ldh,
+                                         const int32_t* ffield, float* accP, const sgcn_plan_t* f_plan,
+                                         void* stream) {
+    SGCN_REQUIRE(n1 >= 0 && nf >= 0 && d >= 0, "vr_aggregate_pre: negative size");
+    if (n1 == 0 || d == 0) return SGCN_OK;
+    SGCN_REQUIRE(f_rowptr && Hbar && accP && ldh >= d, "vr_aggregate_pre: bad operand");
+    SGCN_REQUIRE(nf == 0 || ffield, "vr_aggregate_pre: null ffield");
+    AggArgs a{};
+    a.f_rowptr = f_rowptr; a.f_col = f_col; a.f_val = f_val;
+    a.H = Hbar; a.ldh = ldh; a.ffield = ffield; a.d = d;
+    a.ldw = ((int64_t)d + 3) / 4 * 4;
+    a.accP_out = accP;
+    a.nseg = n1;
+    if (f_plan) {
+        SGCN_REQUIRE(f_plan->dev_seg && f_plan->nseg >= n1, "vr_aggregate_pre: malformed plan");
+        a.seg = f_plan->dev_seg; a.nseg = f_plan->nseg; a.ws = f_plan->dev_ws;
+        if (f_plan->nfix > 0) {
+            SGCN_REQUIRE(f_plan->dev_fix && f_plan->dev_ws, "vr_aggregate_pre: plan needs dev_fix/dev_ws");
+            SGCN_REQUIRE(f_plan->ws_elems >= f_plan->nslots * a.ldw, "vr_aggregate_pre: workspace too small");
+        }
+    }
+    const int vw = pick_vw(d, {Hbar, accP, f_plan ? f_plan->dev_ws : nullptr}, {ldh, a.ldw});
+    a.nvec = (d + vw - 1) / vw;
+    const int G = group_lanes(a.nvec);
+    a.nsegblk = (a.nseg + (kBlock / G) - 1) / (kBlock / G);
+    hipStream_t st = (hipStream_t)stream;
+    if (vw == 4) return launch_agg<4>(G, a, f_plan, st);
+    if (vw == 2) return launch_agg<2>(G, a, f_plan, st);
+    return launch_agg<1>(G, a, f_plan, st);
+}
+
+extern "C" int sgcn_vr_aggregate_post_f32(const int32_t* a_rowptr, const int32_t* a_col, const float* a_val,
+                                          int32_t n1, int32_t n0, int32_t d, const float* h, const float* mu,
+                                          int64_t ldx, const float* Hbar, int64_t ldh, const int32_t* ifield,
+                                          const float* s, float* out_h, float* out_mu, int64_t ldo, int32_t cvd,
+                                          int32_t concat_self, const float* accP, void* stream) {
+    SGCN_REQUIRE(n1 >= 0 && n0 >= 0 && d >= 0, "vr_aggregate_post: negative size");
+    if (n1 == 0 || d == 0) return SGCN_OK;
+    SGCN_REQUIRE(a_rowptr && h && Hbar && ifield && out_h && accP, "vr_aggregate_post: null operand");
+    SGCN_REQUIRE(!cvd || (mu && s && out_mu), "vr_aggregate_post: cvd needs mu, s, out_mu");
+    SGCN_REQUIRE(n1 <= n0 || !concat_self, "vr_aggregate_post: concat_self needs n1 <= n0");
+    const int64_t width = concat_self ? 2 * (int64_t)d : d;
+    SGCN_REQUIRE(ldx >= d && ldh >= d && ldo >= width, "vr_aggregate_post: leading dimension too small");
+    AggArgs a{};
+    a.a_rowptr = a_rowptr; a.a_col = a_col; a.a_val = a_val;
+    a.h = h; a.mu = mu; a.ldx = ldx; a.H = Hbar; a.ldh = ldh; a.ifield = ifield; a.s = s;
+    a.out_h = out_h; a.out_mu = out_mu; a.ldo = ldo;
+    a.d = d; a.cvd = cvd; a.concat = concat_self; a.off = concat_self ? d : 0;
+    a.ldw = ((int64_t)d + 3) / 4 * 4;
+    a.accP_in = accP;
+    int vw = pick_vw(d, {h, mu, Hbar, out_h, out_mu, accP}, {ldx, ldh, ldo, a.ldw});
+    if (concat_self) while (vw > 1 && d % vw != 0) vw >>= 1;
+    a.nvec = (d + vw - 1) / vw;
+    const int G = group_lanes(a.nvec);
+    hipStream_t st = (hipStream_t)stream;
+    if (vw == 4) return launch_agg_post<4>(G, a, n1, st);
+    if (vw == 2) return launch_agg_post<2>(G, a, n1, st);
+    return launch_agg_post<1>(G, a, n1, st);
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
 }
 
 // dx = LN-backward(dy masked by y > 0); per-block column partials of d(offset), d(scale).
-constexpr int kBwdRowsPerWave = 4;
+constexpr int kBwdRowsPerWave = 1;     // one row per wave: 4x the workgroups, a quarter of the dependent chain (the step is GPU-latency-bound)
 __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
     const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ scale,

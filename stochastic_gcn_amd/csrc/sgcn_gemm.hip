@@ -433,12 +433,75 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
 // The whole backward of one dense layer in ONE call (three Python round trips are a quarter of
 // the launch-bound training step):  g = LN/ReLU-backward(dy)  ->  dW += dropout(x)^T . g  ->
 // dx = (g . W^T) * mask.   Same kernels, same order, same results as the three separate entries.
-extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy,
-                                  const float* y, int64_t ldy, const float* xhat, const float* rstd,
-                                  const float* scale, int32_t relu, const float* x, int64_t ldx,
-                                  const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
-                                  float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
-                                  float* g_tmp, float* ws, const int32_t* gidx, void* stream) {
+// ---- the weight-gradient side of a dense layer's backward on a second stream -----------------------
+// dW = x^T g (+ its split-K reduction, + the LayerNorm parameter reduction) and dx = g W^T only share
+// their input g: in the step program (csrc/sgcn_step.cpp) the dW side runs on a library-owned auxiliary
+// stream, forked after the LayerNorm / ReLU backward that produces g, while the main stream goes on with
+// dx and the layers below.  The join is one event wait before the optimizer touches the gradients.
+// Nothing about the arithmetic changes -- same kernels, same operand order -- so results stay
+// bit-identical to the serial path; only buffers that the aux work reads must stay untouched until the
+// join: the caller's activations (the step program's arena gives every intermediate its own storage)
+// and the reduction scratch, which therefore comes from a ring owned by the aux context.
+namespace sgcn {
+namespace {
+struct AuxCtx {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    float* ring = nullptr;
+    int64_t cap = 0, off = 0, want = 0;
+    bool pending = false;
+};
+AuxCtx& aux_ctx() { static AuxCtx c; return c; }
+
+int aux_init(AuxCtx& c) {
+    if (c.st) return SGCN_OK;
+    SGCN_HIP_TRY(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+    SGCN_HIP_TRY(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+    SGCN_HIP_TRY(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
+    return SGCN_OK;
+}
+}  // namespace
+
+// make the auxiliary stream wait for everything `stream` has been given so far, and hand it out: work the
+// caller then issues on it runs beside `stream` until the next aux_join
+int aux_fork(void* stream, void** aux_stream) {
+    AuxCtx& c = aux_ctx();
+    const int rc = aux_init(c);
+    if (rc != SGCN_OK) return rc;
+    SGCN_HIP_TRY(hipEventRecord(c.fork, (hipStream_t)stream));
+    SGCN_HIP_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
+    c.pending = true;
+    *aux_stream = (void*)c.st;
+    return SGCN_OK;
+}
+
+int aux_join(void* stream) {
+    AuxCtx& c = aux_ctx();
+    if (c.pending) {
+        SGCN_HIP_TRY(hipEventRecord(c.join, c.st));
+        SGCN_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c.join, 0));
+        c.pending = false;
+    }
+    c.off = 0;
+    if (c.want > c.cap) {                 // a call did not fit: grow for the next step (nothing is in flight on
+        SGCN_HIP_TRY(hipStreamSynchronize(c.st));          // the aux stream once it is idle)
+        if (c.ring) SGCN_HIP_TRY(hipFree(c.ring));
+        c.ring = nullptr;
+        c.cap = 0;
+        const int64_t cap = c.want + c.want / 2;
+        SGCN_HIP_TRY(hipMalloc((void**)&c.ring, (size_t)cap * sizeof(float)));
+        c.cap = cap;
+    }
+    c.want = 0;
+    return SGCN_OK;
+}
+
+static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy,
+                          const float* y, int64_t ldy, const float* xhat, const float* rstd,
+                          const float* scale, int32_t relu, const float* x, int64_t ldx,
+                          const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
+                          float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
+                          float* g_tmp, float* ws, const int32_t* gidx, void* stream, bool overlap) {
     SGCN_REQUIRE(n >= 0 && N >= 0 && K >= 0, "dense_bwd: negative size");
     if (n == 0 || N == 0 || K == 0) return SGCN_OK;
     SGCN_REQUIRE(dy && x && W && dW, "dense_bwd: null operand");
@@ -449,13 +512,35 @@ extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* 
     // ws = [LayerNorm partials | split-K partials]: both live until the combined reduction
     const int64_t ln_floats = scale ? (sgcn_ln_act_bwd_ws_floats(n, N) + 3) / 4 * 4 : 0;
     float* ws_gemm = ws ? ws + ln_floats : nullptr;
+    // overlapped: the reduction scratch of the dW side comes from the aux ring (it must survive until the join)
+    float* ws_ln = ws;
+    float* ws_dw = ws_gemm;
+    hipStream_t st_dw = st;
+    if (overlap && dx) {
+        AuxCtx& c = aux_ctx();
+        const int rc0 = aux_init(c);
+        if (rc0 != SGCN_OK) return rc0;
+        const int64_t need = ln_floats + (ws ? (sgcn_gemm_ws_floats(K, N, n) + 3) / 4 * 4 : 0);
+        c.want += need;
+        if (c.off + need <= c.cap) {
+            if (ws) { ws_ln = c.ring + c.off; ws_dw = c.ring + c.off + ln_floats; }
+            c.off += need;
+            st_dw = c.st;
+        }
+    }
     if (scale || relu) {
         SGCN_REQUIRE(g_tmp && y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
         SGCN_REQUIRE(!scale || ws, "dense_bwd: LayerNorm backward needs the workspace");
         const int rc = ln_act_bwd_launch(dy, lddy, y, ldy, xhat, rstd, scale, n, N, relu, g_tmp, N, doffset, dscale,
-                                         ws, /*reduce_params=*/false, &nblk, st);
+                                         ws_ln, /*reduce_params=*/false, &nblk, st);
         if (rc != SGCN_OK) return rc;
         g = g_tmp; ldg = N;
+    }
+    if (st_dw != st) {                    // fork: the aux stream sees everything the main stream did so far
+        AuxCtx& c = aux_ctx();
+        SGCN_HIP_TRY(hipEventRecord(c.fork, st));
+        SGCN_HIP_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
+        c.pending = true;
     }
     // dW[K x N] += x^T[K x n] . g[n x N]      (x stored [n x K]: trans_a); its split-K reduction and the
     // LayerNorm parameter reduction share one launch
@@ -466,16 +551,36 @@ extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* 
     a.drop_a = drop_args(drop);
     SGCN_REQUIRE(!a.drop_a.on || a.drop_a.width == K, "dense_bwd: dropout width must be K");
     ReduceJob job{};
-    int rc = launch_gemm(a, 1, 0, ws_gemm, st, &job);
+    int rc = launch_gemm(a, 1, 0, ws_dw, st_dw, &job);
     if (rc != SGCN_OK) return rc;
     if (job.pending || nblk > 0) {
         const int gb = job.pending ? (int)(((int64_t)job.M * job.N + 255) / 256) : 0;
         const int lb = nblk > 0 ? (2 * N + 255) / 256 : 0;
-        hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, st, job, gb, ws, nblk, N,
+        hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, st_dw, job, gb, ws_ln, nblk, N,
                            doffset, dscale);
         SGCN_HIP_TRY(hipGetLastError());
     }
     if (!dx) return SGCN_OK;
     // dx[n x K] = g[n x N] . W^T              (W stored [K x N]: trans_b)
     return sgcn_gemm_f32(0, 1, n, K, N, g, ldg, W, ldw, dx, lddx, 0, ws_gemm, nullptr, drop, stream);
+}
+
+int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                         const float* xhat, const float* rstd, const float* scale, int32_t relu, const float* x,
+                         int64_t ldx, const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
+                         float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop, float* g_tmp, float* ws,
+                         const int32_t* gidx, void* stream) {
+    return dense_bwd_impl(n, N, K, dy, lddy, y, ldy, xhat, rstd, scale, relu, x, ldx, W, ldw, dW, lddw, doffset, dscale,
+                          dx, lddx, drop, g_tmp, ws, gidx, stream, tune_get("step_overlap") != 0);
+}
+}  // namespace sgcn
+
+extern "C" int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy,
+                                  const float* y, int64_t ldy, const float* xhat, const float* rstd,
+                                  const float* scale, int32_t relu, const float* x, int64_t ldx,
+                                  const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
+                                  float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
+                                  float* g_tmp, float* ws, const int32_t* gidx, void* stream) {
+    return sgcn::dense_bwd_impl(n, N, K, dy, lddy, y, ldy, xhat, rstd, scale, relu, x, ldx, W, ldw, dW, lddw, doffset,
+                                dscale, dx, lddx, drop, g_tmp, ws, gidx, stream, false);
 }

@@ -269,7 +269,21 @@ private:
 
     // Uniform sampling w/o replacement, optional control-variate extras (scheduler.cpp:125-180)
     int expand_uniform(int32_t degree, size_t n_out) {
+        // The batch's rows are scattered over a CSR of hundreds of MB (shuffled train ids): every row
+        // starts with two DRAM misses (neighbour ids, weights).  The ids are known up front, so the rows a
+        // few iterations ahead are prefetched -- the row pointer first (it is needed to form the address),
+        // then the first lines of both arrays; the hardware prefetcher follows the rest of a row.
+        constexpr size_t kAheadPtr = 16, kAhead = 8;
         for (size_t i = 0; i < n_out; i++) {
+            if (i + kAheadPtr < n_out) __builtin_prefetch(ptr_.data() + field_[i + kAheadPtr], 0, 1);
+            if (i + kAhead < n_out) {
+                const int32_t pv = ptr_[field_[i + kAhead]];
+                const int32_t pdeg = ptr_[field_[i + kAhead] + 1] - pv;
+                const char* c0 = reinterpret_cast<const char*>(nbr_.data() + pv);
+                const char* w0 = reinterpret_cast<const char*>(wgt_.data() + pv);
+                const int lines = std::min(4, (pdeg * 4 + 63) / 64);
+                for (int q = 0; q < lines; q++) { __builtin_prefetch(c0 + 64 * q, 1, 1); __builtin_prefetch(w0 + 64 * q, 1, 1); }
+            }
             const int32_t v = field_[i];
             int32_t* cols = nbr_.data() + ptr_[v];
             float* vals = wgt_.data() + ptr_[v];
@@ -530,7 +544,7 @@ struct sgcn_mult { sgcn::FenwickMultinomial impl; };
 extern "C" {
 
 const char* sgcn_last_error(void) { return sgcn::error_slot(); }
-int sgcn_abi_version(void) { return 3; }
+int sgcn_abi_version(void) { return 4; }
 
 int sgcn_sched_create(const float* w, const int32_t* idx, const int32_t* ptr, int32_t num_data,
                       int32_t num_edges, int32_t L, int32_t cv, int32_t is, sgcn_sched_t** out) {

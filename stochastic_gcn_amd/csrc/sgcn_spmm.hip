@@ -36,6 +36,7 @@ int g_tune_cs_pace = 0;
 int g_tune_cs_slack = 0;
 int g_tune_cs_generic = 0;
 int g_tune_cs_noextra = 0;
+int g_tune_step_overlap = 1;
 }  // namespace
 
 int tune_get(const char* key) {
@@ -48,6 +49,7 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_slack")) return g_tune_cs_slack;
     if (!strcmp(key, "cs_generic")) return g_tune_cs_generic;
     if (!strcmp(key, "cs_noextra")) return g_tune_cs_noextra;
+    if (!strcmp(key, "step_overlap")) return g_tune_step_overlap;
     return -1;
 }
 
@@ -273,6 +275,7 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "cs_slack")) { SGCN_REQUIRE(value >= 0, "cs_slack >= 0"); g_tune_cs_slack = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_generic")) { g_tune_cs_generic = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_noextra")) { g_tune_cs_noextra = value != 0; return SGCN_OK; }
+    if (!strcmp(key, "step_overlap")) { g_tune_step_overlap = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_unroll")) {
         SGCN_REQUIRE(value == 0 || value == 4 || value == 8, "cs_unroll in {0,4,8}");

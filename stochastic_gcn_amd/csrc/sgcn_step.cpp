@@ -1,0 +1,267 @@
+// Native launch loop of one training / evaluation step (include/sgcn.h sgcn_step_run).
+//
+// The reference runs a step as ONE sess.run of a static TensorFlow graph (gcn/vrgcn.py:72-82,
+// gcn/train.py:187-209).  The eager host path of this build issues the same step as ~17 C-ABI calls
+// from Python, and measures host-bound: 0.30 ms of interpreter time per step around 0.26 ms of GPU
+// work (profiles/host_bound_probe.py).  Here the step is a PROGRAM -- a flat list of C-ABI calls whose
+// arguments are affine in a small table of per-minibatch slots (row counts, addresses inside the
+// minibatch's staging buffer, dropout keys, the Adam step size) -- compiled once per model by
+// stochastic_gcn_amd/step_program.py and executed by ONE foreign call per step.  Every op is one of the
+// library's own entry points, called with exactly the arguments the eager path would pass, so the two
+// paths are bit-identical (tests/test_step_program_gpu.py).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "sgcn_host.h"
+#include "../../include/sgcn.h"
+
+namespace sgcn {
+// sgcn_gemm.hip: sgcn_dense_bwd_f32 with its weight-gradient side (dW GEMM, split-K and LayerNorm-parameter
+// reductions) on the library's auxiliary stream, and the join that makes `stream` wait for that work
+int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                         const float* xhat, const float* rstd, const float* scale, int32_t relu, const float* x,
+                         int64_t ldx, const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
+                         float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop, float* g_tmp, float* ws,
+                         const int32_t* gidx, void* stream);
+int aux_join(void* stream);
+int aux_fork(void* stream, void** aux_stream);
+}  // namespace sgcn
+
+namespace {
+
+inline float f32(int64_t v) {
+    const uint32_t b = (uint32_t)(uint64_t)v;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+template <class T> inline T* ptr(int64_t v) { return reinterpret_cast<T*>((uintptr_t)v); }
+
+struct Args {
+    int64_t v[SGCN_STEP_MAX_ARGS];
+    int n, pos;
+    int64_t next() { return pos < n ? v[pos++] : 0; }
+    template <class T> T* p() { return ptr<T>(next()); }
+    int32_t i() { return (int32_t)next(); }
+    float f() { return f32(next()); }
+    // {on, key, keep, rows, width} -> sgcn_dropout_t (nullptr when off)
+    const sgcn_dropout_t* drop(sgcn_dropout_t* st) {
+        const int64_t on = next();
+        st->key = (uint32_t)next(); st->keep = f(); st->rows = i(); st->width = i();
+        return on ? st : nullptr;
+    }
+    // {on, seg, nseg, fix, nfix, nslots, ws, ws_elems} -> sgcn_plan_t
+    const sgcn_plan_t* plan(sgcn_plan_t* st) {
+        const int64_t on = next();
+        st->dev_seg = p<const sgcn_seg_t>(); st->nseg = next();
+        st->dev_fix = p<const sgcn_fix_t>(); st->nfix = next();
+        st->nslots = next(); st->dev_ws = p<float>(); st->ws_elems = next();
+        if (st->nfix == 0) st->dev_fix = nullptr;
+        return on ? st : nullptr;
+    }
+};
+
+}  // namespace
+
+extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int64_t* slots, int32_t nslots,
+                             void* stream) {
+    if (nops < 0 || (nops > 0 && !ops) || nslots < 0 || (nslots > 0 && !slots))
+        return sgcn::fail(SGCN_ERR_INVALID, "step_run: bad argument");
+    bool memset_on_aux = false;
+    const bool overlap = sgcn_tune_get("step_overlap") != 0;
+    for (int32_t k = 0; k < nops; k++) {
+        const sgcn_step_op_t& op = ops[k];
+        if (op.nargs < 0 || op.nargs > SGCN_STEP_MAX_ARGS)
+            return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d has %d arguments", k, op.nargs);
+        Args a;
+        a.n = op.nargs; a.pos = 0;
+        for (int j = 0; j < op.nargs; j++) {
+            const int32_t s = op.slot[j];
+            if (s >= nslots) return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d reads slot %d of %d", k, s, nslots);
+            a.v[j] = (s < 0 ? 0 : op.mul[j] * slots[s]) + op.add[j];
+        }
+        int rc = SGCN_OK;
+        sgcn_dropout_t dr;
+        sgcn_plan_t pl;
+        // weight-gradient work forked onto the auxiliary stream (DENSE_BWD) is joined before anything that
+        // reads or writes gradients outside the backward chain
+        if (op.op == SGCN_OP_ADAM || op.op == SGCN_OP_L2_PENALTY || op.op == SGCN_OP_SCATTER_ROWS ||
+            op.op == SGCN_OP_MEMSET0 || op.op == SGCN_OP_VR_AGG_POST || (op.op == SGCN_OP_DENSE_BWD && memset_on_aux)) {
+            rc = sgcn::aux_join(stream);
+            if (rc != SGCN_OK) return rc;
+            memset_on_aux = false;
+        }
+        void* side = stream;                 // where an AUX_* / *_PRE op runs
+        if (overlap && (op.op == SGCN_OP_VR_AGG_PRE || op.op == SGCN_OP_AUX_SCATTER_ROWS || op.op == SGCN_OP_AUX_MEMSET0)) {
+            rc = sgcn::aux_fork(stream, &side);
+            if (rc != SGCN_OK) return rc;
+        }
+        switch (op.op) {
+        case SGCN_OP_DENSE_FWD: {
+            const int32_t M = a.i(), N = a.i(), K = a.i();
+            const float* X = a.p<const float>(); const int64_t ldx = a.next();
+            const float* X2 = a.p<const float>(); const int64_t ldx2 = a.next();
+            const int32_t split = a.i();
+            const float* W = a.p<const float>(); const int64_t ldw = a.next();
+            const float* off = a.p<const float>(); const float* sc = a.p<const float>();
+            const float eps = a.f(); const int32_t relu = a.i();
+            float* Y = a.p<float>(); const int64_t ldy = a.next();
+            float* xhat = a.p<float>(); float* rstd = a.p<float>();
+            const sgcn_dropout_t* d = a.drop(&dr);
+            float* ws = a.p<float>(); const int64_t ws_cap = a.next();
+            const int32_t* g1 = a.p<const int32_t>(); const int32_t* g2 = a.p<const int32_t>();
+            // the eager wrapper (ops.dense_fwd): split-K scratch only where the library asks for it
+            const int64_t need = N <= 128 ? sgcn_gemm_ws_floats(M, N, K) : 0;
+            if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
+            rc = sgcn_dense_fwd_f32(M, N, K, X, ldx, X2, ldx2, split, W, ldw, off, sc, eps, relu, Y, ldy, xhat, rstd, d,
+                                    need ? ws : nullptr, g1, g2, stream);
+            break;
+        }
+        case SGCN_OP_DENSE_BWD: {
+            const int32_t n = a.i(), N = a.i(), K = a.i();
+            const float* dy = a.p<const float>(); const int64_t lddy = a.next();
+            const float* y = a.p<const float>(); const int64_t ldy = a.next();
+            const float* xhat = a.p<const float>(); const float* rstd = a.p<const float>();
+            const float* sc = a.p<const float>(); const int32_t relu = a.i();
+            const float* x = a.p<const float>(); const int64_t ldx = a.next();
+            const float* W = a.p<const float>(); const int64_t ldw = a.next();
+            float* dW = a.p<float>(); const int64_t lddw = a.next();
+            float* doff = a.p<float>(); float* dsc = a.p<float>();
+            float* dx = a.p<float>(); const int64_t lddx = a.next();
+            const sgcn_dropout_t* d = a.drop(&dr);
+            float* gtmp = a.p<float>();
+            float* ws = a.p<float>(); const int64_t ws_cap = a.next();
+            const int32_t* gidx = a.p<const int32_t>();
+            const bool norm = xhat != nullptr;
+            const int64_t need = (norm ? (sgcn_ln_act_bwd_ws_floats(n, N) + 3) / 4 * 4 : 0) +
+                                 std::max(sgcn_gemm_ws_floats(K, N, n), sgcn_gemm_ws_floats(n, K, N));
+            if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: backward scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
+            rc = sgcn::dense_bwd_overlapped(n, N, K, dy, lddy, y, ldy, xhat, rstd, sc, relu, x, ldx, W, ldw, dW, lddw, doff,
+                                            dsc, dx, lddx, d, gtmp, need ? ws : nullptr, gidx, stream);
+            break;
+        }
+        case SGCN_OP_VR_AGG: {
+            const int32_t* arp = a.p<const int32_t>(); const int32_t* ac = a.p<const int32_t>(); const float* av = a.p<const float>();
+            const int32_t* frp = a.p<const int32_t>(); const int32_t* fc = a.p<const int32_t>(); const float* fv = a.p<const float>();
+            const int32_t n1 = a.i(), n0 = a.i(), nf = a.i(), d = a.i();
+            const float* h = a.p<const float>(); const float* mu = a.p<const float>(); const int64_t ldx = a.next();
+            const float* H = a.p<const float>(); const int64_t ldh = a.next();
+            const int32_t* ifi = a.p<const int32_t>(); const int32_t* ffi = a.p<const int32_t>();
+            const float* s = a.p<const float>();
+            float* oh = a.p<float>(); float* om = a.p<float>(); const int64_t ldo = a.next();
+            const int32_t cvd = a.i(), concat = a.i();
+            const sgcn_plan_t* p = a.plan(&pl);
+            rc = sgcn_vr_aggregate_f32(arp, ac, av, frp, fc, fv, n1, n0, nf, d, h, mu, ldx, H, ldh, ifi, ffi, s, oh, om, ldo,
+                                       cvd, concat, p, stream);
+            break;
+        }
+        case SGCN_OP_SPMM: {
+            const int32_t* rp = a.p<const int32_t>(); const int32_t* c = a.p<const int32_t>(); const float* v = a.p<const float>();
+            const int32_t M = a.i(), K = a.i(), d = a.i();
+            const float* B = a.p<const float>(); const int64_t ldb = a.next();
+            const int32_t* gidx = a.p<const int32_t>(); const float* rs = a.p<const float>(); const float* cs = a.p<const float>();
+            float* C = a.p<float>(); const int64_t ldc = a.next(); const float beta = a.f();
+            const sgcn_plan_t* p = a.plan(&pl);
+            const float* add = a.p<const float>(); const int64_t ldadd = a.next(); const int32_t add_rows = a.i();
+            rc = add ? sgcn_spmm_csr_add_f32(rp, c, v, M, K, d, B, ldb, gidx, rs, cs, C, ldc, beta, p, add, ldadd, add_rows, stream)
+                     : sgcn_spmm_csr_f32(rp, c, v, M, K, d, B, ldb, gidx, rs, cs, C, ldc, beta, p, stream);
+            break;
+        }
+        case SGCN_OP_SOFTMAX_CE:
+        case SGCN_OP_SIGMOID_CE: {
+            const float* z = a.p<const float>(); const int64_t ldz = a.next();
+            const float* lab = a.p<const float>(); const int64_t ldl = a.next();
+            const int32_t n = a.i(), c = a.i();
+            float* dz = a.p<float>(); const int64_t lddz = a.next();
+            float* pred = a.p<float>(); const int64_t ldp = a.next();
+            float* stats = a.p<float>(); float* rowstat = a.p<float>();
+            rc = op.op == SGCN_OP_SOFTMAX_CE ? sgcn_softmax_ce_f32(z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream)
+                                             : sgcn_sigmoid_ce_f32(z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream);
+            break;
+        }
+        case SGCN_OP_ADAM: {
+            float* th = a.p<float>(); const float* g = a.p<const float>(); float* m = a.p<float>(); float* v = a.p<float>();
+            const int64_t n = a.next();
+            const float lr = a.f(), b1 = a.f(), b2 = a.f(), eps = a.f();
+            rc = sgcn_adam_f32(th, g, m, v, n, lr, b1, b2, eps, stream);
+            break;
+        }
+        case SGCN_OP_SCATTER_ROWS:
+        case SGCN_OP_AUX_SCATTER_ROWS: {
+            float* H = a.p<float>(); const int64_t ldh = a.next();
+            const int32_t* r = a.p<const int32_t>(); const int32_t n = a.i(), d = a.i();
+            const float* src = a.p<const float>(); const int64_t lds = a.next();
+            rc = sgcn_scatter_rows_f32(H, ldh, r, n, d, src, lds, side);
+            break;
+        }
+        case SGCN_OP_VR_AGG_PRE: {
+            const int32_t* frp = a.p<const int32_t>(); const int32_t* fc = a.p<const int32_t>(); const float* fv = a.p<const float>();
+            const int32_t n1 = a.i(), nf = a.i(), d = a.i();
+            const float* H = a.p<const float>(); const int64_t ldh = a.next();
+            const int32_t* ffi = a.p<const int32_t>();
+            float* accP = a.p<float>();
+            const sgcn_plan_t* p = a.plan(&pl);
+            rc = sgcn_vr_aggregate_pre_f32(frp, fc, fv, n1, nf, d, H, ldh, ffi, accP, p, side);
+            break;
+        }
+        case SGCN_OP_VR_AGG_POST: {
+            const int32_t* arp = a.p<const int32_t>(); const int32_t* ac = a.p<const int32_t>(); const float* av = a.p<const float>();
+            const int32_t n1 = a.i(), n0 = a.i(), d = a.i();
+            const float* h = a.p<const float>(); const float* mu = a.p<const float>(); const int64_t ldx = a.next();
+            const float* H = a.p<const float>(); const int64_t ldh = a.next();
+            const int32_t* ifi = a.p<const int32_t>(); const float* s = a.p<const float>();
+            float* oh = a.p<float>(); float* om = a.p<float>(); const int64_t ldo = a.next();
+            const int32_t cvd = a.i(), concat = a.i();
+            const float* accP = a.p<const float>();
+            rc = sgcn_vr_aggregate_post_f32(arp, ac, av, n1, n0, d, h, mu, ldx, H, ldh, ifi, s, oh, om, ldo, cvd, concat, accP, stream);
+            break;
+        }
+        case SGCN_OP_GATHER_ROWS: {
+            const float* in = a.p<const float>(); const int64_t ldi = a.next();
+            const int32_t* r = a.p<const int32_t>(); const int32_t n = a.i(), d = a.i();
+            float* out = a.p<float>(); const int64_t ldo = a.next();
+            rc = sgcn_gather_rows_f32(in, ldi, r, n, d, out, ldo, stream);
+            break;
+        }
+        case SGCN_OP_DROPOUT: {
+            const float* x = a.p<const float>(); const int64_t ldx = a.next();
+            const int32_t n = a.i(), d = a.i();
+            a.drop(&dr);
+            float* out = a.p<float>(); const int64_t ldo = a.next();
+            rc = sgcn_dropout_f32(x, ldx, n, d, &dr, out, ldo, stream);
+            break;
+        }
+        case SGCN_OP_L2_PENALTY: {
+            const float* th = a.p<const float>(); const int64_t lo = a.next(), hi = a.next();
+            const float wd = a.f();
+            float* g = a.p<float>(); float* loss = a.p<float>();
+            rc = sgcn_l2_penalty_f32(th, lo, hi, wd, g, loss, stream);
+            break;
+        }
+        case SGCN_OP_MEMSET0:
+        case SGCN_OP_AUX_MEMSET0: {
+            void* p = a.p<void>(); const int64_t bytes = a.next();
+            if (bytes > 0 && hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)side) != hipSuccess)
+                return sgcn::fail(SGCN_ERR_HIP, "step_run: hipMemsetAsync failed");
+            if (op.op == SGCN_OP_AUX_MEMSET0 && side != stream) memset_on_aux = true;
+            break;
+        }
+        case SGCN_OP_COPY2D: {
+            void* dst = a.p<void>(); const int64_t ldd = a.next();
+            const void* src = a.p<const void>(); const int64_t lds = a.next();
+            const int64_t rows = a.next(), cols = a.next();          // floats
+            if (rows > 0 && cols > 0 &&
+                hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds * 4, (size_t)cols * 4, (size_t)rows,
+                                 hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                return sgcn::fail(SGCN_ERR_HIP, "step_run: hipMemcpy2DAsync failed");
+            break;
+        }
+        default:
+            return sgcn::fail(SGCN_ERR_INVALID, "step_run: unknown opcode %d at op %d", op.op, k);
+        }
+        if (rc != SGCN_OK) { sgcn::aux_join(stream); return rc; }       // the failing entry point has set the message
+    }
+    return sgcn::aux_join(stream);          // a run never returns with work pending on the auxiliary stream
+}

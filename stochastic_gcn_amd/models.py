@@ -577,7 +577,89 @@ class GCN(Model):
                 nn_ops *= 2
             self.nn_ops += nn_ops
 
+    # ---- the step as one call of the native launch loop (step_program.py) -----------------------------
+    def _program(self, feed_dict, dropout):
+        """The compiled step program for this minibatch, or None (eager path): packed batches only, a
+        supported layer stack, and a minibatch that fits the program's buffers."""
+        if not (FLAGS.native_step and self.is_training and isinstance(feed_dict, PackedBatch)):
+            return None
+        key = round(float(dropout), 9)
+        progs = self.__dict__.setdefault('_programs', {})
+        if key not in progs:
+            from .step_program import StepProgram, Unsupported
+            try:
+                progs[key] = StepProgram(self, dropout)
+            except Unsupported as e:
+                progs[key] = None
+                self._program_note = str(e)
+        prog = progs[key]
+        return prog if (prog is not None and prog.fits(feed_dict)) else None
+
+    def _run_program(self, prog, pb, sync):
+        t = time()
+        dev = self.device
+        n_i = max(pb.n_i, 1)
+        if pb.slot is not None:
+            # ONE H2D copy [int32 section | fp32 section], on a COPY stream: the host runs a step or two ahead
+            # of the GPU, so the next minibatch crosses PCIe while the current step computes instead of
+            # queueing behind it (the copy is ~1 MB: 20-25 us of an otherwise idle compute stream per step)
+            main = torch.cuda.current_stream()
+            cs = self.__dict__.get('_copy_stream')
+            if cs is None:
+                cs = self._copy_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(cs):
+                words = pb.slot.buf[:n_i + max(pb.n_f, 1)].to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+            pb.slot.event = ev                # the producer waits on it before reusing the slot
+            main.wait_event(ev)
+            words.record_stream(main)
+            ip = words.data_ptr()
+            fp = ip + 4 * n_i
+            self._live_batch = words
+        else:
+            ib = torch.from_numpy(pb.ibuf[:n_i]).to(dev, non_blocking=True)
+            fb = torch.from_numpy(pb.fbuf[:max(pb.n_f, 1)]).to(dev, non_blocking=True)
+            ip, fp = ib.data_ptr(), fb.data_ptr()
+            self._live_batch = (ib, fb)
+        m, base, ND = pb.m, pb.o_csr, _CSR_DESC
+        self._count_sizes(dict(adj=[m[base + 3 * l * ND + 2] for l in range(self.L)],
+                               fadj=[m[base + (3 * l + 2) * ND + 2] for l in range(self.L)],
+                               fields=[m[5 + 2 * l] for l in range(self.L + 1)]))
+        self.g_t += time() - t
+        t = time()
+        self.adam_t += 1
+        b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
+        lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
+        prog.fill(pb, ip, fp, self.dropout_step, lr_t)
+        stream = torch.cuda.current_stream().cuda_stream
+        if self.grad_hook is None and self.history_hook is None:
+            prog.run('all', stream)
+        else:                                 # data parallel: collectives between the program's phases
+            prog.run('fb', stream)
+            if self.grad_hook is not None:
+                self.grad_hook(self.grad)
+            prog.run('opt', stream)
+            if self.history_hook is None:
+                prog.run('hist', stream)
+            else:
+                for l, nh in prog.new_history.items():
+                    n = m[5 + 2 * l]
+                    idx = words[m[4 + 2 * l]:m[4 + 2 * l] + n] if pb.slot is not None else ib[m[4 + 2 * l]:m[4 + 2 * l] + n]
+                    self.history_hook(self.history[l][0], idx, prog.tensor_of(nh, n), ops.scatter_rows)
+        self.dropout_step += 1
+        loss, acc = prog.loss_t, prog.acc_t
+        if sync:
+            loss, acc = float(loss), float(acc)
+        self.run_t += time() - t
+        return [None, loss, acc]
+
     def run_one_step(self, sess, feed_dict, sync=True):
+        if self.is_training and isinstance(feed_dict, PackedBatch):
+            prog = self._program(feed_dict, float(getattr(feed_dict, 'dropout', 0.0) or 0.0))
+            if prog is not None:
+                self.dropout = prog.dropout
+                return self._run_program(prog, feed_dict, sync)
         t = time()
         if not self.is_training:
             self.dropout = 0.0

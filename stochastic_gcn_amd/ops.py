@@ -234,6 +234,31 @@ def vr_aggregate(A, P, h, mu, Hbar, ifield, ffield, s, cvd, concat_self, out_h=N
     return out_h, out_mu
 
 
+def vr_aggregate_two_phase(A, P, h, mu, Hbar, ifield, ffield, s, cvd, concat_self, stream_pre=None):
+    """The same aggregate as ``vr_aggregate`` through sgcn_vr_aggregate_pre_f32 + _post_f32 (what the step
+    program issues, the first phase beside the dense layers): bit-identical to the fused call."""
+    n1, n0 = A.shape
+    nf = P.shape[1]
+    hptr, ldx = _rows2d(h, "h")
+    d = int(h.shape[1])
+    width = 2 * d if concat_self else d
+    Hptr, ldh = _rows2d(Hbar, "Hbar")
+    ldw = (d + 3) // 4 * 4
+    accP = torch.empty((n1, ldw), dtype=torch.float32, device=h.device)
+    plan = P.plan.struct(d) if P.plan is not None else None
+    check(lib.sgcn_vr_aggregate_pre_f32(P.rowptr.data_ptr(), _ptr(P.col), _ptr(P.val), n1, nf, d, Hptr, ldh,
+                                        _ptr(_dev(ffield, torch.int32, "ffield")), accP.data_ptr(),
+                                        C.byref(plan) if plan is not None else None, _stream()))
+    out_h = torch.empty((n1, width), dtype=torch.float32, device=h.device)
+    out_mu = torch.empty((n1, width), dtype=torch.float32, device=h.device) if cvd else None
+    check(lib.sgcn_vr_aggregate_post_f32(A.rowptr.data_ptr(), _ptr(A.col), _ptr(A.val), n1, n0, d, hptr,
+                                         _rows2d(mu, "mu")[0] if cvd else None, ldx, Hptr, ldh,
+                                         _ptr(_dev(ifield, torch.int32, "ifield")), _ptr(_dev(s, torch.float32, "s")),
+                                         out_h.data_ptr(), _ptr(out_mu), width, int(bool(cvd)), int(bool(concat_self)),
+                                         accP.data_ptr(), _stream()))
+    return out_h, out_mu
+
+
 def gather_rows(inp, idx, out=None, d=None):
     """out[i, :d] = inp[idx[i], :d]   (sgcn_gather_rows_f32)."""
     iptr, ldi = _rows2d(inp, "inp")

@@ -1,0 +1,561 @@
+"""The training step as a PROGRAM for the library's native launch loop (include/sgcn.h sgcn_step_run,
+csrc/sgcn_step.cpp).
+
+The reference executes a step as one ``sess.run`` of a static graph (gcn/vrgcn.py:72-82).  The eager
+path of this package walks ``model.layers`` in Python every step and is host-bound (0.30 ms of
+interpreter time around 0.26 ms of GPU work per Reddit CVD+PP step).  ``StepProgram`` walks the layers
+ONCE, symbolically -- the same decisions as ``layers.py`` (pending dropout rides into the consuming
+GEMM, the first dense layer reads its rows through the field index, the CVD streams run stacked ...) --
+and emits the flat list of C-ABI calls a step consists of, with every argument affine in a small slot
+table.  Per step the host then (1) copies the minibatch's staging buffer to the device, (2) fills the
+slot table from the sampler's descriptor (three NumPy operations) and (3) makes ONE foreign call.
+
+Intermediates live in a preallocated arena sized from the flags' row bounds (|field l| <= batch *
+prod(1 + degree)); a minibatch that does not fit, a feed-dict that is not a PackedBatch, or a layer
+stack outside the supported set (sparse input features, hidden width > 128 with LayerNorm, the
+library-GEMM size class) falls back to the eager path, which stays the reference implementation: both
+run the same kernels with the same arguments and are bit-identical (tests/test_step_program_gpu.py).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops
+from ._ffi import StepOp, check, lib
+from .flags import FLAGS
+from .layers import AugmentedDropoutDense, Dense, Dropout, PlainAggregator, VRAggregator
+from .scheduler import CSR_DESC, PackedBatch
+
+OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
+          DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17)
+MAX_ARGS = 48
+ARENA_LIMIT_BYTES = 2 << 30
+
+
+class Unsupported(Exception):
+    pass
+
+
+def _fbits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def K(v):
+    """constant operand"""
+    return (0, -1, int(v))
+
+
+NULL = K(0)
+
+
+class Rows(object):
+    """row count  mul * slots[slot] + add  with its capacity (upper bound used to size buffers)"""
+    __slots__ = ("mul", "slot", "add", "cap")
+
+    def __init__(self, mul, slot, add, cap):
+        self.mul, self.slot, self.add, self.cap = mul, slot, add, cap
+
+    def op(self):
+        return (self.mul, self.slot, self.add)
+
+    def __add__(self, o):
+        if self.slot != o.slot and self.slot >= 0 and o.slot >= 0:
+            raise Unsupported("row count over two slots")
+        return Rows(self.mul + o.mul, self.slot if self.slot >= 0 else o.slot, self.add + o.add, self.cap + o.cap)
+
+
+class ST(object):
+    """symbolic 2-D fp32 activation: address (affine), rows, cols, ld (floats)"""
+    __slots__ = ("ptr", "rows", "cols", "ld")
+
+    def __init__(self, ptr, rows, cols, ld):
+        self.ptr, self.rows, self.cols, self.ld = ptr, rows, cols, ld
+
+    def head(self, rows):                       # t[:rows]
+        return ST(self.ptr, rows, self.cols, self.ld)
+
+    def tail(self, start):                      # t[start:], start a Rows over one slot; self.ptr constant
+        if self.ptr[1] >= 0:
+            raise Unsupported("row offset of a slot-addressed tensor")
+        rest = Rows(self.rows.mul - start.mul, self.rows.slot, self.rows.add - start.add, self.rows.cap - start.cap)
+        return ST((start.mul * self.ld * 4, start.slot, self.ptr[2] + start.add * self.ld * 4), rest, self.cols, self.ld)
+
+    def cols_from(self, c0, ncols):             # t[:, c0:c0+ncols]
+        return ST((self.ptr[0], self.ptr[1], self.ptr[2] + 4 * c0), self.rows, ncols, self.ld)
+
+
+class SGather(object):
+    """src[idx] that has not been gathered (ops.GatheredRows)"""
+    __slots__ = ("src", "idx", "rows", "_m")
+
+    def __init__(self, src, idx, rows):
+        self.src, self.idx, self.rows, self._m = src, idx, rows, None
+
+    @property
+    def cols(self):
+        return self.src.cols
+
+
+class SDropped(object):
+    """activation with a pending dropout (layers.Dropped)"""
+    __slots__ = ("x", "site", "_m")
+
+    def __init__(self, x, site):
+        self.x, self.site, self._m = x, site, None
+
+
+class StepProgram(object):
+    def __init__(self, model, dropout):
+        self.model = m = model
+        self.dropout = float(dropout)
+        if m.sparse_input or m.multitask and False:
+            raise Unsupported("sparse input features")
+        if not isinstance(m.features_dev, torch.Tensor):
+            raise Unsupported("features are not a dense device tensor")
+        self.dev = m.device
+        self.L = m.L
+        self.cv = bool(m.history)
+        # row bounds from the flags (same bound parallel.py uses for the history exchange)
+        deg = FLAGS.degree if m.is_training else FLAGS.test_degree
+        bs = FLAGS.batch_size if m.is_training else FLAGS.test_batch_size
+        n = int(m.num_data)
+        caps = [0] * (self.L + 1)
+        caps[self.L] = min(n, int(bs))
+        for l in range(self.L - 1, -1, -1):
+            caps[l] = min(n, caps[l + 1] * (1 + int(deg)))
+        self.caps = caps
+        self._pb = PackedBatch(self.L, self.cv, np.zeros(int(lib.sgcn_sched_packed_meta_len(self.L)), np.int64),
+                               None, None, 0, 0, None)          # only for its offsets
+        self.plan_ws_floats = 8 << 20          # partial sums of split rows (checked per step)
+        self.gemm_ws_floats = 4 << 20
+        self.ws_plan = torch.empty(self.plan_ws_floats, dtype=torch.float32, device=self.dev)
+        self.ws_gemm = torch.empty(self.gemm_ws_floats, dtype=torch.float32, device=self.dev)
+        # pass 1 (addresses relative to 0) sizes the arena and numbers the slots; pass 2 emits the program
+        self._arena_base, self._n_meta, self._key_layers = 0, 0, []
+        self._reset()
+        self._build()
+        if self._arena_off * 4 > ARENA_LIMIT_BYTES:
+            raise Unsupported("activation arena of %.1f GB" % (self._arena_off * 4 / 2 ** 30))
+        self.arena = torch.empty(max(self._arena_off, 64), dtype=torch.float32, device=self.dev)
+        self._arena_base, self._n_meta, self._key_layers = self.arena.data_ptr(), len(self._fill), sorted(self._keys_seen)
+        self._reset()
+        self._build()
+        assert len(self._fill) == self._n_meta and sorted(self._keys_seen) == self._key_layers
+        self._finalize()
+
+    def _reset(self):
+        self.ops_fb, self.ops_opt, self.ops_hist = [], [], []
+        self._cur = self.ops_fb
+        self._slot_of, self._fill = {}, []   # slot table: [meta-derived ...][dropout keys ...][lr_t]; fill = (meta index, mul, 0 | 1 ip | 2 fp)
+        self._keys_seen = set()
+        self._arena_off = 0
+        self._nslot_checks = []              # (meta index of nslots, ldw)
+        self._cap_checks = []                # (meta index of a row count, capacity)
+        self.rows = []
+        for l in range(self.L + 1):
+            sl = self._slot('n', 5 + 2 * l)
+            self._cap_checks.append((5 + 2 * l, self.caps[l]))
+            self.rows.append(Rows(1, sl, 0, self.caps[l]))
+
+    # ---- slot bookkeeping ----------------------------------------------------------------------
+    def _slot(self, kind, mi):
+        key = (kind, mi)
+        if key not in self._slot_of:
+            self._slot_of[key] = len(self._fill)
+            self._fill.append((mi, 4 if kind in ('ip', 'fp') else 1, {'n': 0, 'ip': 1, 'fp': 2}[kind]))
+        return self._slot_of[key]
+
+    def _n(self, mi):
+        return (1, self._slot('n', mi), 0)
+
+    def _ip(self, mi):
+        return (1, self._slot('ip', mi), 0)
+
+    def _fp(self, mi):
+        return (1, self._slot('fp', mi), 0)
+
+    def _field_ptr(self, l):
+        return self._ip(4 + 2 * l)
+
+    def _csr(self, l, which):
+        """descriptor base of layer l's adj (0) / adj^T (1) / fadj (2)"""
+        return self._pb.o_csr + (3 * l + which) * CSR_DESC
+
+    def _plan(self, b, d):
+        self._nslot_checks.append((b + 10, (d + 3) // 4 * 4))
+        return [K(1), self._ip(b + 6), self._n(b + 7), self._ip(b + 8), self._n(b + 9), self._n(b + 10),
+                K(self.ws_plan.data_ptr()), K(self.plan_ws_floats)]
+
+    def _key(self, layer_index):
+        self._keys_seen.add(layer_index)
+        pos = self._key_layers.index(layer_index) if layer_index in self._key_layers else 0
+        return (1, self._n_meta + pos, 0)
+
+    def _lr(self):
+        return (1, self._n_meta + len(self._key_layers), 0)
+
+    # ---- arena ------------------------------------------------------------------------------------
+    def _alloc(self, rows, cols, ld=None):
+        ld = cols if ld is None else ld
+        off = self._arena_off
+        self._arena_off += (rows.cap * ld + 63) // 64 * 64
+        return ST(K(self._arena_base + 4 * off), rows, cols, ld)
+
+    def _alloc_vec(self, n_cap):
+        """(operand, offset in floats) of a 1-D scratch vector"""
+        off = self._arena_off
+        self._arena_off += (n_cap + 63) // 64 * 64
+        return K(self._arena_base + 4 * off), off
+
+    # ---- op emission ------------------------------------------------------------------------------
+    def _emit(self, op, args):
+        if len(args) > MAX_ARGS:
+            raise Unsupported("too many arguments")
+        self._cur.append((OP[op], list(args)))
+
+    def _p(self, t):
+        return NULL if t is None else (t.ptr if isinstance(t, ST) else t)
+
+    def _drop_args(self, site, rows_op, width):
+        if site is None:
+            return [K(0), K(0), K(_fbits(1.0)), K(-1), K(width)]
+        keep, li = site
+        return [K(1), self._key(li), K(_fbits(keep)), rows_op, K(width)]
+
+    def _site(self, layer):
+        keep = 1.0 - self.dropout
+        if keep >= 1.0:
+            return None
+        return (keep, layer.index)
+
+    def _materialize(self, x):
+        """dense ST from a pending dropout / pending gather (layers.dense_of)"""
+        if isinstance(x, SGather):
+            if x._m is None:
+                out = self._alloc(x.rows, x.src.cols)
+                self._emit('GATHER_ROWS', [self._p(x.src), K(x.src.ld), x.idx, x.rows.op(), K(x.src.cols), self._p(out), K(out.ld)])
+                x._m = out
+            return x._m
+        if isinstance(x, SDropped):
+            if x._m is None:
+                inner = self._materialize(x.x)
+                out = self._alloc(inner.rows, inner.cols)
+                self._emit('DROPOUT', [self._p(inner), K(inner.ld), inner.rows.op(), K(inner.cols)]
+                           + self._drop_args(x.site, K(-1), inner.cols) + [self._p(out), K(out.ld)])
+                x._m = out
+            return x._m
+        return x
+
+    def _dense_fwd(self, x, W, off, sc, relu, x2=None, site=None):
+        """ops.dense_fwd: returns (y, (xhat, rstd) or None)"""
+        g1 = g2 = NULL
+        if isinstance(x2, SGather):
+            x2, g2, r2 = x2.src, x2.idx, x2.rows
+        elif x2 is not None:
+            r2 = x2.rows
+        if isinstance(x, SGather):
+            x, g1, r1 = x.src, x.idx, x.rows
+        else:
+            r1 = x.rows
+        Kd, N = x.cols, W.cols
+        M = r1 if x2 is None else r1 + r2
+        if M.cap * Kd * N >= ops.GEMM_LIBRARY_THRESHOLD:
+            raise Unsupported("library-sized GEMM")
+        y = self._alloc(M, N)
+        norm = off is not None
+        xhat = self._alloc(M, N) if norm else None
+        rstd = self._alloc_vec(M.cap)[0] if norm else None
+        self._emit('DENSE_FWD', [M.op(), K(N), K(Kd), self._p(x), K(x.ld), self._p(x2), K(x2.ld if x2 is not None else 0),
+                                 r1.op(), self._p(W), K(W.ld), self._p(off), self._p(sc), K(_fbits(1e-9)), K(int(bool(relu))),
+                                 self._p(y), K(N), self._p(xhat), self._p(rstd)]
+                   + self._drop_args(site, r1.op(), Kd) + [K(self.ws_gemm.data_ptr()), K(self.gemm_ws_floats), g1, g2])
+        return y, ((xhat, rstd) if norm else None)
+
+    def _dense_bwd(self, dy, y, ctx, sc, relu, x, W, dW, doff, dsc, need_dx, site):
+        """ops.dense_bwd: returns dx or None"""
+        gidx = NULL
+        if isinstance(x, SGather):
+            x, gidx = x.src, x.idx
+        n, N, Kd = dy.rows, dy.cols, x.cols
+        norm = ctx is not None
+        if site is None and gidx == NULL and n.cap * N * Kd >= ops.GEMM_LIBRARY_THRESHOLD:
+            raise Unsupported("library-sized GEMM")
+        pre = norm or bool(relu)
+        g_tmp = self._alloc(n, N) if pre else None
+        dx = self._alloc(n, Kd) if need_dx else None
+        self._emit('DENSE_BWD', [n.op(), K(N), K(Kd), self._p(dy), K(dy.ld), self._p(y) if pre else NULL, K(y.ld if pre else 0),
+                                 self._p(ctx[0]) if norm else NULL, self._p(ctx[1]) if norm else NULL,
+                                 self._p(sc) if norm else NULL, K(int(bool(relu))), self._p(x), K(x.ld), self._p(W), K(W.ld),
+                                 self._p(dW), K(dW.ld), self._p(doff), self._p(dsc), self._p(dx), K(Kd)]
+                   + self._drop_args(site, K(-1), Kd) + [self._p(g_tmp), K(self.ws_gemm.data_ptr()), K(self.gemm_ws_floats), gidx])
+        return dx
+
+    def _spmm(self, b, B, out, d, cscale=NULL, add=None, add_rows=NULL):
+        """ops.spmm on the CSR described at descriptor base b"""
+        self._emit('SPMM', [self._ip(b + 3), self._ip(b + 4), self._fp(b + 5), self._n(b), self._n(b + 1), K(d),
+                            self._p(B), K(B.ld), NULL, NULL, cscale, self._p(out), K(out.ld), K(_fbits(0.0))]
+                   + self._plan(b, d) + [self._p(add), K(add.ld if add is not None else 0), add_rows])
+
+    # ---- parameters -------------------------------------------------------------------------------
+    def _param(self, layer, name, grad=False):
+        t = (layer.grads if grad else layer.vars).get(name)
+        if t is None:
+            return None
+        rows, cols = int(t.shape[0]), int(t.shape[1])
+        return ST(K(t.data_ptr()), Rows(0, -1, rows, rows), cols, cols)
+
+    # ---- the walk ---------------------------------------------------------------------------------
+    def _build(self):
+        m = self.model
+        F = m.features_dev
+        feat = ST(K(F.data_ptr()), Rows(0, -1, int(F.shape[0]), int(F.shape[0])), int(F.shape[1]), int(F.stride(0)))
+        act = SGather(feat, self._field_ptr(0), self.rows[0])
+        tape = []
+        concat = FLAGS.normalization != 'gcn'
+        self.new_history = {}
+        # Work that depends on nothing this step computes goes to the auxiliary stream first, beside the
+        # dense layers: zeroing the gradient buffer, and every control-variate aggregator's history-only sum
+        # P . Hbar[ffield] (the dominant gather of the step) -- sgcn_vr_aggregate_pre_f32.
+        local_hist = m.history_hook is None
+        if m.is_training:
+            self._emit('AUX_MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
+        accP = {}
+        for layer in m.layers:
+            if isinstance(layer, VRAggregator):
+                l = layer.l
+                bf = self._csr(l, 2)
+                hist = m.history[l][0]
+                d = int(hist.shape[1])
+                ldw = (d + 3) // 4 * 4
+                buf = self._alloc(self.rows[l + 1], ldw)
+                self._emit('VR_AGG_PRE', [self._ip(bf + 3), self._ip(bf + 4), self._fp(bf + 5), self.rows[l + 1].op(), self._n(bf + 1),
+                                          K(d), K(hist.data_ptr()), K(int(hist.stride(0))), self._ip(self._pb.o_ffields + 2 * l),
+                                          self._p(buf)] + self._plan(bf, d))
+                accP[l] = buf
+        for layer in m.layers:
+            if isinstance(layer, AugmentedDropoutDense):
+                if layer.sparse_inputs or layer.output_dim > 128:
+                    raise Unsupported("sparse / wide AugmentedDropoutDense")
+                x, mu = act if isinstance(act, tuple) else (act, act)
+                site = self._site(layer)
+                W, off, sc = self._param(layer, 'weights'), self._param(layer, 'offset') if layer.norm else None, \
+                    self._param(layer, 'scale') if layer.norm else None
+                same = mu is x
+                x = self._materialize(x) if isinstance(x, SDropped) else x
+                mu = x if same else (self._materialize(mu) if isinstance(mu, SDropped) else mu)
+                if mu is x and site is None:
+                    h, ctx = self._dense_fwd(x, W, off, sc, True)
+                    tape.append(('dense', layer, x, h, ctx, None, True))
+                    act = (h, h)
+                else:
+                    n = x.rows
+                    h2, ctx2 = self._dense_fwd(x, W, off, sc, True, x2=mu, site=site)
+                    ctx = (ctx2[0].head(n), ctx2[1]) if ctx2 is not None else None
+                    hx = h2.head(n)
+                    tape.append(('dense', layer, x, hx, ctx, site, True))
+                    act = (hx, h2.tail(n))
+            elif isinstance(layer, Dropout):
+                site = self._site(layer)
+                inp = act[0] if (layer.cvd and isinstance(act, tuple)) else act
+                if isinstance(inp, tuple):
+                    raise Unsupported("det-dropout tuple")
+                if not (layer.fuse_next and isinstance(inp, SGather)):
+                    inp = self._materialize(inp)
+                if site is None:
+                    act = inp
+                    tape.append(('dropout', None, False))
+                elif layer.fuse_next:
+                    act = SDropped(inp, site)
+                    tape.append(('dropout', site, True))
+                else:
+                    act = self._materialize(SDropped(inp, site))
+                    tape.append(('dropout', site, False))
+            elif isinstance(layer, Dense):
+                if layer.sparse_inputs:
+                    raise Unsupported("sparse Dense")
+                x, site = act, None
+                if isinstance(x, SDropped):
+                    x, site = x.x, x.site
+                if not (layer.output_dim <= 128 or not (layer.norm or layer.act)):
+                    raise Unsupported("wide Dense with LayerNorm / ReLU")
+                W = self._param(layer, 'weights')
+                off = self._param(layer, 'offset') if layer.norm else None
+                sc = self._param(layer, 'scale') if layer.norm else None
+                y, ctx = self._dense_fwd(x, W, off, sc, layer.act, site=site)
+                tape.append(('dense', layer, x, y, ctx, site, layer.act))
+                act = y
+            elif isinstance(layer, VRAggregator):
+                l = layer.l
+                ba, bf = self._csr(l, 0), self._csr(l, 2)
+                hist = m.history[l][0]
+                H = ST(K(hist.data_ptr()), Rows(0, -1, int(hist.shape[0]), int(hist.shape[0])), int(hist.shape[1]), int(hist.stride(0)))
+                n1 = self.rows[l + 1]
+                if layer.cvd:
+                    h, mu = (self._materialize(t) for t in act)
+                    d = h.cols
+                    if mu.ld != h.ld:
+                        raise Unsupported("h / mu pitch")
+                    width = 2 * d if concat else d
+                    out_h, out_mu = self._alloc(n1, width), self._alloc(n1, width)
+                    sptr = self._fp(self._pb.o_scales + 2 * l)
+                    if d != int(hist.shape[1]):
+                        raise Unsupported("aggregator width differs from its history")
+                    self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
+                                               self._p(h), self._p(mu), K(h.ld), self._p(H), K(H.ld), self._field_ptr(l), sptr,
+                                               self._p(out_h), self._p(out_mu), K(width), K(1), K(int(concat)), self._p(accP[l])])
+                    if local_hist:
+                        self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
+                                                        K(mu.cols), self._p(mu), K(mu.ld)])
+                    self.new_history[l] = mu
+                    tape.append(('agg', l, d, concat, sptr))
+                    act = (out_h, out_mu)
+                else:
+                    x = self._materialize(act)
+                    d = x.cols
+                    width = 2 * d if concat else d
+                    out_h = self._alloc(n1, width)
+                    if d != int(hist.shape[1]):
+                        raise Unsupported("aggregator width differs from its history")
+                    self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
+                                               self._p(x), NULL, K(x.ld), self._p(H), K(H.ld), self._field_ptr(l), NULL,
+                                               self._p(out_h), NULL, K(width), K(0), K(int(concat)), self._p(accP[l])])
+                    if local_hist:
+                        self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
+                                                        K(x.cols), self._p(x), K(x.ld)])
+                    self.new_history[l] = x
+                    tape.append(('agg', l, d, concat, NULL))
+                    act = out_h
+            elif isinstance(layer, PlainAggregator):
+                l = layer.l
+                x = self._materialize(act)
+                d = x.cols
+                n1 = self.rows[l + 1]
+                ba = self._csr(l, 0)
+                if not concat:
+                    out = self._alloc(n1, d)
+                    self._spmm(ba, x, out, d)
+                else:
+                    out = self._alloc(n1, 2 * d)
+                    self._emit('COPY2D', [self._p(out), K(out.ld), self._p(x), K(x.ld), n1.op(), K(d)])
+                    self._spmm(ba, x, out.cols_from(d, d), d)
+                tape.append(('agg', l, d, concat, NULL))
+                act = out
+            else:
+                raise Unsupported("layer %r" % type(layer).__name__)
+        logits = act
+        if isinstance(logits, (tuple, SDropped, SGather)):
+            raise Unsupported("model output is not a plain activation")
+        nL = self.rows[self.L]
+        c = logits.cols
+        lab_b = self._pb.o_labels
+        stats, self.stats_off = self._alloc_vec(4 + 2 * nL.cap)
+        train = m.is_training
+        dz = self._alloc(nL, c) if train else None
+        self.pred = self._alloc(nL, c) if not train else None
+        rowstat = K(stats[2] + 16)
+        self._emit('SIGMOID_CE' if m.multitask else 'SOFTMAX_CE',
+                   [self._p(logits), K(logits.ld), self._fp(lab_b), K(c), nL.op(), K(c), self._p(dz), K(c), self._p(self.pred), K(c),
+                    stats, rowstat])
+        wd = float(FLAGS.weight_decay)
+        lo, hi = m._wd_range
+        if wd and hi > lo:
+            self._emit('L2_PENALTY', [K(m.theta.data_ptr()), K(lo), K(hi), K(_fbits(wd)), NULL, K(stats[2] + 8)])
+        if train:
+            g = dz
+            first = m._first_param
+            for layer, rec in reversed(list(zip(m.layers, tape))[first:]):
+                if rec[0] == 'dense':
+                    _, lay, x, y, ctx, site, relu = rec
+                    g = self._dense_bwd(g, y, ctx, self._param(lay, 'scale') if lay.norm else None, relu, x,
+                                        self._param(lay, 'weights'), self._param(lay, 'weights', True),
+                                        self._param(lay, 'offset', True) if lay.norm else None,
+                                        self._param(lay, 'scale', True) if lay.norm else None, lay.need_dx, site)
+                elif rec[0] == 'dropout':
+                    _, site, fused = rec
+                    if g is not None and site is not None and not fused:
+                        out = self._alloc(g.rows, g.cols)
+                        self._emit('DROPOUT', [self._p(g), K(g.ld), g.rows.op(), K(g.cols)] + self._drop_args(site, K(-1), g.cols)
+                                   + [self._p(out), K(out.ld)])
+                        g = out
+                elif rec[0] == 'agg':
+                    _, l, d, cc, sptr = rec
+                    bt = self._csr(l, 1)
+                    dx = self._alloc(self.rows[l], d)
+                    if not cc:
+                        self._spmm(bt, g, dx, d, cscale=sptr)
+                    else:
+                        self._spmm(bt, g.cols_from(d, d), dx, d, cscale=sptr, add=g.cols_from(0, d), add_rows=self.rows[l + 1].op())
+                    g = dx
+            if wd and hi > lo:
+                self._emit('L2_PENALTY', [K(m.theta.data_ptr()), K(lo), K(hi), K(_fbits(wd)), K(m.grad.data_ptr()), NULL])
+            self._cur = self.ops_opt
+            self._emit('ADAM', [K(m.theta.data_ptr()), K(m.grad.data_ptr()), K(m.adam_m.data_ptr()), K(m.adam_v.data_ptr()),
+                                K(m.theta.numel()), self._lr(), K(_fbits(FLAGS.beta1)), K(_fbits(FLAGS.beta2)), K(_fbits(1e-8))])
+        self._cur = self.ops_hist
+        for l, nh in ({} if local_hist else self.new_history).items():
+            hist = m.history[l][0]
+            self._emit('SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
+                                        K(nh.cols), self._p(nh), K(nh.ld)])
+
+    # ---- build the ctypes program ------------------------------------------------------------------
+    def _finalize(self):
+        self._key_slots = {li: self._n_meta + i for i, li in enumerate(self._key_layers)}
+        self.lr_slot = self._n_meta + len(self._key_layers)
+        self.nslots = self.lr_slot + 1
+
+        def pack(lst):
+            arr = (StepOp * max(len(lst), 1))()
+            for k, (opc, args) in enumerate(lst):
+                o = arr[k]
+                o.op, o.nargs = opc, len(args)
+                for j, a in enumerate(args):
+                    o.mul[j], o.slot[j], o.add[j] = int(a[0]), int(a[1]), int(a[2])
+            return arr
+        self.c_fb, self.c_opt, self.c_hist = pack(self.ops_fb), pack(self.ops_opt), pack(self.ops_hist)
+        self.n_fb, self.n_opt, self.n_hist = len(self.ops_fb), len(self.ops_opt), len(self.ops_hist)
+        allops = self.ops_fb + self.ops_opt + self.ops_hist       # one contiguous program for the single-GPU case
+        self.c_all, self.n_all = pack(allops), len(allops)
+        f = np.array(self._fill, dtype=np.int64).reshape(-1, 3)
+        self._f_idx, self._f_mul = f[:, 0].copy(), f[:, 1].copy()
+        self._f_ip, self._f_fp = (f[:, 2] == 1).astype(np.int64), (f[:, 2] == 2).astype(np.int64)
+        self.slots = np.zeros(self.nslots, dtype=np.int64)
+        self._slots_ptr = self.slots.ctypes.data
+        chk = np.array(self._cap_checks, dtype=np.int64).reshape(-1, 2)
+        self._cap_idx, self._cap_max = chk[:, 0].copy(), chk[:, 1].copy()
+        ns = np.array(self._nslot_checks, dtype=np.int64).reshape(-1, 2) if self._nslot_checks else np.zeros((0, 2), np.int64)
+        self._ns_idx, self._ns_ldw = ns[:, 0].copy(), ns[:, 1].copy()
+        so = self.stats_off
+        self.loss_t, self.acc_t = self.arena[so + 2], self.arena[so + 3]
+        self._keys = sorted(self._key_slots.items())
+
+    # ---- per step ---------------------------------------------------------------------------------
+    def fits(self, pb):
+        meta = pb.meta
+        if np.any(meta[self._cap_idx] > self._cap_max):
+            return False
+        if self._ns_idx.size and np.any(meta[self._ns_idx] * self._ns_ldw > self.plan_ws_floats):
+            return False
+        return True
+
+    def fill(self, pb, ip, fp, step, lr_t):
+        s = self.slots
+        n = self._f_idx.shape[0]
+        np.multiply(pb.meta[self._f_idx], self._f_mul, out=s[:n])
+        s[:n] += self._f_ip * ip + self._f_fp * fp
+        m = self.model
+        for li, slot in self._keys:
+            s[slot] = ops.dropout_key(m.dropout_seed, li, step)
+        s[self.lr_slot] = _fbits(lr_t)
+
+    def run(self, which, stream):
+        arr, n = {'all': (self.c_all, self.n_all), 'fb': (self.c_fb, self.n_fb), 'opt': (self.c_opt, self.n_opt),
+                  'hist': (self.c_hist, self.n_hist)}[which]
+        if n:
+            check(lib.sgcn_step_run(arr, n, self._slots_ptr, self.nslots, stream))
+
+    def tensor_of(self, t, n):
+        """torch view of the first n rows of an arena activation (multi-GPU history exchange, evaluation output)"""
+        off = (t.ptr[2] - self.arena.data_ptr()) // 4
+        return self.arena[off:off + n * t.ld].view(n, t.ld)[:, :t.cols]

@@ -153,6 +153,35 @@ def test_vr_aggregate_vs_oracle(dev, cvd, concat, d, degree):
             np.testing.assert_array_equal(oh.cpu().numpy()[:, :d], h[:adj.shape[0]])
 
 
+@pytest.mark.parametrize("cvd", [True, False])
+@pytest.mark.parametrize("concat", [True, False])
+@pytest.mark.parametrize("d,plan_t", [(128, 16), (128, 0), (32, 8), (30, 8)])
+def test_vr_aggregate_two_phase_is_bit_identical_to_the_fused_pass(dev, cvd, concat, d, plan_t):
+    """sgcn_vr_aggregate_pre_f32 (history-only sum, what the step program runs beside the dense layers) +
+    sgcn_vr_aggregate_post_f32 == sgcn_vr_aggregate_f32, bit for bit, with and without split rows."""
+    from stochastic_gcn_amd import ops, synthetic
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    n = 3000
+    _, train_adj, _, _, _, _, labels, tr, _, _ = synthetic.reddit_like(n=n, m=60000, f=8, classes=5, splits=(2000, 300, 700),
+                                                                        seed=7, with_features=False)
+    ph = {'adj': ['a'], 'madj': ['m'], 'fadj': ['f'], 'fields': ['f0', 'f1'], 'ffields': ['ff'], 'scales': ['s'], 'labels': 'l'}
+    sch = PyScheduler(train_adj, labels, 1, [2], ph, 3, data=tr.copy(), cv=True)
+    fd = sch.minibatch(200)
+    A = ops.DeviceCSR.from_host(fd[('csr', 'a')], dev)
+    P = ops.DeviceCSR.from_host(fd[('csr', 'f')], dev, plan_T=plan_t or 100000)
+    assert (P.plan.nfix > 0) == bool(plan_t)
+    rng = np.random.RandomState(d)
+    n0 = fd['f0'].shape[0]
+    H = T(rng.uniform(-1, 1, (n, d)).astype(np.float32), dev)
+    h, mu = T(rng.standard_normal((n0, d)).astype(np.float32), dev), T(rng.standard_normal((n0, d)).astype(np.float32), dev)
+    args = (A, P, h, mu if cvd else None, H, T(fd['f0'], dev), T(fd['ff'], dev), T(fd['s'], dev) if cvd else None, cvd, concat)
+    f_h, f_mu = ops.vr_aggregate(*args)
+    t_h, t_mu = ops.vr_aggregate_two_phase(*args)
+    assert torch.equal(f_h, t_h)
+    if cvd:
+        assert torch.equal(f_mu, t_mu)
+
+
 def test_vr_aggregate_fresh_history_identity(dev):
     """Hbar[ifield] == mu and h == mu  =>  h_nbr == mu_nbr == P Hbar[ffield]."""
     from stochastic_gcn_amd import ops

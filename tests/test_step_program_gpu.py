@@ -1,0 +1,103 @@
+"""The compiled step program (stochastic_gcn_amd/step_program.py + sgcn_step_run: ONE foreign call per
+training step) against the eager per-layer host path: same kernels, same arguments -> bit-identical
+weights, Adam moments, history, loss and accuracy over consecutive steps, for every layer stack the
+compiler supports; unsupported stacks (sparse input features, wide LayerNorm layers) fall back."""
+import numpy as np
+import pytest
+import torch
+
+import model_cases as mc
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(case, params, native):
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.vrgcn import VRGCN
+    from stochastic_gcn_amd.plaingcn import PlainGCN
+    FLAGS.reset()
+    FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
+    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'])
+    cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
+    fl = case['flags']
+    m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
+            is_training=True, device=torch.device('cuda:0'))
+    m.set_params(params)
+    return m
+
+
+def _run(case, native, steps, slot):
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.scheduler import StagingSlot
+    params = mc.make_oracle_model(case, seed=3).params
+    m = _model(case, {k: v.copy() for k, v in params.items()}, native)
+    sch = mc.make_scheduler(case, 1)
+    slots = [StagingSlot(pin=True) for _ in range(3)] if slot else None
+    losses = []
+    for step in range(steps):
+        if sch.start >= sch.data.shape[0]:
+            sch.start = 0
+        pb = sch.minibatch_packed(case['cfg']['batch'], FLAGS.plan_t, slots[step % 3] if slot else None)
+        pb.dropout = case['flags']['dropout']
+        out = m.run_one_step(None, pb, sync=False)
+        losses.append((out[1].clone(), out[2].clone()))
+    torch.cuda.synchronize()
+    return m, losses
+
+
+SUPPORTED = ['reddit_cvd_pp', 'reddit_cv_pp', 'cvd_pp_L3', 'cv_nopp_L2', 'ns_nopp_L2', 'ns_nopp_L2_reverse', 'is_pp']
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+@pytest.mark.parametrize("slot", [False, True])
+def test_program_is_bit_identical_to_the_eager_path(name, slot):
+    case = mc.build_case(name)
+    a, la = _run(case, False, 5, slot)
+    b, lb = _run(case, True, 5, slot)
+    progs = getattr(b, '_programs', {})
+    assert progs and all(p is not None for p in progs.values()), getattr(b, '_program_note', 'no program was compiled')
+    assert not getattr(a, '_programs', {})
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    for ha, hb in zip(a.history, b.history):
+        assert torch.equal(ha[0], hb[0])
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
+    assert a.dropout_step == b.dropout_step == 5 and a.adam_t == b.adam_t == 5
+    assert a.amt_data == b.amt_data and np.array_equal(a.field_sizes, b.field_sizes)      # the epoch counters too
+    prog = next(iter(progs.values()))
+    print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
+
+
+def test_dropout_zero_and_weight_decay_variants():
+    for name, extra in (('reddit_cvd_pp', dict(dropout=0.0)), ('reddit_cv_pp', dict(weight_decay=5e-3)),
+                        ('ns_nopp_L2', dict(weight_decay=1e-3, dropout=0.0))):
+        case = mc.build_case(name)
+        case['flags'].update(extra)
+        a, la = _run(case, False, 3, False)
+        b, lb = _run(case, True, 3, False)
+        assert all(p is not None for p in b._programs.values()), getattr(b, '_program_note', None)
+        assert torch.equal(a.theta, b.theta)
+        assert all(torch.equal(x[0], y[0]) for x, y in zip(la, lb))
+
+
+@pytest.mark.parametrize("name", ['pubmed_cvd_pp', 'cora_exact', 'reddit_cvd_pp_wide'])
+def test_unsupported_stacks_fall_back_to_the_eager_path(name):
+    case = mc.build_case(name)
+    b, lb = _run(case, True, 2, False)
+    assert list(b._programs.values()) == [None] and b._program_note
+    a, la = _run(case, False, 2, False)
+    assert torch.equal(a.theta, b.theta)
+
+
+def test_minibatch_that_does_not_fit_runs_eagerly():
+    case = mc.build_case('reddit_cvd_pp')
+    b, _ = _run(case, True, 1, False)
+    prog = next(iter(b._programs.values()))
+    sch = mc.make_scheduler(case, 1)
+    pb = sch.batch_packed(case['train'][:case['cfg']['batch']], 0, None)
+    assert prog.fits(pb)
+    prog._cap_max[:] = 1                      # pretend the arena was sized for one row
+    assert not prog.fits(pb)
+    pb.dropout = case['flags']['dropout']
+    out = b.run_one_step(None, pb, sync=True)             # falls back, still a valid step
+    assert np.isfinite(out[1])
