@@ -102,9 +102,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
 // doffset[c] += sum_b partial[b][0][c]; dscale[c] += sum_b partial[b][1][c]   (fixed order)
 __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_t nblk, int32_t d,
                                        float* __restrict__ doffset, float* __restrict__ dscale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * d) return;
-    ln_param_reduce_col(partial, nblk, d, doffset, dscale, c);
+    ln_param_reduce_cols32(partial, nblk, d, doffset, dscale, (int)blockIdx.x);
 }
 
 // One wavefront per row, as many workgroups as rows need (a single-workgroup version spent
@@ -301,7 +299,7 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
                        st, dy, lddy, y, ldy, xhat, rstd, scale, n, d, norm, relu, dx, lddx, ws);
     if (nblk) *nblk = norm ? (int32_t)blocks : 0;
     if (norm && reduce_params)
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, ws,
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + kLnRedCols - 1) / kLnRedCols), dim3(256), 0, st, ws,
                            (int32_t)blocks, d, doffset, dscale);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;

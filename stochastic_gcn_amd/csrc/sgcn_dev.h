@@ -124,23 +124,38 @@ __device__ __forceinline__ float drop_factor(const DropArgs& a, int row, int col
     return fmix32(idx * 0x9E3779B1u + a.key) < a.thr ? a.scale : 0.0f;
 }
 
-// ---- LayerNorm parameter gradients: column c of the [d(offset) | d(scale)] vector from the
-// per-workgroup partials of ln_act_bwd_kernel, summed in a fixed order (four independent chains
-// keep several loads in flight).  Shared by the standalone reduce and the dense-layer backward's
-// combined reduce (sgcn_gemm.hip).
-__device__ __forceinline__ void ln_param_reduce_col(const float* __restrict__ partial, int nblk, int d,
-                                                    float* __restrict__ doffset, float* __restrict__ dscale, int c) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        s0 += partial[(size_t)(b + 0) * 2 * d + c];
-        s1 += partial[(size_t)(b + 1) * 2 * d + c];
-        s2 += partial[(size_t)(b + 2) * 2 * d + c];
-        s3 += partial[(size_t)(b + 3) * 2 * d + c];
+// ---- LayerNorm parameter gradients: 32 columns of the [d(offset) | d(scale)] vector from the per-workgroup
+// partials of ln_act_bwd_kernel.  One 256-thread workgroup per 32 columns: 8 thread rows each add a
+// contiguous eighth of the partials (two independent chains keep loads in flight), then one thread per
+// column adds the eight sums in order -- a fixed summation order whatever the schedule.  (One thread per
+// column walking all partials took 13-19 us once ln_act_bwd_kernel ran one row per wavefront.)  Shared by
+// the standalone reduce and the dense-layer backward's combined reduce (sgcn_gemm.hip).
+constexpr int kLnRedCols = 32;
+__device__ __forceinline__ void ln_param_reduce_cols32(const float* __restrict__ partial, int nblk, int d,
+                                                       float* __restrict__ doffset, float* __restrict__ dscale,
+                                                       int cblock) {
+    __shared__ float red[8][kLnRedCols];
+    const int lane = threadIdx.x & (kLnRedCols - 1), part = threadIdx.x >> 5;      // 256 threads: 8 x 32
+    const int c = cblock * kLnRedCols + lane;
+    const int chunk = (nblk + 7) / 8;
+    const int b0 = part * chunk, b1 = min(nblk, b0 + chunk);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < 2 * d) {
+        int b = b0;
+        for (; b + 2 <= b1; b += 2) {
+            s0 += partial[(size_t)(b + 0) * 2 * d + c];
+            s1 += partial[(size_t)(b + 1) * 2 * d + c];
+        }
+        if (b < b1) s0 += partial[(size_t)b * 2 * d + c];
     }
-    for (; b < nblk; b++) s0 += partial[(size_t)b * 2 * d + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (c < d) doffset[c] += s; else dscale[c - d] += s;
+    red[part][lane] = s0 + s1;
+    __syncthreads();
+    if (part == 0 && c < 2 * d) {
+        float s = red[0][lane];
+#pragma unroll
+        for (int q = 1; q < 8; q++) s += red[q][lane];
+        if (c < d) doffset[c] += s; else dscale[c - d] += s;
+    }
 }
 
 // sgcn_dense.hip: LN/ReLU backward; with reduce_params == false the parameter-gradient partials stay

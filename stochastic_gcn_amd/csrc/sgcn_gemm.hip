@@ -261,8 +261,7 @@ __global__ void dense_bwd_reduce_kernel(ReduceJob j, int32_t gemm_blocks, const 
         float* p = j.C + (i / j.N) * j.ldc + (i % j.N);
         *p = j.accumulate ? *p + s : s;
     } else {
-        const int c = ((int)blockIdx.x - gemm_blocks) * blockDim.x + threadIdx.x;
-        if (c < 2 * d) ln_param_reduce_col(ln_partial, nblk, d, doffset, dscale, c);
+        ln_param_reduce_cols32(ln_partial, nblk, d, doffset, dscale, (int)blockIdx.x - gemm_blocks);
     }
 }
 
@@ -555,7 +554,7 @@ static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int6
     if (rc != SGCN_OK) return rc;
     if (job.pending || nblk > 0) {
         const int gb = job.pending ? (int)(((int64_t)job.M * job.N + 255) / 256) : 0;
-        const int lb = nblk > 0 ? (2 * N + 255) / 256 : 0;
+        const int lb = nblk > 0 ? (2 * N + kLnRedCols - 1) / kLnRedCols : 0;
         hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, st_dw, job, gb, ws_ln, nblk, N,
                            doffset, dscale);
         SGCN_HIP_TRY(hipGetLastError());
