@@ -556,6 +556,9 @@ class StepProgram(object):
             check(lib.sgcn_step_run(arr, n, self._slots_ptr, self.nslots, stream))
 
     def tensor_of(self, t, n):
-        """torch view of the first n rows of an arena activation (multi-GPU history exchange, evaluation output)"""
-        off = (t.ptr[2] - self.arena.data_ptr()) // 4
+        """torch view of the first n rows of an arena activation under the CURRENT slot table (multi-GPU history
+        exchange)"""
+        mul, slot, add = t.ptr
+        addr = add + (mul * int(self.slots[slot]) if slot >= 0 else 0)
+        off = (addr - self.arena.data_ptr()) // 4
         return self.arena[off:off + n * t.ld].view(n, t.ld)[:, :t.cols]

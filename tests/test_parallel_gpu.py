@@ -95,3 +95,48 @@ def test_sharded_spmm_blocks_tile_the_full_product(dev=None):
     assert max(nnz) - min(nnz) <= 2 * int(np.diff(full_adj.indptr).max())           # balanced by nonzeros
     assert onp.rel_err(torch.cat(cs).cpu().numpy(), want_c.cpu().numpy()) <= TOL
     assert onp.rel_err(torch.cat(dbs).cpu().numpy(), want_db.cpu().numpy()) <= TOL
+
+
+def _train_worker(rank, world, port, native, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGCN_DIST_BACKEND="gloo")
+    import contextlib
+    import io
+    from stochastic_gcn_amd import synthetic
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+    torch.cuda.set_device(0)
+    data = synthetic.reddit_like(n=6000, m=60000, f=32, classes=6, splits=(3600, 800, 1600), seed=5,
+                                 with_features=True, planted=True)
+    FLAGS.reset()
+    FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+                 hidden1=64, num_fc_layers=2, batch_size=256, test_batch_size=512, cv=True, cvd=True, test_cv=True,
+                 degree=1, test_degree=1, seed=1, native_step=native, max_steps=5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        trn = Trainer(data=data, verbose=False)
+        for _ in range(2):
+            trn.train_epoch()
+    torch.cuda.synchronize()
+    m = trn.train_model
+    np.savez(os.path.join(out_dir, "t%d_%d.npz" % (int(native), rank)), theta=m.theta.cpu().numpy(),
+             hist=m.history[0][0].cpu().numpy(), used_program=np.array([bool(getattr(m, '_programs', {}))]))
+    trn.par.shutdown()
+
+
+def test_two_rank_training_program_equals_eager_and_replicas_agree(tmp_path):
+    """Data-parallel minibatch training over two ranks (gradient all-reduce + history all-gather between the
+    phases of the step program): the compiled step program and the eager path give bit-identical weights
+    and history, and the two replicas stay identical."""
+    import torch.multiprocessing as mp
+    res = {}
+    for native in (False, True):
+        port = tg._free_port()
+        mp.spawn(_train_worker, args=(2, port, native, str(tmp_path)), nprocs=2, join=True)
+        res[native] = [np.load(os.path.join(str(tmp_path), "t%d_%d.npz" % (int(native), r))) for r in range(2)]
+    assert res[True][0]["used_program"][0] and not res[False][0]["used_program"][0]
+    for native in (False, True):
+        np.testing.assert_array_equal(res[native][0]["theta"], res[native][1]["theta"])      # replicas in lock-step
+        np.testing.assert_array_equal(res[native][0]["hist"], res[native][1]["hist"])
+    np.testing.assert_array_equal(res[True][0]["theta"], res[False][0]["theta"])
+    np.testing.assert_array_equal(res[True][0]["hist"], res[False][0]["hist"])
+    assert np.abs(res[True][0]["hist"]).sum() > 0
