@@ -60,6 +60,9 @@ def parse(argv=None):
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
+    p.add_argument("--cs-align", type=int, default=1024, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
+    p.add_argument("--cs-g", type=int, default=1, choices=[1, 2],
+                   help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes)")
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
     p.add_argument("--emulate-shard", default=None, metavar="R/W",
@@ -413,9 +416,9 @@ def main(argv=None):
         elif reorder == "labels":
             comm = np.ascontiguousarray(data10[6].argmax(1), dtype=np.int32)
             reorder_info = {"method": "dataset labels", "communities": int(comm.max()) + 1}
-        A = ops.ColumnSweepCSR(full_adj, dev, R=args.cs_r, T=args.cs_t, col_labels=comm, row_labels=comm)
-        A.transpose = None if args.no_backward else ops.ColumnSweepCSR(
-            full_adj.T.tocsr(), dev, R=args.cs_r, T=args.cs_t, col_labels=comm, row_labels=comm)
+        gk = dict(G=2, align=args.cs_align) if (args.cs_g == 2 and comm is None) else dict(R=args.cs_r, col_labels=comm, row_labels=comm)
+        A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
+        A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
         mm = ops.spmm_cs
     else:
         A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)

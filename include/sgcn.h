@@ -111,6 +111,9 @@ typedef struct {
     int32_t pace_ns_per_nnz;        /* sweep clock: a launch lasts (heaviest tile nnz) x this many
                                        ns; found by timing a few values once per plan+width.
                                        0 = library default knob, < 0 = unpaced                  */
+    int32_t G;                      /* lane groups per wavefront: 0 / 1 = one 16-row tile per wave on 304-column
+                                       slabs; 2 = two 16-row bins per wave (lanes 0-31 / 32-63) on 128-column
+                                       slabs, entries interleaved with pads (sgcn_csplan2_*)               */
     int32_t xcd_map;                /* != 0: consecutive tiles of a launch go to the SAME XCD (the
                                        dispatcher deals workgroups round-robin over the 8 XCDs):
                                        with a grouped plan the tiles that share B rows share an L2.
@@ -125,6 +128,18 @@ int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const 
                      int32_t M, int32_t R, int32_t T, const int32_t* host_row_group,
                      int64_t* host_tile_ptr, int32_t* host_colrow, float* host_valout,
                      int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
+/* Plan with TWO lane groups per wavefront (G = 2, R = 16): tile_rows / tile_slots are [ntiles * 32] (bin 0's 16
+ * rows, then bin 1's), colrow / val hold `nentries` interleaved entries (entry 2*step + g is bin g's); pad
+ * entries carry the value bits 0x80000000 (-0.0f; real -0.0f values are stored as +0.0f) and are masked off by
+ * the kernel.  align > 0: a bin advances only while at most `align` columns ahead of the other (keeps the two
+ * halves of a wave inside one L2 window); the tile count is rounded up to whole launches of round_tiles waves
+ * (0: no rounding). */
+int sgcn_csplan2_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
+                       int32_t round_tiles, int32_t align, int64_t* ntiles, int64_t* nentries, int64_t* nfix,
+                       int64_t* nslots);
+int sgcn_csplan2_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
+                      int32_t T, int32_t round_tiles, int32_t align, int64_t* host_tile_ptr, int32_t* host_colrow,
+                      float* host_valout, int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
 /* Community labels of a square CSR pattern by seeded asynchronous label propagation (host, graph
  * only; new -- the reference has no reordering).  comm[n] in [0, *ncomm), numbered by decreasing
  * size; communities smaller than min_size share the last label.  max_iters <= 0: 12 sweeps. */

@@ -4,6 +4,7 @@
 #include "../../include/sgcn.h"
 
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 #include <queue>
 #include <functional>
@@ -172,6 +173,182 @@ int sgcn_csplan_fill(const int32_t* rowptr, const int32_t* col, const float* val
         tbase += nt;
     }
     tile_ptr[tbase] = out;
+    return SGCN_OK;
+}
+
+}  // extern "C"
+
+// ---- two lane groups per wavefront (sgcn_csplan_t.G == 2) ---------------------------------------------
+// A tile is TWO bins of up to 16 virtual rows; lanes 0-31 hold the accumulators of bin 0, lanes 32-63 those of
+// bin 1, each lane one float4 of a 128-column slab.  One dwordx4 load instruction then gathers the 512-byte
+// slab pieces of two DIFFERENT B rows (the microbenchmark's "x4 on 2 rows": 28.4 TB/s from L2, against 17.7
+// for 512-byte pieces fetched as dwordx2), and a wave holds 32 rows of a 128-column slab instead of 16 rows of
+// a 304-column one: twice the rows per register byte of slab width, i.e. half the passes of B through every
+// XCD (fabric bytes ~ 4 K M d / rows-per-XCD).
+// A step applies one entry of each bin.  Entry 2*step + g is bin g's; a PAD entry (value bits 0x80000000, i.e.
+// -0.0f -- real -0.0f values are stored as +0.0f) is masked off by the kernel and never touches an
+// accumulator.  Pads do two jobs: they fill the shorter bin, and they keep the two bins' column positions
+// ALIGNED -- the k-th smallest column of two random 1,400-entry bins differs by thousands of columns, and a
+// wave whose halves gather from places that far apart needs an L2 window the XCD does not have (measured
+// without alignment: 2.6 fetches per B row and pass instead of 1.0).  The schedule walks both sorted lists
+// and lets a bin advance only while it is at most `align` columns ahead of the other.
+// The tile count is rounded up to whole launches of `round_tiles` resident waves so that every launch is full.
+namespace {
+constexpr int kG2R = 16;
+constexpr uint32_t kPadBits = 0x80000000u;
+
+struct G2Ent { int32_t col, lr; float val; };
+
+struct G2Layout {
+    std::vector<VRow> v;
+    std::vector<int64_t> assign;      // [nbins * 16] -> index into v, or -1
+    int64_t ntiles = 0;
+};
+
+void g2_layout(const int32_t* rowptr, int32_t M, int32_t T, int32_t round_tiles, G2Layout& L) {
+    std::vector<int32_t> rows((size_t)M);
+    std::iota(rows.begin(), rows.end(), 0);
+    make_vrows(rowptr, rows.data(), M, T, L.v);
+    const int64_t nv = (int64_t)L.v.size();
+    int64_t nt = (nv + 2 * kG2R - 1) / (2 * kG2R);
+    if (round_tiles > 0 && nt > round_tiles / 2)                       // whole launches (a small matrix just gets enough tiles)
+        nt = (nt + round_tiles - 1) / round_tiles * round_tiles;
+    L.ntiles = nt;
+    L.assign = deal(L.v, kG2R, nt * 2);
+}
+
+// the column-sorted entries of one bin
+void g2_bin(const G2Layout& L, const int32_t* rowptr, const int32_t* col, const float* val, int64_t bin,
+            std::vector<G2Ent>& ents, std::vector<std::pair<int32_t, float>>& rowbuf) {
+    ents.clear();
+    for (int32_t k = 0; k < kG2R; k++) {
+        const int64_t vi = L.assign[(size_t)bin * kG2R + k];
+        if (vi < 0) continue;
+        const VRow& vr = L.v[vi];
+        const int32_t b = rowptr[vr.row], e = rowptr[vr.row + 1];
+        if (vr.npieces == 1) {
+            for (int32_t p = b; p < e; p++) ents.push_back({col[p], k, val ? val[p] : 0.f});
+        } else {
+            rowbuf.clear();
+            for (int32_t p = b; p < e; p++) rowbuf.push_back({col[p], val ? val[p] : 0.f});
+            std::stable_sort(rowbuf.begin(), rowbuf.end(),
+                             [](const std::pair<int32_t, float>& a, const std::pair<int32_t, float>& c2) { return a.first < c2.first; });
+            for (int32_t i = vr.piece; i < e - b; i += vr.npieces) ents.push_back({rowbuf[i].first, k, rowbuf[i].second});
+        }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const G2Ent& a, const G2Ent& b) { return a.col < b.col; });
+}
+
+// Aligned two-bin schedule; emit(step, g, entry-or-null).  Returns the number of steps.
+template <class Emit>
+int64_t g2_schedule(const std::vector<G2Ent>& e0, const std::vector<G2Ent>& e1, int32_t align, Emit emit) {
+    size_t i0 = 0, i1 = 0;
+    int64_t step = 0;
+    while (i0 < e0.size() || i1 < e1.size()) {
+        const bool h0 = i0 < e0.size(), h1 = i1 < e1.size();
+        bool t0 = h0, t1 = h1;
+        if (h0 && h1 && align > 0) {
+            const int64_t c0 = e0[i0].col, c1 = e1[i1].col;
+            t0 = c0 <= c1 + align;
+            t1 = c1 <= c0 + align;
+        }
+        emit(step, 0, t0 ? &e0[i0] : nullptr);
+        emit(step, 1, t1 ? &e1[i1] : nullptr);
+        i0 += t0; i1 += t1;
+        step++;
+    }
+    return step;
+}
+}  // namespace
+
+extern "C" {
+
+int sgcn_csplan2_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles,
+                       int32_t align, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
+    if (M < 0 || (M > 0 && (!rowptr || !col)) || !ntiles || !nentries || !nfix || !nslots)
+        return sgcn::fail(SGCN_ERR_INVALID, "csplan2_count: bad argument");
+    if (T <= 0) T = default_t(rowptr, M);
+    int64_t f = 0, sl = 0;
+    for (int32_t r = 0; r < M; r++) {
+        const int64_t n = (int64_t)rowptr[r + 1] - rowptr[r];
+        if (n < 0) return sgcn::fail(SGCN_ERR_INVALID, "csplan2_count: rowptr not monotone at %d", r);
+        if (n > T) { sl += (n + T - 1) / T; f += 1; }
+    }
+    G2Layout L;
+    g2_layout(rowptr, M, T, round_tiles, L);
+    std::vector<G2Ent> e0, e1;
+    std::vector<std::pair<int32_t, float>> rowbuf;
+    int64_t entries = 0;
+    for (int64_t t = 0; t < L.ntiles; t++) {
+        g2_bin(L, rowptr, col, nullptr, 2 * t, e0, rowbuf);
+        g2_bin(L, rowptr, col, nullptr, 2 * t + 1, e1, rowbuf);
+        entries += 2 * g2_schedule(e0, e1, align, [](int64_t, int, const G2Ent*) {});
+    }
+    *ntiles = L.ntiles; *nentries = entries; *nfix = f; *nslots = sl;
+    return SGCN_OK;
+}
+
+int sgcn_csplan2_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T,
+                      int32_t round_tiles, int32_t align, int64_t* tile_ptr, int32_t* colrow, float* valout,
+                      int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
+    if (M < 0 || (M > 0 && (!rowptr || !col || !val || !tile_ptr || !tile_rows || !tile_slots)))
+        return sgcn::fail(SGCN_ERR_INVALID, "csplan2_fill: bad argument");
+    if (T <= 0) T = default_t(rowptr, M);
+    std::vector<int32_t> first_slot((size_t)M, -1);
+    int32_t slot = 0;
+    int64_t f = 0;
+    for (int32_t r = 0; r < M; r++) {
+        const int32_t n = rowptr[r + 1] - rowptr[r];
+        if (n <= T) continue;
+        const int32_t c = (n + T - 1) / T;
+        first_slot[r] = slot;
+        if (!fix) return sgcn::fail(SGCN_ERR_INVALID, "csplan2_fill: split rows but no fix array");
+        fix[f++] = sgcn_fix_t{r, slot, c};
+        slot += c;
+    }
+    G2Layout L;
+    g2_layout(rowptr, M, T, round_tiles, L);
+    std::vector<G2Ent> e[2];
+    std::vector<std::pair<int32_t, float>> rowbuf;
+    int64_t out = 0;
+    int bad = 0;
+    for (int64_t t = 0; t < L.ntiles; t++) {
+        tile_ptr[t] = out;
+        for (int g = 0; g < 2; g++) {
+            for (int32_t k = 0; k < kG2R; k++) {
+                const int64_t slot_idx = (t * 2 + g) * kG2R + k;
+                const int64_t vi = L.assign[(size_t)slot_idx];
+                if (vi < 0) { tile_rows[slot_idx] = -1; tile_slots[slot_idx] = -1; continue; }
+                const VRow& vr = L.v[vi];
+                tile_rows[slot_idx] = vr.row;
+                tile_slots[slot_idx] = vr.npieces > 1 ? first_slot[vr.row] + vr.piece : -1;
+            }
+            g2_bin(L, rowptr, col, val, 2 * t + g, e[g], rowbuf);
+        }
+        int32_t last[2] = {0, 0};       // a pad points at a column its bin has just used (a certain L2 hit, never applied)
+        g2_schedule(e[0], e[1], align, [&](int64_t, int g, const G2Ent* en) {
+            uint32_t word;
+            float v;
+            if (en) {
+                if (en->col < 0 || en->col >= (1 << 28)) bad = 1;
+                last[g] = en->col;
+                word = (uint32_t)en->col | ((uint32_t)en->lr << 28);
+                v = en->val;
+                uint32_t bits;
+                memcpy(&bits, &v, 4);
+                if (bits == kPadBits) v = 0.0f;          // a real -0.0f: stored as +0.0f (the pad marker is -0.0f)
+            } else {
+                word = (uint32_t)last[g];
+                const uint32_t bits = kPadBits;
+                memcpy(&v, &bits, 4);
+            }
+            colrow[out] = (int32_t)word;
+            valout[out] = v;
+            out++;
+        });
+    }
+    if (bad) return sgcn::fail(SGCN_ERR_INVALID, "csplan2_fill: a column does not fit 28 bits");
+    tile_ptr[L.ntiles] = out;
     return SGCN_OK;
 }
 

@@ -205,6 +205,146 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     }
 }
 
+// ---- two lane groups per wavefront (plan->G == 2): EXPERIMENTAL, not the default -------------------------
+// Lanes 0-31 hold the 16 x float4 accumulators of bin 0, lanes 32-63 those of bin 1 (same pinned registers
+// v[64:127], four planes of 16), one 128-column slab per pass.  A step applies ONE nonzero of each bin: the
+// two column words come from adjacent lanes of the coalesced entry load (v_readlane), a per-lane select
+// gives every lane ITS bin's column, one dwordx4 instruction gathers the 512-byte slab pieces of the two B
+// rows, and the indexed FMA group runs twice under the two half-wave execution masks (a pad entry gets an
+// empty mask and never touches an accumulator).
+// The idea: a wave holds 32 rows of a 128-column slab instead of 16 rows of a 304-column one, so B should
+// pass through every XCD's L2 half as often per register byte, while the gather keeps the full-width rate
+// (28.4 TB/s measured for this shape in profiles/gather_ceiling).  MEASURED on S-Reddit (profiles/g2_*):
+// 4.4 ms against 3.69 ms for the one-group kernel -- the L2 requests and their rate are as predicted, but
+// every B piece is fetched 2.6 times per XCD and pass (1.6 times even when all waves are clock-locked at a
+// third of the speed; 1.04 for the one-group kernel), 24 GB of fabric traffic instead of the 10.6 GB the
+// plan should need, and T = miss/7.2 + hit/28 TB/s then gives exactly the measured time.  Aligning the two
+// bins' column positions with pads (sgcn_csplan2 `align`) costs more steps than it saves.  Kept behind
+// `ColumnSweepCSR(G=2)` / `bench.py --cs-g 2` as a reproducible negative result.
+template <int U>
+__global__ __launch_bounds__(kBlock) void cs_spmm16g2_kernel(CsArgs a) {
+    typedef Vec<4>::type VT;
+    constexpr int kShift = 28;
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= 32;
+    const int li = lane & 31;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int fbase = a.slab * 128;
+    const int f4 = fbase + li * 4;
+    const bool act = f4 < a.d;
+    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const int64_t ldb_bytes = a.ldb * 4;
+    const uint32_t ldb32 = (uint32_t)ldb_bytes;               // the host checks the pitch fits 32 bits
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t ax = {}, ay = {}, az = {}, aw = {};
+
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t tnow = t0;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+    int step0 = 0;
+    for (int64_t p0 = start; p0 < end; p0 += kWave, step0 += kWave / 2) {
+        const int n = (int)min((int64_t)kWave, end - p0);          // entries in this chunk (even)
+        uint32_t mycr = 0;
+        float myv = 0.f;
+        if (lane < n) {
+            mycr = a.colrow[p0 + lane];
+            myv = a.val[p0 + lane];
+            uint32_t c = mycr & kColMask;
+            if (a.cscale && __float_as_int(myv) != (int)0x80000000) {
+                myv *= a.cscale[c];
+                if (__float_as_int(myv) == (int)0x80000000) myv = 0.f;      // a product that rounds to -0 is not a pad
+            }
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; mycr = (mycr & ~kColMask) | c; }
+        }
+        const int nsteps = n / 2;
+        // m0 / m1: all-ones or zero, the half-wave's execution mask (wave-uniform: forced into SGPRs)
+        auto apply2 = [&](uint32_t cr0, float v0, int m0, uint32_t cr1, float v1, int m1, VT b) {
+            const int l0 = (int)(cr0 >> kShift), l1 = (int)(cr1 >> kShift);
+            asm volatile("s_mov_b32 exec_lo, %4\n\t"
+                         "s_mov_b32 exec_hi, 0\n\t"
+                         "s_set_gpr_idx_on %5, 0xc\n\t"
+                         "v_fma_f32 v64, %6, %10, v64\n\t"
+                         "v_fma_f32 v80, %6, %11, v80\n\t"
+                         "v_fma_f32 v96, %6, %12, v96\n\t"
+                         "v_fma_f32 v112, %6, %13, v112\n\t"
+                         "s_set_gpr_idx_off\n\t"
+                         "s_mov_b32 exec_lo, 0\n\t"
+                         "s_mov_b32 exec_hi, %7\n\t"
+                         "s_set_gpr_idx_on %8, 0xc\n\t"
+                         "v_fma_f32 v64, %9, %10, v64\n\t"
+                         "v_fma_f32 v80, %9, %11, v80\n\t"
+                         "v_fma_f32 v96, %9, %12, v96\n\t"
+                         "v_fma_f32 v112, %9, %13, v112\n\t"
+                         "s_set_gpr_idx_off\n\t"
+                         "s_mov_b64 exec, -1"
+                         : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw)
+                         : "s"(m0), "s"(l0), "s"(v0), "s"(m1), "s"(l1), "s"(v1), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+        };
+        auto gather = [&](int j) -> VT {
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j) & kColMask;
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j + 1) & kColMask;
+            const uint32_t c = hi ? c1 : c0;
+            return *reinterpret_cast<const VT*>(Bb + (uint64_t)c * ldb32 + off4);         // one v_mad_u64_u32
+        };
+        auto fma2 = [&](int j, VT b) {
+            const uint32_t cr0 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j);
+            const uint32_t cr1 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j + 1);
+            const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), 2 * j));
+            const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), 2 * j + 1));
+            // pad entries (value bits 0x80000000) get an empty execution mask
+            const int m0 = __builtin_amdgcn_readfirstlane(__float_as_int(v0) == (int)0x80000000 ? 0 : -1);
+            const int m1 = __builtin_amdgcn_readfirstlane(__float_as_int(v1) == (int)0x80000000 ? 0 : -1);
+            apply2(cr0, v0, m0, cr1, v1, m1, b);
+        };
+        const int nb = nsteps / U;
+        for (int k = 0; k < nb; k++) {
+            const int jj = k * U;
+            if (a.cols_per_tick > 0.f) {
+                const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * jj) & kColMask);
+                float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
+                for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {   // bounded: never hangs
+                    __builtin_amdgcn_s_sleep(8);
+                    allowed = (float)(__builtin_amdgcn_s_memrealtime() - t0) * a.cols_per_tick + a.slack_cols;
+                }
+            }
+            VT bb[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) bb[u] = gather(jj + u);
+            if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+            for (int u = 0; u < U; u++) fma2(jj + u, bb[u]);
+        }
+        for (int j = nb * U; j < nsteps; j++) fma2(j, gather(j));
+    }
+
+    const int32_t* rows = a.tile_rows + tile * 32 + (hi ? 16 : 0);
+    const int32_t* slots = a.tile_slots + tile * 32 + (hi ? 16 : 0);
+    const int left = a.d - f4;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rows[r];                       // differs between the two half-waves
+        const VT accv = {ax[r], ay[r], az[r], aw[r]};
+        if (row < 0 || !act) continue;
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc;
+            const float rs = a.rscale ? a.rscale[row] : 1.0f;
+            VT res = accv * rs;
+            if (a.beta != 0.f) {
+                if (left >= 4) res += a.beta * vload<4>(out + f4);
+                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
+            }
+            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
+        }
+    }
+}
+
 template <int R, int VW, int U>
 __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
     typedef typename Vec<VW>::type VT;
@@ -358,6 +498,14 @@ struct CsVariant { int nslab, slab_floats, U; bool pinned, extra; const char* na
 
 CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
     CsVariant v{};
+    if (plan->G == 2) {             // two lane groups per wave: 128-column passes, one dwordx4 per step
+        v.nslab = ((d + 3) / 4 * 4 + 127) / 128;
+        v.slab_floats = 128;
+        v.U = tune_get("cs_unroll") == 4 ? 4 : 8;
+        v.pinned = true; v.extra = false;
+        v.name = v.U == 4 ? "sgcn::cs_spmm16g2_kernel<4>" : "sgcn::cs_spmm16g2_kernel<8>";
+        return v;
+    }
     const int VW = plan->R <= 16 ? 4 : 2;
     const int nvec = (d + VW - 1) / VW;
     v.U = tune_get("cs_unroll") > 0 ? tune_get("cs_unroll") : 8;
@@ -424,6 +572,8 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
     a.xcd_map = plan->xcd_map;
+    SGCN_REQUIRE(plan->G != 2 || plan->R == 16, "spmm_cs: a G = 2 plan needs R = 16");
+    SGCN_REQUIRE(plan->G != 2 || ldb * 4 < (1ll << 32), "spmm_cs: row pitch of B must fit 32 bits");
     if (plan->nfix > 0) {
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
                      "spmm_cs: workspace missing or too small");
@@ -455,7 +605,10 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
 #define SGCN_CS_LAUNCH(RR, VV, UU) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU>), dim3(blocks), dim3(kBlock), 0, st, a)
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
-            if (pinned) {
+            if (plan->G == 2) {
+                if (U == 4) hipLaunchKernelGGL((cs_spmm16g2_kernel<4>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((cs_spmm16g2_kernel<8>), dim3(blocks), dim3(kBlock), 0, st, a);
+            } else if (pinned) {
                 if (extra) { if (U == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }
             } else if (plan->R == 16) {         // generic (hipcc-lowered indexing) reference path

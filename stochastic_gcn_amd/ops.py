@@ -437,8 +437,17 @@ class ColumnSweepCSR(object):
     what the clock pacing provides on a graph without structure).  Results equal the unlabelled
     plan's up to fp32 summation order."""
 
-    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None):
+    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align=1024):
+        """G = 2 (EXPERIMENTAL): two 16-row lane groups per wavefront on 128-column passes (sgcn_csplan2_*).
+        Meant to halve the passes of the dense operand through every XCD; measured slower than the default
+        (4.4 vs 3.69 ms on S-Reddit: 2.6 fetches per B piece and pass) -- DESIGN.md 3.1b."""
         a = a.tocsr()
+        self.G = int(G)
+        if self.G == 2:
+            if col_labels is not None or row_labels is not None or R != 16:
+                raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
+            self._init_g2(a, device, T, round_tiles, int(align))
+            return
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
         val = np.ascontiguousarray(a.data, dtype=np.float32)
@@ -485,6 +494,40 @@ class ColumnSweepCSR(object):
         self.ws, self.device = None, device
         self.nnz = int(col.shape[0])
 
+    def _init_g2(self, a, device, T, round_tiles, align):
+        rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(a.indices, dtype=np.int32)
+        val = np.ascontiguousarray(a.data, dtype=np.float32)
+        M = rowptr.shape[0] - 1
+        rnd = int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))
+        nt, ne, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.sgcn_csplan2_count(rowptr.ctypes.data, col.ctypes.data, M, T, rnd, align, C.byref(nt), C.byref(ne),
+                                     C.byref(nfix), C.byref(nslots)))
+        tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
+        colrow = np.empty(ne.value, dtype=np.int32)
+        valout = np.empty(ne.value, dtype=np.float32)
+        tile_rows = np.empty(nt.value * 32, dtype=np.int32)
+        tile_slots = np.empty(nt.value * 32, dtype=np.int32)
+        fix = np.empty((nfix.value, 3), dtype=np.int32)
+        check(lib.sgcn_csplan2_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, T, rnd, align,
+                                    tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data, tile_rows.ctypes.data,
+                                    tile_slots.ctypes.data, fix.ctypes.data if nfix.value else None))
+        self.pad_fraction = 1.0 - 2.0 * col.shape[0] / max(ne.value, 1) / 2.0 if ne.value else 0.0
+        self.pad_fraction = 1.0 - col.shape[0] / max(ne.value, 1)
+        self.grouped, self.pos2col = False, None
+        self.shape = (int(a.shape[0]), int(a.shape[1]))
+        self.R, self.ntiles, self.nfix, self.nslots = 16, nt.value, nfix.value, nslots.value
+        self.round_tiles = round_tiles
+        self._tile_nnz = (np.diff(tile_ptr) // 2).astype(np.int64)       # steps per tile (what the pace counts)
+        self._hint, self._hint_round = None, None
+        self.pace = {}
+        to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731
+        self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
+        self.tile_rows, self.tile_slots = to(tile_rows), to(tile_slots)
+        self.fix = to(fix) if nfix.value else None
+        self.ws, self.device = None, device
+        self.nnz = int(col.shape[0])
+
     # ---- on-disk plan cache (beside the dataset's .npz) -------------------------
     @staticmethod
     def matrix_key(a):
@@ -498,8 +541,8 @@ class ColumnSweepCSR(object):
         return "%dx%d:%d:%08x" % (a.shape[0], a.shape[1], a.nnz, crc)
 
     def save(self, path, key):
-        if self.grouped:
-            raise ValueError("grouped plans are not cached (they are cheap to rebuild from the labels)")
+        if self.grouped or getattr(self, 'G', 1) != 1:
+            raise ValueError("grouped / G = 2 plans are not cached (they are cheap to rebuild)")
         t = lambda x: x.cpu().numpy()          # noqa: E731
         blob = dict(key=np.array(key), R=self.R, shape=np.array(self.shape, np.int64), nslots=self.nslots,
                     round_tiles=self.round_tiles, tile_ptr=t(self.tile_ptr), colrow=t(self.colrow), val=t(self.val),
@@ -523,7 +566,7 @@ class ColumnSweepCSR(object):
         if str(z["key"]) != key:
             return None
         self = cls.__new__(cls)
-        self.grouped, self.pos2col = False, None
+        self.grouped, self.pos2col, self.G = False, None, 1
         self.shape = tuple(int(x) for x in z["shape"])
         self.R, self.nslots, self.round_tiles = int(z["R"]), int(z["nslots"]), int(z["round_tiles"])
         tile_ptr = z["tile_ptr"]
@@ -578,7 +621,8 @@ class ColumnSweepCSR(object):
                            self.val.data_ptr(), self.tile_rows.data_ptr(), self.tile_slots.data_ptr(),
                            _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
                            0 if self.ws is None else self.ws.numel(), rnd, self._hint.ctypes.data,
-                           -1 if self.grouped else int(self.pace.get(d, 0)), 1 if self.grouped else 0)
+                           -1 if self.grouped else int(self.pace.get(d, 0)), int(getattr(self, 'G', 1)),
+                           1 if self.grouped else 0)
 
     def variant(self, d):
         """The kernel variant / launch geometry sgcn_spmm_cs_f32 uses for this plan and width."""
@@ -587,11 +631,14 @@ class ColumnSweepCSR(object):
         check(lib.sgcn_spmm_cs_variant(C.byref(plan), int(d), buf, 256))
         return buf.value.decode()
 
-    def autotune(self, B, d=None, candidates=(-1, 200, 220, 240, 260, 280, 320, 380), reps=2):
+    def autotune(self, B, d=None, candidates=None, reps=2):
         """Pick the sweep clock for this plan and row width by timing a few candidates (the
         sustainable pace depends on the graph, d and the chip's clocks; too fast loses the
         lock-step and with it the L2 hits, too slow leaves the memory system idle)."""
         d = int(B.shape[1] if d is None else d)
+        if candidates is None:           # ns per step of the heaviest tile (a G = 2 step is one load for two nonzeros)
+            candidates = (-1, 200, 220, 240, 260, 280, 320, 380) if getattr(self, 'G', 1) == 1 else \
+                (-1, 100, 130, 160, 190, 220, 250, 280, 320)
         if self.grouped:                 # grouped plans run unpaced (see the class docstring)
             self.pace[d] = -1
             return (None, -1)

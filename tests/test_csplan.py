@@ -98,3 +98,49 @@ def test_label_propagation_finds_planted_communities_and_nothing_else():
     u = synthetic.reddit_like(n=12000, m=500000, splits=(8000, 1000, 3000), seed=4, with_features=False)
     _, ncu = ops.reorder_labels(u[2])
     assert ncu == 1          # uniform destinations: no structure, the reordering degenerates to a no-op
+
+
+@pytest.mark.parametrize("align", [0, 40])
+def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
+    """sgcn_csplan2_*: interleaved entries (2*step + bin), pads marked by the value bits 0x80000000, 32 row slots
+    per tile, whole launches; with align > 0 the two bins of a tile stay within `align` columns of each other."""
+    rng = np.random.RandomState(5)
+    a = sp.random(900, 700, density=0.04, random_state=rng, format='csr', dtype=np.float32)
+    a = sp.vstack([a, sp.csr_matrix(np.ones((1, 700), np.float32))]).tocsr()
+    a.sort_indices()
+    a.data[3] = -0.0                                      # a real -0.0f must not be taken for a pad
+    rowptr = np.ascontiguousarray(a.indptr, np.int32)
+    col, val = np.ascontiguousarray(a.indices, np.int32), np.ascontiguousarray(a.data, np.float32)
+    M = a.shape[0]
+    for rnd in (0, 8):
+        nt, ne, nf, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.sgcn_csplan2_count(rowptr.ctypes.data, col.ctypes.data, M, 64, rnd, align, C.byref(nt), C.byref(ne),
+                                     C.byref(nf), C.byref(ns)))
+        if rnd:
+            assert nt.value % rnd == 0
+        tp = np.empty(nt.value + 1, np.int64)
+        cr, vo = np.empty(ne.value, np.int32), np.empty(ne.value, np.float32)
+        tr, ts = np.empty(nt.value * 32, np.int32), np.empty(nt.value * 32, np.int32)
+        fx = np.empty((nf.value, 3), np.int32)
+        check(lib.sgcn_csplan2_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, 64, rnd, align, tp.ctypes.data,
+                                    cr.ctypes.data, vo.ctypes.data, tr.ctypes.data, ts.ctypes.data, fx.ctypes.data))
+        assert tp[-1] == ne.value and nf.value >= 1 and (np.diff(tp) % 2 == 0).all()
+        u = cr.view(np.uint32)
+        real = vo.view(np.uint32) != 0x80000000
+        assert real.sum() == a.nnz
+        e = np.arange(ne.value)
+        tile = np.repeat(np.arange(nt.value), np.diff(tp))
+        g = (e - tp[tile]) % 2
+        cols = (u & 0x0FFFFFFF).astype(np.int64)
+        rows = tr[tile * 32 + g * 16 + (u >> 28).astype(np.int64)]
+        assert (rows[real] >= 0).all()
+        b = sp.coo_matrix((vo[real], (rows[real], cols[real])), shape=a.shape).tocsr()
+        assert (abs(a - b)).nnz == 0
+        for t in range(nt.value):
+            for gg in range(2):
+                sel = (tile == t) & (g == gg) & real
+                assert (np.diff(cols[sel]) >= 0).all()                   # column-sorted inside a bin
+            if align:                                                     # the halves of a step stay close
+                s0, s1 = (tile == t) & (g == 0), (tile == t) & (g == 1)
+                both = real[s0] & real[s1]
+                assert (np.abs(cols[s0][both] - cols[s1][both]) <= align).all()

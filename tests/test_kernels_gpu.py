@@ -335,6 +335,58 @@ def test_column_sweep_full_size_matches_row_gather(dev):
     assert torch.equal(ops.spmm_cs(Acs, Bfull[:, :602]), c2)       # deterministic
 
 
+@pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6), (500, 500, 256, 0),
+                                         (64, 64, 130, 2), (90, 70, 30, 2), (5000, 3000, 602, 6)])
+def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad):
+    """G = 2 plan (two 16-row bins per wavefront, 128-column passes, half-wave execution masks): the product,
+    its fusions and beta against the oracle; bit-identical reruns and paces."""
+    from stochastic_gcn_amd import ops
+    a = rand_csr(M, K, 0.08 if M < 1000 else 0.01, M + d, long_rows=[(0, min(K, 300)), (M // 2, min(K, 150))])
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((K, d + pad)).astype(np.float32)
+    A = ops.ColumnSweepCSR(a, dev, T=32, G=2)
+    assert A.nfix >= 1 and A.G == 2
+    Bd = T(B, dev)[:, :d]
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    out = ops.spmm_cs(A, Bd)
+    assert onp.rel_err(out.cpu().numpy(), ref) <= TOL
+    assert torch.equal(ops.spmm_cs(A, Bd), out)
+    for p in (-1, 150, 400):                         # pacing is timing only
+        A.pace[d] = p
+        assert torch.equal(ops.spmm_cs(A, Bd), out)
+    H = rng.standard_normal((K + 500, d + pad)).astype(np.float32)
+    g = rng.choice(K + 500, K, replace=False).astype(np.int32)
+    rs, cs = rng.rand(M).astype(np.float32), rng.rand(K).astype(np.float32)
+    c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
+    o2 = T(c0, dev)
+    ops.spmm_cs(A, T(H, dev)[:, :d], out=o2[:, :d], gidx=T(g, dev), rscale=T(rs, dev), cscale=T(cs, dev), beta=0.5)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, H[:, :d], gidx=g, rscale=rs, cscale=cs, C_in=c0[:, :d], beta=0.5)
+    assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
+    if pad:
+        np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
+    assert "g2" in A.variant(d)
+
+
+def test_two_lane_group_full_size_vs_oracle_rows(dev):
+    from stochastic_gcn_amd import ops, synthetic
+    n, _, full_adj, *_ = synthetic.reddit_like(with_features=False)
+    A = ops.ColumnSweepCSR(full_adj, dev, G=2)
+    assert A.ntiles % 4096 == 0
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    Bfull = torch.zeros((n, 608), device=dev)
+    Bfull[:, :602] = torch.randn((n, 602), device=dev, generator=g)
+    B = Bfull[:, :602]
+    best = A.autotune(B)
+    c = ops.spmm_cs(A, B)
+    deg = np.diff(full_adj.indptr)
+    rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.argsort(deg)[:20],
+                                     np.random.RandomState(1).choice(n, 1500, replace=False)]))
+    sub = full_adj[rows].tocsr()
+    ref = onp.spmm(sub.indptr, sub.indices, sub.data, B.cpu().numpy())
+    assert onp.rel_err(c[torch.from_numpy(rows).to(dev)].cpu().numpy(), ref) <= TOL
+    print("G=2 full size: %.3f ms at pace %s" % best)
+
+
 def test_column_sweep_paced_full_size_vs_oracle_rows(dev):
     """The configuration bench.py times -- full-size S-Reddit, d = 602 (pitch 608), the AUTOTUNED clock
     pace -- against the CPU oracle on sampled rows (incl. the longest), not against another HIP kernel."""
