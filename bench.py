@@ -560,7 +560,7 @@ def main(argv=None):
                     "T_model = miss_bytes/miss_rate + hit_bytes/hit_rate"}
         out["roofline"]["frac_of_gather_ceiling"] = t_floor / (fwd_ms * 1e-3)
     tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
-        if not (args.tune or sh is not None or reorder != "none") else None
+        if not (args.tune or sh is not None or reorder != "none" or args.cs_g != 1) else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model
