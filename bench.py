@@ -21,6 +21,7 @@ One JSON line on stdout (rank 0).  Extra objects:
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -60,7 +61,7 @@ def parse(argv=None):
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
-    p.add_argument("--cs-align", type=int, default=1024, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
+    p.add_argument("--cs-align", type=int, default=2048, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
     p.add_argument("--cs-g", type=int, default=1, choices=[1, 2],
                    help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes)")
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
@@ -523,9 +524,9 @@ def main(argv=None):
                         % (args.shard, sh.lo, sh.hi, sh.local_nnz)) if sh is not None
             else "one S-Reddit vertex-range shard",
             "kernel": args.kernel, "tune": args.tune, "grad_allreduce_ms": ar_ms,
-            # column sweep: ceil(d/320) passes (64 float4 + <= 64 extra floats per lane row) x rounds of 4096 tiles
-            "kernel_launches_per_spmm": (-(-((d + 3) // 4 * 4) // 320) if (d + 3) // 4 > 64 else 1)
-            * (-(-A.ntiles // 4096)) if args.kernel == "cs" else 1,
+            # column sweep: passes over the feature dimension x rounds of resident tiles, as the library reports it
+            "kernel_launches_per_spmm": int(re.search(r" x (\d+) launches", A.variant(d)).group(1))
+            if args.kernel == "cs" else 1,
             "cs_autotune_ms_pace": tuned},
         "roofline": {"bound": "hbm", "kernel": ((A.variant(d) + " + cs_fix_kernel: one SpMM") if args.kernel == "cs"
                                 else "sgcn::spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),

@@ -132,8 +132,8 @@ int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const 
  * rows, then bin 1's), colrow / val hold `nentries` interleaved entries (entry 2*step + g is bin g's); pad
  * entries carry the value bits 0x80000000 (-0.0f; real -0.0f values are stored as +0.0f) and are masked off by
  * the kernel.  align > 0: a bin advances only while at most `align` columns ahead of the other (keeps the two
- * halves of a wave inside one L2 window); the tile count is rounded up to whole launches of round_tiles waves
- * (0: no rounding). */
+ * halves of a wave inside one L2 window); every tile's entry count is padded to a multiple of 64 (the pipelined
+ * kernel has no tail code); the tile count is rounded up to whole launches of round_tiles waves (0: no rounding). */
 int sgcn_csplan2_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
                        int32_t round_tiles, int32_t align, int64_t* ntiles, int64_t* nentries, int64_t* nfix,
                        int64_t* nslots);
@@ -159,7 +159,8 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)
  *   cs_round (tiles per launch), cs_unroll (4|8), cs_pace (ns per nonzero of the heaviest tile,
  *   0 = unpaced), cs_slack (columns), cs_generic (compiler-lowered indexing instead of the pinned
- *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane) : column-sweep kernel
+ *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane), cs_g2_plain (G = 2 plans: the
+ *   unpipelined two-group kernel instead of the pipelined one), cs_g2_wide (force its 64-bit row offsets) : column-sweep kernel
  *   step_overlap (default 1): in sgcn_step_run, weight-gradient GEMMs + reductions on an auxiliary stream */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */

@@ -257,6 +257,12 @@ int64_t g2_schedule(const std::vector<G2Ent>& e0, const std::vector<G2Ent>& e1, 
         i0 += t0; i1 += t1;
         step++;
     }
+    // whole chunks of 64 entries (32 steps): the pipelined kernel runs without tail code
+    while (step % 32 != 0) {
+        emit(step, 0, nullptr);
+        emit(step, 1, nullptr);
+        step++;
+    }
     return step;
 }
 }  // namespace

@@ -37,6 +37,8 @@ int g_tune_cs_slack = 0;
 int g_tune_cs_generic = 0;
 int g_tune_cs_noextra = 0;
 int g_tune_step_overlap = 1;
+int g_tune_cs_g2_plain = 0;
+int g_tune_cs_g2_wide = 0;
 }  // namespace
 
 int tune_get(const char* key) {
@@ -50,6 +52,8 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_generic")) return g_tune_cs_generic;
     if (!strcmp(key, "cs_noextra")) return g_tune_cs_noextra;
     if (!strcmp(key, "step_overlap")) return g_tune_step_overlap;
+    if (!strcmp(key, "cs_g2_plain")) return g_tune_cs_g2_plain;
+    if (!strcmp(key, "cs_g2_wide")) return g_tune_cs_g2_wide;
     return -1;
 }
 
@@ -276,6 +280,8 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "cs_generic")) { g_tune_cs_generic = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_noextra")) { g_tune_cs_noextra = value != 0; return SGCN_OK; }
     if (!strcmp(key, "step_overlap")) { g_tune_step_overlap = value != 0; return SGCN_OK; }
+    if (!strcmp(key, "cs_g2_plain")) { g_tune_cs_g2_plain = value != 0; return SGCN_OK; }
+    if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_unroll")) {
         SGCN_REQUIRE(value == 0 || value == 4 || value == 8, "cs_unroll in {0,4,8}");

@@ -57,6 +57,15 @@ __device__ __forceinline__ int64_t cs_first_tile(const CsArgs& a) {
     return a.tile_base + (int64_t)(start + (b >> 3)) * (kBlock / kWave);
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 #define SGCN_CS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 // R = 16 specialisation with the accumulators PINNED to fixed VGPRs and updated by ONE indexed FMA
@@ -212,15 +221,17 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
 // gives every lane ITS bin's column, one dwordx4 instruction gathers the 512-byte slab pieces of the two B
 // rows, and the indexed FMA group runs twice under the two half-wave execution masks (a pad entry gets an
 // empty mask and never touches an accumulator).
-// The idea: a wave holds 32 rows of a 128-column slab instead of 16 rows of a 304-column one, so B should
-// pass through every XCD's L2 half as often per register byte, while the gather keeps the full-width rate
-// (28.4 TB/s measured for this shape in profiles/gather_ceiling).  MEASURED on S-Reddit (profiles/g2_*):
-// 4.4 ms against 3.69 ms for the one-group kernel -- the L2 requests and their rate are as predicted, but
-// every B piece is fetched 2.6 times per XCD and pass (1.6 times even when all waves are clock-locked at a
-// third of the speed; 1.04 for the one-group kernel), 24 GB of fabric traffic instead of the 10.6 GB the
-// plan should need, and T = miss/7.2 + hit/28 TB/s then gives exactly the measured time.  Aligning the two
-// bins' column positions with pads (sgcn_csplan2 `align`) costs more steps than it saves.  Kept behind
-// `ColumnSweepCSR(G=2)` / `bench.py --cs-g 2` as a reproducible negative result.
+// The idea: a wave holds 32 rows of a 128-column slab instead of 16 rows of a 304-column one, so B passes
+// through every XCD's L2 half as often per register byte, while the gather keeps the full-width rate (28.4 TB/s
+// measured for this shape in profiles/gather_ceiling).  This plain form is kept as the reference the pipelined
+// kernel below is tested against (knob cs_g2_plain); measured history on S-Reddit (profiles/g2_*):
+//  * no alignment of the two bins: 4.4 ms -- every B piece fetched 2.6 times per XCD and pass (1.6 with all
+//    waves clock-locked at a third of the speed).  profiles/l2_sweep_sim.py replays the plan through an LRU of
+//    the L2's size and gives the same numbers: the k-th entries of a wave's two bins sit 2,600 columns apart on
+//    average (p99 9,500) and the pace only governs bin 0, so the halves gather from two windows, not one;
+//  * bins aligned by the plan (sgcn_csplan2 `align` = 2048: 3-4 % pad steps): fetches compulsory (8.4 M lines
+//    per launch) whenever the clock is slow enough, but this kernel cannot follow a clock under ~270 ns per step
+//    (4.5 ms): it is latency- and issue-bound, see the pipelined form.
 template <int U>
 __global__ __launch_bounds__(kBlock) void cs_spmm16g2_kernel(CsArgs a) {
     typedef Vec<4>::type VT;
@@ -344,6 +355,211 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16g2_kernel(CsArgs a) {
         }
     }
 }
+
+// Software-pipelined, instruction-lean form of the two-group kernel (the default for G = 2 plans).
+// The plain form above (a) issues a batch of gathers, waits for ALL of them, applies them and only then issues
+// the next batch, (b) stalls every 32 steps on a dependent load of the next 64 plan entries, and (c) spends
+// ~20 VALU instructions per step, 12 of them moving plan entries from lanes to scalars (v_readlane) and
+// building addresses and masks; with 4 waves per SIMD that is 65 % of the SIMD's issue slots and the sweep
+// cannot be clocked under ~250 ns per step although the L2 would allow it (profiles/g2p_*).  Here:
+//  * the gathers of batch k+1 are in flight while batch k is applied (two register buffers of U float4), the
+//    pipeline runs across chunk boundaries, and the next chunk's entries are fetched a whole chunk ahead;
+//  * a lane gets ITS bin's column and value of a step by ds_bpermute (the LDS crossbar, no VALU slot), the
+//    row offset is one v_mad_u32_u24, the load uses the scalar-base + 32-bit-offset form;
+//  * the 64 local row ids of a chunk are packed into 8 scalars once per chunk (3 DPP ORs + 8 v_readlane) and
+//    picked per step by s_bfe; the chunk's pad mask is ONE v_cmp, tested per step by s_bitcmp;
+//  * the clock comparison is integer scalar arithmetic.
+// 10 VALU instructions per step (8 of them the FMAs).  Requires every tile's entry count to be a multiple of
+// 64 (sgcn_csplan2_fill pads to that).  WIDE: K >= 2^24 or B beyond 4 GiB -- 64-bit row offsets.
+template <int U, bool WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g2p_kernel(CsArgs a) {
+    typedef Vec<4>::type VT;
+    constexpr int kShift = 28;
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    constexpr int kSteps = kWave / 2;                 // steps per chunk of 64 entries
+    constexpr int kBatches = kSteps / U;
+    static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= 32;
+    const int li = lane & 31;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int fbase = a.slab * 128;
+    const int f4 = fbase + li * 4;
+    const bool act = f4 < a.d;
+    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const uint32_t ldb32 = (uint32_t)(a.ldb * 4);
+    const int sel0 = hi ? 4 : 0;                      // ds_bpermute byte address of entry (2 j + bin) is sel0 + 8 j
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t ax = {}, ay = {}, az = {}, aw = {};
+
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t tnow = t0;
+    // columns per tick in 16.16 fixed point (a launch lasts < 2^16 ticks of 10 ns; K / ticks < 2^15)
+    const uint32_t cpt16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.cols_per_tick * 65536.0f));
+    const uint32_t slack = (uint32_t)a.slack_cols;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+
+    // one chunk of plan entries: lane l holds entry l (even lanes bin 0, odd lanes bin 1 of step l / 2)
+    auto entries = [&](int64_t p, uint32_t& cr, float& v) {
+        cr = 0;
+        v = __int_as_float((int)0x80000000);                       // beyond the tile: pads on column 0
+        if (p < end) {
+            cr = a.colrow[p + lane];
+            v = a.val[p + lane];
+            uint32_t c = cr & kColMask;
+            if (a.cscale && __float_as_int(v) != (int)0x80000000) {
+                v *= a.cscale[c];
+                if (__float_as_int(v) == (int)0x80000000) v = 0.f;
+            }
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; cr = (cr & ~kColMask) | c; }
+        }
+    };
+    // per-chunk scalars: the local row ids, 8 lanes x 4 bits per word, and the pad mask
+    struct Meta { uint32_t lr[8]; uint32_t pad_lo, pad_hi; };
+    auto meta = [&](uint32_t cr, float v) -> Meta {
+        Meta m;
+        int x = (int)((cr >> kShift) << (4 * (lane & 7)));
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4 -> lane 8g+7 holds group g
+#pragma unroll
+        for (int g = 0; g < 8; g++) m.lr[g] = (uint32_t)__builtin_amdgcn_readlane(x, 8 * g + 7);
+        const uint64_t pm = __ballot(__float_as_int(v) == (int)0x80000000);
+        m.pad_lo = (uint32_t)pm; m.pad_hi = (uint32_t)(pm >> 32);
+        return m;
+    };
+    auto pace = [&](uint32_t crs, int j) {
+        if (cpt16 != 0) {
+            const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 2 * j) & kColMask;
+            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
+            for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
+            }
+        }
+    };
+    auto gather = [&](uint32_t crs, int j) -> VT {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 8 * j, (int)crs);   // my bin's column word
+        if constexpr (WIDE) {
+            return *reinterpret_cast<const VT*>(Bb + (uint64_t)(c & kColMask) * ldb32 + off4);
+        } else {                                       // u24 multiply: the row id above bit 24 is ignored by the instruction
+            const uint32_t off = __umul24(c, ldb32) + off4;
+            return *reinterpret_cast<const VT*>(Bb + off);
+        }
+    };
+#define SGCN_G2_FMA(PADWORD, BIT0, BIT1)                                                        \
+        asm volatile("s_bitcmp0_b32 %4, " #BIT0 "\n\t"                                          \
+                     "s_cselect_b32 exec_lo, -1, 0\n\t"                                         \
+                     "s_mov_b32 exec_hi, 0\n\t"                                                 \
+                     "s_set_gpr_idx_on %5, 0xc\n\t"                                             \
+                     "v_fma_f32 v64, %7, %8, v64\n\t"                                           \
+                     "v_fma_f32 v80, %7, %9, v80\n\t"                                           \
+                     "v_fma_f32 v96, %7, %10, v96\n\t"                                          \
+                     "v_fma_f32 v112, %7, %11, v112\n\t"                                        \
+                     "s_set_gpr_idx_off\n\t"                                                    \
+                     "s_bitcmp0_b32 %4, " #BIT1 "\n\t"                                          \
+                     "s_mov_b32 exec_lo, 0\n\t"                                                 \
+                     "s_cselect_b32 exec_hi, -1, 0\n\t"                                         \
+                     "s_set_gpr_idx_on %6, 0xc\n\t"                                             \
+                     "v_fma_f32 v64, %7, %8, v64\n\t"                                           \
+                     "v_fma_f32 v80, %7, %9, v80\n\t"                                           \
+                     "v_fma_f32 v96, %7, %10, v96\n\t"                                          \
+                     "v_fma_f32 v112, %7, %11, v112\n\t"                                        \
+                     "s_set_gpr_idx_off\n\t"                                                    \
+                     "s_mov_b64 exec, -1"                                                       \
+                     : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw) \
+                     : "s"(PADWORD), "s"(l0), "s"(l1), "v"(vv), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w) \
+                     : "scc")
+    // step j of the chunk (compile-time j): the value word of my bin by ds_bpermute, the two row ids by s_bfe, the pad
+    // bits 2j / 2j+1 of the chunk's mask by s_bitcmp
+    auto fma2 = [&](const Meta& m, float vs, auto jc, VT b) {
+        constexpr int j = decltype(jc)::value;
+        const float vv = __int_as_float(__builtin_amdgcn_ds_bpermute(sel0 + 8 * j, __float_as_int(vs)));
+        const int l0 = (int)((m.lr[j >> 2] >> ((j & 3) * 8)) & 15u);
+        const int l1 = (int)((m.lr[j >> 2] >> ((j & 3) * 8 + 4)) & 15u);
+        const uint32_t pw = j < 16 ? m.pad_lo : m.pad_hi;
+        constexpr int b0 = (2 * j) & 31;
+        if constexpr (b0 == 0) SGCN_G2_FMA(pw, 0, 1);
+        else if constexpr (b0 == 2) SGCN_G2_FMA(pw, 2, 3);
+        else if constexpr (b0 == 4) SGCN_G2_FMA(pw, 4, 5);
+        else if constexpr (b0 == 6) SGCN_G2_FMA(pw, 6, 7);
+        else if constexpr (b0 == 8) SGCN_G2_FMA(pw, 8, 9);
+        else if constexpr (b0 == 10) SGCN_G2_FMA(pw, 10, 11);
+        else if constexpr (b0 == 12) SGCN_G2_FMA(pw, 12, 13);
+        else if constexpr (b0 == 14) SGCN_G2_FMA(pw, 14, 15);
+        else if constexpr (b0 == 16) SGCN_G2_FMA(pw, 16, 17);
+        else if constexpr (b0 == 18) SGCN_G2_FMA(pw, 18, 19);
+        else if constexpr (b0 == 20) SGCN_G2_FMA(pw, 20, 21);
+        else if constexpr (b0 == 22) SGCN_G2_FMA(pw, 22, 23);
+        else if constexpr (b0 == 24) SGCN_G2_FMA(pw, 24, 25);
+        else if constexpr (b0 == 26) SGCN_G2_FMA(pw, 26, 27);
+        else if constexpr (b0 == 28) SGCN_G2_FMA(pw, 28, 29);
+        else SGCN_G2_FMA(pw, 30, 31);
+    };
+#undef SGCN_G2_FMA_DECL
+
+    uint32_t ccr, ncr;
+    float cv, nv;
+    entries(start, ccr, cv);
+    entries(start + kWave, ncr, nv);
+    Meta cm = meta(ccr, cv);
+    VT buf[2][U];
+    pace(ccr, 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
+    if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    for (int64_t p0 = start; p0 < end; p0 += kWave) {
+        static_for<kBatches>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // batch k+1 goes in flight (the first batch of the NEXT chunk after this chunk's last) ...
+            if constexpr (k + 1 < kBatches) {
+                pace(ccr, (k + 1) * U);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
+            } else {
+                pace(ncr, 0);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
+            }
+            if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            // ... while batch k is applied
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                fma2(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
+            });
+        });
+        ccr = ncr; cv = nv;
+        cm = meta(ccr, cv);
+        entries(p0 + 2 * kWave, ncr, nv);
+    }
+
+    const int32_t* rows = a.tile_rows + tile * 32 + (hi ? 16 : 0);
+    const int32_t* slots = a.tile_slots + tile * 32 + (hi ? 16 : 0);
+    const int left = a.d - f4;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rows[r];
+        const VT accv = {ax[r], ay[r], az[r], aw[r]};
+        if (row < 0 || !act) continue;
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc;
+            const float rs = a.rscale ? a.rscale[row] : 1.0f;
+            VT res = accv * rs;
+            if (a.beta != 0.f) {
+                if (left >= 4) res += a.beta * vload<4>(out + f4);
+                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
+            }
+            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
+        }
+    }
+}
+#undef SGCN_G2_FMA
 
 template <int R, int VW, int U>
 __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
@@ -501,9 +717,14 @@ CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
     if (plan->G == 2) {             // two lane groups per wave: 128-column passes, one dwordx4 per step
         v.nslab = ((d + 3) / 4 * 4 + 127) / 128;
         v.slab_floats = 128;
-        v.U = tune_get("cs_unroll") == 4 ? 4 : 8;
         v.pinned = true; v.extra = false;
-        v.name = v.U == 4 ? "sgcn::cs_spmm16g2_kernel<4>" : "sgcn::cs_spmm16g2_kernel<8>";
+        if (tune_get("cs_g2_plain") > 0) {
+            v.U = tune_get("cs_unroll") == 4 ? 4 : 8;
+            v.name = v.U == 4 ? "sgcn::cs_spmm16g2_kernel<4>" : "sgcn::cs_spmm16g2_kernel<8>";
+        } else {                    // software-pipelined: two buffers of U gathers
+            v.U = 4;
+            v.name = "sgcn::cs_spmm16g2p_kernel<4, false>";     // <4, true> when B needs 64-bit row offsets
+        }
         return v;
     }
     const int VW = plan->R <= 16 ? 4 : 2;
@@ -605,9 +826,14 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
 #define SGCN_CS_LAUNCH(RR, VV, UU) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU>), dim3(blocks), dim3(kBlock), 0, st, a)
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
-            if (plan->G == 2) {
+            if (plan->G == 2 && tune_get("cs_g2_plain") > 0) {
                 if (U == 4) hipLaunchKernelGGL((cs_spmm16g2_kernel<4>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else hipLaunchKernelGGL((cs_spmm16g2_kernel<8>), dim3(blocks), dim3(kBlock), 0, st, a);
+            } else if (plan->G == 2) {
+                const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
+                                  tune_get("cs_g2_wide") > 0;
+                if (wide) hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
             } else if (pinned) {
                 if (extra) { if (U == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }

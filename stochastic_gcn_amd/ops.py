@@ -437,10 +437,12 @@ class ColumnSweepCSR(object):
     what the clock pacing provides on a graph without structure).  Results equal the unlabelled
     plan's up to fp32 summation order."""
 
-    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align=1024):
-        """G = 2 (EXPERIMENTAL): two 16-row lane groups per wavefront on 128-column passes (sgcn_csplan2_*).
-        Meant to halve the passes of the dense operand through every XCD; measured slower than the default
-        (4.4 vs 3.69 ms on S-Reddit: 2.6 fetches per B piece and pass) -- DESIGN.md 3.1b."""
+    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align=2048):
+        """G = 2 (opt-in): two 16-row lane groups per wavefront on 128-column passes (sgcn_csplan2_*), half the
+        passes of the dense operand through every XCD per register byte.  ``align``: columns one bin of a wave
+        may run ahead of the other (the plan pads the bin that is ahead).  With aligned bins and the pipelined
+        kernel it is level with the default at d = 602 (3.49 vs 3.56 ms on S-Reddit: 10 launches against 8) and
+        ahead on narrower operands (S-RMAT d = 256: 2.61 vs 2.82 ms) -- DESIGN.md 3.1b."""
         a = a.tocsr()
         self.G = int(G)
         if self.G == 2:
@@ -631,20 +633,19 @@ class ColumnSweepCSR(object):
         check(lib.sgcn_spmm_cs_variant(C.byref(plan), int(d), buf, 256))
         return buf.value.decode()
 
-    def autotune(self, B, d=None, candidates=None, reps=2):
+    def autotune(self, B, d=None, candidates=None, reps=2, refine=True):
         """Pick the sweep clock for this plan and row width by timing a few candidates (the
         sustainable pace depends on the graph, d and the chip's clocks; too fast loses the
         lock-step and with it the L2 hits, too slow leaves the memory system idle)."""
         d = int(B.shape[1] if d is None else d)
         if candidates is None:           # ns per step of the heaviest tile (a G = 2 step is one load for two nonzeros)
             candidates = (-1, 200, 220, 240, 260, 280, 320, 380) if getattr(self, 'G', 1) == 1 else \
-                (-1, 100, 130, 160, 190, 220, 250, 280, 320)
+                (-1, 130, 160, 190, 210, 230, 250, 280, 320)
         if self.grouped:                 # grouped plans run unpaced (see the class docstring)
             self.pace[d] = -1
             return (None, -1)
         out = torch.empty((self.shape[0], (d + 3) // 4 * 4), dtype=torch.float32, device=B.device)[:, :d]
-        best = None
-        for p in candidates:
+        def timed(p):
             self.pace[d] = p
             spmm_cs(self, B, out=out, d=d)                       # warm
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -653,9 +654,23 @@ class ColumnSweepCSR(object):
                 spmm_cs(self, B, out=out, d=d)
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1) / reps
+            return e0.elapsed_time(e1) / reps
+
+        best = None
+        for p in candidates:
+            t = timed(p)
             if best is None or t < best[0]:
                 best = (t, p)
+        if refine and best[1] > 0:
+            # The optimum sits right above a cliff (too fast a clock and the waves lose the lock-step for good),
+            # and a two-launch burst tolerates a faster clock than a sustained run does (measured: 268 ns wins the
+            # burst, 7.5 ms per fwd+bwd sustained; 274 ns: 7.2; 280: 7.4).  So: a finer look around the coarse
+            # winner, then a 2 % guard band above the fastest clock that held.
+            for p in sorted({int(best[1] * f) for f in (0.94, 0.96, 0.98, 1.02)} - set(candidates)):
+                t = timed(p)
+                if t < best[0]:
+                    best = (t, p)
+            best = (best[0], int(best[1] * 1.02 + 0.5))
         self.pace[d] = best[1]
         return best
 

@@ -364,7 +364,21 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad):
     assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
     if pad:
         np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
-    assert "g2" in A.variant(d)
+    assert "g2p" in A.variant(d)
+    # the pipelined kernel (default), its 64-bit-offset form and the plain two-group kernel apply every bin's
+    # entries in the same order: bit-identical products
+    from stochastic_gcn_amd._ffi import lib
+    try:
+        for knob in (b"cs_g2_wide", b"cs_g2_plain"):
+            lib.sgcn_tune(knob, 1)
+            assert torch.equal(ops.spmm_cs(A, Bd), out)
+            o3 = T(c0, dev)
+            ops.spmm_cs(A, T(H, dev)[:, :d], out=o3[:, :d], gidx=T(g, dev), rscale=T(rs, dev), cscale=T(cs, dev), beta=0.5)
+            assert torch.equal(o3, o2)
+            lib.sgcn_tune(knob, 0)
+    finally:
+        lib.sgcn_tune(b"cs_g2_wide", 0)
+        lib.sgcn_tune(b"cs_g2_plain", 0)
 
 
 def test_two_lane_group_full_size_vs_oracle_rows(dev):
