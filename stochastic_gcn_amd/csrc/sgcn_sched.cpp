@@ -19,6 +19,7 @@
 #include "sgcn_host.h"
 #include "../../include/sgcn.h"
 
+#include <immintrin.h>
 #include <pthread.h>
 #include <sched.h>
 
@@ -129,7 +130,10 @@ public:
 
         field_.swap(next_);
         for (int32_t v : field_) slot_[v] = -1;
-        for (int32_t v : ffield_) fslot_[v] = -1;
+        // fslot_ entries are stamped (fbase_ + position): advancing the base un-marks this hop's
+        // full-neighbour field without touching its ~43 k scattered table entries again
+        fbase_ += (int32_t)ffield_.size();
+        if (fbase_ > (1 << 30)) { std::fill(fslot_.begin(), fslot_.end(), -1); fbase_ = 0; }
         transpose_ready_ = false;
         return rc;
     }
@@ -260,11 +264,52 @@ private:
     }
     int32_t fplace(int32_t v) {
         int32_t& s = fslot_[v];
-        if (s < 0) {
-            s = (int32_t)ffield_.size();
+        if (s < fbase_) {
+            s = fbase_ + (int32_t)ffield_.size();
             ffield_.push_back(v);
         }
-        return s;
+        return s - fbase_;
+    }
+
+    // fplace() over a whole neighbour list, 16 entries per step (AVX-512: gather the table entries, give the
+    // unseen vertices consecutive positions in list order with an expand, scatter the new stamps, append the
+    // new vertices with a compress-store).  Same first-seen numbering as the scalar loop: the entries of a
+    // vector are applied "at once", which differs from one-by-one only if a vertex occurs twice among the
+    // unseen lanes -- detected with vpconflictd and handed to the scalar loop.  This loop was 2/3 of the
+    // sampler's time (50 k table lookups per Reddit batch).
+    __attribute__((target("avx512f,avx512cd")))
+    void fplace_row_avx512(const int32_t* cols, int32_t deg, int32_t* ft) {
+        const size_t old = ffield_.size();
+        ffield_.resize(old + (size_t)deg);                 // room for the worst case; trimmed below
+        int32_t* fnew = ffield_.data();
+        int32_t next = (int32_t)old;
+        const __m512i base = _mm512_set1_epi32(fbase_);
+        const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        for (int32_t k = 0; k < deg; k += 16) {
+            const __mmask16 m = deg - k >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << (deg - k)) - 1u);
+            const __m512i v = _mm512_maskz_loadu_epi32(m, cols + k);
+            __m512i sl = _mm512_mask_i32gather_epi32(_mm512_set1_epi32(-1), m, v, fslot_.data(), 4);
+            const __mmask16 fresh = _mm512_mask_cmplt_epi32_mask(m, sl, base);
+            if (fresh) {
+                const __m512i conf = _mm512_conflict_epi32(_mm512_mask_mov_epi32(_mm512_sub_epi32(_mm512_setzero_si512(), _mm512_add_epi32(iota, _mm512_set1_epi32(1))), fresh, v));
+                if (_mm512_mask_test_epi32_mask(fresh, conf, conf)) {      // a repeated unseen vertex: one by one
+                    ffield_.resize((size_t)next);
+                    for (int32_t q = k; q < std::min(deg, k + 16); q++) ft[q] = fplace(cols[q]);
+                    next = (int32_t)ffield_.size();
+                    ffield_.resize(old + (size_t)deg);
+                    fnew = ffield_.data();
+                    continue;
+                }
+                const __m512i ids = _mm512_maskz_expand_epi32(fresh, _mm512_add_epi32(iota, _mm512_set1_epi32(next)));
+                const __m512i stamped = _mm512_add_epi32(ids, base);
+                _mm512_mask_i32scatter_epi32(fslot_.data(), fresh, v, stamped, 4);
+                _mm512_mask_compressstoreu_epi32(fnew + next, fresh, v);
+                next += __builtin_popcount((unsigned)fresh);
+                sl = _mm512_mask_mov_epi32(sl, fresh, stamped);
+            }
+            _mm512_mask_storeu_epi32(ft + k, m, _mm512_sub_epi32(sl, base));
+        }
+        ffield_.resize((size_t)next);
     }
 
     // Uniform sampling w/o replacement, optional control-variate extras (scheduler.cpp:125-180)
@@ -317,7 +362,8 @@ private:
                 fedg_t_.resize(base + (size_t)deg);
                 fedg_w_.resize(base + (size_t)deg);
                 int32_t* ft = fedg_t_.data() + base;
-                for (int32_t k = 0; k < deg; k++) ft[k] = fplace(cols[k]);
+                if (avx512_) fplace_row_avx512(cols, deg, ft);
+                else for (int32_t k = 0; k < deg; k++) ft[k] = fplace(cols[k]);
                 if (deg) memcpy(fedg_w_.data() + base, vals, (size_t)deg * sizeof(float));
                 if (want_coo_) fedg_s_.insert(fedg_s_.end(), (size_t)deg, (int32_t)i);
                 fedg_p_.push_back((int32_t)fedg_t_.size());
@@ -413,6 +459,8 @@ private:
     std::vector<float> wgt_;
     std::vector<int32_t> ptr_;
     std::vector<int32_t> slot_, fslot_;
+    int32_t fbase_ = 0;                    // stamp base of fslot_: an entry >= fbase_ is a position in this hop's ffield_
+    const bool avx512_ = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && !getenv("SGCN_NO_AVX512");
     std::vector<float> importance_;
     std::vector<int32_t> field_, next_, ffield_;
     std::vector<float> scales_;

@@ -266,3 +266,60 @@ def test_csplan_covers_matrix_and_balances_tiles():
         for row, first, cnt in fx[:nf.value]:
             got = sorted(ts[(tr == row) & (ts >= 0)].tolist())
             assert got == list(range(first, first + cnt))
+
+
+def test_vector_and_scalar_full_neighbour_placement_agree(monkeypatch):
+    """The AVX-512 placement of a row's full neighbour list (sgcn_sched.cpp fplace_row_avx512) and the
+    one-by-one loop give the same fields and CSRs over consecutive batches -- on a graph with long rows, rows
+    shorter than a vector, and a MULTIGRAPH row whose repeated neighbours fall into the same 16-entry vector
+    (the conflict path)."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(5)
+    n = 400
+    rows, cols = [], []
+    for r in range(n):
+        deg = [0, 1, 3, 15, 16, 17, 40, 120][r % 8]
+        c = rng.choice(n, deg, replace=False)
+        if r % 16 == 6 and deg >= 3:
+            c[2] = c[0]                       # repeated neighbour inside one vector
+            c[-1] = c[1]                      # ... and across vectors
+        rows += [r] * deg
+        cols += c.tolist()
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    adj = sp.csr_matrix((rng.rand(len(cols)).astype(np.float32), np.array(cols, np.int32), ptr), shape=(n, n))
+    labels = np.zeros((n, 2), np.float32)
+    out = []
+    for novec in ("", "1"):
+        if novec:
+            monkeypatch.setenv("SGCN_NO_AVX512", novec)
+        else:
+            monkeypatch.delenv("SGCN_NO_AVX512", raising=False)
+        sch = PyScheduler(adj, labels, 2, [2, 2], gu.placeholders(2), 3, cv=True)
+        rng2 = np.random.RandomState(9)
+        fds = []
+        for it in range(4):              # rows 6 + 16 i are the multigraph rows: two of them in every batch
+            rest = np.setdiff1d(rng2.choice(n, 64, replace=False), [6 + 32 * it, 22 + 32 * it])
+            fds.append(sch.batch(np.concatenate([[6 + 32 * it, 22 + 32 * it], rest]).astype(np.int32)))
+        out.append(fds)
+    from stochastic_gcn_amd.scheduler import HostCSR
+
+    def same(va, vb, k):
+        if isinstance(va, HostCSR):
+            for f in HostCSR.__slots__:
+                same(getattr(va, f), getattr(vb, f), (k, f))
+        elif isinstance(va, (tuple, list)):
+            assert len(va) == len(vb), k
+            for xa, xb in zip(va, vb):
+                same(xa, xb, k)
+        elif va is None:
+            assert vb is None, k
+        else:
+            np.testing.assert_array_equal(np.asarray(va), np.asarray(vb), err_msg=str(k))
+
+    n_f = 0
+    for fa, fb in zip(*out):
+        assert fa.keys() == fb.keys()
+        for k in fa:
+            same(fa[k], fb[k], k)
+            n_f += str(k).startswith("('csr', 'fadj") or "fadj" in str(k)
+    assert n_f >= 8                    # the full-neighbour CSRs were among what was compared
