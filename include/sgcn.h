@@ -301,6 +301,27 @@ int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int6
                                                   the minibatch's feature rows (history.dense_slice,
                                                   gcn/vrgcn.py:43-45) happens inside the GEMM */,
                        const int32_t* dev_gidx2 /* the same for X2 */, void* stream);
+/* Two dense layers of the same rows in ONE launch (new; the reference runs them as consecutive graph ops,
+ * gcn/models.py:149-155):  Y1 = layer1(X),  Y2 = layer2(Y1)  with each layer described exactly as the
+ * arguments of sgcn_dense_fwd_f32.  Layer 2 must read layer 1's output in place: l2->M == l1->M,
+ * l2->K == l1->N, l2->X == l1->Y (ldx == ldy), l2->X2 NULL or the rows of Y1 from l2->split on
+ * (Y + split * ldy), no row indirection; both N <= 128.  l2->drop masks Y1 as it is read (rows < drop->rows).
+ * Y1 and both LayerNorm contexts are stored as by two separate calls; the K sums are cut inside the workgroup
+ * instead of across workgroups (a different summation tree): results agree with the separate calls to fp32
+ * rounding, not bit for bit. */
+typedef struct {
+    int32_t M, N, K;
+    const float* X; int64_t ldx;
+    const float* X2; int64_t ldx2; int32_t split;
+    const float* W; int64_t ldw;
+    const float* offset; const float* scale; float eps; int32_t relu;
+    float* Y; int64_t ldy;
+    float* xhat; float* rstd;
+    const sgcn_dropout_t* drop;
+    const int32_t* gidx; const int32_t* gidx2;
+} sgcn_dense_layer_t;
+int sgcn_dense2_fwd_f32(const sgcn_dense_layer_t* l1, const sgcn_dense_layer_t* l2, void* stream);
+
 /* The backward of one dense layer in one call: g = LN/ReLU-backward(dy) (skipped when scale == NULL
  * and relu == 0), dW[K x N] += dropout(x)^T . g, dx[n x K] = (g . W^T) * mask (dx nullable).
  * g_tmp: n * N floats; ws: sgcn_ln_act_bwd_ws_floats(n, N) (rounded up to 4) + max(
@@ -473,7 +494,9 @@ enum {
     SGCN_OP_VR_AGG_PRE = 14,  /* sgcn_vr_aggregate_pre_f32, issued on the auxiliary stream (forked from `stream`) */
     SGCN_OP_VR_AGG_POST = 15, /* `stream` waits for the auxiliary stream, then sgcn_vr_aggregate_post_f32 */
     SGCN_OP_AUX_SCATTER_ROWS = 16, /* sgcn_scatter_rows_f32 on the auxiliary stream (forked from `stream`) */
-    SGCN_OP_AUX_MEMSET0 = 17  /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
+    SGCN_OP_AUX_MEMSET0 = 17, /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
+    SGCN_OP_DENSE_FWD_PAIR = 18 /* DENSE_FWD arguments; the NEXT op must be a DENSE_FWD on this op's output: both run as
+                                 * one sgcn_dense2_fwd_f32 */
 };
 typedef struct {
     int32_t op, nargs;

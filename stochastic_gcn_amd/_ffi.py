@@ -49,6 +49,15 @@ class StepOp(C.Structure):
                 ("slot", C.c_int32 * STEP_MAX_ARGS), ("add", C.c_int64 * STEP_MAX_ARGS)]
 
 
+class DenseLayer(C.Structure):
+    """sgcn_dense_layer_t: one dense layer as the arguments of sgcn_dense_fwd_f32 (sgcn_dense2_fwd_f32)"""
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("X", C.c_void_p), ("ldx", C.c_int64),
+                ("X2", C.c_void_p), ("ldx2", C.c_int64), ("split", C.c_int32), ("W", C.c_void_p), ("ldw", C.c_int64),
+                ("offset", C.c_void_p), ("scale", C.c_void_p), ("eps", C.c_float), ("relu", C.c_int32),
+                ("Y", C.c_void_p), ("ldy", C.c_int64), ("xhat", C.c_void_p), ("rstd", C.c_void_p),
+                ("drop", C.c_void_p), ("gidx", C.c_void_p), ("gidx2", C.c_void_p)]
+
+
 class Dropout(C.Structure):
     """include/sgcn.h sgcn_dropout_t"""
     _fields_ = [("key", C.c_uint32), ("keep", C.c_float), ("rows", C.c_int32), ("width", C.c_int32)]
@@ -107,6 +116,7 @@ SIGNATURES = {
                                 C.c_int64, P, C.c_int64, C.c_int32, P, P, P, P]),
     "sgcn_dense_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, C.c_int32,
                                      P, C.c_int64, P, P, C.c_float, C.c_int32, P, C.c_int64, P, P, P, P, P, P, P]),
+    "sgcn_dense2_fwd_f32": (C.c_int, [P, P, P]),
     "sgcn_dense_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P, P,
                                      C.c_int32, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, P, P, C.c_int64,
                                      P, P, P, P, P]),

@@ -231,6 +231,217 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---- two chained dense layers of the same rows in ONE launch -------------------------------------------
+//   Y1 = act1(LN1(dropA(X) . W1))      Y2 = act2(LN2(drop2(Y1) . W2))        N1, N2 <= 128
+// The step's dense layers come in pairs on the same rows (the two AugmentedDropoutDense layers below the
+// aggregator: 2,042 x 1,204 -> 128 -> 128; the two Dense layers above it: 512 x 256 -> 128 -> 41).  At these
+// sizes a kernel is a chain of dependent memory round trips (~1 us each from L2, ~2 from HBM) behind ~3 us of
+// dispatch; run separately the pair costs four launches (the first GEMM is cut over K across workgroups to fill
+// the chip: partials out, a reduce + LayerNorm kernel back in) -- 46 us and 25 us of the step's critical path.
+// Here a workgroup owns a 32-row block for BOTH layers and never talks to another workgroup (cutting K across
+// workgroups inside one launch was tried: the agent-scope release / acquire the partial tiles need is a
+// write-back + invalidate of the XCD's whole L2 on gfx950, 50 us):
+//   * the operand rows are brought into LDS in chunks of up to 384 columns, ALL loads of a chunk issued at once
+//     (row gather, dropout and the stacked second operand applied on the way) and the next chunk's loads in
+//     flight while the current one is multiplied: one exposed HBM round trip per pair instead of one per K-step;
+//   * KG groups of four wavefronts take alternating K-steps with their own W tiles (streamed from L2 one step
+//     ahead) and add their partial tiles through LDS in group order;
+//   * layer 1's LayerNorm epilogue sends Y1 and its context to memory (the backward pass needs them) and leaves
+//     the activated tile in LDS, already multiplied by layer 2's dropout mask; layer 2 multiplies it by W2 from
+//     there (W2's first tiles are requested before the epilogue) and runs its own epilogue.
+// MEASURED (profiles/dense2_probe.py, the Reddit step's first pair): 53 us against 16 + 5 + 16 us for the three
+// kernels it replaces, and 22 us against 25 for the second pair -- no gain on the GPU: the first layer's fp32 MFMA
+// work runs on as many CUs as there are row blocks (64: 16 us) and an ablation shows the phases of a workgroup do
+// not overlap at all (skeleton 18 us + operand chunks 5 + W tiles 14 + MFMA 16).  What it saves is four launches
+// of host time; the epoch is 0.066 s with it and 0.064 s without, so --fuse_dense is off by default.
+// g describes layer 1 exactly as sgcn_dense_fwd_f32 does; of g2 only B / N / the epilogue fields / C / drop_a
+// (the mask on Y1) are used.
+constexpr int kD2Chunk = 384;                          // operand columns a workgroup keeps in LDS at a time
+
+template <int KG>
+__global__ __launch_bounds__(kBlock * KG) void dense2_fwd_kernel(GemmArgs g, GemmArgs g2) {
+    extern __shared__ float smem[];
+    const int kg = threadIdx.x / kBlock;
+    const int tid = threadIdx.x % kBlock, lane = tid & 63, wave = tid >> 6;
+    float (*Bs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + kg * kBsFloats);
+    float (*Cs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem);                                  // group 0's Bs
+    float (*Ys)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + KG * kBsFloats);                 // layer 2's operand
+    constexpr int kALd = kD2Chunk + 1;                                                                 // odd pitch: no bank conflicts
+    float* Ablk = smem + KG * kBsFloats + kTM * (kTN + 4);                                              // [32][kD2Chunk + 1]
+    const int m0 = blockIdx.x * kTM;
+    const int fi = lane & 31, fk = lane >> 5;
+    const int cj = wave * 32 + fi;
+    float rb[16];
+
+    auto ld4 = [&](const float* p, bool vec, bool rowok, int first, int limit, float* out) {
+        if (vec && rowok && first + 3 < limit) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[e] = (rowok && first + e < limit) ? p[e] : 0.f;
+        }
+    };
+    auto fetch_b = [&](const GemmArgs& q, int k0, int klim) {        // B is [K x N]: 4 consecutive columns of one k
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4, k = k0 + kk;
+            ld4(q.B + (int64_t)k * q.ldb + jq, q.vec_b, k < klim, jq, q.N, rb + r * 4);
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4;
+            *reinterpret_cast<float4*>(&Bs[kk][jq]) = make_float4(rb[r * 4], rb[r * 4 + 1], rb[r * 4 + 2], rb[r * 4 + 3]);
+        }
+    };
+    // partial tiles of groups 1.. -> their own Bs region -> group 0 adds them in group order -> Cs
+    auto reduce_groups = [&](f16acc& acc) {
+        if (KG > 1) {
+            if (kg > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) Bs[(r & 3) + 8 * (r >> 2) + 4 * fk][cj] = acc[r];
+            }
+            __syncthreads();
+            if (kg == 0) {
+                for (int o = 1; o < KG; o++) {
+                    float (*P)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + o * kBsFloats);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] += P[(r & 3) + 8 * (r >> 2) + 4 * fk][cj];
+                }
+            }
+            __syncthreads();
+        }
+        if (kg == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) Cs[(r & 3) + 8 * (r >> 2) + 4 * fk][cj] = acc[r];
+        }
+        __syncthreads();
+    };
+    // one wavefront per row of the tile in Cs: the layer's epilogue to memory; `keep`: also into Ys, masked for layer 2
+    auto epilogue = [&](const GemmArgs& q, bool keep) {
+        for (int rr = kg * (kBlock / kWave) + wave; rr < kTM; rr += KG * (kBlock / kWave)) {
+            const int row = m0 + rr;
+            const bool ok = row < q.M;
+            float* yr = q.C + (int64_t)row * q.ldc;
+            float mean = 0.f, rs = 1.f;
+            if (q.epi == 2) {
+                float s1 = 0.f;
+                for (int c = lane; c < q.N; c += kWave) s1 += Cs[rr][c];
+                mean = wsum(s1) / (float)q.N;
+                float sq = 0.f;
+                for (int c = lane; c < q.N; c += kWave) { const float t = Cs[rr][c] - mean; sq += t * t; }
+                rs = rsqrtf(wsum(sq) / (float)q.N + q.eps);
+                if (lane == 0 && ok) q.rstd[row] = rs;
+            }
+            for (int c = lane; c < kTN; c += kWave) {
+                float v = 0.f;
+                if (c < q.N && ok) {
+                    v = Cs[rr][c];
+                    if (q.epi == 2) {
+                        const float h = (v - mean) * rs;
+                        q.xhat[(int64_t)row * q.N + c] = h;
+                        v = h * q.scale[c] + q.offset[c];
+                    }
+                    if (q.epi != 0 && q.relu) v = fmaxf(v, 0.f);
+                    yr[c] = v;
+                    if (keep && g2.drop_a.on) v *= drop_factor(g2.drop_a, row, c);
+                }
+                if (keep) Ys[rr][c] = v;               // columns >= N1 and rows >= M are zero: layer 2 may read them
+            }
+        }
+    };
+
+    // ---- the operand rows, a chunk of kD2Chunk columns at a time --------------------------------------
+    constexpr int kTPR = kBlock * KG / kTM;                            // threads sharing a row (8 * KG)
+    constexpr int kPasses = kD2Chunk / (kTPR * 4);                     // float4 loads per thread and chunk
+    static_assert(kD2Chunk % (kTPR * 4) == 0, "a chunk is whole passes of the row's threads");
+    const int arow_i = threadIdx.x / kTPR, aq0 = (threadIdx.x % kTPR) * 4, arow = m0 + arow_i;
+    const float* ar;                                                   // this thread's operand row (gather resolved once)
+    if (g.A2 && arow >= g.a_split) {
+        const int r2 = arow - g.a_split;
+        ar = g.A2 + (int64_t)((g.a_gidx2 && arow < g.M) ? g.a_gidx2[r2] : r2) * g.lda2;
+    } else {
+        ar = g.A + (int64_t)((g.a_gidx && arow < g.M) ? g.a_gidx[arow] : arow) * g.lda;
+    }
+    float ra[kPasses][4];
+    auto fetch_chunk = [&](int c0) {                                   // all loads of the chunk in flight at once
+#pragma unroll
+        for (int p = 0; p < kPasses; p++) {
+            const int c = c0 + aq0 + p * kTPR * 4;
+            ld4(ar + c, g.vec_a, arow < g.M, c, g.K, ra[p]);
+        }
+    };
+    auto store_chunk = [&](int c0) {
+        float* dst = Ablk + arow_i * kALd + aq0;
+#pragma unroll
+        for (int p = 0; p < kPasses; p++) {
+            const int c = c0 + aq0 + p * kTPR * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = ra[p][e];
+                if (g.drop_a.on) v *= drop_factor(g.drop_a, arow, c + e);
+                dst[p * kTPR * 4 + e] = v;
+            }
+        }
+    };
+
+    f16acc acc = {};
+    const int nchunks = (g.K + kD2Chunk - 1) / kD2Chunk;
+    if (nchunks > 0) fetch_chunk(0);
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int c0 = ch * kD2Chunk, cend = min(g.K, c0 + kD2Chunk);
+        store_chunk(c0);                                               // (waits for this chunk's loads)
+        if (ch + 1 < nchunks) fetch_chunk(c0 + kD2Chunk);              // next chunk's loads fly during the K-steps below
+        const int iters = ((cend - c0 + kTK - 1) / kTK + KG - 1) / KG;
+        fetch_b(g, c0 + kg * kTK, cend);
+        for (int it = 0; it < iters; it++) {
+            const int kr = (it * KG + kg) * kTK;                       // relative to c0
+            stage_b();
+            __syncthreads();                                           // (first pass: also the operand chunk)
+            if (it + 1 < iters) fetch_b(g, c0 + kr + KG * kTK, cend);
+            if (c0 + kr < cend) {
+                const float* arow_p = Ablk + fi * kALd + kr + fk;
+#pragma unroll
+                for (int kk2 = 0; kk2 < kTK / 2; kk2++) {
+                    const float a = arow_p[kk2 * 2];
+                    const float b = Bs[kk2 * 2 + fk][cj];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // layer 2's first W2 tile is requested before the partial tiles are exchanged
+    const int K2 = g.N;
+    fetch_b(g2, kg * kTK, K2);
+    reduce_groups(acc);
+    epilogue(g, true);
+    __syncthreads();
+
+    // ---- layer 2: operand = Ys (32 x N1, zero beyond N1), K-steps of 32 over N1 -----------------------
+    f16acc acc2 = {};
+    const int iters2 = ((K2 + kTK - 1) / kTK + KG - 1) / KG;
+    for (int it = 0; it < iters2; it++) {
+        const int k0 = (it * KG + kg) * kTK;
+        if (it > 0) fetch_b(g2, k0, K2);
+        stage_b();
+        __syncthreads();
+        if (k0 < K2) {
+#pragma unroll
+            for (int kk2 = 0; kk2 < kTK / 2; kk2++) {
+                const float a = Ys[fi][k0 + kk2 * 2 + fk];
+                const float b = Bs[kk2 * 2 + fk][cj];
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    reduce_groups(acc2);
+    epilogue(g2, false);
+}
+
 // C (+)= sum_z ws[z]   in z order (deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int32_t S, int32_t M, int32_t N,
                                      float* __restrict__ C, int64_t ldc, int32_t accumulate) {
@@ -427,6 +638,63 @@ extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* 
     g.drop_a = drop_args(drop);
     SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
     return launch_gemm(g, 0, 0, N <= kTN ? ws : nullptr, (hipStream_t)stream);
+}
+
+static int fill_dense_args(const sgcn_dense_layer_t* l, GemmArgs& g, const char* what) {
+    SGCN_REQUIRE(l->X && l->W && l->Y, "%s: null operand", what);
+    const int norm = (l->offset && l->scale) ? 1 : 0;
+    SGCN_REQUIRE(!norm || (l->xhat && l->rstd), "%s: LayerNorm needs xhat / rstd", what);
+    SGCN_REQUIRE(l->N <= kTN, "%s: N <= 128", what);
+    g.A = l->X; g.lda = l->ldx; g.B = l->W; g.ldb = l->ldw; g.C = l->Y; g.ldc = l->ldy;
+    g.M = l->M; g.N = l->N; g.K = l->K; g.offset = l->offset; g.scale = l->scale; g.eps = l->eps; g.relu = l->relu;
+    g.xhat = l->xhat; g.rstd = l->rstd; g.epi = norm ? 2 : (l->relu ? 1 : 0);
+    SGCN_REQUIRE(!l->X2 || (l->split >= 0 && l->split <= l->M), "%s: bad split", what);
+    g.A2 = l->X2; g.lda2 = l->ldx2; g.a_split = l->split;
+    g.a_gidx = l->gidx; g.a_gidx2 = l->gidx2;
+    g.drop_a = drop_args(l->drop);
+    SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == l->K, "%s: dropout width must be K", what);
+    auto al = [](const void* p, int64_t ld) { return p && ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
+    g.vec_a = al(g.A, g.lda) && (!g.A2 || al(g.A2, g.lda2));
+    g.vec_b = al(g.B, g.ldb);
+    return SGCN_OK;
+}
+
+template <int KG>
+static void launch_dense2(const GemmArgs& g1, const GemmArgs& g2, hipStream_t st) {
+    const size_t lds = ((size_t)KG * kBsFloats + (size_t)kTM * (kTN + 4) + (size_t)kTM * (kD2Chunk + 1)) * sizeof(float);
+    static bool raised = false;          // > 64 KB of dynamic LDS needs the attribute once per kernel
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_fwd_kernel<KG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL((dense2_fwd_kernel<KG>), dim3((unsigned)((g1.M + kTM - 1) / kTM)), dim3(kBlock * KG), lds, st, g1, g2);
+}
+
+extern "C" int sgcn_dense2_fwd_f32(const sgcn_dense_layer_t* l1, const sgcn_dense_layer_t* l2, void* stream) {
+    SGCN_REQUIRE(l1 && l2, "dense2_fwd: null layer");
+    SGCN_REQUIRE(l1->M >= 0 && l1->N >= 0 && l1->K >= 0 && l2->N >= 0, "dense2_fwd: negative size");
+    if (l1->M == 0) return SGCN_OK;
+    SGCN_REQUIRE(l1->N > 0 && l2->N > 0, "dense2_fwd: empty layer");
+    SGCN_REQUIRE(l2->M == l1->M && l2->K == l1->N, "dense2_fwd: layer 2 must take layer 1's output (M, K)");
+    SGCN_REQUIRE(l2->X == l1->Y && l2->ldx == l1->ldy, "dense2_fwd: layer 2 must read layer 1's Y in place");
+    SGCN_REQUIRE(!l2->X2 || (l2->ldx2 == l1->ldy && l2->X2 == l1->Y + (int64_t)l2->split * l1->ldy),
+                 "dense2_fwd: layer 2's second operand must be the rows of Y from `split` on");
+    SGCN_REQUIRE(!l2->gidx && !l2->gidx2, "dense2_fwd: no row indirection on layer 2");
+    GemmArgs g1{}, g2{};
+    int rc = fill_dense_args(l1, g1, "dense2_fwd (layer 1)");
+    if (rc != SGCN_OK) return rc;
+    rc = fill_dense_args(l2, g2, "dense2_fwd (layer 2)");
+    if (rc != SGCN_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // K-groups inside the workgroup: the grid never fills the chip (one workgroup per 32 rows), so the per-workgroup
+    // chain is what counts; 4 groups while there are few row blocks, fewer once every CU has work anyway
+    const int blocks = (l1->M + kTM - 1) / kTM;
+    if (blocks <= 256) launch_dense2<4>(g1, g2, st);
+    else if (blocks <= 1024) launch_dense2<2>(g1, g2, st);
+    else launch_dense2<1>(g1, g2, st);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
 }
 
 // The whole backward of one dense layer in ONE call (three Python round trips are a quarter of

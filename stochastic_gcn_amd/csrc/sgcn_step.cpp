@@ -99,6 +99,42 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             if (rc != SGCN_OK) return rc;
         }
         switch (op.op) {
+        case SGCN_OP_DENSE_FWD_PAIR: {
+            // this op and the next one (a DENSE_FWD on this op's output) as one launch
+            if (k + 1 >= nops || ops[k + 1].op != SGCN_OP_DENSE_FWD)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d (DENSE_FWD_PAIR) is not followed by a DENSE_FWD", k);
+            const sgcn_step_op_t& op2 = ops[k + 1];
+            if (op2.nargs < 0 || op2.nargs > SGCN_STEP_MAX_ARGS)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d has %d arguments", k + 1, op2.nargs);
+            Args b;
+            b.n = op2.nargs; b.pos = 0;
+            for (int j = 0; j < op2.nargs; j++) {
+                const int32_t s = op2.slot[j];
+                if (s >= nslots) return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d reads slot %d of %d", k + 1, s, nslots);
+                b.v[j] = (s < 0 ? 0 : op2.mul[j] * slots[s]) + op2.add[j];
+            }
+            sgcn_dropout_t dr2;
+            sgcn_dense_layer_t l1, l2;
+            auto decode = [](Args& q, sgcn_dropout_t* d, sgcn_dense_layer_t& l) {
+                l.M = q.i(); l.N = q.i(); l.K = q.i();
+                l.X = q.p<const float>(); l.ldx = q.next();
+                l.X2 = q.p<const float>(); l.ldx2 = q.next();
+                l.split = q.i();
+                l.W = q.p<const float>(); l.ldw = q.next();
+                l.offset = q.p<const float>(); l.scale = q.p<const float>();
+                l.eps = q.f(); l.relu = q.i();
+                l.Y = q.p<float>(); l.ldy = q.next();
+                l.xhat = q.p<float>(); l.rstd = q.p<float>();
+                l.drop = q.drop(d);
+                (void)q.p<float>(); (void)q.next();          // split-K scratch: the pair does not split across workgroups
+                l.gidx = q.p<const int32_t>(); l.gidx2 = q.p<const int32_t>();
+            };
+            decode(a, &dr, l1);
+            decode(b, &dr2, l2);
+            rc = sgcn_dense2_fwd_f32(&l1, &l2, stream);
+            k++;                                             // the second op is done
+            break;
+        }
         case SGCN_OP_DENSE_FWD: {
             const int32_t M = a.i(), N = a.i(), K = a.i();
             const float* X = a.p<const float>(); const int64_t ldx = a.next();

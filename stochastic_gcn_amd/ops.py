@@ -883,3 +883,49 @@ def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
                                  float(eps), int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), dr,
                                  _ptr(ws), _ptr(gidx), _ptr(gidx2), _stream()))
     return y, ((xhat, rstd) if norm else None)
+
+
+def dense2_fwd(x, W1, off1, sc1, relu1, W2, off2, sc2, relu2, eps=1e-9, x2=None, drop1=None, drop2=None):
+    """Two chained dense layers of the same rows in ONE launch (sgcn_dense2_fwd_f32):
+    y1 = act1(LN1([drop1(x) ; x2] @ W1)), y2 = act2(LN2([drop2(y1[:n1]) ; y1[n1:]] @ W2)).
+    Returns (y1, ctx1, y2, ctx2) -- what two dense_fwd calls return, equal to them to fp32 rounding."""
+    gidx = gidx2 = None
+    if isinstance(x2, GatheredRows):
+        x2, gidx2 = x2.src, x2.idx
+    if isinstance(x, GatheredRows):
+        x, gidx = x.src, x.idx
+    n1 = int(x.shape[0] if gidx is None else gidx.shape[0])
+    K, N1, N2 = int(x.shape[1]), int(W1.shape[1]), int(W2.shape[1])
+    M = n1 + (0 if x2 is None else int(x2.shape[0] if gidx2 is None else gidx2.shape[0]))
+    dev = x.device
+    y1 = torch.empty((M, N1), dtype=torch.float32, device=dev)
+    y2 = torch.empty((M, N2), dtype=torch.float32, device=dev)
+    ctx = []
+    layers = []
+    keep = []
+    for (Wk, off, sc, relu, y, Kk, Nk, first) in ((W1, off1, sc1, relu1, y1, K, N1, True), (W2, off2, sc2, relu2, y2, N1, N2, False)):
+        norm = off is not None
+        xhat = torch.empty((M, Nk), dtype=torch.float32, device=dev) if norm else None
+        rstd = torch.empty((M,), dtype=torch.float32, device=dev) if norm else None
+        ctx.append((xhat, rstd) if norm else None)
+        drop = drop1 if first else drop2
+        ds = drop.struct(Kk, rows=n1) if drop is not None else None
+        keep.append(ds)
+        L = _ffi.DenseLayer()
+        L.M, L.N, L.K = M, Nk, Kk
+        if first:
+            L.X, L.ldx = _rows2d(x, "x")
+            L.X2, L.ldx2 = _rows2d(x2, "x2") if x2 is not None else (None, 0)
+            L.gidx, L.gidx2 = _ptr(gidx), _ptr(gidx2)
+        else:
+            L.X, L.ldx = y1.data_ptr(), N1
+            L.X2, L.ldx2 = (y1.data_ptr() + n1 * N1 * 4, N1) if x2 is not None else (None, 0)
+        L.split = n1
+        L.W, L.ldw = _rows2d(Wk, "W")
+        L.offset, L.scale, L.eps, L.relu = _ptr(off), _ptr(sc), float(eps), int(bool(relu))
+        L.Y, L.ldy = y.data_ptr(), Nk
+        L.xhat, L.rstd = _ptr(xhat), _ptr(rstd)
+        L.drop = C.cast(C.pointer(ds), C.c_void_p) if ds is not None else None
+        layers.append(L)
+    check(lib.sgcn_dense2_fwd_f32(C.byref(layers[0]), C.byref(layers[1]), _stream()))
+    return y1, ctx[0], y2, ctx[1]

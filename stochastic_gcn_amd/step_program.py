@@ -29,7 +29,7 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18)
 MAX_ARGS = 48
 ARENA_LIMIT_BYTES = 2 << 30
 
@@ -500,7 +500,36 @@ class StepProgram(object):
                                         K(nh.cols), self._p(nh), K(nh.ld)])
 
     # ---- build the ctypes program ------------------------------------------------------------------
+    def _pair_dense_fwd(self, lst):
+        """Peephole: a DENSE_FWD whose output is the next DENSE_FWD's operand, in place and on the same rows,
+        becomes DENSE_FWD_PAIR -- the two run as one sgcn_dense2_fwd_f32 (the library re-checks the chain
+        at run time and refuses a pair that is not one)."""
+        F = OP['DENSE_FWD']
+        null = (0, -1, 0)
+        fused = 0
+        k = 0
+        while k + 1 < len(lst):
+            (oa, a), (ob, b) = lst[k], lst[k + 1]
+            ok = oa == F and ob == F
+            if ok:
+                a, b = [tuple(int(v) for v in t) for t in a], [tuple(int(v) for v in t) for t in b]
+                const = lambda t: t[1] < 0          # noqa: E731
+                ok = (b[0] == a[0] and b[2] == a[1] and b[3] == a[14] and b[4] == a[15] and b[25] == null and b[26] == null
+                      and const(a[1]) and const(b[1]) and a[1][2] <= 128 and b[1][2] <= 128 and const(a[14]) and const(a[15]))
+                if ok and b[5] != null:             # second operand: the rows of Y from `split` on
+                    ld4 = 4 * a[15][2]
+                    sp = b[7]
+                    ok = b[6] == a[15] and b[5] == (ld4 * sp[0] if sp[1] >= 0 else 0, sp[1], a[14][2] + (ld4 * sp[2] if sp[1] >= 0 else ld4 * sp[2]))
+            if ok:
+                lst[k] = (OP['DENSE_FWD_PAIR'], lst[k][1])
+                fused += 1
+                k += 2
+            else:
+                k += 1
+        return fused
+
     def _finalize(self):
+        self.n_pairs = self._pair_dense_fwd(self.ops_fb) if FLAGS.fuse_dense else 0
         self._key_slots = {li: self._n_meta + i for i, li in enumerate(self._key_layers)}
         self.lr_slot = self._n_meta + len(self._key_layers)
         self.nslots = self.lr_slot + 1

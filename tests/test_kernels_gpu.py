@@ -742,3 +742,68 @@ def test_csr_transpose_index_is_the_stable_transpose(dev, n, f, per):
     E.coo_rows = torch.zeros(0, dtype=torch.int32, device=dev)
     tp, tr_, ts = ops.csr_transpose_index(E)
     assert tp.cpu().numpy().tolist() == [0] * 8 and tr_.numel() == 0
+
+
+# ---- two chained dense layers in one launch (sgcn_dense2_fwd_f32) ------------------------------------------
+@pytest.mark.parametrize("n1,n2,K,N1,N2,norm1,norm2,relu2,keep,gather", [
+    (1021, 1021, 1204, 128, 128, True, True, True, 0.8, True),     # the two CVD layers below the aggregator
+    (512, 0, 256, 128, 41, True, False, False, 0.8, False),        # the two layers above it
+    (37, 5, 50, 32, 7, True, True, False, 0.5, False),
+    (1, 0, 3, 41, 16, False, True, True, 1.0, False),
+    (300, 300, 130, 96, 128, False, False, True, 0.9, True),
+    (5000, 0, 64, 128, 128, True, True, True, 0.8, False)])
+def test_dense2_fwd_equals_two_dense_fwd_and_the_oracle(dev, n1, n2, K, N1, N2, norm1, norm2, relu2, keep, gather):
+    """One launch for two dense layers of the same rows: stacked dropout / clean streams, row gather and dropout
+    on layer 1's operand, layer 2's dropout on the stored Y1 -- against two sgcn_dense_fwd_f32 calls (same
+    arithmetic, different K split: fp32 rounding) and against the NumPy oracle."""
+    from stochastic_gcn_amd import ops
+    from oracle import model_np as mnp
+    rng = np.random.RandomState(n1 + K + N2)
+    src = rng.standard_normal((n1 + n2 + 50, K)).astype(np.float32)
+    W1 = (rng.standard_normal((K, N1)) / np.sqrt(K)).astype(np.float32)
+    W2 = (rng.standard_normal((N1, N2)) / np.sqrt(N1)).astype(np.float32)
+    o1, s1 = 0.1 * rng.standard_normal((1, N1)).astype(np.float32), (1 + 0.1 * rng.standard_normal((1, N1))).astype(np.float32)
+    o2, s2 = 0.1 * rng.standard_normal((1, N2)).astype(np.float32), (1 + 0.1 * rng.standard_normal((1, N2))).astype(np.float32)
+    i1 = rng.permutation(n1 + n2 + 50)[:n1].astype(np.int32)
+    i2 = rng.permutation(n1 + n2 + 50)[:n2].astype(np.int32)
+    sd = T(src, dev)
+    if gather:
+        x = ops.GatheredRows(sd, T(i1, dev))
+        x2 = ops.GatheredRows(sd, T(i2, dev)) if n2 else None
+    else:
+        x = T(src[i1], dev)
+        x2 = T(src[i2], dev) if n2 else None
+    d1 = ops.Drop(keep, 77) if keep < 1.0 else None
+    d2 = ops.Drop(keep, 91) if keep < 1.0 else None
+    args1 = (T(W1, dev), T(o1, dev) if norm1 else None, T(s1, dev) if norm1 else None, True)
+    args2 = (T(W2, dev), T(o2, dev) if norm2 else None, T(s2, dev) if norm2 else None, relu2)
+    y1, c1, y2, c2 = ops.dense2_fwd(x, *args1, *args2, x2=x2, drop1=d1, drop2=d2)
+    # two separate launches
+    r1, rc1 = ops.dense_fwd(x, *args1, x2=x2, drop=d1)
+    r2, rc2 = ops.dense_fwd(r1[:n1], *args2, x2=r1[n1:] if n2 else None, drop=d2)
+    tol = 2e-5
+    assert onp.rel_err(y1.cpu().numpy(), r1.cpu().numpy()) <= tol
+    assert onp.rel_err(y2.cpu().numpy(), r2.cpu().numpy()) <= tol
+    for c, rc in ((c1, rc1), (c2, rc2)):
+        assert (c is None) == (rc is None)
+        if c is not None:
+            assert onp.rel_err(c[0].cpu().numpy(), rc[0].cpu().numpy()) <= 1e-4      # xhat amplifies by rstd
+            assert onp.rel_err(c[1].cpu().numpy(), rc[1].cpu().numpy()) <= tol
+    assert torch.equal(ops.dense2_fwd(x, *args1, *args2, x2=x2, drop1=d1, drop2=d2)[2], y2)     # deterministic
+    # oracle
+    X = np.concatenate([src[i1], src[i2]]) if n2 else src[i1]
+    if d1 is not None:
+        X = X.copy(); X[:n1] = mnp.dropout_fwd(X[:n1], keep, mnp.hash_mask(77, X[:n1].shape, keep))
+    h = (X @ W1).astype(np.float32)
+    if norm1:
+        h, _ = mnp.layer_norm_fwd(h, o1, s1)
+    h = np.maximum(h, 0)
+    assert onp.rel_err(y1.cpu().numpy(), h) <= TOL
+    if d2 is not None:
+        h = h.copy(); h[:n1] = mnp.dropout_fwd(h[:n1], keep, mnp.hash_mask(91, h[:n1].shape, keep))
+    z = (h @ W2).astype(np.float32)
+    if norm2:
+        z, _ = mnp.layer_norm_fwd(z, o2, s2)
+    if relu2:
+        z = np.maximum(z, 0)
+    assert onp.rel_err(y2.cpu().numpy(), z) <= TOL

@@ -11,13 +11,13 @@ import model_cases as mc
 pytestmark = pytest.mark.gpu
 
 
-def _model(case, params, native):
+def _model(case, params, native, fuse=False):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.vrgcn import VRGCN
     from stochastic_gcn_amd.plaingcn import PlainGCN
     FLAGS.reset()
     FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
-    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'])
+    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], fuse_dense=fuse)
     cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
     fl = case['flags']
     m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
@@ -26,11 +26,11 @@ def _model(case, params, native):
     return m
 
 
-def _run(case, native, steps, slot):
+def _run(case, native, steps, slot, fuse=False):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.scheduler import StagingSlot
     params = mc.make_oracle_model(case, seed=3).params
-    m = _model(case, {k: v.copy() for k, v in params.items()}, native)
+    m = _model(case, {k: v.copy() for k, v in params.items()}, native, fuse)
     sch = mc.make_scheduler(case, 1)
     slots = [StagingSlot(pin=True) for _ in range(3)] if slot else None
     losses = []
@@ -66,6 +66,27 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot):
     assert a.amt_data == b.amt_data and np.array_equal(a.field_sizes, b.field_sizes)      # the epoch counters too
     prog = next(iter(progs.values()))
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
+
+
+@pytest.mark.parametrize("name,pairs", [('reddit_cvd_pp', 2), ('reddit_cv_pp', 2), ('cvd_pp_L3', 0), ('is_pp', 0), ('ns_nopp_L2', 0)])
+def test_fused_dense_pairs_agree_with_the_eager_path_to_rounding(name, pairs):
+    """--fuse_dense (default): consecutive dense layers of the same rows run as ONE launch (DENSE_FWD_PAIR ->
+    sgcn_dense2_fwd_f32).  Same arithmetic, the K sums cut inside the workgroup instead of across workgroups:
+    loss and accuracy agree to fp32 rounding over consecutive steps; the weights after 5 Adam steps agree except
+    where a gradient is rounding noise around zero (Adam divides by its own magnitude there)."""
+    case = mc.build_case(name)
+    a, la = _run(case, False, 5, False)
+    b, lb = _run(case, True, 5, False, fuse=True)
+    prog = next(iter(b._programs.values()))
+    assert prog is not None and prog.n_pairs >= pairs, (prog.n_pairs if prog else None)
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l1)))
+        assert abs(float(a1) - float(a2)) <= 2.0 / case['cfg']['batch']
+    d = (a.theta - b.theta).abs()
+    assert float((d > 1e-5).float().mean()) < 2e-3 and float(d.max()) < 0.05
+    for ha, hb in zip(a.history, b.history):
+        assert float((ha[0] - hb[0]).abs().max()) <= 1e-4 * max(1.0, float(ha[0].abs().max()))
+    print("%s: %d ops per step, %d dense pairs" % (name, prog.n_all, prog.n_pairs))
 
 
 def test_dropout_zero_and_weight_decay_variants():
