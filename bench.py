@@ -62,8 +62,9 @@ def parse(argv=None):
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
     p.add_argument("--cs-align", type=int, default=2048, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
-    p.add_argument("--cs-g", type=int, default=1, choices=[1, 2],
-                   help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes)")
+    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2],
+                   help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes; "
+                        "0: what ops.ColumnSweepCSR.choose_g picks for d -- also what the training path uses)")
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
     p.add_argument("--grad-floats", type=int, default=0, help="size of the all-reduced gradient buffer")
     p.add_argument("--emulate-shard", default=None, metavar="R/W",
@@ -417,7 +418,8 @@ def main(argv=None):
         elif reorder == "labels":
             comm = np.ascontiguousarray(data10[6].argmax(1), dtype=np.int32)
             reorder_info = {"method": "dataset labels", "communities": int(comm.max()) + 1}
-        gk = dict(G=2, align=args.cs_align) if (args.cs_g == 2 and comm is None) else dict(R=args.cs_r, col_labels=comm, row_labels=comm)
+        cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d) if (comm is None and args.cs_r == 16) else 1)
+        gk = dict(G=2, align=args.cs_align) if (cs_g == 2 and comm is None) else dict(R=args.cs_r, col_labels=comm, row_labels=comm)
         A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
         A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
         mm = ops.spmm_cs
@@ -560,8 +562,9 @@ def main(argv=None):
             "note": "hits and misses do not overlap in the vector memory path (mixed launch = sum of the two): "
                     "T_model = miss_bytes/miss_rate + hit_bytes/hit_rate"}
         out["roofline"]["frac_of_gather_ceiling"] = t_floor / (fwd_ms * 1e-3)
-    tr = profiled_traffic("void sgcn::cs_spmm" if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
-        if not (args.tune or sh is not None or reorder != "none" or args.cs_g != 1) else None
+    # the committed PMC record of exactly the kernel variant that was dispatched
+    tr = profiled_traffic(("void " + A.variant(d).split(" x ")[0]) if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
+        if not (args.tune or sh is not None or reorder != "none") else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model

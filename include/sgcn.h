@@ -160,7 +160,8 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  *   cs_round (tiles per launch), cs_unroll (4|8), cs_pace (ns per nonzero of the heaviest tile,
  *   0 = unpaced), cs_slack (columns), cs_generic (compiler-lowered indexing instead of the pinned
  *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane), cs_g2_plain (G = 2 plans: the
- *   unpipelined two-group kernel instead of the pipelined one), cs_g2_wide (force its 64-bit row offsets) : column-sweep kernel
+ *   unpipelined two-group kernel instead of the pipelined one), cs_g2_wide (force its 64-bit row offsets), cs_last_pct (default 90: clock of a
+ *   last pass that covers <= 3/4 of a slab, in percent of the plan's pace; 0 = off) : column-sweep kernel
  *   step_overlap (default 1): in sgcn_step_run, weight-gradient GEMMs + reductions on an auxiliary stream */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */

@@ -39,6 +39,7 @@ int g_tune_cs_noextra = 0;
 int g_tune_step_overlap = 1;
 int g_tune_cs_g2_plain = 0;
 int g_tune_cs_g2_wide = 0;
+int g_tune_cs_last_pct = 90;
 }  // namespace
 
 int tune_get(const char* key) {
@@ -54,6 +55,7 @@ int tune_get(const char* key) {
     if (!strcmp(key, "step_overlap")) return g_tune_step_overlap;
     if (!strcmp(key, "cs_g2_plain")) return g_tune_cs_g2_plain;
     if (!strcmp(key, "cs_g2_wide")) return g_tune_cs_g2_wide;
+    if (!strcmp(key, "cs_last_pct")) return g_tune_cs_last_pct;
     return -1;
 }
 
@@ -282,6 +284,7 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "step_overlap")) { g_tune_step_overlap = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_g2_plain")) { g_tune_cs_g2_plain = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
+    if (!strcmp(key, "cs_last_pct")) { SGCN_REQUIRE(value >= 0 && value <= 100, "cs_last_pct in [0, 100]"); g_tune_cs_last_pct = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_unroll")) {
         SGCN_REQUIRE(value == 0 || value == 4 || value == 8, "cs_unroll in {0,4,8}");

@@ -807,3 +807,27 @@ def test_dense2_fwd_equals_two_dense_fwd_and_the_oracle(dev, n1, n2, K, N1, N2, 
     if relu2:
         z = np.maximum(z, 0)
     assert onp.rel_err(y2.cpu().numpy(), z) <= TOL
+
+
+def test_column_sweep_plan_cache_round_trip_both_group_counts(dev, tmp_path):
+    """ColumnSweepCSR.cached: a plan written to disk (G = 1 and G = 2, with its autotuned pace) is re-loaded
+    for the same matrix and the same group count only, and multiplies bit-identically."""
+    from stochastic_gcn_amd import ops
+    a = rand_csr(3000, 2500, 0.02, 11, long_rows=[(7, 900)])
+    B = T(np.random.RandomState(2).standard_normal((2500, 160)).astype(np.float32), dev)
+    for G in (1, 2):
+        path = str(tmp_path / ("plan%d.npz" % G))
+        A, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=G)
+        assert not hit and A.G == G
+        A.pace[160] = 300
+        A.store_if_cached()
+        ref = ops.spmm_cs(A, B)
+        A2, hit2 = ops.ColumnSweepCSR.cached(a, dev, path, G=G)
+        assert hit2 and A2.G == G and A2.pace == {160: 300}
+        assert torch.equal(ops.spmm_cs(A2, B), ref)
+        assert A2.variant(160) == A.variant(160)
+        other, hit3 = ops.ColumnSweepCSR.cached(a, dev, path, G=3 - G)          # same file, other group count: rebuilt
+        assert not hit3 and other.G == 3 - G
+        b = a.copy(); b.data = b.data * 2
+        assert not ops.ColumnSweepCSR.cached(b, dev, path, G=G)[1]              # another matrix: rebuilt
+    assert [ops.ColumnSweepCSR.choose_g(d) for d in (32, 128, 256, 320, 602, 640)] == [2, 2, 2, 1, 2, 2]

@@ -138,6 +138,9 @@ def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monk
             assert onp.rel_err(got, want) <= 1e-4
             assert np.array_equal(model.features_dev[:, :f].cpu().numpy(), feats)
     assert len(stats[0]) == 2 and all("cs_spmm" in s["kernel"] for s in stats[0] + stats[1])
+    from stochastic_gcn_amd import ops
+    assert ops.ColumnSweepCSR.choose_g(feats.shape[1]) == 2                      # f = 32: one 128-column pass, two lane groups
+    assert all("cs_spmm16g2p" in s["kernel"] for s in stats[0] + stats[1])      # ... built, cached and re-loaded as such
     assert [s["plan_from_cache"] for s in stats[0]] == [False, False]
     assert [s["plan_from_cache"] for s in stats[1]] == [True, True]          # second run: plans (and paces) from disk
     assert [s["pace"] for s in stats[0]] == [s["pace"] for s in stats[1]]
