@@ -140,6 +140,17 @@ int sgcn_csplan2_count(const int32_t* host_rowptr, const int32_t* host_col, int3
 int sgcn_csplan2_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
                       int32_t T, int32_t round_tiles, int32_t align, int64_t* host_tile_ptr, int32_t* host_colrow,
                       float* host_valout, int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
+/* The same plan with `ngroups` (2 or 4) lane groups per wavefront (sgcn_csplan_t.G): ngroups bins of 16 rows per tile
+ * (tile_rows / tile_slots are [ntiles * ngroups * 16]), entry ngroups*step + g is bin g's, a bin advances only while
+ * at most `align` columns ahead of the slowest bin of its tile, every tile's entry count a multiple of 64.  G = 4:
+ * lanes 16g..16g+15 hold bin g's accumulators on a 64-column slab -- 64 rows per wavefront. */
+int sgcn_csplang_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
+                       int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries,
+                       int64_t* nfix, int64_t* nslots);
+int sgcn_csplang_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
+                      int32_t T, int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* host_tile_ptr,
+                      int32_t* host_colrow, float* host_valout, int32_t* host_tile_rows, int32_t* host_tile_slots,
+                      sgcn_fix_t* host_fix);
 /* Community labels of a square CSR pattern by seeded asynchronous label propagation (host, graph
  * only; new -- the reference has no reordering).  comm[n] in [0, *ncomm), numbered by decreasing
  * size; communities smaller than min_size share the last label.  max_iters <= 0: 12 sweeps. */

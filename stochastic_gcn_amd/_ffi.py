@@ -91,6 +91,9 @@ SIGNATURES = {
     "sgcn_csplan2_count": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_csplan2_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P]),
+    "sgcn_csplang_count": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sgcn_csplang_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P]),
     "sgcn_reorder_lp": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, P, C.POINTER(C.c_int32)]),
     "sgcn_spmm_cs_variant": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_char_p, C.c_int32]),
     "sgcn_spmm_cs_f32": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,

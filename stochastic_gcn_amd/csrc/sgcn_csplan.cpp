@@ -4,6 +4,8 @@
 #include "../../include/sgcn.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -205,16 +207,16 @@ struct G2Layout {
     int64_t ntiles = 0;
 };
 
-void g2_layout(const int32_t* rowptr, int32_t M, int32_t T, int32_t round_tiles, G2Layout& L) {
+void g2_layout(const int32_t* rowptr, int32_t M, int32_t T, int32_t round_tiles, G2Layout& L, int NG = 2) {
     std::vector<int32_t> rows((size_t)M);
     std::iota(rows.begin(), rows.end(), 0);
     make_vrows(rowptr, rows.data(), M, T, L.v);
     const int64_t nv = (int64_t)L.v.size();
-    int64_t nt = (nv + 2 * kG2R - 1) / (2 * kG2R);
+    int64_t nt = (nv + NG * kG2R - 1) / (NG * kG2R);
     if (round_tiles > 0 && nt > round_tiles / 2)                       // whole launches (a small matrix just gets enough tiles)
         nt = (nt + round_tiles - 1) / round_tiles * round_tiles;
     L.ntiles = nt;
-    L.assign = deal(L.v, kG2R, nt * 2);
+    L.assign = deal(L.v, kG2R, nt * NG);
 }
 
 // the column-sorted entries of one bin
@@ -239,66 +241,65 @@ void g2_bin(const G2Layout& L, const int32_t* rowptr, const int32_t* col, const 
     std::stable_sort(ents.begin(), ents.end(), [](const G2Ent& a, const G2Ent& b) { return a.col < b.col; });
 }
 
-// Aligned two-bin schedule; emit(step, g, entry-or-null).  Returns the number of steps.
+// Aligned NG-bin schedule; emit(step, g, entry-or-null).  Returns the number of steps.  A bin applies its next
+// entry in a step only while that entry is at most `align` columns ahead of the slowest bin that still has
+// entries (the others get a pad): the bins of a wave then gather from one L2 window.  The step count is padded to
+// whole chunks of 64 entries (64 / NG steps): the pipelined kernels run without tail code.
 template <class Emit>
-int64_t g2_schedule(const std::vector<G2Ent>& e0, const std::vector<G2Ent>& e1, int32_t align, Emit emit) {
-    size_t i0 = 0, i1 = 0;
-    int64_t step = 0;
-    while (i0 < e0.size() || i1 < e1.size()) {
-        const bool h0 = i0 < e0.size(), h1 = i1 < e1.size();
-        bool t0 = h0, t1 = h1;
-        if (h0 && h1 && align > 0) {
-            const int64_t c0 = e0[i0].col, c1 = e1[i1].col;
-            t0 = c0 <= c1 + align;
-            t1 = c1 <= c0 + align;
+int64_t gn_schedule(const std::vector<G2Ent>* e, int NG, int32_t align, Emit emit) {
+    size_t pos[4] = {0, 0, 0, 0};
+    int64_t step = 0, window = 0;
+    for (;;) {
+        int64_t lo = INT64_MAX;
+        for (int g = 0; g < NG; g++)
+            if (pos[g] < e[g].size()) lo = std::min<int64_t>(lo, e[g][pos[g]].col);
+        if (lo == INT64_MAX) break;
+        window = lo;
+        for (int g = 0; g < NG; g++) {
+            const bool has = pos[g] < e[g].size();
+            const bool take = has && (align <= 0 || e[g][pos[g]].col <= lo + align);
+            emit(step, g, take ? &e[g][pos[g]] : nullptr, window);
+            pos[g] += take;
         }
-        emit(step, 0, t0 ? &e0[i0] : nullptr);
-        emit(step, 1, t1 ? &e1[i1] : nullptr);
-        i0 += t0; i1 += t1;
         step++;
     }
-    // whole chunks of 64 entries (32 steps): the pipelined kernel runs without tail code
-    while (step % 32 != 0) {
-        emit(step, 0, nullptr);
-        emit(step, 1, nullptr);
+    const int64_t per_chunk = 64 / NG;
+    while (step % per_chunk != 0) {
+        for (int g = 0; g < NG; g++) emit(step, g, nullptr, window);
         step++;
     }
     return step;
 }
-}  // namespace
 
-extern "C" {
-
-int sgcn_csplan2_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles,
-                       int32_t align, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
-    if (M < 0 || (M > 0 && (!rowptr || !col)) || !ntiles || !nentries || !nfix || !nslots)
-        return sgcn::fail(SGCN_ERR_INVALID, "csplan2_count: bad argument");
+int gn_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles, int32_t align, int NG,
+             int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
+    if (M < 0 || (M > 0 && (!rowptr || !col)) || !ntiles || !nentries || !nfix || !nslots || (NG != 2 && NG != 4))
+        return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: bad argument");
     if (T <= 0) T = default_t(rowptr, M);
     int64_t f = 0, sl = 0;
     for (int32_t r = 0; r < M; r++) {
         const int64_t n = (int64_t)rowptr[r + 1] - rowptr[r];
-        if (n < 0) return sgcn::fail(SGCN_ERR_INVALID, "csplan2_count: rowptr not monotone at %d", r);
+        if (n < 0) return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: rowptr not monotone at %d", r);
         if (n > T) { sl += (n + T - 1) / T; f += 1; }
     }
     G2Layout L;
-    g2_layout(rowptr, M, T, round_tiles, L);
-    std::vector<G2Ent> e0, e1;
+    g2_layout(rowptr, M, T, round_tiles, L, NG);
+    std::vector<G2Ent> e[4];
     std::vector<std::pair<int32_t, float>> rowbuf;
     int64_t entries = 0;
     for (int64_t t = 0; t < L.ntiles; t++) {
-        g2_bin(L, rowptr, col, nullptr, 2 * t, e0, rowbuf);
-        g2_bin(L, rowptr, col, nullptr, 2 * t + 1, e1, rowbuf);
-        entries += 2 * g2_schedule(e0, e1, align, [](int64_t, int, const G2Ent*) {});
+        for (int g = 0; g < NG; g++) g2_bin(L, rowptr, col, nullptr, NG * t + g, e[g], rowbuf);
+        entries += NG * gn_schedule(e, NG, align, [](int64_t, int, const G2Ent*, int64_t) {});
     }
     *ntiles = L.ntiles; *nentries = entries; *nfix = f; *nslots = sl;
     return SGCN_OK;
 }
 
-int sgcn_csplan2_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T,
-                      int32_t round_tiles, int32_t align, int64_t* tile_ptr, int32_t* colrow, float* valout,
-                      int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
-    if (M < 0 || (M > 0 && (!rowptr || !col || !val || !tile_ptr || !tile_rows || !tile_slots)))
-        return sgcn::fail(SGCN_ERR_INVALID, "csplan2_fill: bad argument");
+int gn_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T, int32_t round_tiles,
+            int32_t align, int NG, int64_t* tile_ptr, int32_t* colrow, float* valout, int32_t* tile_rows,
+            int32_t* tile_slots, sgcn_fix_t* fix) {
+    if (M < 0 || (M > 0 && (!rowptr || !col || !val || !tile_ptr || !tile_rows || !tile_slots)) || (NG != 2 && NG != 4))
+        return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: bad argument");
     if (T <= 0) T = default_t(rowptr, M);
     std::vector<int32_t> first_slot((size_t)M, -1);
     int32_t slot = 0;
@@ -308,43 +309,42 @@ int sgcn_csplan2_fill(const int32_t* rowptr, const int32_t* col, const float* va
         if (n <= T) continue;
         const int32_t c = (n + T - 1) / T;
         first_slot[r] = slot;
-        if (!fix) return sgcn::fail(SGCN_ERR_INVALID, "csplan2_fill: split rows but no fix array");
+        if (!fix) return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: split rows but no fix array");
         fix[f++] = sgcn_fix_t{r, slot, c};
         slot += c;
     }
     G2Layout L;
-    g2_layout(rowptr, M, T, round_tiles, L);
-    std::vector<G2Ent> e[2];
+    g2_layout(rowptr, M, T, round_tiles, L, NG);
+    std::vector<G2Ent> e[4];
     std::vector<std::pair<int32_t, float>> rowbuf;
     int64_t out = 0;
     int bad = 0;
     for (int64_t t = 0; t < L.ntiles; t++) {
         tile_ptr[t] = out;
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < NG; g++) {
             for (int32_t k = 0; k < kG2R; k++) {
-                const int64_t slot_idx = (t * 2 + g) * kG2R + k;
+                const int64_t slot_idx = (t * NG + g) * kG2R + k;
                 const int64_t vi = L.assign[(size_t)slot_idx];
                 if (vi < 0) { tile_rows[slot_idx] = -1; tile_slots[slot_idx] = -1; continue; }
                 const VRow& vr = L.v[vi];
                 tile_rows[slot_idx] = vr.row;
                 tile_slots[slot_idx] = vr.npieces > 1 ? first_slot[vr.row] + vr.piece : -1;
             }
-            g2_bin(L, rowptr, col, val, 2 * t + g, e[g], rowbuf);
+            g2_bin(L, rowptr, col, val, NG * t + g, e[g], rowbuf);
         }
-        int32_t last[2] = {0, 0};       // a pad points at a column its bin has just used (a certain L2 hit, never applied)
-        g2_schedule(e[0], e[1], align, [&](int64_t, int g, const G2Ent* en) {
+        // a pad gathers from the column the wave's slowest bin is at: inside the L2 window, never applied
+        gn_schedule(e, NG, align, [&](int64_t, int, const G2Ent* en, int64_t window) {
             uint32_t word;
             float v;
             if (en) {
                 if (en->col < 0 || en->col >= (1 << 28)) bad = 1;
-                last[g] = en->col;
                 word = (uint32_t)en->col | ((uint32_t)en->lr << 28);
                 v = en->val;
                 uint32_t bits;
                 memcpy(&bits, &v, 4);
                 if (bits == kPadBits) v = 0.0f;          // a real -0.0f: stored as +0.0f (the pad marker is -0.0f)
             } else {
-                word = (uint32_t)last[g];
+                word = (uint32_t)window;
                 const uint32_t bits = kPadBits;
                 memcpy(&v, &bits, 4);
             }
@@ -353,9 +353,34 @@ int sgcn_csplan2_fill(const int32_t* rowptr, const int32_t* col, const float* va
             out++;
         });
     }
-    if (bad) return sgcn::fail(SGCN_ERR_INVALID, "csplan2_fill: a column does not fit 28 bits");
+    if (bad) return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: a column does not fit 28 bits");
     tile_ptr[L.ntiles] = out;
     return SGCN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sgcn_csplan2_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles,
+                       int32_t align, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
+    return gn_count(rowptr, col, M, T, round_tiles, align, 2, ntiles, nentries, nfix, nslots);
+}
+
+int sgcn_csplan2_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T,
+                      int32_t round_tiles, int32_t align, int64_t* tile_ptr, int32_t* colrow, float* valout,
+                      int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
+    return gn_fill(rowptr, col, val, M, T, round_tiles, align, 2, tile_ptr, colrow, valout, tile_rows, tile_slots, fix);
+}
+
+int sgcn_csplang_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles,
+                       int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
+    return gn_count(rowptr, col, M, T, round_tiles, align, ngroups, ntiles, nentries, nfix, nslots);
+}
+
+int sgcn_csplang_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T,
+                      int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* tile_ptr, int32_t* colrow,
+                      float* valout, int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
+    return gn_fill(rowptr, col, val, M, T, round_tiles, align, ngroups, tile_ptr, colrow, valout, tile_rows, tile_slots, fix);
 }
 
 // Graph-only locality labelling: asynchronous label propagation (Raghavan et al. 2007) on the

@@ -561,6 +561,213 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }
 #undef SGCN_G2_FMA
 
+// Four lane groups per wavefront (plan->G == 4): lanes 16 g .. 16 g + 15 hold the 16 x float4 accumulators of bin g on a
+// 64-column slab -- 64 rows per wavefront, so the 4,096 resident wavefronts cover 262 k rows: S-Reddit in ONE round of
+// tiles, B streamed through every XCD once per 64-column pass.  Same structure as the two-group kernel above (pipelined
+// gathers, ds_bpermute operand selection, row ids packed per chunk, scalar clock arithmetic); a step applies four
+// entries: four indexed FMA groups under quarter-wave execution masks.
+// MEASURED on S-Reddit (profiles/g2_probe.py with G=4): 4.43 ms against 3.49 for two groups -- 10 launches of ~1,740
+// steps either way, but the time no longer follows the clock (4.45-4.6 ms from 220 to 280 ns per step): a step costs
+// ~255 ns of instruction issue, four times (execution-mask write, s_set_gpr_idx_on, four quarter-occupied FMAs,
+// s_set_gpr_idx_off) with four waves per SIMD.  The halved fabric traffic cannot be cashed in.  Opt-in
+// (`ColumnSweepCSR(G=4)`, `bench.py --cs-g 4`), parity-tested with the two-group kernel; a reproducible negative result.
+template <int U, bool WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g4p_kernel(CsArgs a) {
+    typedef Vec<4>::type VT;
+    constexpr int kShift = 28;
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    constexpr int kSteps = kWave / 4;                 // steps per chunk of 64 entries (four bins per step)
+    constexpr int kBatches = kSteps / U;
+    static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4;                          // my bin: lanes 16 q .. 16 q + 15
+    const int li = lane & 15;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int fbase = a.slab * 64;
+    const int f4 = fbase + li * 4;
+    const bool act = f4 < a.d;
+    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const uint32_t ldb32 = (uint32_t)(a.ldb * 4);
+    const int sel0 = q * 4;                           // ds_bpermute byte address of entry (4 j + bin) is sel0 + 16 j
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t ax = {}, ay = {}, az = {}, aw = {};
+
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t tnow = t0;
+    // columns per tick in 16.16 fixed point (a launch lasts < 2^16 ticks of 10 ns; K / ticks < 2^15)
+    const uint32_t cpt16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.cols_per_tick * 65536.0f));
+    const uint32_t slack = (uint32_t)a.slack_cols;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+
+    // one chunk of plan entries: lane l holds entry l (even lanes bin 0, odd lanes bin 1 of step l / 2)
+    auto entries = [&](int64_t p, uint32_t& cr, float& v) {
+        cr = 0;
+        v = __int_as_float((int)0x80000000);                       // beyond the tile: pads on column 0
+        if (p < end) {
+            cr = a.colrow[p + lane];
+            v = a.val[p + lane];
+            uint32_t c = cr & kColMask;
+            if (a.cscale && __float_as_int(v) != (int)0x80000000) {
+                v *= a.cscale[c];
+                if (__float_as_int(v) == (int)0x80000000) v = 0.f;
+            }
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; cr = (cr & ~kColMask) | c; }
+        }
+    };
+    // per-chunk scalars: the local row ids, 8 lanes x 4 bits per word, and the pad mask
+    struct Meta { uint32_t lr[8]; uint32_t pad_lo, pad_hi; };
+    auto meta = [&](uint32_t cr, float v) -> Meta {
+        Meta m;
+        int x = (int)((cr >> kShift) << (4 * (lane & 7)));
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4 -> lane 8g+7 holds group g
+#pragma unroll
+        for (int g = 0; g < 8; g++) m.lr[g] = (uint32_t)__builtin_amdgcn_readlane(x, 8 * g + 7);
+        const uint64_t pm = __ballot(__float_as_int(v) == (int)0x80000000);
+        m.pad_lo = (uint32_t)pm; m.pad_hi = (uint32_t)(pm >> 32);
+        return m;
+    };
+    auto pace = [&](uint32_t crs, int j) {
+        if (cpt16 != 0) {
+            const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 4 * j) & kColMask;
+            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
+            for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
+            }
+        }
+    };
+    auto gather = [&](uint32_t crs, int j) -> VT {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 16 * j, (int)crs);  // my bin's column word
+        if constexpr (WIDE) {
+            return *reinterpret_cast<const VT*>(Bb + (uint64_t)(c & kColMask) * ldb32 + off4);
+        } else {                                       // u24 multiply: the row id above bit 24 is ignored by the instruction
+            const uint32_t off = __umul24(c, ldb32) + off4;
+            return *reinterpret_cast<const VT*>(Bb + off);
+        }
+    };
+#define SGCN_G4_FMA(PADWORD, B0, B1, B2, B3)                                                     \
+        asm volatile("s_bitcmp0_b32 %4, " #B0 "\n\t"                                            \
+                     "s_cselect_b32 exec_lo, 0xffff, 0\n\t"                                     \
+                     "s_mov_b32 exec_hi, 0\n\t"                                                 \
+                     "s_set_gpr_idx_on %5, 0xc\n\t"                                             \
+                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
+                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
+                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
+                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
+                     "s_set_gpr_idx_off\n\t"                                                    \
+                     "s_bitcmp0_b32 %4, " #B1 "\n\t"                                            \
+                     "s_cselect_b32 exec_lo, 0xffff0000, 0\n\t"                                 \
+                     "s_set_gpr_idx_on %6, 0xc\n\t"                                             \
+                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
+                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
+                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
+                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
+                     "s_set_gpr_idx_off\n\t"                                                    \
+                     "s_bitcmp0_b32 %4, " #B2 "\n\t"                                            \
+                     "s_mov_b32 exec_lo, 0\n\t"                                                 \
+                     "s_cselect_b32 exec_hi, 0xffff, 0\n\t"                                     \
+                     "s_set_gpr_idx_on %7, 0xc\n\t"                                             \
+                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
+                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
+                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
+                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
+                     "s_set_gpr_idx_off\n\t"                                                    \
+                     "s_bitcmp0_b32 %4, " #B3 "\n\t"                                            \
+                     "s_cselect_b32 exec_hi, 0xffff0000, 0\n\t"                                 \
+                     "s_set_gpr_idx_on %8, 0xc\n\t"                                             \
+                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
+                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
+                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
+                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
+                     "s_set_gpr_idx_off\n\t"                                                    \
+                     "s_mov_b64 exec, -1"                                                       \
+                     : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw) \
+                     : "s"(PADWORD), "s"(l0), "s"(l1), "s"(l2), "s"(l3), "v"(vv), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w) \
+                     : "scc")
+    // step j of the chunk (compile-time j): the value word of my bin by ds_bpermute, the four row ids by s_bfe (entries
+    // 4j..4j+3 = four nibbles of word j / 2), the pad bits 4j..4j+3 of the chunk's mask by s_bitcmp
+    auto fma2 = [&](const Meta& m, float vs, auto jc, VT b) {
+        constexpr int j = decltype(jc)::value;
+        const float vv = __int_as_float(__builtin_amdgcn_ds_bpermute(sel0 + 16 * j, __float_as_int(vs)));
+        const uint32_t w = m.lr[j >> 1] >> ((j & 1) * 16);
+        const int l0 = (int)(w & 15u), l1 = (int)((w >> 4) & 15u), l2 = (int)((w >> 8) & 15u), l3 = (int)((w >> 12) & 15u);
+        const uint32_t pw = j < 8 ? m.pad_lo : m.pad_hi;
+        constexpr int b0 = (4 * j) & 31;
+        if constexpr (b0 == 0) SGCN_G4_FMA(pw, 0, 1, 2, 3);
+        else if constexpr (b0 == 4) SGCN_G4_FMA(pw, 4, 5, 6, 7);
+        else if constexpr (b0 == 8) SGCN_G4_FMA(pw, 8, 9, 10, 11);
+        else if constexpr (b0 == 12) SGCN_G4_FMA(pw, 12, 13, 14, 15);
+        else if constexpr (b0 == 16) SGCN_G4_FMA(pw, 16, 17, 18, 19);
+        else if constexpr (b0 == 20) SGCN_G4_FMA(pw, 20, 21, 22, 23);
+        else if constexpr (b0 == 24) SGCN_G4_FMA(pw, 24, 25, 26, 27);
+        else SGCN_G4_FMA(pw, 28, 29, 30, 31);
+    };
+
+    uint32_t ccr, ncr;
+    float cv, nv;
+    entries(start, ccr, cv);
+    entries(start + kWave, ncr, nv);
+    Meta cm = meta(ccr, cv);
+    VT buf[2][U];
+    pace(ccr, 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
+    if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    for (int64_t p0 = start; p0 < end; p0 += kWave) {
+        static_for<kBatches>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // batch k+1 goes in flight (the first batch of the NEXT chunk after this chunk's last) ...
+            if constexpr (k + 1 < kBatches) {
+                pace(ccr, (k + 1) * U);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
+            } else {
+                pace(ncr, 0);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
+            }
+            if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            // ... while batch k is applied
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                fma2(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
+            });
+        });
+        ccr = ncr; cv = nv;
+        cm = meta(ccr, cv);
+        entries(p0 + 2 * kWave, ncr, nv);
+    }
+
+    const int32_t* rows = a.tile_rows + tile * 64 + q * 16;
+    const int32_t* slots = a.tile_slots + tile * 64 + q * 16;
+    const int left = a.d - f4;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rows[r];
+        const VT accv = {ax[r], ay[r], az[r], aw[r]};
+        if (row < 0 || !act) continue;
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc;
+            const float rs = a.rscale ? a.rscale[row] : 1.0f;
+            VT res = accv * rs;
+            if (a.beta != 0.f) {
+                if (left >= 4) res += a.beta * vload<4>(out + f4);
+                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
+            }
+            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
+        }
+    }
+}
+#undef SGCN_G4_FMA
+
 template <int R, int VW, int U>
 __global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
     typedef typename Vec<VW>::type VT;
@@ -714,6 +921,14 @@ struct CsVariant { int nslab, slab_floats, U; bool pinned, extra; const char* na
 
 CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
     CsVariant v{};
+    if (plan->G == 4) {             // four lane groups per wave: 64-column passes
+        v.nslab = ((d + 3) / 4 * 4 + 63) / 64;
+        v.slab_floats = 64;
+        v.pinned = true; v.extra = false;
+        v.U = 4;
+        v.name = "sgcn::cs_spmm16g4p_kernel<4, false>";
+        return v;
+    }
     if (plan->G == 2) {             // two lane groups per wave: 128-column passes, one dwordx4 per step
         v.nslab = ((d + 3) / 4 * 4 + 127) / 128;
         v.slab_floats = 128;
@@ -793,7 +1008,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
     a.xcd_map = plan->xcd_map;
-    SGCN_REQUIRE(plan->G != 2 || plan->R == 16, "spmm_cs: a G = 2 plan needs R = 16");
+    SGCN_REQUIRE((plan->G != 2 && plan->G != 4) || plan->R == 16, "spmm_cs: a G = 2 / 4 plan needs R = 16");
     SGCN_REQUIRE(plan->G != 2 || ldb * 4 < (1ll << 32), "spmm_cs: row pitch of B must fit 32 bits");
     if (plan->nfix > 0) {
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
@@ -831,7 +1046,12 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
 #define SGCN_CS_LAUNCH(RR, VV, UU) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU>), dim3(blocks), dim3(kBlock), 0, st, a)
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
-            if (plan->G == 2 && tune_get("cs_g2_plain") > 0) {
+            if (plan->G == 4) {
+                const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
+                                  tune_get("cs_g2_wide") > 0;
+                if (wide) hipLaunchKernelGGL((cs_spmm16g4p_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((cs_spmm16g4p_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+            } else if (plan->G == 2 && tune_get("cs_g2_plain") > 0) {
                 if (U == 4) hipLaunchKernelGGL((cs_spmm16g2_kernel<4>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else hipLaunchKernelGGL((cs_spmm16g2_kernel<8>), dim3(blocks), dim3(kBlock), 0, st, a);
             } else if (plan->G == 2) {

@@ -445,9 +445,11 @@ class ColumnSweepCSR(object):
         ahead on narrower operands (S-RMAT d = 256: 2.61 vs 2.82 ms) -- DESIGN.md 3.1b."""
         a = a.tocsr()
         self.G = int(G)
-        if self.G == 2:
+        if self.G not in (1, 2, 4):
+            raise ValueError("G must be 1, 2 or 4")
+        if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
-                raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
+                raise ValueError("G = 2 / 4 plans are ungrouped and use 16-row bins")
             self._init_g2(a, device, T, round_tiles, int(align))
             return
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
@@ -497,30 +499,31 @@ class ColumnSweepCSR(object):
         self.nnz = int(col.shape[0])
 
     def _init_g2(self, a, device, T, round_tiles, align):
+        """G = 2 / 4 lane groups per wavefront (sgcn_csplang_*)"""
+        G = self.G
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
         val = np.ascontiguousarray(a.data, dtype=np.float32)
         M = rowptr.shape[0] - 1
         rnd = int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))
         nt, ne, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplan2_count(rowptr.ctypes.data, col.ctypes.data, M, T, rnd, align, C.byref(nt), C.byref(ne),
+        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, T, rnd, align, G, C.byref(nt), C.byref(ne),
                                      C.byref(nfix), C.byref(nslots)))
         tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
         colrow = np.empty(ne.value, dtype=np.int32)
         valout = np.empty(ne.value, dtype=np.float32)
-        tile_rows = np.empty(nt.value * 32, dtype=np.int32)
-        tile_slots = np.empty(nt.value * 32, dtype=np.int32)
+        tile_rows = np.empty(nt.value * 16 * G, dtype=np.int32)
+        tile_slots = np.empty(nt.value * 16 * G, dtype=np.int32)
         fix = np.empty((nfix.value, 3), dtype=np.int32)
-        check(lib.sgcn_csplan2_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, T, rnd, align,
+        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, T, rnd, align, G,
                                     tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data, tile_rows.ctypes.data,
                                     tile_slots.ctypes.data, fix.ctypes.data if nfix.value else None))
-        self.pad_fraction = 1.0 - 2.0 * col.shape[0] / max(ne.value, 1) / 2.0 if ne.value else 0.0
         self.pad_fraction = 1.0 - col.shape[0] / max(ne.value, 1)
         self.grouped, self.pos2col = False, None
         self.shape = (int(a.shape[0]), int(a.shape[1]))
         self.R, self.ntiles, self.nfix, self.nslots = 16, nt.value, nfix.value, nslots.value
         self.round_tiles = round_tiles
-        self._tile_nnz = (np.diff(tile_ptr) // 2).astype(np.int64)       # steps per tile (what the pace counts)
+        self._tile_nnz = (np.diff(tile_ptr) // G).astype(np.int64)       # steps per tile (what the pace counts)
         self._hint, self._hint_round = None, None
         self.pace = {}
         to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731

@@ -337,15 +337,16 @@ def test_column_sweep_full_size_matches_row_gather(dev):
 
 @pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6), (500, 500, 256, 0),
                                          (64, 64, 130, 2), (90, 70, 30, 2), (5000, 3000, 602, 6)])
-def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad):
+@pytest.mark.parametrize("G", [2, 4])
+def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G):
     """G = 2 plan (two 16-row bins per wavefront, 128-column passes, half-wave execution masks): the product,
     its fusions and beta against the oracle; bit-identical reruns and paces."""
     from stochastic_gcn_amd import ops
     a = rand_csr(M, K, 0.08 if M < 1000 else 0.01, M + d, long_rows=[(0, min(K, 300)), (M // 2, min(K, 150))])
     rng = np.random.RandomState(d)
     B = rng.standard_normal((K, d + pad)).astype(np.float32)
-    A = ops.ColumnSweepCSR(a, dev, T=32, G=2)
-    assert A.nfix >= 1 and A.G == 2
+    A = ops.ColumnSweepCSR(a, dev, T=32, G=G)
+    assert A.nfix >= 1 and A.G == G
     Bd = T(B, dev)[:, :d]
     ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
     out = ops.spmm_cs(A, Bd)
@@ -364,12 +365,12 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad):
     assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
     if pad:
         np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
-    assert "g2p" in A.variant(d)
-    # the pipelined kernel (default), its 64-bit-offset form and the plain two-group kernel apply every bin's
-    # entries in the same order: bit-identical products
+    assert ("g%dp" % G) in A.variant(d)
+    # the pipelined kernel (default), its 64-bit-offset form and (G = 2) the plain two-group kernel apply every
+    # bin's entries in the same order: bit-identical products
     from stochastic_gcn_amd._ffi import lib
     try:
-        for knob in (b"cs_g2_wide", b"cs_g2_plain"):
+        for knob in (b"cs_g2_wide", b"cs_g2_plain") if G == 2 else (b"cs_g2_wide",):
             lib.sgcn_tune(knob, 1)
             assert torch.equal(ops.spmm_cs(A, Bd), out)
             o3 = T(c0, dev)
