@@ -21,6 +21,15 @@
 // not overlap in the vector memory path -- T ~ miss_bytes / 7.2 TB/s + hit_bytes / 30 TB/s -- and
 // the kernel sits on that line; the levers left are fewer fabric bytes (rows resident per XCD) and
 // graphs with locality (grouped plans, xcd_map).
+//
+// Kernels in this file:
+//   cs_spmm16_kernel<U, EXTRA>     one 16-row tile per wavefront, pinned accumulators, up to 320 columns per pass
+//   cs_spmm16g2_kernel<U>          two 16-row bins per wavefront (half-wave execution masks), plain form
+//   cs_spmm16g2p_kernel<U, WIDE>   the same, software-pipelined and instruction-lean: what ColumnSweepCSR.choose_g
+//                                  selects for most widths (bench default at d = 602: 3.51 ms against 3.67)
+//   cs_spmm16g4p_kernel<U, WIDE>   four bins per wavefront: parity-green, instruction-bound (negative result)
+//   cs_spmm_kernel<R, VW, U>       generic compiler-indexed form (reference for the pinned ones; R = 32 tiles)
+//   cs_fix_kernel<VW>              ordered sum of a split row's workspace slots
 #include "sgcn_dev.h"
 
 namespace sgcn {
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     }
 }
 
-// ---- two lane groups per wavefront (plan->G == 2): EXPERIMENTAL, not the default -------------------------
+// ---- two lane groups per wavefront (plan->G == 2): plain form (the reference of the pipelined kernel below) ---
 // Lanes 0-31 hold the 16 x float4 accumulators of bin 0, lanes 32-63 those of bin 1 (same pinned registers
 // v[64:127], four planes of 16), one 128-column slab per pass.  A step applies ONE nonzero of each bin: the
 // two column words come from adjacent lanes of the coalesced entry load (v_readlane), a per-lane select

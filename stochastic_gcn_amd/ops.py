@@ -438,11 +438,12 @@ class ColumnSweepCSR(object):
     plan's up to fp32 summation order."""
 
     def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align=2048):
-        """G = 2 (opt-in): two 16-row lane groups per wavefront on 128-column passes (sgcn_csplan2_*), half the
-        passes of the dense operand through every XCD per register byte.  ``align``: columns one bin of a wave
-        may run ahead of the other (the plan pads the bin that is ahead).  With aligned bins and the pipelined
-        kernel it is level with the default at d = 602 (3.49 vs 3.56 ms on S-Reddit: 10 launches against 8) and
-        ahead on narrower operands (S-RMAT d = 256: 2.61 vs 2.82 ms) -- DESIGN.md 3.1b."""
+        """G = 2: two 16-row lane groups per wavefront on 128-column passes (sgcn_csplang_*), half the passes of
+        the dense operand through every XCD per register byte; ``align``: columns one bin of a wave may run ahead
+        of the slowest (the plan pads the bins that are ahead).  What ``choose_g(d)`` picks for most widths -- the
+        bench and the training path call it: S-Reddit d = 602 3.51 vs 3.67 ms sustained, S-RMAT d = 256 2.61 vs
+        2.82 ms.  G = 4 (four groups, 64-column passes) is parity-tested but instruction-bound (4.4 ms):
+        DESIGN.md 3.1b."""
         a = a.tocsr()
         self.G = int(G)
         if self.G not in (1, 2, 4):
