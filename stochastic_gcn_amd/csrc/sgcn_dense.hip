@@ -313,27 +313,46 @@ extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y
                                    true, nullptr, (hipStream_t)stream);
 }
 
+namespace sgcn {
+int aux_fork(void* stream, void** aux_stream);          // sgcn_gemm.hip
+// The loss kernels with the statistics reduction (loss / accuracy sums: nothing in the step depends on them
+// before the optimizer's join) on the auxiliary stream when `overlap`: one kernel less on the step's chain.
+int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
+            float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream,
+            bool overlap) {
+    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "%s: bad operand", softmax ? "softmax_ce" : "sigmoid_ce");
+    hipStream_t st = (hipStream_t)stream;
+    if (softmax)
+        hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, logits, ldz, labels, ldl,
+                           n, c, dlogits, lddz, pred, ldp, rowstat);
+    else
+        hipLaunchKernelGGL(sigmoid_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, logits, ldz, labels, ldl,
+                           n, c, dlogits, lddz, pred, ldp, rowstat);
+    hipStream_t ss = st;
+    if (overlap) {
+        void* side = nullptr;
+        const int rc = aux_fork(stream, &side);
+        if (rc != SGCN_OK) return rc;
+        ss = (hipStream_t)side;
+    }
+    if (softmax) hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(kBlock), 0, ss, rowstat, n, stats);
+    else hipLaunchKernelGGL(sigmoid_stats_kernel, dim3(1), dim3(kBlock), 0, ss, rowstat, n, c, stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+}  // namespace sgcn
+
 extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float* labels,
                                    int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
                                    float* pred, int64_t ldp, float* stats, float* rowstat,
                                    void* stream) {
-    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "softmax_ce: bad operand");
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0,
-                       (hipStream_t)stream, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, rowstat);
-    hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, rowstat, n, stats);
-    SGCN_HIP_TRY(hipGetLastError());
-    return SGCN_OK;
+    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false);
 }
 
 extern "C" int sgcn_sigmoid_ce_f32(const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n,
                                    int32_t c, float* dlogits, int64_t lddz, float* pred, int64_t ldp,
                                    float* stats, float* rowstat, void* stream) {
-    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "sigmoid_ce: bad operand");
-    hipLaunchKernelGGL(sigmoid_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0,
-                       (hipStream_t)stream, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, rowstat);
-    hipLaunchKernelGGL(sigmoid_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, rowstat, n, c, stats);
-    SGCN_HIP_TRY(hipGetLastError());
-    return SGCN_OK;
+    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false);
 }
 
 extern "C" int sgcn_l2_penalty_f32(const float* theta, int64_t lo, int64_t hi, float wd, float* grad,

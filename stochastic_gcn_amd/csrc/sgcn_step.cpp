@@ -27,6 +27,8 @@ int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64
                          const int32_t* gidx, void* stream);
 int aux_join(void* stream);
 int aux_fork(void* stream, void** aux_stream);
+int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
+            float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap);
 }  // namespace sgcn
 
 namespace {
@@ -213,8 +215,8 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             float* dz = a.p<float>(); const int64_t lddz = a.next();
             float* pred = a.p<float>(); const int64_t ldp = a.next();
             float* stats = a.p<float>(); float* rowstat = a.p<float>();
-            rc = op.op == SGCN_OP_SOFTMAX_CE ? sgcn_softmax_ce_f32(z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream)
-                                             : sgcn_sigmoid_ce_f32(z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream);
+            // the loss / accuracy sums run beside the backward pass (joined before L2_PENALTY / ADAM)
+            rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream, overlap);
             break;
         }
         case SGCN_OP_ADAM: {
