@@ -406,7 +406,8 @@ def main(argv=None):
             import types
             r_, w_ = (int(x) for x in args.emulate_shard.split("/"))
             par = types.SimpleNamespace(rank=r_, world=w_, active=False)    # no peers: no collectives
-        sh = ShardedSpMM(par, full_adj, dev, kernel=args.kernel, with_transpose=not args.no_backward)
+        sh = ShardedSpMM(par, full_adj, dev, kernel=args.kernel, with_transpose=not args.no_backward,
+                         d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d))
         A = sh.A
     elif args.kernel == "cs":
         comm = None

@@ -182,7 +182,9 @@ class ShardedSpMM(object):
         layer activation sharded like C: the ranks all-gather their row blocks first
         (xGMI-bound for large operands; bench.py reports both variants)."""
 
-    def __init__(self, par, adj, device, kernel="cs", with_transpose=True):
+    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None):
+        """d: width of the dense operand, when known up front -- picks the sweep's lane-group count for it
+        (ops.ColumnSweepCSR.choose_g); None: one group per wavefront."""
         from . import ops
         adj = adj.tocsr()
         if adj.shape[0] != adj.shape[1]:
@@ -202,8 +204,9 @@ class ShardedSpMM(object):
         if self.hi == self.lo:          # more ranks than row blocks: this rank only joins collectives
             pass
         elif kernel == "cs":
-            self.A = ops.ColumnSweepCSR(blk, device)
-            self.AT = ops.ColumnSweepCSR(blk_t, device) if with_transpose else None
+            G = ops.ColumnSweepCSR.choose_g(d) if d else 1
+            self.A = ops.ColumnSweepCSR(blk, device, G=G)
+            self.AT = ops.ColumnSweepCSR(blk_t, device, G=G) if with_transpose else None
             self._mm = ops.spmm_cs
         else:
             self.A = ops.DeviceCSR.from_scipy(blk, device)
