@@ -663,7 +663,7 @@ class ColumnSweepCSR(object):
             self.pace[d] = -1
             return (None, -1)
         out = torch.empty((self.shape[0], (d + 3) // 4 * 4), dtype=torch.float32, device=B.device)[:, :d]
-        def timed(p):
+        def timed(p, reps=reps):
             self.pace[d] = p
             spmm_cs(self, B, out=out, d=d)                       # warm
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -689,6 +689,15 @@ class ColumnSweepCSR(object):
                 if t < best[0]:
                     best = (t, p)
             best = (best[0], int(best[1] * 1.02 + 0.5))
+            # ... and a sustained check of the choice: a run of back-to-back products must not cost more than the
+            # burst did (a lost lock-step costs 60 %, not a few); if it does, back the clock off in 4 % steps
+            burst = best[0]
+            for _ in range(4):
+                t = timed(best[1], reps=6)
+                if t <= 1.06 * burst:
+                    best = (t, best[1])
+                    break
+                best = (t, int(best[1] * 1.04 + 0.5))
         self.pace[d] = best[1]
         return best
 
