@@ -419,7 +419,7 @@ def main(argv=None):
         elif reorder == "labels":
             comm = np.ascontiguousarray(data10[6].argmax(1), dtype=np.int32)
             reorder_info = {"method": "dataset labels", "communities": int(comm.max()) + 1}
-        cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d) if (comm is None and args.cs_r == 16) else 1)
+        cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1)) if (comm is None and args.cs_r == 16) else 1)
         gk = dict(G=cs_g, align=args.cs_align) if (cs_g != 1 and comm is None) else dict(R=args.cs_r, col_labels=comm, row_labels=comm)
         A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
         A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)

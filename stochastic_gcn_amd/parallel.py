@@ -204,7 +204,7 @@ class ShardedSpMM(object):
         if self.hi == self.lo:          # more ranks than row blocks: this rank only joins collectives
             pass
         elif kernel == "cs":
-            G = ops.ColumnSweepCSR.choose_g(d) if d else 1
+            G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1)) if d else 1
             self.A = ops.ColumnSweepCSR(blk, device, G=G)
             self.AT = ops.ColumnSweepCSR(blk_t, device, G=G) if with_transpose else None
             self._mm = ops.spmm_cs

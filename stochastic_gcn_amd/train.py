@@ -88,7 +88,7 @@ def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats
         X = Xp[:, :d]
     out = []
     for a, path in zip((train_adj, full_adj), cache):
-        A, hit = ops.ColumnSweepCSR.cached(a, device, path, G=ops.ColumnSweepCSR.choose_g(d))
+        A, hit = ops.ColumnSweepCSR.cached(a, device, path, G=ops.ColumnSweepCSR.choose_g(d, a.nnz / max(a.shape[0], 1)))
         if d not in A.pace:
             A.autotune(X)               # once per plan and width; stored with the cached plan
         A.store_if_cached()
