@@ -507,8 +507,10 @@ enum {
     SGCN_OP_VR_AGG_POST = 15, /* `stream` waits for the auxiliary stream, then sgcn_vr_aggregate_post_f32 */
     SGCN_OP_AUX_SCATTER_ROWS = 16, /* sgcn_scatter_rows_f32 on the auxiliary stream (forked from `stream`) */
     SGCN_OP_AUX_MEMSET0 = 17, /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
-    SGCN_OP_DENSE_FWD_PAIR = 18 /* DENSE_FWD arguments; the NEXT op must be a DENSE_FWD on this op's output: both run as
-                                 * one sgcn_dense2_fwd_f32 */
+    SGCN_OP_DENSE_FWD_PAIR = 18, /* DENSE_FWD arguments; the NEXT op must be a DENSE_FWD on this op's output: both run as
+                                  * one sgcn_dense2_fwd_f32 */
+    SGCN_OP_DENSE_FWD_CE = 19   /* DENSE_FWD arguments of a plain layer; the NEXT op must be the SOFTMAX_CE of its output:
+                                 * the loss runs in the GEMM's epilogue (same arithmetic, one launch less) */
 };
 typedef struct {
     int32_t op, nargs;

@@ -16,6 +16,10 @@ sys.path.insert(0, ROOT)
 def run(epochs):
     import torch
     import bench
+    from stochastic_gcn_amd import _ffi
+    for kv in os.environ.get("SGCN_TUNE", "").split():          # library knobs for this run: SGCN_TUNE="key=value ..."
+        k, v = kv.split("=")
+        _ffi.tune(k, int(v))
     from stochastic_gcn_amd import synthetic
     data = synthetic.reddit_like(seed=1, with_features=False)
     te = bench.train_epoch_leg(data, torch.device("cuda:0"), epochs=epochs)
@@ -73,6 +77,20 @@ def gaps(src):
         per = np.diff(st[adam]) / 1e3
         print("step period (adam to adam): median %.1f us; kernels per step %.1f"
               % (np.median(per), (adam[-1] - adam[0]) / (len(adam) - 1)))
+    # the step's dependency chain, independent of how fast the (traced, slowed) host launches: per queue, kernels
+    # and summed kernel time per step -- the compute queue's sum is the floor of the step on the GPU
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    if qcol and len(adam) > 2:
+        qs = [r[0] for r in t.execute("select %s from %s order by start" % (qcol, view))]
+        a, b = adam[0], adam[-1]
+        nsteps = len(adam) - 1
+        per_q = {}
+        for i in range(a, b):
+            k = per_q.setdefault(qs[i], [0, 0.0])
+            k[0] += 1
+            k[1] += (en[i] - st[i]) / 1e3
+        for q, (cnt, us) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
+            print("queue %s: %.1f kernels and %.1f us of kernel time per step" % (q, cnt / nsteps, us / nsteps))
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--gaps":

@@ -314,6 +314,11 @@ extern "C" int sgcn_ln_act_bwd_f32(const float* dy, int64_t lddy, const float* y
 }
 
 namespace sgcn {
+int softmax_stats_launch(const float* rowstat, int32_t n, float* stats, void* stream) {
+    hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, rowstat, n, stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
 int aux_fork(void* stream, void** aux_stream);          // sgcn_gemm.hip
 // The loss kernels with the statistics reduction (loss / accuracy sums: nothing in the step depends on them
 // before the optimizer's join) on the auxiliary stream when `overlap`: one kernel less on the step's chain.

@@ -37,6 +37,12 @@ struct GemmArgs {
     int32_t vec_a, vec_b;            // operand rows 16-byte aligned: 4-float runs load as one float4
     const int32_t* a_gidx;           // row indirection of the stored A (and of A2): row r reads A[gidx[r]]
     const int32_t* a_gidx2;          //   -- the minibatch's feature rows are gathered by the GEMM itself
+    // softmax cross-entropy on the output rows, in the epilogue (epi == 1, relu == 0, N <= 128): what
+    // softmax_ce_kernel (sgcn_dense.hip) computes from the stored logits, same arithmetic, one launch less
+    const float* ce_lab; int64_t ce_ldl;
+    float* ce_dz; int64_t ce_lddz;
+    float* ce_pred; int64_t ce_ldp;
+    float* ce_rowstat;               // [2][M]: per-row loss, per-row hit
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -212,6 +218,37 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
         float* yr = g.C + (int64_t)row * g.ldc;
         if (g.epi == 1) {
             for (int c = lane; c < g.N; c += kWave) { const float v = Cs[rr][c]; yr[c] = g.relu ? fmaxf(v, 0.f) : v; }
+            if (g.ce_lab) {          // the row's logits are Cs[rr][0..N): softmax_ce_kernel's arithmetic, line for line
+                const float* zr = Cs[rr];
+                const float* lr = g.ce_lab + (int64_t)row * g.ce_ldl;
+                const float inv_n = 1.0f / (float)g.M;
+                float m = -INFINITY, lm = -INFINITY;
+                int am = 0, alm = 0;
+                for (int k = lane; k < g.N; k += kWave) {
+                    if (zr[k] > m) { m = zr[k]; am = k; }
+                    if (lr[k] > lm) { lm = lr[k]; alm = k; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float om = __shfl_xor(m, o, 64); const int oa = __shfl_xor(am, o, 64);
+                    if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+                    const float ol = __shfl_xor(lm, o, 64); const int ola = __shfl_xor(alm, o, 64);
+                    if (ol > lm || (ol == lm && ola < alm)) { lm = ol; alm = ola; }
+                }
+                float se = 0.f, sl = 0.f;
+                for (int k = lane; k < g.N; k += kWave) { se += __expf(zr[k] - m); sl += lr[k]; }
+                se = wsum(se); sl = wsum(sl);
+                const float lse = m + __logf(se);
+                float l = 0.f;
+                for (int k = lane; k < g.N; k += kWave) {
+                    const float logp = zr[k] - lse, p = __expf(logp);
+                    l -= lr[k] * logp;
+                    if (g.ce_dz) g.ce_dz[(int64_t)row * g.ce_lddz + k] = (p * sl - lr[k]) * inv_n;
+                    if (g.ce_pred) g.ce_pred[(int64_t)row * g.ce_ldp + k] = p;
+                }
+                l = wsum(l);
+                if (lane == 0) { g.ce_rowstat[row] = l; g.ce_rowstat[g.M + row] = (am == alm) ? 1.f : 0.f; }
+            }
             continue;
         }
         float s = 0.f;
@@ -527,12 +564,14 @@ using namespace sgcn;
 
 // Split-K factor: a weight-gradient GEMM (dW = X^T g) has a tiny output (128 x 128: FOUR tiles)
 // and a long K (the ~1,000 rows of the minibatch), so the K range is cut across blockIdx.z until
-// the grid has ~256 workgroups, every slice keeping at least three K-steps (so the K = 128 GEMMs
-// of the step are never split: the reduction is a second launch and must buy more than it costs).
+// the grid has ~256 workgroups, every slice keeping at least five K-steps (so the K = 128 and K = 256 GEMMs
+// of the step are never split: the reduction is a second launch on the step's chain and must buy more than it
+// costs -- measured on the step's compute queue: 17 -> 16 kernels, -7 us of kernel time with 5 instead of 3).
 static int split_factor(int M, int N, int K) {
     const int tiles = ((M + kTM - 1) / kTM) * ((N + kTN - 1) / kTN);
     int s = 256 / std::max(tiles, 1);
-    s = std::min(s, K / (3 * kTK));
+    const int min_steps = tune_get("gemm_min_steps") > 0 ? tune_get("gemm_min_steps") : 5;
+    s = std::min(s, K / (min_steps * kTK));
     return std::max(s, 1);
 }
 
@@ -615,6 +654,34 @@ extern "C" int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_
     if (g.drop_c.on) ws = nullptr;           // the output mask is applied in the GEMM's own epilogue
     return launch_gemm(g, trans_a, trans_b, ws, (hipStream_t)stream);
 }
+
+namespace sgcn {
+// sgcn_dense_fwd_f32 of a plain (no LayerNorm, no ReLU) layer with the softmax cross-entropy of its output rows in the
+// GEMM's epilogue + the statistics reduction (on the auxiliary stream when `overlap`): DENSE_FWD + SOFTMAX_CE of the
+// step program as one launch on the step's chain.  Bit-identical to the two separate calls.
+int aux_fork(void* stream, void** aux_stream);
+int softmax_stats_launch(const float* rowstat, int32_t n, float* stats, void* stream);      // sgcn_dense.hip
+int dense_fwd_ce(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y,
+                 int64_t ldy, const sgcn_dropout_t* drop, const float* labels, int64_t ldl, float* dlogits, int64_t lddz,
+                 float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap) {
+    SGCN_REQUIRE(M > 0 && N > 0 && N <= kTN && K >= 0 && X && W && Y && labels && stats && rowstat, "dense_fwd_ce: bad operand");
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+    g.M = M; g.N = N; g.K = K; g.epi = 1; g.relu = 0;
+    g.drop_a = drop_args(drop);
+    SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd_ce: dropout width must be K");
+    g.ce_lab = labels; g.ce_ldl = ldl; g.ce_dz = dlogits; g.ce_lddz = lddz; g.ce_pred = pred; g.ce_ldp = ldp;
+    g.ce_rowstat = rowstat;
+    int rc = launch_gemm(g, 0, 0, nullptr, (hipStream_t)stream);            // no split-K: the epilogue needs whole rows
+    if (rc != SGCN_OK) return rc;
+    void* side = stream;
+    if (overlap) {
+        rc = aux_fork(stream, &side);
+        if (rc != SGCN_OK) return rc;
+    }
+    return softmax_stats_launch(rowstat, M, stats, side);
+}
+}  // namespace sgcn
 
 extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
                                   const float* X2, int64_t ldx2, int32_t split,

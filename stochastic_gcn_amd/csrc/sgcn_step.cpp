@@ -27,6 +27,9 @@ int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64
                          const int32_t* gidx, void* stream);
 int aux_join(void* stream);
 int aux_fork(void* stream, void** aux_stream);
+int dense_fwd_ce(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y,
+                 int64_t ldy, const sgcn_dropout_t* drop, const float* labels, int64_t ldl, float* dlogits, int64_t lddz,
+                 float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap);
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap);
 }  // namespace sgcn
@@ -135,6 +138,42 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             decode(b, &dr2, l2);
             rc = sgcn_dense2_fwd_f32(&l1, &l2, stream);
             k++;                                             // the second op is done
+            break;
+        }
+        case SGCN_OP_DENSE_FWD_CE: {
+            if (k + 1 >= nops || ops[k + 1].op != SGCN_OP_SOFTMAX_CE)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d (DENSE_FWD_CE) is not followed by a SOFTMAX_CE", k);
+            const sgcn_step_op_t& op2 = ops[k + 1];
+            if (op2.nargs < 0 || op2.nargs > SGCN_STEP_MAX_ARGS)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d has %d arguments", k + 1, op2.nargs);
+            Args b;
+            b.n = op2.nargs; b.pos = 0;
+            for (int j = 0; j < op2.nargs; j++) {
+                const int32_t s = op2.slot[j];
+                if (s >= nslots) return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d reads slot %d of %d", k + 1, s, nslots);
+                b.v[j] = (s < 0 ? 0 : op2.mul[j] * slots[s]) + op2.add[j];
+            }
+            const int32_t M = a.i(), N = a.i(), K = a.i();
+            const float* X = a.p<const float>(); const int64_t ldx = a.next();
+            const float* X2 = a.p<const float>(); (void)a.next(); (void)a.i();
+            const float* W = a.p<const float>(); const int64_t ldw = a.next();
+            const float* off = a.p<const float>(); const float* sc = a.p<const float>();
+            (void)a.f(); const int32_t relu = a.i();
+            float* Y = a.p<float>(); const int64_t ldy = a.next();
+            (void)a.p<float>(); (void)a.p<float>();
+            const sgcn_dropout_t* d = a.drop(&dr);
+            (void)a.p<float>(); (void)a.next();
+            const int32_t* g1 = a.p<const int32_t>(); const int32_t* g2 = a.p<const int32_t>();
+            const float* z = b.p<const float>(); const int64_t ldz = b.next();
+            const float* lab = b.p<const float>(); const int64_t ldl = b.next();
+            const int32_t n = b.i(), c = b.i();
+            float* dz = b.p<float>(); const int64_t lddz = b.next();
+            float* pred = b.p<float>(); const int64_t ldp = b.next();
+            float* stats = b.p<float>(); float* rowstat = b.p<float>();
+            if (X2 || off || sc || relu || g1 || g2 || z != Y || ldz != ldy || n != M || c != N)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d (DENSE_FWD_CE): not a plain layer feeding its own loss", k);
+            rc = sgcn::dense_fwd_ce(M, N, K, X, ldx, W, ldw, Y, ldy, d, lab, ldl, dz, lddz, pred, ldp, stats, rowstat, stream, overlap);
+            k++;
             break;
         }
         case SGCN_OP_DENSE_FWD: {

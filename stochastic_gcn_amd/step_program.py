@@ -29,7 +29,7 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19)
 MAX_ARGS = 48
 ARENA_LIMIT_BYTES = 2 << 30
 
@@ -528,8 +528,26 @@ class StepProgram(object):
                 k += 1
         return fused
 
+    def _fuse_loss(self, lst):
+        """Peephole: a plain DENSE_FWD (no LayerNorm, no ReLU, one operand) whose output is the logits of the
+        following SOFTMAX_CE becomes DENSE_FWD_CE: the loss runs in the GEMM's epilogue (bit-identical)."""
+        F, CE = OP['DENSE_FWD'], OP['SOFTMAX_CE']
+        null = (0, -1, 0)
+        n = 0
+        for k in range(len(lst) - 1):
+            (oa, a), (ob, b) = lst[k], lst[k + 1]
+            if oa != F or ob != CE or (k > 0 and lst[k - 1][0] == OP['DENSE_FWD_PAIR']):      # (second half of a pair)
+                continue
+            a, b = [tuple(int(v) for v in t) for t in a], [tuple(int(v) for v in t) for t in b]
+            if (a[5] == null and a[10] == null and a[11] == null and a[13] == null and a[25] == null and a[26] == null
+                    and a[1][1] < 0 and a[1][2] <= 128 and b[0] == a[14] and b[1] == a[15] and b[4] == a[0] and b[5] == a[1]):
+                lst[k] = (OP['DENSE_FWD_CE'], lst[k][1])
+                n += 1
+        return n
+
     def _finalize(self):
         self.n_pairs = self._pair_dense_fwd(self.ops_fb) if FLAGS.fuse_dense else 0
+        self.n_loss_fused = self._fuse_loss(self.ops_fb) if FLAGS.fuse_loss else 0
         self._key_slots = {li: self._n_meta + i for i, li in enumerate(self._key_layers)}
         self.lr_slot = self._n_meta + len(self._key_layers)
         self.nslots = self.lr_slot + 1

@@ -65,6 +65,7 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot):
     assert a.dropout_step == b.dropout_step == 5 and a.adam_t == b.adam_t == 5
     assert a.amt_data == b.amt_data and np.array_equal(a.field_sizes, b.field_sizes)      # the epoch counters too
     prog = next(iter(progs.values()))
+    assert prog.n_loss_fused == 1            # the loss runs in the last GEMM's epilogue -- and nothing changed, bit for bit
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
 
 
