@@ -509,8 +509,11 @@ enum {
     SGCN_OP_AUX_MEMSET0 = 17, /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
     SGCN_OP_DENSE_FWD_PAIR = 18, /* DENSE_FWD arguments; the NEXT op must be a DENSE_FWD on this op's output: both run as
                                   * one sgcn_dense2_fwd_f32 */
-    SGCN_OP_DENSE_FWD_CE = 19   /* DENSE_FWD arguments of a plain layer; the NEXT op must be the SOFTMAX_CE of its output:
+    SGCN_OP_DENSE_FWD_CE = 19,  /* DENSE_FWD arguments of a plain layer; the NEXT op must be the SOFTMAX_CE of its output:
                                  * the loss runs in the GEMM's epilogue (same arithmetic, one launch less) */
+    SGCN_OP_DENSE_BWD_PAIR = 20 /* DENSE_BWD arguments; the NEXT op must be the DENSE_BWD of the layer below, reading this
+                                 * op's dx as its dy: that layer's LayerNorm / ReLU backward runs in the epilogue of this
+                                 * op's input-gradient GEMM (bit-identical, one launch less) */
 };
 typedef struct {
     int32_t op, nargs;

@@ -21,6 +21,14 @@ def run(epochs):
         k, v = kv.split("=")
         _ffi.tune(k, int(v))
     from stochastic_gcn_amd import synthetic
+    from stochastic_gcn_amd.flags import FLAGS
+    over = {}
+    for kv in os.environ.get("SGCN_FLAGS", "").split():         # trainer flags for this run: SGCN_FLAGS="fuse_bwd=0 ..."
+        k, v = kv.split("=")
+        over[k] = type(getattr(FLAGS, k))(int(v)) if isinstance(getattr(FLAGS, k), (bool, int)) else float(v)
+    if over:
+        orig = FLAGS.update
+        FLAGS.update = lambda **kw: (orig(**kw), orig(**over))[0]
     data = synthetic.reddit_like(seed=1, with_features=False)
     te = bench.train_epoch_leg(data, torch.device("cuda:0"), epochs=epochs)
     print(te, file=sys.stderr)

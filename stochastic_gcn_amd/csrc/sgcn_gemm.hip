@@ -12,6 +12,7 @@
 // column reads of the A fragment are bank-conflict free), epilogue through LDS so a wavefront
 // owns whole rows for the LayerNorm statistics.
 #include "sgcn_dev.h"
+#include "sgcn_bwd.h"
 
 namespace sgcn {
 
@@ -43,6 +44,14 @@ struct GemmArgs {
     float* ce_dz; int64_t ce_lddz;
     float* ce_pred; int64_t ce_ldp;
     float* ce_rowstat;               // [2][M]: per-row loss, per-row hit
+    // LayerNorm / ReLU backward of the layer BELOW on the output rows, in the epilogue (epi == 3, N <= 128): the rows
+    // this GEMM produces are that layer's dy; what ln_act_bwd_kernel (sgcn_dense.hip) computes from the stored dy --
+    // same arithmetic and the same 4-row partial blocks, so the parameter gradients come out bit-identical
+    const float* lb_y; int64_t lb_ldy;
+    const float* lb_xhat; const float* lb_rstd; const float* lb_scale;   // scale NULL: ReLU mask only
+    int32_t lb_relu;
+    float* lb_out; int64_t lb_ldo;   // g of the layer below
+    float* lb_partial;               // [ceil(M / 4)][2][N]
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -152,6 +161,20 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
         }
     };
 
+    if (g.epi == 3) {
+        // the LayerNorm-backward epilogue reads the lower layer's y and xhat rows of this tile: fetch them into its two
+        // LDS tiles NOW, behind the K loop (read per row in the epilogue they were a chain of exposed round trips:
+        // 25 us for the GEMM against 8 + 5 for the two separate kernels)
+        float (*Gs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + KG * kGroupFloats);
+        float (*Hs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + KG * kGroupFloats + kTM * (kTN + 4));
+        const bool norm = g.lb_scale != nullptr;
+        for (int i = threadIdx.x; i < kTM * kTN; i += kBlock * KG) {
+            const int rr = i / kTN, c = i % kTN, row = m0 + rr;
+            const bool ok = row < g.M && c < g.N;
+            Gs[rr][c] = ok ? g.lb_y[(int64_t)row * g.lb_ldy + c] : 0.f;
+            Hs[rr][c] = (ok && norm) ? g.lb_xhat[(int64_t)row * g.N + c] : 0.f;
+        }
+    }
     // every group runs the same number of iterations (uniform barriers); a step past kend loads zeros
     const int iters = ((kend - kbeg + kTK - 1) / kTK + KG - 1) / KG;
     if (iters > 0) fetch(kbeg + kg * kTK);
@@ -212,6 +235,64 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
         for (int r = 0; r < 16; r++) Cs[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][cj] = acc[r];
     }
     __syncthreads();
+    if (g.epi == 3) {
+        // Gs / Hs: per row g and g * xhat of the layer below (zero for rows past M), summed into 4-row partial blocks
+        float (*Gs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + KG * kGroupFloats);
+        float (*Hs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + KG * kGroupFloats + kTM * (kTN + 4));
+        const int d = g.N;
+        const bool norm = g.lb_scale != nullptr;
+        for (int rr = kg * (kBlock / kWave) + wave; rr < kTM; rr += KG * (kBlock / kWave)) {
+            const int row = m0 + rr;
+            if (row >= g.M) continue;                  // (its tile rows were zero-filled by the prefetch)
+            const float* yr = Gs[rr];                 // prefetched y row; overwritten below by g (same lane, read first)
+            float* dr = g.lb_out + (int64_t)row * g.lb_ldo;
+            // the row of dy: the GEMM's output times the dropout mask of the layer's input (drop_c)
+            auto dyv = [&](int c) { float v = Cs[rr][c]; if (g.drop_c.on) v *= drop_factor(g.drop_c, row, c); return v; };
+            if (!norm) {
+                for (int c = lane; c < d; c += kWave) dr[c] = (g.lb_relu && !(yr[c] > 0.f)) ? 0.f : dyv(c);
+                continue;
+            }
+            // d <= 128: a lane owns columns lane and lane + 64 -- its y / xhat values are read into registers, then the
+            // same LDS cells receive g and g * xhat for the partial blocks
+            float gv[2], hv[2];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = lane + e * kWave;
+                gv[e] = 0.f; hv[e] = 0.f;
+                if (c < d) {
+                    const float gg = (g.lb_relu && !(yr[c] > 0.f)) ? 0.f : dyv(c);
+                    const float h = Hs[rr][c];
+                    gv[e] = gg; hv[e] = h;
+                    const float t = gg * g.lb_scale[c];
+                    s1 += t;
+                    s2 += t * h;
+                }
+            }
+            const float m1 = wsum(s1) / (float)d, m2 = wsum(s2) / (float)d, r = g.lb_rstd[row];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = lane + e * kWave;
+                if (c < d) {
+                    dr[c] = r * (gv[e] * g.lb_scale[c] - m1 - hv[e] * m2);
+                    Gs[rr][c] = 0.f + gv[e];          // (ln_act_bwd_kernel adds the row into a zeroed per-wave column sum)
+                    Hs[rr][c] = 0.f + gv[e] * hv[e];
+                }
+            }
+        }
+        if (!norm) return;
+        __syncthreads();
+        // block b of four rows -> partial[(m0 / 4 + b)][2][d], rows added as (r0 + r1) + (r2 + r3) like the four waves of
+        // an ln_act_bwd_kernel workgroup
+        for (int i = threadIdx.x; i < (kTM / 4) * 2 * d; i += kBlock * KG) {
+            const int b = i / (2 * d), c2 = i % (2 * d);
+            if (m0 + 4 * b >= g.M) continue;
+            float (*T)[kTN + 4] = c2 < d ? Gs : Hs;
+            const int c = c2 < d ? c2 : c2 - d;
+            g.lb_partial[((int64_t)(m0 / 4 + b) * 2) * d + c2] = (T[4 * b][c] + T[4 * b + 1][c]) + (T[4 * b + 2][c] + T[4 * b + 3][c]);
+        }
+        return;
+    }
     for (int rr = kg * (kBlock / kWave) + wave; rr < kTM; rr += KG * (kBlock / kWave)) {
         const int row = m0 + rr;
         if (row >= g.M) break;
@@ -577,11 +658,12 @@ static int split_factor(int M, int N, int K) {
 
 template <bool TA, bool TB, int KG>
 static void launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-    const size_t lds = (size_t)KG * kGroupFloats * sizeof(float);
+    const size_t extra = (size_t)2 * kTM * (kTN + 4) * sizeof(float);          // the LayerNorm-backward epilogue's two tiles
+    const size_t lds = (size_t)KG * kGroupFloats * sizeof(float) + (g.epi == 3 ? extra : 0);
     static bool raised = false;          // > 64 KB of dynamic LDS needs the attribute once per kernel
     if (lds > 64 * 1024 && !raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, KG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)KG * kGroupFloats * sizeof(float) + extra));
         raised = true;
     }
     hipLaunchKernelGGL((gemm_kernel<TA, TB, KG>), grid, dim3(kBlock * KG), lds, st, g);
@@ -830,47 +912,56 @@ int aux_join(void* stream) {
     return SGCN_OK;
 }
 
-static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy,
-                          const float* y, int64_t ldy, const float* xhat, const float* rstd,
-                          const float* scale, int32_t relu, const float* x, int64_t ldx,
-                          const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
-                          float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
-                          float* g_tmp, float* ws, const int32_t* gidx, void* stream, bool overlap) {
-    SGCN_REQUIRE(n >= 0 && N >= 0 && K >= 0, "dense_bwd: negative size");
-    if (n == 0 || N == 0 || K == 0) return SGCN_OK;
-    SGCN_REQUIRE(dy && x && W && dW, "dense_bwd: null operand");
-    hipStream_t st = (hipStream_t)stream;
-    const float* g = dy;
-    int64_t ldg = lddy;
-    int32_t nblk = 0;
-    // ws = [LayerNorm partials | split-K partials]: both live until the combined reduction
-    const int64_t ln_floats = scale ? (sgcn_ln_act_bwd_ws_floats(n, N) + 3) / 4 * 4 : 0;
-    float* ws_gemm = ws ? ws + ln_floats : nullptr;
-    // overlapped: the reduction scratch of the dW side comes from the aux ring (it must survive until the join)
-    float* ws_ln = ws;
-    float* ws_dw = ws_gemm;
-    hipStream_t st_dw = st;
-    if (overlap && dx) {
+struct BwdScratch { float* ws_ln; float* ws_dw; float* ws_gemm; hipStream_t st_dw; };
+
+// where a layer's reduction scratch lives and on which stream its weight-gradient side runs (overlapped: the aux
+// ring and the aux stream -- only when there is an input-gradient GEMM to run beside)
+static int bwd_scratch(const DenseBwdArgs& a, hipStream_t st, bool overlap, BwdScratch& s) {
+    const int64_t ln_floats = a.scale ? (sgcn_ln_act_bwd_ws_floats(a.n, a.N) + 3) / 4 * 4 : 0;
+    s.ws_gemm = a.ws ? a.ws + ln_floats : nullptr;
+    s.ws_ln = a.ws;
+    s.ws_dw = s.ws_gemm;
+    s.st_dw = st;
+    if (overlap && a.dx) {
         AuxCtx& c = aux_ctx();
         const int rc0 = aux_init(c);
         if (rc0 != SGCN_OK) return rc0;
-        const int64_t need = ln_floats + (ws ? (sgcn_gemm_ws_floats(K, N, n) + 3) / 4 * 4 : 0);
+        const int64_t need = ln_floats + (a.ws ? (sgcn_gemm_ws_floats(a.K, a.N, a.n) + 3) / 4 * 4 : 0);
         c.want += need;
         if (c.off + need <= c.cap) {
-            if (ws) { ws_ln = c.ring + c.off; ws_dw = c.ring + c.off + ln_floats; }
+            if (a.ws) { s.ws_ln = c.ring + c.off; s.ws_dw = c.ring + c.off + ln_floats; }
             c.off += need;
-            st_dw = c.st;
+            s.st_dw = c.st;
         }
     }
-    if (scale || relu) {
-        SGCN_REQUIRE(g_tmp && y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
-        SGCN_REQUIRE(!scale || ws, "dense_bwd: LayerNorm backward needs the workspace");
-        const int rc = ln_act_bwd_launch(dy, lddy, y, ldy, xhat, rstd, scale, n, N, relu, g_tmp, N, doffset, dscale,
-                                         ws_ln, /*reduce_params=*/false, &nblk, st);
-        if (rc != SGCN_OK) return rc;
-        g = g_tmp; ldg = N;
+    return SGCN_OK;
+}
+
+// One dense layer's backward.  g_ready: the LayerNorm / ReLU backward of THIS layer has already been done by the
+// layer above (its input-gradient GEMM's epilogue wrote g into g_tmp and the parameter partials into s.ws_ln).
+// lower / ls: run the LayerNorm / ReLU backward of the layer BELOW in this layer's input-gradient GEMM's epilogue.
+static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* stream, bool g_ready,
+                         const DenseBwdArgs* lower, const BwdScratch* ls) {
+    SGCN_REQUIRE(a.n >= 0 && a.N >= 0 && a.K >= 0, "dense_bwd: negative size");
+    if (a.n == 0 || a.N == 0 || a.K == 0) return SGCN_OK;
+    SGCN_REQUIRE(a.dy && a.x && a.W && a.dW, "dense_bwd: null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const float* g = a.dy;
+    int64_t ldg = a.lddy;
+    int32_t nblk = 0;
+    if (a.scale || a.relu) {
+        SGCN_REQUIRE(a.g_tmp && a.y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
+        SGCN_REQUIRE(!a.scale || a.ws, "dense_bwd: LayerNorm backward needs the workspace");
+        if (g_ready) {
+            nblk = a.scale ? (int32_t)((a.n + 3) / 4) : 0;
+        } else {
+            const int rc = ln_act_bwd_launch(a.dy, a.lddy, a.y, a.ldy, a.xhat, a.rstd, a.scale, a.n, a.N, a.relu, a.g_tmp, a.N,
+                                             a.doffset, a.dscale, s.ws_ln, /*reduce_params=*/false, &nblk, st);
+            if (rc != SGCN_OK) return rc;
+        }
+        g = a.g_tmp; ldg = a.N;
     }
-    if (st_dw != st) {                    // fork: the aux stream sees everything the main stream did so far
+    if (s.st_dw != st) {                  // fork: the aux stream sees everything the main stream did so far
         AuxCtx& c = aux_ctx();
         SGCN_HIP_TRY(hipEventRecord(c.fork, st));
         SGCN_HIP_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
@@ -878,25 +969,67 @@ static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int6
     }
     // dW[K x N] += x^T[K x n] . g[n x N]      (x stored [n x K]: trans_a); its split-K reduction and the
     // LayerNorm parameter reduction share one launch
-    GemmArgs a{};
-    a.A = x; a.lda = ldx; a.B = g; a.ldb = ldg; a.C = dW; a.ldc = lddw;
-    a.M = K; a.N = N; a.K = n; a.accumulate = 1; a.epi = 0;
-    a.a_gidx = gidx;                       // x rows gathered on the fly (x = features, gidx = the field)
-    a.drop_a = drop_args(drop);
-    SGCN_REQUIRE(!a.drop_a.on || a.drop_a.width == K, "dense_bwd: dropout width must be K");
+    GemmArgs q{};
+    q.A = a.x; q.lda = a.ldx; q.B = g; q.ldb = ldg; q.C = a.dW; q.ldc = a.lddw;
+    q.M = a.K; q.N = a.N; q.K = a.n; q.accumulate = 1; q.epi = 0;
+    q.a_gidx = a.gidx;                     // x rows gathered on the fly (x = features, gidx = the field)
+    q.drop_a = drop_args(a.drop);
+    SGCN_REQUIRE(!q.drop_a.on || q.drop_a.width == a.K, "dense_bwd: dropout width must be K");
     ReduceJob job{};
-    int rc = launch_gemm(a, 1, 0, ws_dw, st_dw, &job);
+    int rc = launch_gemm(q, 1, 0, s.ws_dw, s.st_dw, &job);
     if (rc != SGCN_OK) return rc;
     if (job.pending || nblk > 0) {
         const int gb = job.pending ? (int)(((int64_t)job.M * job.N + 255) / 256) : 0;
-        const int lb = nblk > 0 ? (2 * N + kLnRedCols - 1) / kLnRedCols : 0;
-        hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, st_dw, job, gb, ws_ln, nblk, N,
-                           doffset, dscale);
+        const int lb = nblk > 0 ? (2 * a.N + kLnRedCols - 1) / kLnRedCols : 0;
+        hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, s.st_dw, job, gb, s.ws_ln, nblk, a.N,
+                           a.doffset, a.dscale);
         SGCN_HIP_TRY(hipGetLastError());
     }
-    if (!dx) return SGCN_OK;
+    if (!a.dx) return SGCN_OK;
     // dx[n x K] = g[n x N] . W^T              (W stored [K x N]: trans_b)
-    return sgcn_gemm_f32(0, 1, n, K, N, g, ldg, W, ldw, dx, lddx, 0, ws_gemm, nullptr, drop, stream);
+    if (!lower) return sgcn_gemm_f32(0, 1, a.n, a.K, a.N, g, ldg, a.W, a.ldw, a.dx, a.lddx, 0, s.ws_gemm, nullptr, a.drop, stream);
+    // ... with the LayerNorm / ReLU backward of the layer below in the epilogue: the rows of dx never leave the chip
+    GemmArgs e{};
+    e.A = g; e.lda = ldg; e.B = a.W; e.ldb = a.ldw; e.C = a.dx; e.ldc = a.lddx;
+    e.M = a.n; e.N = a.K; e.K = a.N; e.epi = 3;
+    e.drop_c = drop_args(a.drop);
+    SGCN_REQUIRE(!e.drop_c.on || e.drop_c.width == a.K, "dense_bwd: dropout width must be K");
+    e.lb_y = lower->y; e.lb_ldy = lower->ldy; e.lb_xhat = lower->xhat; e.lb_rstd = lower->rstd; e.lb_scale = lower->scale;
+    e.lb_relu = lower->relu; e.lb_out = lower->g_tmp; e.lb_ldo = lower->N; e.lb_partial = ls->ws_ln;
+    return launch_gemm(e, 0, 1, nullptr, st);             // no split-K: the epilogue needs whole rows
+}
+
+static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy,
+                          const float* y, int64_t ldy, const float* xhat, const float* rstd,
+                          const float* scale, int32_t relu, const float* x, int64_t ldx,
+                          const float* W, int64_t ldw, float* dW, int64_t lddw, float* doffset,
+                          float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop,
+                          float* g_tmp, float* ws, const int32_t* gidx, void* stream, bool overlap) {
+    const DenseBwdArgs a{n, N, K, dy, lddy, y, ldy, xhat, rstd, scale, relu, x, ldx, W, ldw, dW, lddw, doffset, dscale,
+                         dx, lddx, drop, g_tmp, ws, gidx};
+    if (n == 0 || N == 0 || K == 0) return n >= 0 && N >= 0 && K >= 0 ? SGCN_OK : fail(SGCN_ERR_INVALID, "dense_bwd: negative size");
+    BwdScratch s{};
+    const int rc = bwd_scratch(a, (hipStream_t)stream, overlap, s);
+    if (rc != SGCN_OK) return rc;
+    return dense_bwd_run(a, s, stream, false, nullptr, nullptr);
+}
+
+// Two consecutive layers' backward, upper first, where the upper layer's dx IS the lower layer's dy (same buffer, same
+// rows, width <= 128): the lower layer's LayerNorm / ReLU backward runs in the epilogue of the upper layer's
+// input-gradient GEMM -- one kernel less on the step's chain, bit-identical to the two separate calls.
+int dense_bwd_pair(const DenseBwdArgs& U, const DenseBwdArgs& L, void* stream, bool overlap) {
+    SGCN_REQUIRE(U.dx && U.dx == L.dy && U.lddx == L.lddy && U.n == L.n && U.K == L.N && L.N <= kTN && (L.scale || L.relu) &&
+                 L.g_tmp && L.y && U.n > 0 && U.N > 0 && U.K > 0 && L.K > 0,
+                 "dense_bwd_pair: the upper layer's dx must be the lower layer's dy (<= 128 wide, with LayerNorm or ReLU)");
+    BwdScratch su{}, sl{};
+    int rc = bwd_scratch(U, (hipStream_t)stream, overlap, su);
+    if (rc != SGCN_OK) return rc;
+    rc = bwd_scratch(L, (hipStream_t)stream, overlap, sl);
+    if (rc != SGCN_OK) return rc;
+    SGCN_REQUIRE(!L.scale || sl.ws_ln, "dense_bwd_pair: LayerNorm backward needs the workspace");
+    rc = dense_bwd_run(U, su, stream, false, &L, &sl);
+    if (rc != SGCN_OK) return rc;
+    return dense_bwd_run(L, sl, stream, true, nullptr, nullptr);
 }
 
 int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy, const float* y, int64_t ldy,

@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "sgcn_host.h"
+#include "sgcn_bwd.h"
 #include "../../include/sgcn.h"
 
 namespace sgcn {
@@ -194,6 +195,57 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
             rc = sgcn_dense_fwd_f32(M, N, K, X, ldx, X2, ldx2, split, W, ldw, off, sc, eps, relu, Y, ldy, xhat, rstd, d,
                                     need ? ws : nullptr, g1, g2, stream);
+            break;
+        }
+        case SGCN_OP_DENSE_BWD_PAIR: {
+            // this op and the next one (the DENSE_BWD of the layer below, whose dy is this op's dx) as one sequence
+            if (k + 1 >= nops || ops[k + 1].op != SGCN_OP_DENSE_BWD)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d (DENSE_BWD_PAIR) is not followed by a DENSE_BWD", k);
+            const sgcn_step_op_t& op2 = ops[k + 1];
+            if (op2.nargs < 0 || op2.nargs > SGCN_STEP_MAX_ARGS)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d has %d arguments", k + 1, op2.nargs);
+            Args b;
+            b.n = op2.nargs; b.pos = 0;
+            for (int j = 0; j < op2.nargs; j++) {
+                const int32_t s = op2.slot[j];
+                if (s >= nslots) return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d reads slot %d of %d", k + 1, s, nslots);
+                b.v[j] = (s < 0 ? 0 : op2.mul[j] * slots[s]) + op2.add[j];
+            }
+            sgcn_dropout_t dr2;
+            int64_t cap[2] = {0, 0};
+            auto decode = [](Args& q, sgcn_dropout_t* d, sgcn::DenseBwdArgs& w, int64_t* ws_cap) {
+                w.n = q.i(); w.N = q.i(); w.K = q.i();
+                w.dy = q.p<const float>(); w.lddy = q.next();
+                w.y = q.p<const float>(); w.ldy = q.next();
+                w.xhat = q.p<const float>(); w.rstd = q.p<const float>();
+                w.scale = q.p<const float>(); w.relu = q.i();
+                w.x = q.p<const float>(); w.ldx = q.next();
+                w.W = q.p<const float>(); w.ldw = q.next();
+                w.dW = q.p<float>(); w.lddw = q.next();
+                w.doffset = q.p<float>(); w.dscale = q.p<float>();
+                w.dx = q.p<float>(); w.lddx = q.next();
+                w.drop = q.drop(d);
+                w.g_tmp = q.p<float>();
+                w.ws = q.p<float>(); *ws_cap = q.next();
+                w.gidx = q.p<const int32_t>();
+            };
+            sgcn::DenseBwdArgs U{}, Lw{};
+            decode(a, &dr, U, &cap[0]);
+            decode(b, &dr2, Lw, &cap[1]);
+            const sgcn::DenseBwdArgs* both[2] = {&U, &Lw};
+            for (int q = 0; q < 2; q++) {
+                const sgcn::DenseBwdArgs& w = *both[q];
+                const int64_t need = (w.xhat ? (sgcn_ln_act_bwd_ws_floats(w.n, w.N) + 3) / 4 * 4 : 0) +
+                                     std::max(sgcn_gemm_ws_floats(w.K, w.N, w.n), sgcn_gemm_ws_floats(w.n, w.K, w.N));
+                if (need > cap[q]) return sgcn::fail(SGCN_ERR_INVALID, "step_run: backward scratch %lld > %lld floats", (long long)need, (long long)cap[q]);
+            }
+            if (memset_on_aux) {            // (the join the plain DENSE_BWD takes before it touches the gradient buffer)
+                rc = sgcn::aux_join(stream);
+                if (rc != SGCN_OK) return rc;
+                memset_on_aux = false;
+            }
+            rc = sgcn::dense_bwd_pair(U, Lw, stream, overlap);
+            k++;
             break;
         }
         case SGCN_OP_DENSE_BWD: {

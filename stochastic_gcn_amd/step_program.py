@@ -29,7 +29,7 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19, DENSE_BWD_PAIR=20)
 MAX_ARGS = 48
 ARENA_LIMIT_BYTES = 2 << 30
 
@@ -545,7 +545,30 @@ class StepProgram(object):
                 n += 1
         return n
 
+    def _pair_dense_bwd(self, lst):
+        """Peephole: a DENSE_BWD whose dx is the dy of the next DENSE_BWD (the layer below, <= 128 wide, with a
+        LayerNorm or ReLU to back-propagate through) becomes DENSE_BWD_PAIR."""
+        B = OP['DENSE_BWD']
+        null = (0, -1, 0)
+        n = 0
+        k = 0
+        while k + 1 < len(lst):
+            (oa, a), (ob, b) = lst[k], lst[k + 1]
+            ok = oa == B and ob == B
+            if ok:
+                a, b = [tuple(int(v) for v in t) for t in a], [tuple(int(v) for v in t) for t in b]
+                ok = (a[19] != null and b[3] == a[19] and b[4] == a[20] and b[0] == a[0] and b[1] == a[2] and a[2][1] < 0
+                      and a[2][2] <= 128 and (b[9] != null or b[10] != null) and b[26] != null and b[5] != null)
+            if ok:
+                lst[k] = (OP['DENSE_BWD_PAIR'], lst[k][1])
+                n += 1
+                k += 2
+            else:
+                k += 1
+        return n
+
     def _finalize(self):
+        self.n_bwd_pairs = self._pair_dense_bwd(self.ops_fb) if FLAGS.fuse_bwd else 0
         self.n_pairs = self._pair_dense_fwd(self.ops_fb) if FLAGS.fuse_dense else 0
         self.n_loss_fused = self._fuse_loss(self.ops_fb) if FLAGS.fuse_loss else 0
         self._key_slots = {li: self._n_meta + i for i, li in enumerate(self._key_layers)}

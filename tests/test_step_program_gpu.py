@@ -11,13 +11,13 @@ import model_cases as mc
 pytestmark = pytest.mark.gpu
 
 
-def _model(case, params, native, fuse=False):
+def _model(case, params, native, fuse=False, epi=False):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.vrgcn import VRGCN
     from stochastic_gcn_amd.plaingcn import PlainGCN
     FLAGS.reset()
     FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
-    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], fuse_dense=fuse)
+    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], fuse_dense=fuse, fuse_loss=epi, fuse_bwd=epi)
     cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
     fl = case['flags']
     m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
@@ -26,11 +26,11 @@ def _model(case, params, native, fuse=False):
     return m
 
 
-def _run(case, native, steps, slot, fuse=False):
+def _run(case, native, steps, slot, fuse=False, epi=False):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.scheduler import StagingSlot
     params = mc.make_oracle_model(case, seed=3).params
-    m = _model(case, {k: v.copy() for k, v in params.items()}, native, fuse)
+    m = _model(case, {k: v.copy() for k, v in params.items()}, native, fuse, epi)
     sch = mc.make_scheduler(case, 1)
     slots = [StagingSlot(pin=True) for _ in range(3)] if slot else None
     losses = []
@@ -49,11 +49,13 @@ SUPPORTED = ['reddit_cvd_pp', 'reddit_cv_pp', 'cvd_pp_L3', 'cv_nopp_L2', 'ns_nop
 
 
 @pytest.mark.parametrize("name", SUPPORTED)
-@pytest.mark.parametrize("slot", [False, True])
-def test_program_is_bit_identical_to_the_eager_path(name, slot):
+@pytest.mark.parametrize("slot,epi", [(False, False), (True, False), (True, True)])
+def test_program_is_bit_identical_to_the_eager_path(name, slot, epi):
+    """epi: with --fuse_loss --fuse_bwd (the loss and the lower layer's LayerNorm backward in GEMM epilogues: same
+    arithmetic, same summation blocks) the program is STILL bit-identical to the eager path"""
     case = mc.build_case(name)
     a, la = _run(case, False, 5, slot)
-    b, lb = _run(case, True, 5, slot)
+    b, lb = _run(case, True, 5, slot, epi=epi)
     progs = getattr(b, '_programs', {})
     assert progs and all(p is not None for p in progs.values()), getattr(b, '_program_note', 'no program was compiled')
     assert not getattr(a, '_programs', {})
@@ -65,7 +67,9 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot):
     assert a.dropout_step == b.dropout_step == 5 and a.adam_t == b.adam_t == 5
     assert a.amt_data == b.amt_data and np.array_equal(a.field_sizes, b.field_sizes)      # the epoch counters too
     prog = next(iter(progs.values()))
-    assert prog.n_loss_fused == 1            # the loss runs in the last GEMM's epilogue -- and nothing changed, bit for bit
+    assert prog.n_loss_fused == (1 if epi else 0)
+    if name.startswith('reddit_'):           # LayerNorm backwards in the epilogue of the GEMM above (Dense4 -> Dense3, ADD2 -> ADD1)
+        assert prog.n_bwd_pairs == (2 if epi else 0), prog.n_bwd_pairs
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
 
 
