@@ -645,13 +645,13 @@ using namespace sgcn;
 
 // Split-K factor: a weight-gradient GEMM (dW = X^T g) has a tiny output (128 x 128: FOUR tiles)
 // and a long K (the ~1,000 rows of the minibatch), so the K range is cut across blockIdx.z until
-// the grid has ~256 workgroups, every slice keeping at least five K-steps (so the K = 128 and K = 256 GEMMs
-// of the step are never split: the reduction is a second launch on the step's chain and must buy more than it
-// costs -- measured on the step's compute queue: 17 -> 16 kernels, -7 us of kernel time with 5 instead of 3).
+// the grid has ~256 workgroups, every slice keeping at least three K-steps (so the K = 128 GEMMs of the step
+// are never split: the reduction is a second launch and must buy more than it costs; knob gemm_min_steps --
+// measured on the step's compute queue, one box: 3 -> 18 kernels, 150 us of kernel time; 5 -> 17 kernels, 154 us).
 static int split_factor(int M, int N, int K) {
     const int tiles = ((M + kTM - 1) / kTM) * ((N + kTN - 1) / kTN);
     int s = 256 / std::max(tiles, 1);
-    const int min_steps = tune_get("gemm_min_steps") > 0 ? tune_get("gemm_min_steps") : 5;
+    const int min_steps = tune_get("gemm_min_steps") > 0 ? tune_get("gemm_min_steps") : 3;
     s = std::min(s, K / (min_steps * kTK));
     return std::max(s, 1);
 }
