@@ -97,6 +97,39 @@ def test_sharded_spmm_blocks_tile_the_full_product(dev=None):
     assert onp.rel_err(torch.cat(dbs).cpu().numpy(), want_db.cpu().numpy()) <= TOL
 
 
+def test_sharded_spmm_rmat_eight_blocks_d256():
+    """BASELINE config 5 in miniature: an R-MAT graph (2^18 vertices, 5 M edges, the generator's skewed
+    rows and columns), d = 256, eight nnz-balanced row blocks with the operand resident -- each block built
+    with the lane-group count ShardedSpMM picks for the width and the block's density (two groups per wavefront at
+    d = 256, one for the block of the heaviest rows); the
+    blocks tile the unsharded product of the row-gather kernel, forward and backward."""
+    import types
+    from stochastic_gcn_amd import ops, synthetic
+    from stochastic_gcn_amd.parallel import ShardedSpMM
+    from oracle import oracle_np as onp
+    dev = torch.device("cuda:0")
+    n = 1 << 18
+    adj = synthetic.rmat_like(n, 5_000_000, seed=2)
+    d = 256
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    B = torch.randn((n, d), device=dev, generator=g)
+    dC = torch.randn((n, d), device=dev, generator=g)
+    whole = ops.DeviceCSR.from_scipy(adj, dev, with_transpose=True)
+    want_c, want_db = ops.spmm(whole, B), ops.spmm(whole.transpose, dC)
+    rows, cs, dbs, groups = 0, [], [], set()
+    for r in range(8):
+        sh = ShardedSpMM(types.SimpleNamespace(rank=r, world=8, active=False), adj, dev, d=d)
+        assert sh.lo == rows
+        rows = sh.hi
+        groups.add(sh.A.G)
+        cs.append(sh.forward(B))
+        dbs.append(sh.backward(dC))
+    # the block of the heaviest rows is dense enough (average degree > 300) to keep one group; the others take two
+    assert rows == n and 2 in groups and groups <= {1, 2}
+    assert onp.rel_err(torch.cat(cs).cpu().numpy(), want_c.cpu().numpy()) <= TOL
+    assert onp.rel_err(torch.cat(dbs).cpu().numpy(), want_db.cpu().numpy()) <= TOL
+
+
 def _train_worker(rank, world, port, native, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGCN_DIST_BACKEND="gloo")
