@@ -136,7 +136,8 @@ def make_graph(args, rank):
         return data[0], data[2], "S-Reddit-114M full-graph CSR x dense (N=232965, avg degree ~490)", None
     elif args.workload == "rmat-10m":       # BASELINE config 5 (SURVEY.md 8d S-RMAT); minutes of host time
         n = 10_000_000
-        return n, synthetic.rmat_like(n, 200_000_000, seed=1), "S-RMAT 10 M vertices, 200 M edges", None
+        return n, synthetic.cached_graph("rmat_10m_200m_seed1", lambda: synthetic.rmat_like(n, 200_000_000, seed=1)), \
+            "S-RMAT 10 M vertices, 200 M edges", None
     else:
         n = 1 << 20
         return n, synthetic.rmat_like(n, 20 * n, seed=1 + rank), "S-RMAT 2^20 vertices, 20 M edges", None

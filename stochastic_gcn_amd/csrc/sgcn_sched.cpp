@@ -19,7 +19,9 @@
 #include "sgcn_host.h"
 #include "../../include/sgcn.h"
 
-#include <immintrin.h>
+#if defined(__x86_64__)
+#include <immintrin.h>          // the AVX-512 placement loop; every other host takes the scalar loop (same numbering)
+#endif
 #include <pthread.h>
 #include <sched.h>
 
@@ -271,6 +273,7 @@ private:
         return s - fbase_;
     }
 
+#if defined(__x86_64__)
     // fplace() over a whole neighbour list, 16 entries per step (AVX-512: gather the table entries, give the
     // unseen vertices consecutive positions in list order with an expand, scatter the new stamps, append the
     // new vertices with a compress-store).  Same first-seen numbering as the scalar loop: the entries of a
@@ -311,6 +314,11 @@ private:
         }
         ffield_.resize((size_t)next);
     }
+#else
+    void fplace_row_avx512(const int32_t* cols, int32_t deg, int32_t* ft) {          // never taken: avx512_ is false
+        for (int32_t k = 0; k < deg; k++) ft[k] = fplace(cols[k]);
+    }
+#endif
 
     // Uniform sampling w/o replacement, optional control-variate extras (scheduler.cpp:125-180)
     int expand_uniform(int32_t degree, size_t n_out) {
@@ -460,7 +468,11 @@ private:
     std::vector<int32_t> ptr_;
     std::vector<int32_t> slot_, fslot_;
     int32_t fbase_ = 0;                    // stamp base of fslot_: an entry >= fbase_ is a position in this hop's ffield_
+#if defined(__x86_64__)
     const bool avx512_ = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && !getenv("SGCN_NO_AVX512");
+#else
+    const bool avx512_ = false;
+#endif
     std::vector<float> importance_;
     std::vector<int32_t> field_, next_, ffield_;
     std::vector<float> scales_;

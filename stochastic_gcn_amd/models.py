@@ -583,7 +583,13 @@ class GCN(Model):
         supported layer stack, and a minibatch that fits the program's buffers."""
         if not (FLAGS.native_step and self.is_training and isinstance(feed_dict, PackedBatch)):
             return None
-        key = round(float(dropout), 9)
+        # a program bakes in raw addresses (weights, gradients, Adam moments, history, features) and whether the
+        # history update is local: all of that is part of its identity, so a tensor re-allocated or a hook
+        # attached after the first step builds a NEW program instead of leaving a stale one in use
+        key = (round(float(dropout), 9), self.history_hook is None, self.theta.data_ptr(), self.grad.data_ptr(),
+               self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+               self.features_dev.data_ptr() if isinstance(self.features_dev, torch.Tensor) else 0,
+               tuple(h.data_ptr() for hs in self.history for h in hs))
         progs = self.__dict__.setdefault('_programs', {})
         if key not in progs:
             from .step_program import StepProgram, Unsupported
@@ -655,6 +661,12 @@ class GCN(Model):
         return [None, loss, acc]
 
     def run_one_step(self, sess, feed_dict, sync=True):
+        """One step (gcn/vrgcn.py:72-84): [_, loss, acc] in training, [loss, acc, pred] in evaluation.
+
+        ``sync=False`` leaves loss / acc on the device.  On the step-program path they are VIEWS of the
+        program's statistics slot, which the next step overwrites: read (or ``.clone()``) them before the
+        next ``run_one_step`` -- the Trainer reads the last step's only (tests/test_step_program_gpu.py
+        asserts the aliasing).  The eager path returns fresh tensors."""
         if self.is_training and isinstance(feed_dict, PackedBatch):
             prog = self._program(feed_dict, float(getattr(feed_dict, 'dropout', 0.0) or 0.0))
             if prog is not None:

@@ -569,11 +569,21 @@ class ColumnSweepCSR(object):
                     fix=t(self.fix) if self.fix is not None else np.zeros((0, 3), np.int32),
                     pace=np.array([[d, p] for d, p in sorted(self.pace.items())], np.int64).reshape(-1, 2))
         import os
+        import tempfile
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        tmp = path + ".tmp.npz"
-        with open(tmp, "wb") as f:
-            np.savez(f, **blob)
-        os.replace(tmp, path)
+        # every rank of a data-parallel job may get here at the same time: each writes its OWN temporary
+        # file (same directory, so the rename stays atomic) and the last complete one wins
+        fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=os.path.dirname(path) or ".")
+        try:
+            with os.fdopen(fd, "wb") as f:
+                np.savez(f, **blob)
+            os.replace(tmp, path)
+        except BaseException:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
 
     @classmethod
     def load(cls, path, device, key, g=None):
@@ -582,6 +592,13 @@ class ColumnSweepCSR(object):
         import os
         if not os.path.exists(path):
             return None
+        try:
+            return cls._load(path, device, key, g)
+        except Exception:            # truncated / corrupt / foreign file: a cache miss, never a crash at startup
+            return None
+
+    @classmethod
+    def _load(cls, path, device, key, g):
         z = np.load(path)
         if str(z["key"]) != key:
             return None
@@ -612,7 +629,8 @@ class ColumnSweepCSR(object):
         plan of this very matrix, otherwise built (and written to ``path``).  Returns (plan, came_from_cache)."""
         if path is None:
             return cls(a, device, G=G), False
-        key = cls.matrix_key(a)
+        # the identity of the matrix AND of the build parameters the plan depends on (tiles per launch round)
+        key = "%s:r%d:T0:a2048" % (cls.matrix_key(a), int(_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))   # cached() builds with the default T / align
         hit = cls.load(path, device, key, g=G)
         if hit is not None:
             return hit, True

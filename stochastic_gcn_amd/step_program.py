@@ -31,6 +31,7 @@ OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCAT
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
           AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19, DENSE_BWD_PAIR=20)
 MAX_ARGS = 48
+GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
 
 
@@ -110,7 +111,7 @@ class StepProgram(object):
     def __init__(self, model, dropout):
         self.model = m = model
         self.dropout = float(dropout)
-        if m.sparse_input or m.multitask and False:
+        if m.sparse_input:
             raise Unsupported("sparse input features")
         if not isinstance(m.features_dev, torch.Tensor):
             raise Unsupported("features are not a dense device tensor")
@@ -129,15 +130,21 @@ class StepProgram(object):
         self._pb = PackedBatch(self.L, self.cv, np.zeros(int(lib.sgcn_sched_packed_meta_len(self.L)), np.int64),
                                None, None, 0, 0, None)          # only for its offsets
         self.plan_ws_floats = 8 << 20          # partial sums of split rows (checked per step)
-        self.gemm_ws_floats = 4 << 20
         self.ws_plan = torch.empty(self.plan_ws_floats, dtype=torch.float32, device=self.dev)
-        self.ws_gemm = torch.empty(self.gemm_ws_floats, dtype=torch.float32, device=self.dev)
-        # pass 1 (addresses relative to 0) sizes the arena and numbers the slots; pass 2 emits the program
+        # pass 1 (addresses relative to 0) sizes the arena AND the dense ops' scratch (split-K partial tiles,
+        # LayerNorm-backward partial sums: evaluated at every op's row CAPACITY, so a batch that fits() can never
+        # fail inside sgcn_step_run for want of scratch) and numbers the slots; pass 2 emits the program
+        self.gemm_ws_floats, self._ws_gemm_ptr, self._ws_need = 0, 0, 0
         self._arena_base, self._n_meta, self._key_layers = 0, 0, []
         self._reset()
         self._build()
         if self._arena_off * 4 > ARENA_LIMIT_BYTES:
             raise Unsupported("activation arena of %.1f GB" % (self._arena_off * 4 / 2 ** 30))
+        if self._ws_need * 4 > ARENA_LIMIT_BYTES:
+            raise Unsupported("dense-layer scratch of %.1f GB" % (self._ws_need * 4 / 2 ** 30))
+        self.gemm_ws_floats = max(self._ws_need, 4 << 20)
+        self.ws_gemm = torch.empty(self.gemm_ws_floats, dtype=torch.float32, device=self.dev)
+        self._ws_gemm_ptr = self.ws_gemm.data_ptr()
         self.arena = torch.empty(max(self._arena_off, 64), dtype=torch.float32, device=self.dev)
         self._arena_base, self._n_meta, self._key_layers = self.arena.data_ptr(), len(self._fill), sorted(self._keys_seen)
         self._reset()
@@ -263,6 +270,7 @@ class StepProgram(object):
         M = r1 if x2 is None else r1 + r2
         if M.cap * Kd * N >= ops.GEMM_LIBRARY_THRESHOLD:
             raise Unsupported("library-sized GEMM")
+        self._ws_need = max(self._ws_need, GEMM_WS_BOUND)
         y = self._alloc(M, N)
         norm = off is not None
         xhat = self._alloc(M, N) if norm else None
@@ -270,7 +278,7 @@ class StepProgram(object):
         self._emit('DENSE_FWD', [M.op(), K(N), K(Kd), self._p(x), K(x.ld), self._p(x2), K(x2.ld if x2 is not None else 0),
                                  r1.op(), self._p(W), K(W.ld), self._p(off), self._p(sc), K(_fbits(1e-9)), K(int(bool(relu))),
                                  self._p(y), K(N), self._p(xhat), self._p(rstd)]
-                   + self._drop_args(site, r1.op(), Kd) + [K(self.ws_gemm.data_ptr()), K(self.gemm_ws_floats), g1, g2])
+                   + self._drop_args(site, r1.op(), Kd) + [K(self._ws_gemm_ptr), K(self.gemm_ws_floats), g1, g2])
         return y, ((xhat, rstd) if norm else None)
 
     def _dense_bwd(self, dy, y, ctx, sc, relu, x, W, dW, doff, dsc, need_dx, site):
@@ -283,13 +291,17 @@ class StepProgram(object):
         if site is None and gidx == NULL and n.cap * N * Kd >= ops.GEMM_LIBRARY_THRESHOLD:
             raise Unsupported("library-sized GEMM")
         pre = norm or bool(relu)
+        # LayerNorm-backward partials grow with the rows (monotonic: evaluated at the capacity); the split-K scratch
+        # of either GEMM is bounded whatever the batch
+        self._ws_need = max(self._ws_need, ((int(lib.sgcn_ln_act_bwd_ws_floats(n.cap, N)) + 3) // 4 * 4 if norm else 0)
+                            + GEMM_WS_BOUND)
         g_tmp = self._alloc(n, N) if pre else None
         dx = self._alloc(n, Kd) if need_dx else None
         self._emit('DENSE_BWD', [n.op(), K(N), K(Kd), self._p(dy), K(dy.ld), self._p(y) if pre else NULL, K(y.ld if pre else 0),
                                  self._p(ctx[0]) if norm else NULL, self._p(ctx[1]) if norm else NULL,
                                  self._p(sc) if norm else NULL, K(int(bool(relu))), self._p(x), K(x.ld), self._p(W), K(W.ld),
                                  self._p(dW), K(dW.ld), self._p(doff), self._p(dsc), self._p(dx), K(Kd)]
-                   + self._drop_args(site, K(-1), Kd) + [self._p(g_tmp), K(self.ws_gemm.data_ptr()), K(self.gemm_ws_floats), gidx])
+                   + self._drop_args(site, K(-1), Kd) + [self._p(g_tmp), K(self._ws_gemm_ptr), K(self.gemm_ws_floats), gidx])
         return dx
 
     def _spmm(self, b, B, out, d, cscale=NULL, add=None, add_rows=NULL):

@@ -10,6 +10,8 @@ value of ``load_data`` has the reference's 10-tuple layout (gcn/utils.py:183,335
 gcn/utils.py:169-170,321-322) are left as ``None`` here: the training driver computes them
 on the GPU with the SpMM kernel (that product is K11 of the hot path).
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -206,17 +208,33 @@ def pubmed_like(normalization='gcn', seed=123, planted=False):
 
 
 def rmat_edges(scale_log2, m, rng, abcd=(0.57, 0.19, 0.19, 0.05)):
-    """R-MAT directed edge list on 2^scale vertices (S-RMAT)."""
+    """R-MAT directed edge list on 2^scale vertices (S-RMAT): per bit level one uniform draw per
+    edge picks the quadrant.  The draws are taken level by level from ``rng`` (that fixes the graph of a seed);
+    the per-edge bit arithmetic runs in place on int32/int64 id arrays, in slices on a few host threads (NumPy
+    releases the interpreter lock), which is what makes the 10 M / 200 M graph a matter of a minute."""
+    from concurrent.futures import ThreadPoolExecutor
     a, b, c, _ = abcd
-    src = np.zeros(m, dtype=np.int64)
-    dst = np.zeros(m, dtype=np.int64)
-    for _bit in range(scale_log2):
-        r = rng.random_sample(m)
-        right = (r >= a) & ((r < a + b) | (r >= a + b + c))     # quadrants b, d
-        down = r >= a + b                                        # quadrants c, d
-        src = (src << 1) | down
-        dst = (dst << 1) | right
-    return src, dst
+    dt = np.int32 if scale_log2 <= 30 else np.int64
+    src = np.zeros(m, dtype=dt)
+    dst = np.zeros(m, dtype=dt)
+    nthr = max(1, min(8, os.cpu_count() or 1, m // (1 << 20) + 1))
+    cuts = [(m * k) // nthr for k in range(nthr + 1)]
+
+    def work(k, r):
+        lo, hi = cuts[k], cuts[k + 1]
+        rr, s_, d_ = r[lo:hi], src[lo:hi], dst[lo:hi]
+        down = rr >= a + b                                       # quadrants c, d
+        right = (rr >= a) & ((rr < a + b) | (rr >= a + b + c))   # quadrants b, d
+        np.left_shift(s_, 1, out=s_)
+        np.bitwise_or(s_, down, out=s_, casting='unsafe')
+        np.left_shift(d_, 1, out=d_)
+        np.bitwise_or(d_, right, out=d_, casting='unsafe')
+
+    with ThreadPoolExecutor(nthr) as pool:
+        for _bit in range(scale_log2):
+            r = rng.random_sample(m)
+            list(pool.map(lambda k: work(k, r), range(nthr)))
+    return src.astype(np.int64, copy=False), dst.astype(np.int64, copy=False)
 
 
 def rmat_like(n, m, seed=1):
@@ -231,6 +249,30 @@ def rmat_like(n, m, seed=1):
     a = sp.coo_matrix((val, (src, dst)), shape=(n, n)).tocsr()   # sums duplicates
     a.sort_indices()
     return _row_normalize(a)
+
+
+def cached_graph(name, build):
+    """``build()`` (a SciPy CSR), kept as raw arrays under ``$TMPDIR/sgcn_graphs/<name>.npz`` so that the big
+    generators (S-RMAT 10 M / 200 M: a minute or two of host time) run once per box, not once per test / bench leg.
+    A file that does not load is rebuilt."""
+    import tempfile
+    d = os.path.join(os.environ.get("TMPDIR") or tempfile.gettempdir(), "sgcn_graphs")
+    path = os.path.join(d, name + ".npz")
+    try:
+        z = np.load(path)
+        return sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(int(x) for x in z["shape"]))
+    except Exception:
+        pass
+    a = build().tocsr()
+    try:
+        os.makedirs(d, exist_ok=True)
+        fd, tmp = tempfile.mkstemp(suffix=".tmp", dir=d)
+        with os.fdopen(fd, "wb") as f:
+            np.savez(f, data=a.data, indices=a.indices, indptr=a.indptr, shape=np.array(a.shape, np.int64))
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return a
 
 
 def load_data(dataset, normalization='gcn', scale=1.0, seed=None):

@@ -128,8 +128,16 @@ def planetoid_case(which):
                 L_sched=1, ph=placeholders(1, cfg['classes']))
 
 
+# BASELINE config 4's model at a size the NumPy oracle still finishes in seconds: the Reddit recipe (two hidden
+# layers with LayerNorm, graphsage concat, CVD + PP, degree 1) on an S-Reddit-shaped graph of 12 k vertices; used by the
+# two-rank tests only (it is not in CASES, whose entries all have golden vectors)
+REDDIT_MID = dict(n=12000, avg=40, f=96, classes=41, sparse=False, model='vr', batch=256,
+                  flags=dict(normalization='graphsage', weight_decay=0.0, dropout=0.2, layer_norm=True, hidden1=64,
+                             num_fc_layers=2, cv=True, cvd=True, degree=1, preprocess=True))
+
+
 def build_case(name, seed=0):
-    c = CASES[name]
+    c = CASES[name] if isinstance(name, str) else name
     fl = mnp.make_flags(**c['flags'])
     rng = np.random.RandomState(seed)
     adj = _graph(c['n'], c['avg'], seed + 1, fl['normalization'])

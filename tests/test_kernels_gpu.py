@@ -400,6 +400,24 @@ def test_two_lane_group_full_size_vs_oracle_rows(dev):
     ref = onp.spmm(sub.indptr, sub.indices, sub.data, B.cpu().numpy())
     assert onp.rel_err(c[torch.from_numpy(rows).to(dev)].cpu().numpy(), ref) <= TOL
     print("G=2 full size: %.3f ms at pace %s" % best)
+    # ... and the BACKWARD product bench.py times beside it: dB = A^T . dC on its own, separately built and separately
+    # autotuned G = 2 plan of the transpose, against the oracle on sampled rows of A^T (heaviest columns of A included)
+    full_t = full_adj.T.tocsr()
+    full_t.sort_indices()
+    AT = ops.ColumnSweepCSR(full_t, dev, G=2)
+    dCfull = torch.zeros((n, 608), device=dev)
+    dCfull[:, :602] = torch.randn((n, 602), device=dev, generator=g)
+    dC = dCfull[:, :602]
+    best_t = AT.autotune(dC)
+    assert "g2p" in AT.variant(602)
+    db = ops.spmm_cs(AT, dC)
+    degt = np.diff(full_t.indptr)
+    rows = np.unique(np.concatenate([np.argsort(degt)[-20:], np.argsort(degt)[:20],
+                                     np.random.RandomState(2).choice(n, 1500, replace=False)]))
+    sub = full_t[rows].tocsr()
+    ref = onp.spmm(sub.indptr, sub.indices, sub.data, dC.cpu().numpy())
+    assert onp.rel_err(db[torch.from_numpy(rows).to(dev)].cpu().numpy(), ref) <= TOL
+    print("G=2 full size, A^T: %.3f ms at pace %s" % best_t)
 
 
 def test_column_sweep_paced_full_size_vs_oracle_rows(dev):

@@ -114,8 +114,11 @@ def test_sharded_spmm_rmat_eight_blocks_d256():
     g = torch.Generator(device=dev); g.manual_seed(1)
     B = torch.randn((n, d), device=dev, generator=g)
     dC = torch.randn((n, d), device=dev, generator=g)
-    whole = ops.DeviceCSR.from_scipy(adj, dev, with_transpose=True)
-    want_c, want_db = ops.spmm(whole, B), ops.spmm(whole.transpose, dC)
+    # the reference product is the CPU ORACLE's (oracle_np.spmm on the whole matrix), not another HIP kernel
+    adj_t = adj.T.tocsr()
+    Bh, dCh = B.cpu().numpy(), dC.cpu().numpy()
+    want_c = onp.spmm(adj.indptr, adj.indices, adj.data, Bh)
+    want_db = onp.spmm(adj_t.indptr, adj_t.indices, adj_t.data, dCh)
     rows, cs, dbs, groups = 0, [], [], set()
     for r in range(8):
         sh = ShardedSpMM(types.SimpleNamespace(rank=r, world=8, active=False), adj, dev, d=d)
@@ -126,8 +129,60 @@ def test_sharded_spmm_rmat_eight_blocks_d256():
         dbs.append(sh.backward(dC))
     # the block of the heaviest rows is dense enough (average degree > 300) to keep one group; the others take two
     assert rows == n and 2 in groups and groups <= {1, 2}
-    assert onp.rel_err(torch.cat(cs).cpu().numpy(), want_c.cpu().numpy()) <= TOL
-    assert onp.rel_err(torch.cat(dbs).cpu().numpy(), want_db.cpu().numpy()) <= TOL
+    assert onp.rel_err(torch.cat(cs).cpu().numpy(), want_c) <= TOL
+    assert onp.rel_err(torch.cat(dbs).cpu().numpy(), want_db) <= TOL
+
+
+def _sampled_rows_vs_oracle(blk, rows, X, got, dev):
+    """max-norm relative error of ``got[rows]`` against the oracle's product of the rows ``rows`` of the CSR block
+    ``blk`` with the device operand X (only the operand rows those nonzeros reference leave the device)."""
+    from oracle import oracle_np as onp
+    sub = blk[rows].tocsr()
+    cols = np.unique(sub.indices)
+    remap = np.searchsorted(cols, sub.indices).astype(np.int32)
+    Xh = X[torch.from_numpy(cols.astype(np.int64)).to(dev)].cpu().numpy()
+    ref = onp.spmm(sub.indptr, remap, sub.data, Xh)
+    return onp.rel_err(got[torch.from_numpy(rows.astype(np.int64)).to(dev)].cpu().numpy(), ref), ref
+
+
+def test_rmat_10m_one_block_of_eight_full_size_vs_oracle():
+    """BASELINE config 5 at its REAL size (SURVEY.md 8d S-RMAT: 10 M vertices, 200 M R-MAT edges, d = 256): one GPU's
+    block of the 8-way nnz-balanced sharding -- the block an 8-GPU job's rank 3 owns, built by the same ShardedSpMM
+    code path (emulated rank 3 of 8), the 10.24 GB dense operand resident -- forward C[lo:hi] = A[lo:hi,:] . B and
+    backward dB[lo:hi] = A^T[lo:hi,:] . dC on the autotuned column sweep, against the CPU oracle on 1,540 sampled rows
+    of the block including its heaviest, plus size-independent properties on ALL rows (A . 1 = row sums, linearity)."""
+    import types
+    from stochastic_gcn_amd import ops, synthetic
+    from stochastic_gcn_amd.parallel import ShardedSpMM
+    dev = torch.device("cuda:0")
+    n, d = 10_000_000, 256
+    adj = synthetic.cached_graph("rmat_10m_200m_seed1", lambda: synthetic.rmat_like(n, 200_000_000, seed=1))
+    assert adj.shape == (n, n) and adj.nnz == 196_949_452
+    sh = ShardedSpMM(types.SimpleNamespace(rank=3, world=8, active=False), adj, dev, d=d)
+    assert abs(sh.local_nnz - adj.nnz / 8) <= 0.02 * adj.nnz / 8 and sh.A.G == 2
+    adj_t = adj.T.tocsr()
+    blk, blk_t = adj[sh.lo:sh.hi].tocsr(), adj_t[sh.lo:sh.hi].tocsr()
+    del adj, adj_t
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    B = torch.empty((n, d), device=dev).uniform_(-1, 1, generator=g)
+    dC = torch.empty((n, d), device=dev).uniform_(-1, 1, generator=g)
+    sh.autotune(B, dC)
+    c, db = sh.forward(B), sh.backward(dC)
+    assert c.shape == (sh.hi - sh.lo, d) and db.shape == (sh.hi - sh.lo, d)
+    rng = np.random.RandomState(11)
+    for name, m, X, got in (("fwd", blk, B, c), ("bwd", blk_t, dC, db)):
+        deg = np.diff(m.indptr)
+        rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.argsort(deg)[:20], rng.choice(m.shape[0], 1500, replace=False)]))
+        e, _ = _sampled_rows_vs_oracle(m, rows, X, got, dev)
+        assert e <= TOL, (name, e)
+        print("S-RMAT 10M block 3/8 %s: %d sampled rows (heaviest %d nnz), rel err %.1e" % (name, rows.shape[0], deg.max(), e))
+    # every row: A . 1 = row sums (fp64 on the host), and linearity  A.(2B + dC) = 2 A.B + A.dC
+    ones = torch.ones((n, 4), device=dev)
+    s1 = sh.forward(ones)[:, 0].cpu().numpy().astype(np.float64)
+    want = np.asarray(blk.astype(np.float64).sum(axis=1)).ravel()
+    assert np.abs(s1 - want).max() <= TOL * max(1.0, np.abs(want).max())
+    lin = sh.forward(2 * B + dC)
+    assert float((lin - (2 * c + sh.forward(dC))).abs().max() / lin.abs().max()) <= TOL
 
 
 def _train_worker(rank, world, port, native, out_dir):
@@ -173,3 +228,107 @@ def test_two_rank_training_program_equals_eager_and_replicas_agree(tmp_path):
     np.testing.assert_array_equal(res[True][0]["theta"], res[False][0]["theta"])
     np.testing.assert_array_equal(res[True][0]["hist"], res[False][0]["hist"])
     assert np.abs(res[True][0]["hist"]).sum() > 0
+
+
+def _oracle_pair_worker(rank, world, port, steps, out_dir):
+    """One rank of BASELINE config 4 in miniature: the HIP training step with the data-parallel hooks (gradient
+    all-reduce, rank-ordered history all-gather; gloo rendezvous, both ranks on cuda:0) next to the 2-rank NumPy
+    oracle of tests/test_parallel_gloo.py:w_train_step, which exchanges ITS gradients and history rows over the
+    same process group on CPU tensors.  Each side keeps its own weights, Adam moments and history throughout."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGCN_DIST_BACKEND="gloo")
+    import model_cases as mc
+    import test_model_gpu as tm
+    from oracle import oracle_np as onp
+    from stochastic_gcn_amd.parallel import DataParallel
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    par = DataParallel(backend="gloo", device=dev)
+    try:
+        case = mc.build_case(mc.REDDIT_MID)
+        fl, c, ph = case['flags'], case['cfg'], case['ph']
+        om = mc.make_oracle_model(case, seed=3)
+        dm = tm._make_device_model(case, {k: v.copy() for k, v in om.params.items()})
+        par.attach(dm)                                    # hooks, per-rank dropout seed, weights from rank 0
+        par.history_cap = c['batch'] * 2
+        names = sorted(om.params)
+        train = par.shard_ids(np.sort(case['train']), c['n']).astype(np.int32)
+        sch = PyScheduler(case['adj'], case['labels'], 1, [1], ph, par.sampler_seed(1), data=train, cv=True)
+        out = dict(n_train=[len(train)], err_act=[], err_grad=[], err_param=[], err_hist=[], loss=[], oloss=[], acc=[], oacc=[])
+        well = {}
+        for step in range(steps):
+            if sch.start >= sch.data.shape[0]:
+                sch.start = 0
+            feed = sch.minibatch(c['batch'])
+            feed[ph['dropout']] = fl['dropout']
+            masks = tm._masks(dm, 1.0 - fl['dropout'])
+            # device: forward, backward, all-reduce(mean) of the flat gradient, Adam, history all-gather + scatter
+            outs = dm.run_one_step(None, feed)
+            d_acts, dg = [tm._np(a) for a in dm.activations[1:]], dm.get_grads()
+            # oracle: the same step, its own collectives on CPU tensors
+            logits, o_acts = om.forward(feed, ph, fl['dropout'], masks)
+            o_loss, o_acc, _, dlogits = om.loss_and_grad(logits, feed[ph['labels']])
+            grads = om.backward(dlogits)
+            flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in names]))
+            par.allreduce_mean_(flat)
+            off = 0
+            for k in names:
+                sz = grads[k].size
+                grads[k] = flat.numpy()[off:off + sz].reshape(grads[k].shape).copy()
+                off += sz
+            om.adam_step(grads)
+            hist = torch.from_numpy(om.history[0])
+            par.sync_history(hist, torch.from_numpy(feed[ph['fields'][0]]), torch.from_numpy(om._new_hist[0]),
+                             lambda h, i, r: onp.scatter_rows(h.numpy(), i.numpy(), r.numpy()))
+            worst = 0.0
+            for da, oa in zip(d_acts, o_acts):
+                for dd, oo in (zip(da, oa) if isinstance(oa, tuple) else [(da, oa)]):
+                    worst = max(worst, onp.rel_err(dd, oo))
+            out['err_act'].append(worst)
+            out['err_grad'].append(max(onp.rel_err(dg[k], grads[k]) for k in names))        # the AVERAGED gradient
+            dp = dm.get_params()
+            e = 0.0
+            for k in names:
+                well[k] = well.get(k, True) & (np.abs(grads[k]) > 1e-6)
+                e = max(e, float(np.abs(dp[k] - om.params[k])[well[k]].max() / np.abs(om.params[k]).max()))
+            out['err_param'].append(e)
+            out['err_hist'].append(onp.rel_err(dm.history[0][0].cpu().numpy(), om.history[0]))
+            out['loss'].append(outs[1]); out['oloss'].append(float(o_loss))
+            out['acc'].append(outs[2]); out['oacc'].append(float(o_acc))
+        torch.cuda.synchronize()
+        out['theta'] = dm.theta.cpu().numpy()
+        out['hist'] = dm.history[0][0].cpu().numpy()
+        out['otheta'] = np.concatenate([om.params[k].ravel() for k in names])
+        out['ohist'] = om.history[0]
+        np.savez(os.path.join(out_dir, "o%d.npz" % rank), **{k: np.asarray(v) for k, v in out.items()})
+    finally:
+        par.shutdown()
+
+
+def test_two_rank_cvd_pp_training_steps_match_the_two_rank_oracle(tmp_path):
+    """BASELINE config 4 (Reddit CVD+PP, vertex-range sharding, gradient all-reduce, H-a history exchange) on the GPU
+    against the ORACLE, not against itself: two ranks x three consecutive steps of the Reddit recipe on a 12 k-vertex
+    S-Reddit-shaped graph, HIP path vs the 2-rank NumPy oracle -- every layer activation, loss, accuracy, the averaged
+    gradient, the Adam-updated weights and the rank-ordered history; the device replicas (and the oracle replicas)
+    stay identical across the ranks."""
+    import torch.multiprocessing as mp
+    steps, port = 3, tg._free_port()
+    mp.spawn(_oracle_pair_worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "o%d.npz" % k)) for k in range(2)]
+    assert r[0]["n_train"][0] + r[1]["n_train"][0] == 256 * 3 and min(r[0]["n_train"][0], r[1]["n_train"][0]) > 256
+    for k in range(2):
+        assert r[k]["err_act"].max() <= TOL, ("activations", k, r[k]["err_act"])
+        assert r[k]["err_grad"].max() <= 1e-4, ("mean gradient", k, r[k]["err_grad"])
+        assert r[k]["err_param"].max() <= 5e-4, ("weights", k, r[k]["err_param"])
+        assert r[k]["err_hist"].max() <= TOL, ("history", k, r[k]["err_hist"])
+        assert np.abs(r[k]["loss"] - r[k]["oloss"]).max() <= 1e-4 * max(1.0, np.abs(r[k]["oloss"]).max())
+        assert np.abs(r[k]["acc"] - r[k]["oacc"]).max() <= 1e-6
+    np.testing.assert_array_equal(r[0]["theta"], r[1]["theta"])          # device replicas in lock-step
+    np.testing.assert_array_equal(r[0]["hist"], r[1]["hist"])
+    np.testing.assert_array_equal(r[0]["otheta"], r[1]["otheta"])        # and the oracle's
+    np.testing.assert_array_equal(r[0]["ohist"], r[1]["ohist"])
+    assert np.abs(r[0]["hist"]).sum() > 0 and not np.array_equal(r[0]["loss"], r[1]["loss"])   # two different shards
+    print("2-rank CVD+PP vs 2-rank oracle, 3 steps: activations %.1e  mean gradient %.1e  weights %.1e  history %.1e"
+          % (max(x["err_act"].max() for x in r), max(x["err_grad"].max() for x in r),
+             max(x["err_param"].max() for x in r), max(x["err_hist"].max() for x in r)))

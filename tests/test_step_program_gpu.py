@@ -127,3 +127,73 @@ def test_minibatch_that_does_not_fit_runs_eagerly():
     pb.dropout = case['flags']['dropout']
     out = b.run_one_step(None, pb, sync=True)             # falls back, still a valid step
     assert np.isfinite(out[1])
+
+
+def test_unsynchronised_results_alias_the_programs_statistics_slot():
+    """run_one_step(sync=False) on the program path hands out VIEWS of the program's statistics slot (documented on
+    run_one_step): the next step overwrites them, so a caller that keeps per-step values clones them."""
+    from stochastic_gcn_amd.flags import FLAGS
+    case = mc.build_case('reddit_cvd_pp')
+    params = mc.make_oracle_model(case, seed=3).params
+    m = _model(case, {k: v.copy() for k, v in params.items()}, True)
+    sch = mc.make_scheduler(case, 1)
+    outs, kept = [], []
+    for _ in range(2):
+        pb = sch.minibatch_packed(case['cfg']['batch'], FLAGS.plan_t, None)
+        pb.dropout = case['flags']['dropout']
+        o = m.run_one_step(None, pb, sync=False)
+        outs.append(o)
+        kept.append(o[1].clone())
+    torch.cuda.synchronize()
+    assert outs[0][1].data_ptr() == outs[1][1].data_ptr()            # same slot ...
+    assert float(outs[0][1]) == float(kept[1]) != float(kept[0])     # ... holding the LAST step's loss
+
+
+def test_program_is_rebuilt_when_what_it_baked_in_changes():
+    """A program bakes in raw addresses and whether the history update is local: a hook attached, or a
+    tensor re-allocated, after the first step must compile a new program instead of running the stale one."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd import ops
+    case = mc.build_case('reddit_cvd_pp')
+    params = mc.make_oracle_model(case, seed=3).params
+    m = _model(case, {k: v.copy() for k, v in params.items()}, True)
+    ref = _model(case, {k: v.copy() for k, v in params.items()}, False)
+    sch, sch2 = mc.make_scheduler(case, 1), mc.make_scheduler(case, 1)
+
+    def step(model, s):
+        pb = s.minibatch_packed(case['cfg']['batch'], FLAGS.plan_t, None)
+        pb.dropout = case['flags']['dropout']
+        return model.run_one_step(None, pb, sync=True)
+    step(m, sch), step(ref, sch2)
+    assert len(m._programs) == 1
+    calls = []
+
+    def hook(hist, idx, rows, scatter):          # what parallel.DataParallel.sync_history does on one rank
+        calls.append(int(rows.shape[0]))
+        scatter(hist, idx, rows)
+    m.history_hook = hook
+    step(m, sch), step(ref, sch2)
+    assert len(m._programs) == 2 and len(calls) == 1          # a second program, whose history update went through the hook
+    m.history[0][0] = m.history[0][0].clone()                  # the history tensor moves
+    step(m, sch), step(ref, sch2)
+    assert len(m._programs) == 3
+    torch.cuda.synchronize()
+    assert torch.equal(m.theta, ref.theta) and torch.equal(m.history[0][0], ref.history[0][0])
+
+
+def test_dense_scratch_is_sized_for_the_row_capacity():
+    """The program's dense-layer scratch covers every op at its ROW CAPACITY (LayerNorm-backward partials grow with
+    the rows; ADVICE r2: a fixed 4M-float buffer failed inside sgcn_step_run for narrow layers on large row caps)."""
+    from stochastic_gcn_amd._ffi import lib
+    from stochastic_gcn_amd.step_program import StepProgram, GEMM_WS_BOUND
+    case = mc.build_case('reddit_cvd_pp')
+    params = mc.make_oracle_model(case, seed=3).params
+    m = _model(case, {k: v.copy() for k, v in params.items()}, True)
+    prog = StepProgram(m, 0.2)
+    h = case['flags']['hidden1']
+    need = (int(lib.sgcn_ln_act_bwd_ws_floats(2 * prog.caps[0], h)) + 3) // 4 * 4 + GEMM_WS_BOUND
+    assert prog._ws_need >= need and prog.gemm_ws_floats >= prog._ws_need
+    for M in (1, 31, 512, 2042, 70000):
+        for N in (16, 41, 128):
+            for K in (24, 128, 1204):
+                assert lib.sgcn_gemm_ws_floats(M, N, K) <= GEMM_WS_BOUND and lib.sgcn_gemm_ws_floats(K, N, M) <= GEMM_WS_BOUND
