@@ -570,6 +570,190 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }
 #undef SGCN_G2_FMA
 
+// Packed form of the pipelined two-group kernel (round 3; the default for G = 2 plans).  profiles/issue_probe.hip says what
+// a step costs on the instruction side of gfx950: a v_fma_f32 occupies its SIMD for 4.4 clocks WHATEVER the execution
+// mask (a half-wave update is not cheaper than a full one), a v_pk_fma_f32 for 5.0 (two columns per lane), a scalar
+// instruction 1.05 clocks of the CU's one scalar unit, a ds_bpermute 6 clocks of the CU's LDS pipeline (three times a
+// ds_read_b64).  The kernel above spends 8 FMAs + 15 scalar instructions + 2 ds_bpermute per step; this one keeps a row's
+// (x, y) and (z, w) in adjacent register pairs and spends 4 packed FMAs + 2 v_readlane, 8 scalar instructions and ONE
+// ds_bpermute.  Same plan, same entry order per accumulator, fused multiply-adds either way: bit-identical products.
+template <int U, bool WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g2k_kernel(CsArgs a) {
+    typedef Vec<4>::type VT;
+    constexpr int kShift = 28;
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    constexpr int kSteps = kWave / 2;                 // steps per chunk of 64 entries
+    constexpr int kBatches = kSteps / U;
+    static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= 32;
+    const int li = lane & 31;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int fbase = a.slab * 128;
+    const int f4 = fbase + li * 4;
+    const bool act = f4 < a.d;
+    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const uint32_t ldb32 = (uint32_t)(a.ldb * 4);
+    const int sel0 = hi ? 4 : 0;                      // ds_bpermute byte address of entry (2 j + bin) is sel0 + 8 j
+
+    // row r of a bin: (x, y) = axy[2 r], axy[2 r + 1] and (z, w) = azw[2 r], azw[2 r + 1] -- adjacent, even-aligned register
+    // pairs, so that ONE v_pk_fma_f32 updates two columns
+    typedef float accv_t __attribute__((ext_vector_type(32)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    accv_t axy = {}, azw = {};
+    const uint64_t lo64 = 0x00000000ffffffffull, hi64 = 0xffffffff00000000ull;
+
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t tnow = t0;
+    // columns per tick in 16.16 fixed point (a launch lasts < 2^16 ticks of 10 ns; K / ticks < 2^15)
+    const uint32_t cpt16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.cols_per_tick * 65536.0f));
+    const uint32_t slack = (uint32_t)a.slack_cols;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+
+    // one chunk of plan entries: lane l holds entry l (even lanes bin 0, odd lanes bin 1 of step l / 2)
+    auto entries = [&](int64_t p, uint32_t& cr, float& v) {
+        cr = 0;
+        v = __int_as_float((int)0x80000000);                       // beyond the tile: pads on column 0
+        if (p < end) {
+            cr = a.colrow[p + lane];
+            v = a.val[p + lane];
+            uint32_t c = cr & kColMask;
+            if (a.cscale && __float_as_int(v) != (int)0x80000000) {
+                v *= a.cscale[c];
+                if (__float_as_int(v) == (int)0x80000000) v = 0.f;
+            }
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; cr = (cr & ~kColMask) | c; }
+        }
+    };
+    // per-chunk scalars: the register offset (2 x local row id) of every entry's accumulator pair, 4 lanes x 8 bits per
+    // word -- s_set_gpr_idx_on / _idx read the low byte of their operand, so an id costs at most one shift -- and the pad mask
+    struct Meta { uint32_t lr[16]; uint32_t pad_lo, pad_hi; };
+    auto meta = [&](uint32_t cr, float v) -> Meta {
+        Meta m;
+        int x = (int)(((cr >> kShift) << 1) << (8 * (lane & 3)));
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2 -> lane 4g+3 holds group g
+#pragma unroll
+        for (int g = 0; g < 16; g++) m.lr[g] = (uint32_t)__builtin_amdgcn_readlane(x, 4 * g + 3);
+        const uint64_t pm = __ballot(__float_as_int(v) == (int)0x80000000);
+        m.pad_lo = (uint32_t)pm; m.pad_hi = (uint32_t)(pm >> 32);
+        return m;
+    };
+    auto pace = [&](uint32_t crs, int j) {
+        if (cpt16 != 0) {
+            const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 2 * j) & kColMask;
+            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
+            for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
+            }
+        }
+    };
+    auto gather = [&](uint32_t crs, int j) -> VT {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 8 * j, (int)crs);   // my bin's column word
+        if constexpr (WIDE) {
+            return *reinterpret_cast<const VT*>(Bb + (uint64_t)(c & kColMask) * ldb32 + off4);
+        } else {                                       // u24 multiply: the row id above bit 24 is ignored by the instruction
+            const uint32_t off = __umul24(c, ldb32) + off4;
+            return *reinterpret_cast<const VT*>(Bb + off);
+        }
+    };
+    // step j of the chunk (compile-time j).  The two values come down by v_readlane into FIXED scalar pairs (the packed
+    // FMA takes a 64-bit scalar operand and, with op_sel_hi:[0,1,1], uses its low word for both columns); a pad's
+    // execution mask is empty (s_bitcmp0 on the chunk's pad mask + ONE s_cselect_b64); the indexing mode is switched on
+    // once per step and re-pointed for the second bin.  6 VALU (2 v_readlane + 4 v_pk_fma_f32) and 8 scalar instructions
+    // per step against 9 + 15 in the kernel above, and one ds_bpermute (the column word) instead of two.
+    auto fma2 = [&](const Meta& m, float vs, auto jc, VT b) {
+        constexpr int j = decltype(jc)::value;
+        const int l0 = (int)(m.lr[j >> 1] >> ((j & 1) * 16));
+        const int l1 = (int)(m.lr[j >> 1] >> ((j & 1) * 16 + 8));
+        const uint32_t pw = j < 16 ? m.pad_lo : m.pad_hi;
+        const f2_t bxy = {b.x, b.y}, bzw = {b.z, b.w};
+        accv_t& rxy = axy;               // (named here: operands that appear only inside a dependent asm statement are not captured)
+        accv_t& rzw = azw;
+        const uint64_t mlo = lo64, mhi = hi64;
+        asm volatile("v_readlane_b32 s20, %[vs], %[e0]\n\t"
+                     "v_readlane_b32 s22, %[vs], %[e1]\n\t"
+                     "s_bitcmp0_b32 %[pw], %[b0]\n\t"
+                     "s_cselect_b64 exec, %[lo], 0\n\t"
+                     "s_set_gpr_idx_on %[l0], 0xc\n\t"
+                     "v_pk_fma_f32 v[64:65], s[20:21], %[bxy], v[64:65] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[96:97], s[20:21], %[bzw], v[96:97] op_sel_hi:[0,1,1]\n\t"
+                     "s_bitcmp0_b32 %[pw], %[b1]\n\t"
+                     "s_cselect_b64 exec, %[hi], 0\n\t"
+                     "s_set_gpr_idx_idx %[l1]\n\t"
+                     "v_pk_fma_f32 v[64:65], s[22:23], %[bxy], v[64:65] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[96:97], s[22:23], %[bzw], v[96:97] op_sel_hi:[0,1,1]\n\t"
+                     "s_set_gpr_idx_off\n\t"
+                     "s_mov_b64 exec, -1"
+                     : "+{v[64:95]}"(rxy), "+{v[96:127]}"(rzw)
+                     : [vs] "v"(vs), [e0] "i"(2 * j), [e1] "i"(2 * j + 1), [pw] "s"(pw), [b0] "i"((2 * j) & 31),
+                       [b1] "i"(((2 * j) & 31) + 1), [lo] "s"(mlo), [hi] "s"(mhi), [l0] "s"(l0), [l1] "s"(l1),
+                       [bxy] "v"(bxy), [bzw] "v"(bzw)
+                     : "s20", "s21", "s22", "s23", "scc");
+    };
+
+    uint32_t ccr, ncr;
+    float cv, nv;
+    entries(start, ccr, cv);
+    entries(start + kWave, ncr, nv);
+    Meta cm = meta(ccr, cv);
+    VT buf[2][U];
+    pace(ccr, 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
+    if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    for (int64_t p0 = start; p0 < end; p0 += kWave) {
+        static_for<kBatches>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // batch k+1 goes in flight (the first batch of the NEXT chunk after this chunk's last) ...
+            if constexpr (k + 1 < kBatches) {
+                pace(ccr, (k + 1) * U);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
+            } else {
+                pace(ncr, 0);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
+            }
+            if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            // ... while batch k is applied
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                fma2(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
+            });
+        });
+        ccr = ncr; cv = nv;
+        cm = meta(ccr, cv);
+        entries(p0 + 2 * kWave, ncr, nv);
+    }
+
+    const int32_t* rows = a.tile_rows + tile * 32 + (hi ? 16 : 0);
+    const int32_t* slots = a.tile_slots + tile * 32 + (hi ? 16 : 0);
+    const int left = a.d - f4;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rows[r];
+        const VT accv = {axy[2 * r], axy[2 * r + 1], azw[2 * r], azw[2 * r + 1]};
+        if (row < 0 || !act) continue;
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc;
+            const float rs = a.rscale ? a.rscale[row] : 1.0f;
+            VT res = accv * rs;
+            if (a.beta != 0.f) {
+                if (left >= 4) res += a.beta * vload<4>(out + f4);
+                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
+            }
+            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
+        }
+    }
+}
+
 // Four lane groups per wavefront (plan->G == 4): lanes 16 g .. 16 g + 15 hold the 16 x float4 accumulators of bin g on a
 // 64-column slab -- 64 rows per wavefront, so the 4,096 resident wavefronts cover 262 k rows: S-Reddit in ONE round of
 // tiles, B streamed through every XCD once per 64-column pass.  Same structure as the two-group kernel above (pipelined
@@ -945,9 +1129,12 @@ CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
         if (tune_get("cs_g2_plain") > 0) {
             v.U = tune_get("cs_unroll") == 4 ? 4 : 8;
             v.name = v.U == 4 ? "sgcn::cs_spmm16g2_kernel<4>" : "sgcn::cs_spmm16g2_kernel<8>";
-        } else {                    // software-pipelined: two buffers of U gathers
+        } else if (tune_get("cs_g2_unpacked") > 0) {   // software-pipelined: two buffers of U gathers
             v.U = 4;
             v.name = "sgcn::cs_spmm16g2p_kernel<4, false>";     // <4, true> when B needs 64-bit row offsets
+        } else {                    // ... with packed FMAs (the default)
+            v.U = 4;
+            v.name = "sgcn::cs_spmm16g2k_kernel<4, false>";
         }
         return v;
     }
@@ -1066,8 +1253,13 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             } else if (plan->G == 2) {
                 const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
                                   tune_get("cs_g2_wide") > 0;
-                if (wide) hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                if (tune_get("cs_g2_unpacked") > 0) {
+                    if (wide) hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                    else hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                } else {
+                    if (wide) hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                    else hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                }
             } else if (pinned) {
                 if (extra) { if (U == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }

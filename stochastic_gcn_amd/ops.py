@@ -548,15 +548,15 @@ class ColumnSweepCSR(object):
 
     @staticmethod
     def choose_g(d, avg_degree=None):
-        """1 or 2 lane groups per wavefront for operands of width d: a G = 2 launch is ~0.79 of a G = 1 launch
-        (measured on S-Reddit: 0.35 vs 0.445 ms) and a plan needs half the rounds of resident tiles, but
+        """1 or 2 lane groups per wavefront for operands of width d: a G = 2 launch is ~0.73 of a G = 1 launch
+        (measured on S-Reddit: 0.323 ms with the packed-FMA kernel vs 0.445 ms) and a plan needs half the rounds of resident tiles, but
         ceil(d / 128) passes over the feature dimension instead of ceil(d / 320).  What two groups buy is fewer
         fabric misses; a graph dense enough to hit the L2 anyway (S-Reddit-114M, average degree 490: 15.1 vs
         14.7 ms) keeps one group."""
         if avg_degree is not None and avg_degree > 300:
             return 1
         dp = (int(d) + 3) // 4 * 4
-        return 2 if -(-dp // 128) * 0.79 <= -(-dp // 320) * 2 else 1
+        return 2 if -(-dp // 128) * 0.73 <= -(-dp // 320) * 2 else 1
 
     def save(self, path, key):
         if self.grouped:

@@ -365,12 +365,12 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G):
     assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
     if pad:
         np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
-    assert ("g%dp" % G) in A.variant(d)
+    assert ("g2k" if G == 2 else "g4p") in A.variant(d)       # G = 2: the packed-FMA kernel is the default
     # the pipelined kernel (default), its 64-bit-offset form and (G = 2) the plain two-group kernel apply every
     # bin's entries in the same order: bit-identical products
     from stochastic_gcn_amd._ffi import lib
     try:
-        for knob in (b"cs_g2_wide", b"cs_g2_plain") if G == 2 else (b"cs_g2_wide",):
+        for knob in (b"cs_g2_wide", b"cs_g2_unpacked", b"cs_g2_plain") if G == 2 else (b"cs_g2_wide",):
             lib.sgcn_tune(knob, 1)
             assert torch.equal(ops.spmm_cs(A, Bd), out)
             o3 = T(c0, dev)
@@ -380,6 +380,7 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G):
     finally:
         lib.sgcn_tune(b"cs_g2_wide", 0)
         lib.sgcn_tune(b"cs_g2_plain", 0)
+        lib.sgcn_tune(b"cs_g2_unpacked", 0)
 
 
 def test_two_lane_group_full_size_vs_oracle_rows(dev):
@@ -409,7 +410,7 @@ def test_two_lane_group_full_size_vs_oracle_rows(dev):
     dCfull[:, :602] = torch.randn((n, 602), device=dev, generator=g)
     dC = dCfull[:, :602]
     best_t = AT.autotune(dC)
-    assert "g2p" in AT.variant(602)
+    assert "g2k" in AT.variant(602)
     db = ops.spmm_cs(AT, dC)
     degt = np.diff(full_t.indptr)
     rows = np.unique(np.concatenate([np.argsort(degt)[-20:], np.argsort(degt)[:20],

@@ -140,7 +140,7 @@ def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monk
     assert len(stats[0]) == 2 and all("cs_spmm" in s["kernel"] for s in stats[0] + stats[1])
     from stochastic_gcn_amd import ops
     assert ops.ColumnSweepCSR.choose_g(feats.shape[1]) == 2                      # f = 32: one 128-column pass, two lane groups
-    assert all("cs_spmm16g2p" in s["kernel"] for s in stats[0] + stats[1])      # ... built, cached and re-loaded as such
+    assert all("cs_spmm16g2k" in s["kernel"] for s in stats[0] + stats[1])      # ... built, cached and re-loaded as such
     assert [s["plan_from_cache"] for s in stats[0]] == [False, False]
     assert [s["plan_from_cache"] for s in stats[1]] == [True, True]          # second run: plans (and paces) from disk
     assert [s["pace"] for s in stats[0]] == [s["pace"] for s in stats[1]]
