@@ -172,12 +172,58 @@ def train_epoch_leg(data, dev, epochs=6):
     le = trn.last_epoch
     best = min(walls[1:]) if len(walls) > 1 else walls[0]
     edges = le['sampled_edges'] + le['full_edges']
+    chain = step_chain_probe(trn)
     # each aggregation edge is used by the forward aggregate; sampled edges again by the backward
     return {"epoch_time_s": best, "epoch_times_s": walls, "steps": le['steps'], "batch_size": 512,
             "ms_per_step": best / le['steps'] * 1e3, "sch_wait_s": le['sch_wait_s'],
             "producer_busy_s": le.get('producer_s'),
+            "gpu_chain_us": chain.get("gpu_chain_us"), "host_launch_us": chain.get("host_launch_us"), "chain_probe": chain,
             "agg_edges_per_epoch": edges, "agg_edges_per_s": edges / best,
             "recipe": "reddit.config + --cv --cvd --degree=1 (CVD+PP), validation excluded"}
+
+
+def step_chain_probe(trn, reps=20):
+    """Host noise separated from the GPU's own step: the compiled step program of the LAST minibatch (its staging
+    buffer is still on the device) replayed `reps` times behind a ~15 ms PLUG (two large library GEMMs on the same
+    stream), so that the host has queued every launch of every replay before the GPU starts on the first -- no
+    sampler, no H2D copy, no Python, and no launching host in the measured interval.  `gpu_chain_us` = device-elapsed
+    time per replay between the plug's end and the last replay's end (HIP events on the step's stream): the step's
+    chain of dependent kernels incl. the GPU's own dispatch gaps, i.e. what the GPU needs per step when it never waits
+    for the host; `host_launch_us` = host time per sgcn_step_run call while queueing (launch calls only, nothing
+    waits).  The epoch's ms_per_step is max(these two, the sampler's ms per batch) plus what the epoch loop adds."""
+    import time
+    import torch
+    m = trn.train_model
+    progs = [p for p in getattr(m, '_programs', {}).values() if p is not None]
+    if not progs or (m.grad_hook is not None) or (m.history_hook is not None):
+        return {"note": "no single-GPU step program to replay"}
+    prog = progs[-1]
+    dev = m.device
+    stream = torch.cuda.current_stream().cuda_stream
+    a = torch.randn((8192, 8192), device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        prog.run('all', stream)
+    torch.mm(a, a, out=b)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(a, a, out=b)
+        torch.mm(b, a, out=b)
+        e0.record()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            prog.run('all', stream)
+        host = time.perf_counter() - t0
+        e1.record()
+        e1.synchronize()
+        dev_s = e0.elapsed_time(e1) * 1e-3
+        if best is None or dev_s < best[0]:
+            best = (dev_s, host)
+    return {"gpu_chain_us": best[0] / reps * 1e6, "host_launch_us": best[1] / reps * 1e6, "replays": reps, "ops_per_step": prog.n_all,
+            "what": "last minibatch's step program replayed behind a GEMM plug: device-elapsed per replay (GPU never waits "
+                    "for the host) and host time per sgcn_step_run while queueing"}
 
 
 def profiled_traffic(kernel_prefix, nnz, d):

@@ -511,9 +511,19 @@ enum {
                                   * one sgcn_dense2_fwd_f32 */
     SGCN_OP_DENSE_FWD_CE = 19,  /* DENSE_FWD arguments of a plain layer; the NEXT op must be the SOFTMAX_CE of its output:
                                  * the loss runs in the GEMM's epilogue (same arithmetic, one launch less) */
-    SGCN_OP_DENSE_BWD_PAIR = 20 /* DENSE_BWD arguments; the NEXT op must be the DENSE_BWD of the layer below, reading this
+    SGCN_OP_DENSE_BWD_PAIR = 20, /* DENSE_BWD arguments; the NEXT op must be the DENSE_BWD of the layer below, reading this
                                  * op's dx as its dy: that layer's LayerNorm / ReLU backward runs in the epilogue of this
                                  * op's input-gradient GEMM (bit-identical, one launch less) */
+    SGCN_OP_DW_FLUSH = 21,      /* no arguments.  A program that contains this op runs in DEFERRED weight-gradient mode: every
+                                 * DENSE_BWD before it only records its dW GEMM (+ split-K and LayerNorm-parameter
+                                 * reductions); this op issues all of them as ONE grouped GEMM launch + ONE reduction launch
+                                 * on `stream` (bit-identical to the layer-by-layer launches, 2 HIP calls instead of 4 per
+                                 * layer) */
+    SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD
+                                 * writes its dW / doffset / dscale instead of adding to them, so the program zeroes nothing
+                                 * (it must write every parameter gradient exactly once per step); and the statistics
+                                 * reduction of SOFTMAX_CE / SIGMOID_CE runs in the launch of an ADAM op later in the SAME run
+                                 * when no L2_PENALTY adds to the loss in between (otherwise at the end of the run) */
 };
 typedef struct {
     int32_t op, nargs;

@@ -247,6 +247,41 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
     }
 }
 
+// Adam with the step's loss / accuracy statistics riding along: workgroups [0, gridDim.x - 1) are adam_kernel, the LAST one
+// is softmax_stats_kernel / sigmoid_stats_kernel (same code, same summation order -> the same bits).  Nothing in a step
+// reads the statistics before the optimizer has run, so they need neither a launch nor a stream of their own.
+__global__ __launch_bounds__(kBlock) void adam_stats_kernel(float* __restrict__ theta, const float* __restrict__ grad,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                            float lr_t, float b1, float b2, float eps,
+                                                            const float* __restrict__ rowstat, int32_t rows, int32_t c,
+                                                            int32_t softmax, float* __restrict__ stats) {
+    const int nb = (int)gridDim.x - 1;
+    if ((int)blockIdx.x < nb) {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)nb * kBlock) {
+            const float g = grad[i];
+            const float mi = b1 * m[i] + (1.f - b1) * g;
+            const float vi = b2 * v[i] + (1.f - b2) * g * g;
+            m[i] = mi; v[i] = vi;
+            theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        }
+        return;
+    }
+    __shared__ float red[2][kBlock];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < rows; i += kBlock) { a += rowstat[i]; b += rowstat[rows + i]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float cnt = softmax ? (float)rows : (float)rows * (float)c;
+        stats[0] = red[0][0]; stats[1] = red[1][0];
+        stats[2] = red[0][0] / cnt; stats[3] = red[1][0] / cnt;
+    }
+}
+
 // out = x * mask / keep with the hash mask of sgcn_dropout_t (unfused form and its own backward)
 __global__ __launch_bounds__(kBlock) void dropout_kernel(const float* __restrict__ x, int64_t ldx,
                                                          int32_t n, int32_t d, DropArgs a,
@@ -320,6 +355,39 @@ int softmax_stats_launch(const float* rowstat, int32_t n, float* stats, void* st
     return SGCN_OK;
 }
 int aux_fork(void* stream, void** aux_stream);          // sgcn_gemm.hip
+
+// The statistics reduction of the step's loss kernel, parked until the optimizer's launch (stats_defer(1) .. the next
+// sgcn::adam_with_stats or stats_flush): {softmax?, rowstat, rows, c, stats}
+namespace {
+struct PendingStats { int on = 0, armed = 0, softmax = 0; const float* rowstat = nullptr; int32_t n = 0, c = 0; float* stats = nullptr; };
+PendingStats& pending_stats() { static PendingStats p; return p; }
+}  // namespace
+void stats_defer(int on) { pending_stats().on = on; }
+// whatever is parked runs now, on `stream` (a program without an optimizer step after its loss; the end of a run)
+int stats_flush(void* stream) {
+    PendingStats& p = pending_stats();
+    if (!p.armed) return SGCN_OK;
+    p.armed = 0;
+    if (p.softmax) hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, p.rowstat, p.n, p.stats);
+    else hipLaunchKernelGGL(sigmoid_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, p.rowstat, p.n, p.c, p.stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                    float eps, void* stream) {
+    PendingStats& p = pending_stats();
+    if (!p.armed || n <= 0) {
+        const int rc = stats_flush(stream);
+        return rc != SGCN_OK ? rc : sgcn_adam_f32(theta, grad, m, v, n, lr_t, beta1, beta2, eps, stream);
+    }
+    p.armed = 0;
+    SGCN_REQUIRE(theta && grad && m && v, "adam: null operand");
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(adam_stats_kernel, dim3(blocks + 1), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m, v, n, lr_t,
+                       beta1, beta2, eps, p.rowstat, p.n, p.c, p.softmax, p.stats);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
 // The loss kernels with the statistics reduction (loss / accuracy sums: nothing in the step depends on them
 // before the optimizer's join) on the auxiliary stream when `overlap`: one kernel less on the step's chain.
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
@@ -333,6 +401,12 @@ int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels,
     else
         hipLaunchKernelGGL(sigmoid_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, logits, ldz, labels, ldl,
                            n, c, dlogits, lddz, pred, ldp, rowstat);
+    if (pending_stats().on) {            // parked for the optimizer's launch
+        PendingStats& p = pending_stats();
+        p.armed = 1; p.softmax = softmax ? 1 : 0; p.rowstat = rowstat; p.n = n; p.c = c; p.stats = stats;
+        SGCN_HIP_TRY(hipGetLastError());
+        return SGCN_OK;
+    }
     hipStream_t ss = st;
     if (overlap) {
         void* side = nullptr;

@@ -133,7 +133,7 @@ __device__ __forceinline__ float drop_factor(const DropArgs& a, int row, int col
 constexpr int kLnRedCols = 32;
 __device__ __forceinline__ void ln_param_reduce_cols32(const float* __restrict__ partial, int nblk, int d,
                                                        float* __restrict__ doffset, float* __restrict__ dscale,
-                                                       int cblock) {
+                                                       int cblock, bool accumulate = true) {
     __shared__ float red[8][kLnRedCols];
     const int lane = threadIdx.x & (kLnRedCols - 1), part = threadIdx.x >> 5;      // 256 threads: 8 x 32
     const int c = cblock * kLnRedCols + lane;
@@ -154,7 +154,8 @@ __device__ __forceinline__ void ln_param_reduce_cols32(const float* __restrict__
         float s = red[0][lane];
 #pragma unroll
         for (int q = 1; q < 8; q++) s += red[q][lane];
-        if (c < d) doffset[c] += s; else dscale[c - d] += s;
+        if (c < d) doffset[c] = accumulate ? doffset[c] + s : s;
+        else dscale[c - d] = accumulate ? dscale[c - d] + s : s;
     }
 }
 

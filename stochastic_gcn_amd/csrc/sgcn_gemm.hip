@@ -73,15 +73,17 @@ __device__ __forceinline__ float wsum(float v) {
 constexpr int kAsFloats = kTM * (kTK + 1), kBsFloats = kTK * (kTN + 4);
 constexpr int kGroupFloats = kAsFloats + kBsFloats;
 
+// (bx, by, bz): the tile (row block, column block) and the K slice -- the workgroup id of a plain launch, decoded from a
+// linear workgroup index by the grouped launch below
 template <bool TA, bool TB, int KG>
-__global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     extern __shared__ float smem[];
     const int kg = threadIdx.x / kBlock;                       // K-group of this thread
     const int tid = threadIdx.x % kBlock, lane = tid & 63, wave = tid >> 6;
     float (*As)[kTK + 1] = reinterpret_cast<float (*)[kTK + 1]>(smem + kg * kGroupFloats);            // [i][kk]
     float (*Bs)[kTN + 4] = reinterpret_cast<float (*)[kTN + 4]>(smem + kg * kGroupFloats + kAsFloats); // [kk][j]
-    const int m0 = blockIdx.x * kTM, n0 = blockIdx.y * kTN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int m0 = bx * kTM, n0 = by * kTN;
+    const int kbeg = bz * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     f16acc acc = {};
     float ra[4], rb[16];
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
     }
     if (g.epi == 0) {
         if (kg != 0) return;
-        float* base = g.ws ? g.ws + (int64_t)blockIdx.z * g.M * g.N : g.C;
+        float* base = g.ws ? g.ws + (int64_t)bz * g.M * g.N : g.C;
         const int64_t ld = g.ws ? g.N : g.ldc;
         const bool add = !g.ws && g.accumulate;
 #pragma unroll
@@ -347,6 +349,33 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
             yr[c] = g.relu ? fmaxf(v, 0.f) : v;
         }
     }
+}
+
+template <bool TA, bool TB, int KG>
+__global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
+    gemm_body<TA, TB, KG>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several independent plain GEMMs (epi == 0) of the same operand layout in ONE launch: workgroups [first[j], first[j + 1])
+// run job j exactly as its own launch would (same tiles, same K slices, same order of additions) -- the weight-gradient
+// GEMMs of a training step, which depend on nothing but their layer's g and are needed only by the optimizer.
+constexpr int kMaxGroup = 6;
+struct GemmGroup {
+    GemmArgs g[kMaxGroup];
+    int32_t first[kMaxGroup + 1];
+    int32_t gx[kMaxGroup], gy[kMaxGroup];
+    int32_t n;
+};
+
+template <bool TA, bool TB, int KG>
+__global__ __launch_bounds__(kBlock * KG) void gemm_group_kernel(GemmGroup G) {
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxGroup; q++) j += (q < G.n && b >= G.first[q]) ? 1 : 0;
+    const int l = b - G.first[j];
+    const int gx = G.gx[j], gy = G.gy[j];
+    gemm_body<TA, TB, KG>(G.g[j], l % gx, (l / gx) % gy, l / (gx * gy));
 }
 
 // ---- two chained dense layers of the same rows in ONE launch -------------------------------------------
@@ -580,7 +609,7 @@ struct ReduceJob {                // a split-K reduction the caller wants to lau
 // dW (workgroups [0, gemm_blocks)) and the LayerNorm parameter-gradient partials (the rest).
 __global__ void dense_bwd_reduce_kernel(ReduceJob j, int32_t gemm_blocks, const float* __restrict__ ln_partial,
                                         int32_t nblk, int32_t d, float* __restrict__ doffset,
-                                        float* __restrict__ dscale) {
+                                        float* __restrict__ dscale, int32_t ln_accumulate) {
     if ((int)blockIdx.x < gemm_blocks) {
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const int64_t mn = (int64_t)j.M * j.N;
@@ -590,7 +619,42 @@ __global__ void dense_bwd_reduce_kernel(ReduceJob j, int32_t gemm_blocks, const 
         float* p = j.C + (i / j.N) * j.ldc + (i % j.N);
         *p = j.accumulate ? *p + s : s;
     } else {
-        ln_param_reduce_cols32(ln_partial, nblk, d, doffset, dscale, (int)blockIdx.x - gemm_blocks);
+        ln_param_reduce_cols32(ln_partial, nblk, d, doffset, dscale, (int)blockIdx.x - gemm_blocks, ln_accumulate != 0);
+    }
+}
+
+// The reductions of SEVERAL dense layers' backward in one launch (the step program's deferred weight-gradient group):
+// workgroups [gfirst[j], gfirst[j + 1]) add job j's split-K partial tiles, workgroups [lfirst[j], lfirst[j + 1]) its
+// LayerNorm parameter partials -- each exactly as that layer's own dense_bwd_reduce_kernel launch would.
+struct ReduceMulti {
+    ReduceJob j[kMaxGroup];
+    const float* ln_partial[kMaxGroup];
+    float* doffset[kMaxGroup];
+    float* dscale[kMaxGroup];
+    int32_t nblk[kMaxGroup], d[kMaxGroup];
+    int32_t gfirst[kMaxGroup + 1], lfirst[kMaxGroup + 1];
+    int32_t n, ln_accumulate;
+};
+
+__global__ void dense_bwd_reduce_multi_kernel(ReduceMulti R) {
+    const int b = (int)blockIdx.x;
+    if (b < R.gfirst[R.n]) {
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < kMaxGroup; t++) q += (t < R.n && b >= R.gfirst[t]) ? 1 : 0;
+        const ReduceJob& j = R.j[q];
+        const int64_t i = (int64_t)(b - R.gfirst[q]) * blockDim.x + threadIdx.x;
+        const int64_t mn = (int64_t)j.M * j.N;
+        if (i >= mn) return;
+        float s = 0.f;
+        for (int z = 0; z < j.S; z++) s += j.ws[(int64_t)z * mn + i];
+        float* p = j.C + (i / j.N) * j.ldc + (i % j.N);
+        *p = j.accumulate ? *p + s : s;
+    } else {
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < kMaxGroup; t++) q += (t < R.n && b >= R.lfirst[t]) ? 1 : 0;
+        ln_param_reduce_cols32(R.ln_partial[q], R.nblk[q], R.d[q], R.doffset[q], R.dscale[q], b - R.lfirst[q], R.ln_accumulate != 0);
     }
 }
 
@@ -676,8 +740,10 @@ static void launch_kg(const GemmArgs& g, dim3 grid, int kgroups, hipStream_t st)
     else launch_one<TA, TB, 1>(g, grid, st);
 }
 
-static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st, ReduceJob* defer = nullptr) {
-    if (defer) defer->pending = 0;
+// what launch_gemm decides before it launches: alignment flags, the K slicing (written into g), grid and K-groups
+struct GemmPlan { dim3 grid; int kgroups, S, epi; };
+
+static GemmPlan prepare_gemm(GemmArgs& g, float* ws) {
     auto al = [](const void* p, int64_t ld) { return p && ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
     g.vec_a = al(g.A, g.lda) && (!g.A2 || al(g.A2, g.lda2));
     g.vec_b = al(g.B, g.ldb);
@@ -686,18 +752,31 @@ static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st, Re
     S = g.K > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
     if (g.K == 0) g.kchunk = kTK;
     g.ws = S > 1 ? ws : nullptr;
-    const int epi = g.epi;
+    GemmPlan p;
+    p.epi = g.epi;
+    p.S = S;
     if (S > 1) g.epi = 0;                 // partial tiles are plain; the epilogue moves to the reduce
-    dim3 grid((unsigned)((g.M + kTM - 1) / kTM), (unsigned)((g.N + kTN - 1) / kTN), (unsigned)S);
+    p.grid = dim3((unsigned)((g.M + kTM - 1) / kTM), (unsigned)((g.N + kTN - 1) / kTN), (unsigned)S);
     // K-groups inside the workgroup: worth it while the grid leaves most CUs idle and the
     // per-workgroup K chain is long
     const int steps = (std::min(g.kchunk, g.K) + kTK - 1) / kTK;
-    const int blocks = (int)(grid.x * grid.y * grid.z);
-    const int kgroups = (blocks <= 128 && steps >= 8) ? 4 : ((blocks <= 256 && steps >= 4) ? 2 : 1);
-    if (!ta && !tb) launch_kg<false, false>(g, grid, kgroups, st);
-    else if (ta && !tb) launch_kg<true, false>(g, grid, kgroups, st);
-    else if (!ta && tb) launch_kg<false, true>(g, grid, kgroups, st);
-    else launch_kg<true, true>(g, grid, kgroups, st);
+    const int blocks = (int)(p.grid.x * p.grid.y * p.grid.z);
+    p.kgroups = (blocks <= 128 && steps >= 8) ? 4 : ((blocks <= 256 && steps >= 4) ? 2 : 1);
+    return p;
+}
+
+static void launch_prepared(const GemmArgs& g, const GemmPlan& p, int ta, int tb, hipStream_t st) {
+    if (!ta && !tb) launch_kg<false, false>(g, p.grid, p.kgroups, st);
+    else if (ta && !tb) launch_kg<true, false>(g, p.grid, p.kgroups, st);
+    else if (!ta && tb) launch_kg<false, true>(g, p.grid, p.kgroups, st);
+    else launch_kg<true, true>(g, p.grid, p.kgroups, st);
+}
+
+static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st, ReduceJob* defer = nullptr) {
+    if (defer) defer->pending = 0;
+    const GemmPlan p = prepare_gemm(g, ws);
+    const int S = p.S, epi = p.epi;
+    launch_prepared(g, p, ta, tb, st);
     if (S > 1 && epi != 0) {
         g.epi = epi;
         const unsigned rb = (unsigned)((g.M + (kBlock / kWave) - 1) / (kBlock / kWave));
@@ -868,6 +947,10 @@ struct AuxCtx {
     bool pending = false;
 };
 AuxCtx& aux_ctx() { static AuxCtx c; return c; }
+int g_dw_recorded = 0;          // weight-gradient jobs recorded for the group launch: their ring regions are live
+int g_grad_store = 0;           // step program in gradient-STORE mode: every parameter gradient is written exactly once per
+                                // step, so the weight-gradient GEMMs and the LayerNorm-parameter reductions store instead of
+                                // adding to a zeroed buffer (the step needs no memset, and no join on it)
 
 int aux_init(AuxCtx& c) {
     if (c.st) return SGCN_OK;
@@ -898,6 +981,7 @@ int aux_join(void* stream) {
         SGCN_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c.join, 0));
         c.pending = false;
     }
+    if (g_dw_recorded > 0) return SGCN_OK;          // recorded jobs still own their regions of the ring
     c.off = 0;
     if (c.want > c.cap) {                 // a call did not fit: grow for the next step (nothing is in flight on
         SGCN_HIP_TRY(hipStreamSynchronize(c.st));          // the aux stream once it is idle)
@@ -912,7 +996,100 @@ int aux_join(void* stream) {
     return SGCN_OK;
 }
 
-struct BwdScratch { float* ws_ln; float* ws_dw; float* ws_gemm; hipStream_t st_dw; };
+struct BwdScratch { float* ws_ln; float* ws_dw; float* ws_gemm; hipStream_t st_dw; bool deferred; };
+
+// ---- the step's weight-gradient GEMMs as ONE launch ------------------------------------------------------
+// A layer's dW = x^T . g (+ its split-K reduction and LayerNorm-parameter reduction) depends on that layer's g only
+// and is read by the optimizer only.  Run layer by layer beside the input-gradient chain (above) it costs the launching
+// host four HIP calls per layer (event record + wait, GEMM, reduce) -- sixteen of the ~45 calls of a Reddit step, on a
+// step whose period is set by the host on a slow box (BENCH_r02: 0.277 ms per step against 0.21 here).  Between
+// dw_group_begin() and dw_group_flush() the layers' weight-gradient jobs are RECORDED instead (operands, K slicing
+// and grids exactly as their own launches would have them; reduction scratch from the aux ring, one region per
+// layer) and the flush issues all of them as one gemm_group_kernel + one dense_bwd_reduce_multi_kernel on the
+// step's stream: two launches, no events, bit-identical gradients.
+namespace {
+struct DwJob { GemmArgs q; GemmPlan p; ReduceJob rj; const float* ws_ln; int32_t nblk, N; float* doffset; float* dscale; };
+struct DwGroupState { DwJob jobs[kMaxGroup]; int n = 0; bool active = false; };
+DwGroupState& dw_state() { static DwGroupState s; return s; }
+}  // namespace
+
+void grad_store_mode(int on) { g_grad_store = on; }
+
+int dw_group_begin() {
+    DwGroupState& d = dw_state();
+    d.n = 0;
+    d.active = true;
+    return SGCN_OK;
+}
+
+template <int KG>
+static void launch_group(const GemmGroup& G, unsigned blocks, hipStream_t st) {
+    const size_t lds = (size_t)KG * kGroupFloats * sizeof(float);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<true, false, KG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemm_group_kernel<true, false, KG>), dim3(blocks), dim3(kBlock * KG), lds, st, G);
+}
+
+void dw_group_abort() {
+    DwGroupState& d = dw_state();
+    d.active = false;
+    d.n = 0;
+    g_dw_recorded = 0;
+}
+
+int dw_group_flush(void* stream) {
+    DwGroupState& d = dw_state();
+    d.active = false;
+    const int n = d.n;
+    d.n = 0;
+    g_dw_recorded = 0;
+    if (n == 0) return SGCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    bool uniform = true;
+    for (int k = 1; k < n; k++) uniform = uniform && d.jobs[k].p.kgroups == d.jobs[0].p.kgroups;
+    if (uniform && n > 1) {
+        GemmGroup G{};
+        G.n = n;
+        int first = 0;
+        for (int k = 0; k < n; k++) {
+            G.g[k] = d.jobs[k].q;
+            G.first[k] = first;
+            G.gx[k] = (int32_t)d.jobs[k].p.grid.x; G.gy[k] = (int32_t)d.jobs[k].p.grid.y;
+            first += (int)(d.jobs[k].p.grid.x * d.jobs[k].p.grid.y * d.jobs[k].p.grid.z);
+        }
+        for (int k = n; k <= kMaxGroup; k++) G.first[k] = first;
+        const int kg = d.jobs[0].p.kgroups;
+        if (kg >= 4) launch_group<4>(G, (unsigned)first, st);
+        else if (kg == 2) launch_group<2>(G, (unsigned)first, st);
+        else launch_group<1>(G, (unsigned)first, st);
+    } else {
+        for (int k = 0; k < n; k++) launch_prepared(d.jobs[k].q, d.jobs[k].p, 1, 0, st);
+    }
+    ReduceMulti R{};
+    R.n = n;
+    R.ln_accumulate = g_grad_store ? 0 : 1;
+    int b = 0;
+    for (int k = 0; k < n; k++) {
+        R.j[k] = d.jobs[k].rj;
+        R.gfirst[k] = b;
+        if (d.jobs[k].rj.pending) b += (int)(((int64_t)d.jobs[k].rj.M * d.jobs[k].rj.N + 255) / 256);
+    }
+    for (int k = n; k <= kMaxGroup; k++) R.gfirst[k] = b;
+    for (int k = 0; k < n; k++) {
+        R.ln_partial[k] = d.jobs[k].ws_ln; R.nblk[k] = d.jobs[k].nblk; R.d[k] = d.jobs[k].N;
+        R.doffset[k] = d.jobs[k].doffset; R.dscale[k] = d.jobs[k].dscale;
+        R.lfirst[k] = b;
+        if (d.jobs[k].nblk > 0) b += (2 * d.jobs[k].N + kLnRedCols - 1) / kLnRedCols;
+    }
+    for (int k = n; k <= kMaxGroup; k++) R.lfirst[k] = b;
+    if (b > 0) hipLaunchKernelGGL(dense_bwd_reduce_multi_kernel, dim3((unsigned)b), dim3(256), 0, st, R);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
 
 // where a layer's reduction scratch lives and on which stream its weight-gradient side runs (overlapped: the aux
 // ring and the aux stream -- only when there is an input-gradient GEMM to run beside)
@@ -922,6 +1099,22 @@ static int bwd_scratch(const DenseBwdArgs& a, hipStream_t st, bool overlap, BwdS
     s.ws_ln = a.ws;
     s.ws_dw = s.ws_gemm;
     s.st_dw = st;
+    s.deferred = false;
+    if (dw_state().active && dw_state().n < kMaxGroup) {
+        // recorded for the group launch: the layer's reduction scratch must outlive this call -- its own region of the
+        // aux ring (a ring that is still too small grows at the end of the step; until then the layer runs at once)
+        AuxCtx& c = aux_ctx();
+        const int rc0 = aux_init(c);
+        if (rc0 != SGCN_OK) return rc0;
+        const int64_t need = ln_floats + (a.ws ? (sgcn_gemm_ws_floats(a.K, a.N, a.n) + 3) / 4 * 4 : 0);
+        c.want += need;
+        if (c.off + need <= c.cap) {
+            if (a.ws) { s.ws_ln = c.ring + c.off; s.ws_dw = c.ring + c.off + ln_floats; }
+            c.off += need;
+            s.deferred = true;
+        }
+        return SGCN_OK;
+    }
     if (overlap && a.dx) {
         AuxCtx& c = aux_ctx();
         const int rc0 = aux_init(c);
@@ -971,18 +1164,29 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
     // LayerNorm parameter reduction share one launch
     GemmArgs q{};
     q.A = a.x; q.lda = a.ldx; q.B = g; q.ldb = ldg; q.C = a.dW; q.ldc = a.lddw;
-    q.M = a.K; q.N = a.N; q.K = a.n; q.accumulate = 1; q.epi = 0;
+    q.M = a.K; q.N = a.N; q.K = a.n; q.accumulate = g_grad_store ? 0 : 1; q.epi = 0;
     q.a_gidx = a.gidx;                     // x rows gathered on the fly (x = features, gidx = the field)
     q.drop_a = drop_args(a.drop);
     SGCN_REQUIRE(!q.drop_a.on || q.drop_a.width == a.K, "dense_bwd: dropout width must be K");
     ReduceJob job{};
-    int rc = launch_gemm(q, 1, 0, s.ws_dw, s.st_dw, &job);
-    if (rc != SGCN_OK) return rc;
-    if (job.pending || nblk > 0) {
+    int rc = SGCN_OK;
+    if (s.deferred) {
+        DwGroupState& dg = dw_state();
+        DwJob& J = dg.jobs[dg.n++];
+        g_dw_recorded = dg.n;
+        J.q = q;
+        J.p = prepare_gemm(J.q, s.ws_dw);
+        J.rj = ReduceJob{J.q.ws, J.p.S, J.q.M, J.q.N, J.q.C, J.q.ldc, J.q.accumulate, J.p.S > 1 ? 1 : 0};
+        J.ws_ln = s.ws_ln; J.nblk = nblk; J.N = a.N; J.doffset = a.doffset; J.dscale = a.dscale;
+    } else {
+        rc = launch_gemm(q, 1, 0, s.ws_dw, s.st_dw, &job);
+        if (rc != SGCN_OK) return rc;
+    }
+    if (!s.deferred && (job.pending || nblk > 0)) {
         const int gb = job.pending ? (int)(((int64_t)job.M * job.N + 255) / 256) : 0;
         const int lb = nblk > 0 ? (2 * a.N + kLnRedCols - 1) / kLnRedCols : 0;
         hipLaunchKernelGGL(dense_bwd_reduce_kernel, dim3((unsigned)(gb + lb)), dim3(256), 0, s.st_dw, job, gb, s.ws_ln, nblk, a.N,
-                           a.doffset, a.dscale);
+                           a.doffset, a.dscale, g_grad_store ? 0 : 1);
         SGCN_HIP_TRY(hipGetLastError());
     }
     if (!a.dx) return SGCN_OK;

@@ -28,6 +28,14 @@ int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64
                          const int32_t* gidx, void* stream);
 int aux_join(void* stream);
 int aux_fork(void* stream, void** aux_stream);
+int dw_group_begin();                    // sgcn_gemm.hip: record the weight-gradient GEMMs of the following DENSE_BWD ops ...
+int dw_group_flush(void* stream);        // ... and issue them as one grouped launch + one reduction launch
+void dw_group_abort();
+void grad_store_mode(int on);            // sgcn_gemm.hip: parameter gradients are stored, not added to a zeroed buffer
+void stats_defer(int on);                // sgcn_dense.hip: the loss kernel's statistics reduction rides in the optimizer's launch
+int stats_flush(void* stream);
+int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                    float eps, void* stream);
 int dense_fwd_ce(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y,
                  int64_t ldy, const sgcn_dropout_t* drop, const float* labels, int64_t ldl, float* dlogits, int64_t lddz,
                  float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap);
@@ -77,6 +85,25 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         return sgcn::fail(SGCN_ERR_INVALID, "step_run: bad argument");
     bool memset_on_aux = false;
     const bool overlap = sgcn_tune_get("step_overlap") != 0;
+    bool grouped = false, store = false, l2 = false;
+    int ce_at = -1, adam_at = -1;
+    for (int32_t k = 0; k < nops; k++) {
+        grouped = grouped || ops[k].op == SGCN_OP_DW_FLUSH;
+        store = store || ops[k].op == SGCN_OP_GRAD_STORE;
+        l2 = l2 || ops[k].op == SGCN_OP_L2_PENALTY;
+        if (ops[k].op == SGCN_OP_SOFTMAX_CE || ops[k].op == SGCN_OP_SIGMOID_CE) ce_at = k;
+        if (ops[k].op == SGCN_OP_ADAM) adam_at = k;
+    }
+    // the loss statistics ride in the optimizer's launch when this very run has one after the loss and nothing (the
+    // weight-decay term) adds to the loss slot in between
+    const bool park_stats = store && ce_at >= 0 && adam_at > ce_at && !l2;
+    if (grouped) sgcn::dw_group_begin();
+    sgcn::grad_store_mode(store ? 1 : 0);
+    sgcn::stats_defer(park_stats ? 1 : 0);
+    struct Guard {                       // an early return leaves no recorded job / mode behind
+        bool on; void* st;
+        ~Guard() { if (on) sgcn::dw_group_abort(); sgcn::grad_store_mode(0); sgcn::stats_defer(0); sgcn::stats_flush(st); }
+    } guard{grouped, stream};
     for (int32_t k = 0; k < nops; k++) {
         const sgcn_step_op_t& op = ops[k];
         if (op.nargs < 0 || op.nargs > SGCN_STEP_MAX_ARGS)
@@ -271,6 +298,11 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
                                             dsc, dx, lddx, d, gtmp, need ? ws : nullptr, gidx, stream);
             break;
         }
+        case SGCN_OP_DW_FLUSH:
+            rc = sgcn::dw_group_flush(stream);
+            break;
+        case SGCN_OP_GRAD_STORE:         // (mode of the whole run: set before the loop)
+            break;
         case SGCN_OP_VR_AGG: {
             const int32_t* arp = a.p<const int32_t>(); const int32_t* ac = a.p<const int32_t>(); const float* av = a.p<const float>();
             const int32_t* frp = a.p<const int32_t>(); const int32_t* fc = a.p<const int32_t>(); const float* fv = a.p<const float>();
@@ -314,7 +346,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             float* th = a.p<float>(); const float* g = a.p<const float>(); float* m = a.p<float>(); float* v = a.p<float>();
             const int64_t n = a.next();
             const float lr = a.f(), b1 = a.f(), b2 = a.f(), eps = a.f();
-            rc = sgcn_adam_f32(th, g, m, v, n, lr, b1, b2, eps, stream);
+            rc = sgcn::adam_with_stats(th, g, m, v, n, lr, b1, b2, eps, stream);
             break;
         }
         case SGCN_OP_SCATTER_ROWS:

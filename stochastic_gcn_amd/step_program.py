@@ -29,7 +29,7 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19, DENSE_BWD_PAIR=20)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19, DENSE_BWD_PAIR=20, DW_FLUSH=21, GRAD_STORE=22)
 MAX_ARGS = 48
 GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
@@ -331,8 +331,17 @@ class StepProgram(object):
         # dense layers: zeroing the gradient buffer, and every control-variate aggregator's history-only sum
         # P . Hbar[ffield] (the dominant gather of the step) -- sgcn_vr_aggregate_pre_f32.
         local_hist = m.history_hook is None
+        # the history scatter: beside the step on the auxiliary stream (one event pair, a barrier on the compute queue), or
+        # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
+        self._hist_last = bool(FLAGS.lean_sync) and local_hist
         if m.is_training:
-            self._emit('AUX_MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
+            if FLAGS.lean_sync:
+                # gradient-STORE mode (include/sgcn.h SGCN_OP_GRAD_STORE): every layer of a supported stack writes each of
+                # its parameter gradients exactly once per step, so nothing is zeroed (no memset, no join on it) and the
+                # loss statistics ride in the optimizer's launch
+                self._emit('GRAD_STORE', [])
+            else:
+                self._emit('AUX_MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
         accP = {}
         for layer in m.layers:
             if isinstance(layer, VRAggregator):
@@ -417,7 +426,7 @@ class StepProgram(object):
                     self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
                                                self._p(h), self._p(mu), K(h.ld), self._p(H), K(H.ld), self._field_ptr(l), sptr,
                                                self._p(out_h), self._p(out_mu), K(width), K(1), K(int(concat)), self._p(accP[l])])
-                    if local_hist:
+                    if local_hist and not self._hist_last:
                         self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                                         K(mu.cols), self._p(mu), K(mu.ld)])
                     self.new_history[l] = mu
@@ -433,7 +442,7 @@ class StepProgram(object):
                     self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
                                                self._p(x), NULL, K(x.ld), self._p(H), K(H.ld), self._field_ptr(l), NULL,
                                                self._p(out_h), NULL, K(width), K(0), K(int(concat)), self._p(accP[l])])
-                    if local_hist:
+                    if local_hist and not self._hist_last:
                         self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                                         K(x.cols), self._p(x), K(x.ld)])
                     self.new_history[l] = x
@@ -500,13 +509,17 @@ class StepProgram(object):
                     else:
                         self._spmm(bt, g.cols_from(d, d), dx, d, cscale=sptr, add=g.cols_from(0, d), add_rows=self.rows[l + 1].op())
                     g = dx
+            if FLAGS.group_dw:
+                # deferred weight-gradient mode (include/sgcn.h SGCN_OP_DW_FLUSH): the DENSE_BWD ops above only recorded their
+                # dW GEMMs; all of them + their reductions run here as two launches
+                self._emit('DW_FLUSH', [])
             if wd and hi > lo:
                 self._emit('L2_PENALTY', [K(m.theta.data_ptr()), K(lo), K(hi), K(_fbits(wd)), K(m.grad.data_ptr()), NULL])
             self._cur = self.ops_opt
             self._emit('ADAM', [K(m.theta.data_ptr()), K(m.grad.data_ptr()), K(m.adam_m.data_ptr()), K(m.adam_v.data_ptr()),
                                 K(m.theta.numel()), self._lr(), K(_fbits(FLAGS.beta1)), K(_fbits(FLAGS.beta2)), K(_fbits(1e-8))])
         self._cur = self.ops_hist
-        for l, nh in ({} if local_hist else self.new_history).items():
+        for l, nh in ({} if (local_hist and not self._hist_last) else self.new_history).items():
             hist = m.history[l][0]
             self._emit('SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                         K(nh.cols), self._p(nh), K(nh.ld)])

@@ -11,13 +11,13 @@ import model_cases as mc
 pytestmark = pytest.mark.gpu
 
 
-def _model(case, params, native, fuse=False, epi=False):
+def _model(case, params, native, fuse=False, epi=False, group=True):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.vrgcn import VRGCN
     from stochastic_gcn_amd.plaingcn import PlainGCN
     FLAGS.reset()
     FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
-    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], fuse_dense=fuse, fuse_loss=epi, fuse_bwd=epi)
+    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], fuse_dense=fuse, fuse_loss=epi, fuse_bwd=epi, group_dw=group, lean_sync=group)
     cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
     fl = case['flags']
     m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
@@ -26,11 +26,11 @@ def _model(case, params, native, fuse=False, epi=False):
     return m
 
 
-def _run(case, native, steps, slot, fuse=False, epi=False):
+def _run(case, native, steps, slot, fuse=False, epi=False, group=True):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.scheduler import StagingSlot
     params = mc.make_oracle_model(case, seed=3).params
-    m = _model(case, {k: v.copy() for k, v in params.items()}, native, fuse, epi)
+    m = _model(case, {k: v.copy() for k, v in params.items()}, native, fuse, epi, group)
     sch = mc.make_scheduler(case, 1)
     slots = [StagingSlot(pin=True) for _ in range(3)] if slot else None
     losses = []
@@ -49,13 +49,18 @@ SUPPORTED = ['reddit_cvd_pp', 'reddit_cv_pp', 'cvd_pp_L3', 'cv_nopp_L2', 'ns_nop
 
 
 @pytest.mark.parametrize("name", SUPPORTED)
-@pytest.mark.parametrize("slot,epi", [(False, False), (True, False), (True, True)])
-def test_program_is_bit_identical_to_the_eager_path(name, slot, epi):
+@pytest.mark.parametrize("slot,epi,group", [(False, False, True), (True, False, True), (True, True, True), (True, False, False),
+                                            (False, True, False)])
+def test_program_is_bit_identical_to_the_eager_path(name, slot, epi, group):
     """epi: with --fuse_loss --fuse_bwd (the loss and the lower layer's LayerNorm backward in GEMM epilogues: same
-    arithmetic, same summation blocks) the program is STILL bit-identical to the eager path"""
+    arithmetic, same summation blocks) the program is STILL bit-identical to the eager path.
+    group: the layers' weight-gradient GEMMs recorded and issued as ONE grouped launch + ONE reduction launch, gradients
+    STORED (no memset), loss statistics in the optimizer's launch, history scatter after the optimizer (the defaults:
+    --group_dw --lean_sync) or everything layer by layer / on the auxiliary stream -- the same tiles, K slices and
+    order of additions either way."""
     case = mc.build_case(name)
     a, la = _run(case, False, 5, slot)
-    b, lb = _run(case, True, 5, slot, epi=epi)
+    b, lb = _run(case, True, 5, slot, epi=epi, group=group)
     progs = getattr(b, '_programs', {})
     assert progs and all(p is not None for p in progs.values()), getattr(b, '_program_note', 'no program was compiled')
     assert not getattr(a, '_programs', {})
@@ -67,6 +72,10 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot, epi):
     assert a.dropout_step == b.dropout_step == 5 and a.adam_t == b.adam_t == 5
     assert a.amt_data == b.amt_data and np.array_equal(a.field_sizes, b.field_sizes)      # the epoch counters too
     prog = next(iter(progs.values()))
+    from stochastic_gcn_amd.step_program import OP
+    assert sum(1 for o, _ in prog.ops_fb if o == OP['DW_FLUSH']) == (1 if group else 0)
+    assert sum(1 for o, _ in prog.ops_fb if o == OP['GRAD_STORE']) == (1 if group else 0)
+    assert sum(1 for o, _ in prog.ops_fb if o == OP['AUX_MEMSET0']) == (0 if group else 1)
     assert prog.n_loss_fused == (1 if epi else 0)
     if name.startswith('reddit_'):           # LayerNorm backwards in the epilogue of the GEMM above (Dense4 -> Dense3, ADD2 -> ADD1)
         assert prog.n_bwd_pairs == (2 if epi else 0), prog.n_bwd_pairs
