@@ -53,6 +53,7 @@ def parse(argv=None):
     p.add_argument("--tune", action="append", default=[], help="key=value passed to sgcn_tune")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epoch", action="store_true")
+    p.add_argument("--no-strong", action="store_true", help="--gpus N > 1: skip the strong-scaling leg (ONE graph row-block sharded)")
     p.add_argument("--epoch-timeout", type=int, default=240, help="watchdog of the train-epoch leg, s")
     p.add_argument("--no-backward", action="store_true")
     p.add_argument("--kernel", default="cs", choices=["rows", "cs"],
@@ -353,6 +354,61 @@ def sampler_baseline(data10):
     return res
 
 
+def strong_leg(args, dev, world, rank, full_adj0, d, pitch, steps):
+    """STRONG scaling beside the weak step: ONE S-Reddit graph (rank 0's) row-block sharded over
+    the ranks by nonzeros (parallel.ShardedSpMM), forward A.X + backward A^T.dC per step, with the dense operand
+    (a) resident on every GPU -- no collective on the data path -- and (b) sharded like the output and all-gathered
+    before each product (7/8 of it crosses xGMI per GPU).  Barrier + synchronize on both sides, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from stochastic_gcn_amd.parallel import DataParallel, ShardedSpMM
+    par = DataParallel(device=dev, init=False)
+    n = full_adj0.shape[0]
+    sh = ShardedSpMM(par, full_adj0, dev, kernel=args.kernel, d=d)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321)                              # the same operand on every rank
+    Xp = torch.zeros((n, pitch), device=dev)
+    Xp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
+    dCp = torch.zeros((n, pitch), device=dev)
+    dCp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
+    X, dC = Xp[:, :d], dCp[:, :d]
+    if args.kernel == "cs":
+        sh.autotune(X, dC)
+    C = torch.zeros((n, pitch), device=dev)[sh.lo:sh.hi, :d]
+    dX = torch.zeros((n, pitch), device=dev)[sh.lo:sh.hi, :d]
+    Xl, dCl = X[sh.lo:sh.hi].contiguous(), dC[sh.lo:sh.hi].contiguous()
+    res = {}
+    for name, gather in (("resident", False), ("allgather", True)):
+        def one():
+            sh.forward(sh.allgather_rows(Xl) if gather else X, out=C)
+            sh.backward(sh.allgather_rows(dCl) if gather else dC, out=dX)
+        for _ in range(2):
+            one()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        res[name + "_ms"] = el / steps * 1e3
+    nnz = int(full_adj0.nnz)
+    res["edges_per_s"] = {"resident": 2 * nnz / (res["resident_ms"] * 1e-3), "allgather": 2 * nnz / (res["allgather_ms"] * 1e-3)}
+    res["what"] = ("ONE S-Reddit graph (%d nnz), nnz-balanced row blocks over %d rank(s), fwd A.X + bwd A^T.dC per step, d=%d; "
+                   "resident: dense operand on every GPU, no data-path collective; allgather: operand sharded like the "
+                   "output, all-gathered (RCCL) before each product" % (nnz, world, d))
+    res["steps"] = steps
+    res["rows_rank0"] = [int(sh.lo), int(sh.hi)]
+    return res
+
+
 def dry_run(args, world, rank):
     """The distributed skeleton of a run without any GPU work (CPU test of `--gpus N`): rendezvous,
     an all-gather of the ranks, the timed loop's barrier / all-reduce pattern, one JSON line."""
@@ -379,10 +435,25 @@ def dry_run(args, world, rank):
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    strong = None
+    if world > 1:
+        # the strong-scaling leg's partition + all-gather on CPU tensors (no kernels): every rank's row block of ONE
+        # graph travels through ShardedSpMM.allgather_rows and must come back as the whole operand
+        from stochastic_gcn_amd import synthetic
+        from stochastic_gcn_amd.parallel import DataParallel, ShardedSpMM
+        a = synthetic.rmat_like(1 << 10, 12 << 10, seed=1)
+        par = DataParallel(device=torch.device("cpu"), init=False)
+        sh = ShardedSpMM(par, a, torch.device("cpu"), kernel=None)
+        full = torch.arange(a.shape[0] * 6, dtype=torch.float32).view(a.shape[0], 6)
+        got = sh.allgather_rows(full[sh.lo:sh.hi].contiguous())
+        strong = {"resident_ms": None, "allgather_ms": None, "edges_per_s": None, "dry_run": True,
+                  "allgather_ok": bool(torch.equal(got, full)), "rows": [int(sh.lo), int(sh.hi)],
+                  "local_nnz": int(sh.local_nnz), "nnz": int(a.nnz)}
+    if world > 1:
         dist.destroy_process_group()
     out = {"metric": "training edges/s (SpMM)", "value": None, "unit": "edges/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / max(args.steps, 1) * 1e3,
-           "dry_run": True, "ranks": ranks, "allreduce_of_rank_plus_1": total}
+           "dry_run": True, "ranks": ranks, "allreduce_of_rank_plus_1": total, "strong": strong}
     if rank == 0:
         print(json.dumps(out), flush=True)
     return out
@@ -626,6 +697,17 @@ def main(argv=None):
             t_model = miss_b / (gc["miss"] * 1e12) + hit_b / (gc["hit"] * 1e12)
             out["roofline"]["gather_ceiling"]["ms_model_for_profiled_traffic"] = t_model * 1e3
             out["roofline"]["frac_of_traffic_model"] = t_model / (fwd_ms * 1e-3)
+    if world > 1 and sh is None and not args.no_strong:
+        # the weak line above is ~N x by construction (every rank its own graph + a 0.84 MB all-reduce); the
+        # informative numbers of a multi-GPU run are these
+        try:
+            adj0 = full_adj if rank == 0 else make_graph(args, 0)[1]
+            del A
+            torch.cuda.empty_cache()
+            out["strong"] = strong_leg(args, dev, world, rank, adj0, d, pitch, max(3, min(args.steps, 10)))
+            out["strong"]["grad_allreduce_ms"] = ar_ms
+        except Exception as e:
+            out["strong"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
         if data10 is not None:
@@ -648,6 +730,7 @@ def main(argv=None):
         dog = threading.Timer(args.epoch_timeout, bail)
         dog.daemon = True
         dog.start()
+        A = None
         del A, Xp, dCp, X, dC, C, dX
         torch.cuda.empty_cache()
         try:

@@ -201,8 +201,8 @@ class ShardedSpMM(object):
         self.local_nnz = int(blk.nnz)
         self.distinct_cols = int(np.unique(blk.indices).shape[0])     # rows of B this block touches
         self.A = self.AT = self._mm = None
-        if self.hi == self.lo:          # more ranks than row blocks: this rank only joins collectives
-            pass
+        if self.hi == self.lo or kernel is None:   # more ranks than row blocks (this rank only joins collectives), or the
+            pass                                   # partition + collectives alone (kernel=None: the CPU dry run of bench.py)
         elif kernel == "cs":
             G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1)) if d else 1
             self.A = ops.ColumnSweepCSR(blk, device, G=G)

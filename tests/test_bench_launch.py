@@ -29,6 +29,11 @@ def test_gpus_2_spawns_two_distinct_ranks_that_share_an_allreduce(monkeypatch, c
     assert line["n_gpus"] == 2 and line["dry_run"] is True
     assert sorted(line["ranks"]) == [0, 1]                  # two distinct ranks met in the all-gather
     assert line["allreduce_of_rank_plus_1"] == 3.0          # 1 + 2: both contributed to the all-reduce
+    # the strong-scaling record rides in the SAME line: keys present, and its partition + all-gather
+    # skeleton (one graph, nnz-balanced row blocks) ran over the two ranks
+    st = line["strong"]
+    assert {"resident_ms", "allgather_ms", "edges_per_s"} <= set(st) and st["allgather_ok"] is True
+    assert st["rows"][0] == 0 and 0 < st["rows"][1] < 1024 and abs(st["local_nnz"] - st["nnz"] / 2) < 0.1 * st["nnz"]
     out = capfd.readouterr().out
     printed = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
     assert len(printed) == 1 and printed[0]["n_gpus"] == 2   # ONE line, from rank 0
