@@ -174,11 +174,30 @@ def train_epoch_leg(data, dev, epochs=6):
     best = min(walls[1:]) if len(walls) > 1 else walls[0]
     edges = le['sampled_edges'] + le['full_edges']
     chain = step_chain_probe(trn)
+    # validation (gcn/train.py:133-160; the reference's epoch line reports it as ttime): one sweep over the 23,699
+    # validation vertices through the compiled evaluation program, and the same sweep on the eager per-layer path
+    val = {}
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            for name, native in (("program", True), ("eager", False), ("program", True), ("eager", False)):
+                FLAGS.update(native_step=native)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                trn.evaluate(trn.val_d)
+                torch.cuda.synchronize()
+                val[name] = min(val.get(name, 1e9), time.perf_counter() - t0)
+        FLAGS.update(native_step=True)
+        val = {"val_sweep_s": val["program"], "val_sweep_eager_s": val["eager"],
+               "batches": -(-len(trn.val_d) // FLAGS.test_batch_size),
+               "epoch_plus_validation_s": best + val["program"], "epoch_plus_validation_eager_eval_s": best + val["eager"]}
+    except Exception as e:
+        val = {"error": repr(e)}
     # each aggregation edge is used by the forward aggregate; sampled edges again by the backward
     return {"epoch_time_s": best, "epoch_times_s": walls, "steps": le['steps'], "batch_size": 512,
             "ms_per_step": best / le['steps'] * 1e3, "sch_wait_s": le['sch_wait_s'],
             "producer_busy_s": le.get('producer_s'),
             "gpu_chain_us": chain.get("gpu_chain_us"), "host_launch_us": chain.get("host_launch_us"), "chain_probe": chain,
+            "validation": val,
             "agg_edges_per_epoch": edges, "agg_edges_per_s": edges / best,
             "recipe": "reddit.config + --cv --cvd --degree=1 (CVD+PP), validation excluded"}
 

@@ -63,6 +63,14 @@ def make_template(name, func):
     return create
 
 
+class _EvalCur(object):
+    """what Trainer.evaluate reads of `model.cur` after an evaluation step run as a program: the batch's labels"""
+    __slots__ = ("labels",)
+
+    def __init__(self, labels):
+        self.labels = labels
+
+
 class DevFeed(object):
     """One minibatch on device."""
 
@@ -581,13 +589,13 @@ class GCN(Model):
     def _program(self, feed_dict, dropout):
         """The compiled step program for this minibatch, or None (eager path): packed batches only, a
         supported layer stack, and a minibatch that fits the program's buffers."""
-        if not (FLAGS.native_step and self.is_training and isinstance(feed_dict, PackedBatch)):
+        if not (FLAGS.native_step and isinstance(feed_dict, PackedBatch)):
             return None
         # a program bakes in raw addresses (weights, gradients, Adam moments, history, features) and whether the
         # history update is local: all of that is part of its identity, so a tensor re-allocated or a hook
         # attached after the first step builds a NEW program instead of leaving a stale one in use
         key = (round(float(dropout), 9), self.history_hook is None, self.theta.data_ptr(), self.grad.data_ptr(),
-               self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+               self.adam_m.data_ptr() if self.is_training else 0, self.adam_v.data_ptr() if self.is_training else 0,
                self.features_dev.data_ptr() if isinstance(self.features_dev, torch.Tensor) else 0,
                tuple(h.data_ptr() for hs in self.history for h in hs))
         progs = self.__dict__.setdefault('_programs', {})
@@ -634,11 +642,29 @@ class GCN(Model):
                                fields=[m[5 + 2 * l] for l in range(self.L + 1)]))
         self.g_t += time() - t
         t = time()
-        self.adam_t += 1
-        b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
-        lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
+        lr_t = 0.0
+        if self.is_training:
+            self.adam_t += 1
+            b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
+            lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
         prog.fill(pb, ip, fp, self.dropout_step, lr_t)
         stream = torch.cuda.current_stream().cuda_stream
+        if not self.is_training:
+            # evaluation (gcn/train.py:133-160): forward + loss + prediction + the test model's history scatter as ONE
+            # foreign call.  pred is copied out of the program's arena (the next batch overwrites it); the labels stay a
+            # view of this batch's own staging copy
+            prog.run('all', stream)
+            nL, c = m[5 + 2 * self.L], int(prog.pred.cols)
+            pred = prog.tensor_of(prog.pred, nL).clone()
+            off, r_, c_ = m[pb.o_labels], m[pb.o_labels + 1], m[pb.o_labels + 2]
+            src = words[n_i + off:n_i + off + r_ * c_] if pb.slot is not None else fb[off:off + r_ * c_].view(torch.int32)
+            self.cur = _EvalCur(src.view(torch.float32).view(r_, c_))
+            self.dropout_step += 1
+            loss, acc = prog.loss_t, prog.acc_t
+            if sync:
+                loss, acc, pred = float(loss), float(acc), pred.cpu().numpy()
+            self.run_t += time() - t
+            return [loss, acc, pred]
         if self.grad_hook is None and self.history_hook is None:
             prog.run('all', stream)
         else:                                 # data parallel: collectives between the program's phases
@@ -667,8 +693,9 @@ class GCN(Model):
         program's statistics slot, which the next step overwrites: read (or ``.clone()``) them before the
         next ``run_one_step`` -- the Trainer reads the last step's only (tests/test_step_program_gpu.py
         asserts the aliasing).  The eager path returns fresh tensors."""
-        if self.is_training and isinstance(feed_dict, PackedBatch):
-            prog = self._program(feed_dict, float(getattr(feed_dict, 'dropout', 0.0) or 0.0))
+        if isinstance(feed_dict, PackedBatch):
+            drop = float(getattr(feed_dict, 'dropout', 0.0) or 0.0) if self.is_training else 0.0
+            prog = self._program(feed_dict, drop)
             if prog is not None:
                 self.dropout = prog.dropout
                 return self._run_program(prog, feed_dict, sync)

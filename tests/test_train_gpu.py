@@ -145,3 +145,32 @@ def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monk
     assert [s["plan_from_cache"] for s in stats[1]] == [True, True]          # second run: plans (and paces) from disk
     assert [s["pace"] for s in stats[0]] == [s["pace"] for s in stats[1]]
     assert len(list(tmp_path.glob("*.csplan.*.npz"))) == 2
+
+
+def test_evaluation_through_the_step_program_equals_the_eager_path():
+    """Evaluation (gcn/train.py:133-160: forward + loss + prediction + the TEST model's own history scatter, with
+    --test_cv warm-up sweeps reading what the previous sweep wrote) as compiled step programs -- one foreign call per
+    batch -- against the eager per-layer path: loss, accuracy, both F1 scores and the test history, bit for bit."""
+    import torch
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+    res = {}
+    for native in (False, True):
+        FLAGS.reset()
+        FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+                     hidden1=64, num_fc_layers=2, batch_size=256, test_batch_size=512, learning_rate=0.01, seed=1,
+                     prefetch=2, cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, native_step=native)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Trainer(data=_data(), verbose=False)
+            tr.train_epoch()
+            sweeps = [tr.evaluate(tr.val_d)[:4] for _ in range(2)]
+            sweeps.append(tr.evaluate(tr.test_d)[:4])
+        torch.cuda.synchronize()
+        progs = getattr(tr.test_model, '_programs', {})
+        res[native] = (sweeps, tr.test_model.history[0][0].clone(), bool(progs) and all(p is not None for p in progs.values()),
+                       getattr(tr.test_model, '_program_note', None))
+    assert res[True][2], res[True][3]                 # the test model really ran as a program ...
+    assert not res[False][2]
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])      # ... and gave the same numbers
+    assert torch.equal(res[True][1], res[False][1]) and float(res[True][1].abs().sum()) > 0
+    assert res[True][0][0] != res[True][0][1]         # the second sweep read the history the first one wrote
