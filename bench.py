@@ -61,9 +61,8 @@ def parse(argv=None):
     p.add_argument("--cs-t", type=int, default=0)
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
-    p.add_argument("--cs-r", type=int, default=16, choices=[16, 32])
     p.add_argument("--cs-align", type=int, default=2048, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
-    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2, 4],
+    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2],
                    help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes; "
                         "0: what ops.ColumnSweepCSR.choose_g picks for d -- also what the training path uses)")
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
@@ -556,8 +555,8 @@ def main(argv=None):
         elif reorder == "labels":
             comm = np.ascontiguousarray(data10[6].argmax(1), dtype=np.int32)
             reorder_info = {"method": "dataset labels", "communities": int(comm.max()) + 1}
-        cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1)) if (comm is None and args.cs_r == 16) else 1)
-        gk = dict(G=cs_g, align=args.cs_align) if (cs_g != 1 and comm is None) else dict(R=args.cs_r, col_labels=comm, row_labels=comm)
+        cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1)) if comm is None else 1)
+        gk = dict(G=cs_g, align=args.cs_align) if (cs_g != 1 and comm is None) else dict(col_labels=comm, row_labels=comm)
         A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
         A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
         mm = ops.spmm_cs

@@ -113,7 +113,7 @@ typedef struct {
                                        0 = library default knob, < 0 = unpaced                  */
     int32_t G;                      /* lane groups per wavefront: 0 / 1 = one 16-row tile per wave on 304-column
                                        slabs; 2 = two 16-row bins per wave (lanes 0-31 / 32-63) on 128-column
-                                       slabs, entries interleaved with pads (sgcn_csplan2_*)               */
+                                       slabs, entries interleaved with pads (sgcn_csplang_*)               */
     int32_t xcd_map;                /* != 0: consecutive tiles of a launch go to the SAME XCD (the
                                        dispatcher deals workgroups round-robin over the 8 XCDs):
                                        with a grouped plan the tiles that share B rows share an L2.
@@ -128,22 +128,14 @@ int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const 
                      int32_t M, int32_t R, int32_t T, const int32_t* host_row_group,
                      int64_t* host_tile_ptr, int32_t* host_colrow, float* host_valout,
                      int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
-/* Plan with TWO lane groups per wavefront (G = 2, R = 16): tile_rows / tile_slots are [ntiles * 32] (bin 0's 16
- * rows, then bin 1's), colrow / val hold `nentries` interleaved entries (entry 2*step + g is bin g's); pad
- * entries carry the value bits 0x80000000 (-0.0f; real -0.0f values are stored as +0.0f) and are masked off by
- * the kernel.  align > 0: a bin advances only while at most `align` columns ahead of the other (keeps the two
- * halves of a wave inside one L2 window); every tile's entry count is padded to a multiple of 64 (the pipelined
- * kernel has no tail code); the tile count is rounded up to whole launches of round_tiles waves (0: no rounding). */
-int sgcn_csplan2_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
-                       int32_t round_tiles, int32_t align, int64_t* ntiles, int64_t* nentries, int64_t* nfix,
-                       int64_t* nslots);
-int sgcn_csplan2_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
-                      int32_t T, int32_t round_tiles, int32_t align, int64_t* host_tile_ptr, int32_t* host_colrow,
-                      float* host_valout, int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
-/* The same plan with `ngroups` (2 or 4) lane groups per wavefront (sgcn_csplan_t.G): ngroups bins of 16 rows per tile
- * (tile_rows / tile_slots are [ntiles * ngroups * 16]), entry ngroups*step + g is bin g's, a bin advances only while
- * at most `align` columns ahead of the slowest bin of its tile, every tile's entry count a multiple of 64.  G = 4:
- * lanes 16g..16g+15 hold bin g's accumulators on a 64-column slab -- 64 rows per wavefront. */
+/* Plan with TWO lane groups per wavefront (sgcn_csplan_t.G = 2, 16-row bins; `ngroups` must be 2): tile_rows / tile_slots
+ * are [ntiles * 32] (bin 0's 16 rows, then bin 1's), colrow / val hold `nentries` interleaved entries (entry 2*step + g
+ * is bin g's); pad entries carry the value bits 0x80000000 (-0.0f; real -0.0f values are stored as +0.0f) and are masked
+ * off by the kernel.  align > 0: a bin advances only while at most `align` columns ahead of the other (keeps the two
+ * halves of a wave inside one L2 window); every tile's entry count is padded to a multiple of 64 (the pipelined kernel
+ * has no tail code); the tile count is rounded up to whole launches of round_tiles waves (0: no rounding).
+ * (Round 2 also built ngroups = 4 -- 64 rows per wavefront on 64-column slabs; its kernel was instruction-bound and is
+ * not part of the product: profiles/experiments/) */
 int sgcn_csplang_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
                        int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries,
                        int64_t* nfix, int64_t* nslots);
@@ -169,11 +161,12 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
 /* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)
  *   cs_round (tiles per launch), cs_unroll (4|8), cs_pace (ns per nonzero of the heaviest tile,
- *   0 = unpaced), cs_slack (columns), cs_generic (compiler-lowered indexing instead of the pinned
- *   indexed-FMA kernel), cs_noextra (no fifth fp32 accumulator plane), cs_g2_plain (G = 2 plans: the
- *   unpipelined two-group kernel instead of the pipelined one), cs_g2_wide (force its 64-bit row offsets), cs_last_pct (default 90: clock of a
- *   last pass that covers <= 3/4 of a slab, in percent of the plan's pace; 0 = off) : column-sweep kernel
- *   step_overlap (default 1): in sgcn_step_run, weight-gradient GEMMs + reductions on an auxiliary stream */
+ *   0 = unpaced), cs_slack (columns), cs_noextra (no fifth fp32 accumulator plane), cs_g2_wide (G = 2 plans: force the
+ *   64-bit row offsets), cs_last_pct (default 90: clock of a last pass that covers <= 3/4 of a slab, in percent of the
+ *   plan's pace; 0 = off) : column-sweep kernels
+ *   step_overlap (default 1): in sgcn_step_run, the history-only half of the aggregator (and, without --group_dw /
+ *   --lean_sync, weight-gradient GEMMs, memset, scatter, statistics) on an auxiliary stream
+ *   gemm_min_steps: K-steps a split-K slice keeps at least (default 3) */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */
 
@@ -313,27 +306,6 @@ int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* dev_X, int6
                                                   the minibatch's feature rows (history.dense_slice,
                                                   gcn/vrgcn.py:43-45) happens inside the GEMM */,
                        const int32_t* dev_gidx2 /* the same for X2 */, void* stream);
-/* Two dense layers of the same rows in ONE launch (new; the reference runs them as consecutive graph ops,
- * gcn/models.py:149-155):  Y1 = layer1(X),  Y2 = layer2(Y1)  with each layer described exactly as the
- * arguments of sgcn_dense_fwd_f32.  Layer 2 must read layer 1's output in place: l2->M == l1->M,
- * l2->K == l1->N, l2->X == l1->Y (ldx == ldy), l2->X2 NULL or the rows of Y1 from l2->split on
- * (Y + split * ldy), no row indirection; both N <= 128.  l2->drop masks Y1 as it is read (rows < drop->rows).
- * Y1 and both LayerNorm contexts are stored as by two separate calls; the K sums are cut inside the workgroup
- * instead of across workgroups (a different summation tree): results agree with the separate calls to fp32
- * rounding, not bit for bit. */
-typedef struct {
-    int32_t M, N, K;
-    const float* X; int64_t ldx;
-    const float* X2; int64_t ldx2; int32_t split;
-    const float* W; int64_t ldw;
-    const float* offset; const float* scale; float eps; int32_t relu;
-    float* Y; int64_t ldy;
-    float* xhat; float* rstd;
-    const sgcn_dropout_t* drop;
-    const int32_t* gidx; const int32_t* gidx2;
-} sgcn_dense_layer_t;
-int sgcn_dense2_fwd_f32(const sgcn_dense_layer_t* l1, const sgcn_dense_layer_t* l2, void* stream);
-
 /* The backward of one dense layer in one call: g = LN/ReLU-backward(dy) (skipped when scale == NULL
  * and relu == 0), dW[K x N] += dropout(x)^T . g, dx[n x K] = (g . W^T) * mask (dx nullable).
  * g_tmp: n * N floats; ws: sgcn_ln_act_bwd_ws_floats(n, N) (rounded up to 4) + max(
@@ -507,13 +479,8 @@ enum {
     SGCN_OP_VR_AGG_POST = 15, /* `stream` waits for the auxiliary stream, then sgcn_vr_aggregate_post_f32 */
     SGCN_OP_AUX_SCATTER_ROWS = 16, /* sgcn_scatter_rows_f32 on the auxiliary stream (forked from `stream`) */
     SGCN_OP_AUX_MEMSET0 = 17, /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
-    SGCN_OP_DENSE_FWD_PAIR = 18, /* DENSE_FWD arguments; the NEXT op must be a DENSE_FWD on this op's output: both run as
-                                  * one sgcn_dense2_fwd_f32 */
-    SGCN_OP_DENSE_FWD_CE = 19,  /* DENSE_FWD arguments of a plain layer; the NEXT op must be the SOFTMAX_CE of its output:
-                                 * the loss runs in the GEMM's epilogue (same arithmetic, one launch less) */
-    SGCN_OP_DENSE_BWD_PAIR = 20, /* DENSE_BWD arguments; the NEXT op must be the DENSE_BWD of the layer below, reading this
-                                 * op's dx as its dy: that layer's LayerNorm / ReLU backward runs in the epilogue of this
-                                 * op's input-gradient GEMM (bit-identical, one launch less) */
+    /* 18, 19, 20: retired with ABI v6 (two dense layers as one launch; the loss / the lower layer's LayerNorm backward in
+     * a GEMM epilogue -- measured slower than the separate launches in round 2: DESIGN.md 3.6, profiles/experiments/) */
     SGCN_OP_DW_FLUSH = 21,      /* no arguments.  A program that contains this op runs in DEFERRED weight-gradient mode: every
                                  * DENSE_BWD before it only records its dW GEMM (+ split-K and LayerNorm-parameter
                                  * reductions); this op issues all of them as ONE grouped GEMM launch + ONE reduction launch

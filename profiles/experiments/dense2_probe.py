@@ -25,7 +25,6 @@ for rep in range(20):
     # D: plain GEMM without split-K scratch (S = 1)
     big = torch.cat([xd, x2d])
     out = torch.empty(2042, 128, device=dev)
-    ops.GEMM_LIBRARY_THRESHOLD = 1 << 62
     from stochastic_gcn_amd._ffi import lib, check
     check(lib.sgcn_gemm_f32(0, 0, 2042, 128, 1204, big.data_ptr(), 1204, W1.data_ptr(), 128, out.data_ptr(), 128, 0, None, None, None, None))
 torch.cuda.synchronize()

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 5          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 6          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -47,15 +47,6 @@ class StepOp(C.Structure):
     """include/sgcn.h sgcn_step_op_t"""
     _fields_ = [("op", C.c_int32), ("nargs", C.c_int32), ("mul", C.c_int64 * STEP_MAX_ARGS),
                 ("slot", C.c_int32 * STEP_MAX_ARGS), ("add", C.c_int64 * STEP_MAX_ARGS)]
-
-
-class DenseLayer(C.Structure):
-    """sgcn_dense_layer_t: one dense layer as the arguments of sgcn_dense_fwd_f32 (sgcn_dense2_fwd_f32)"""
-    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("X", C.c_void_p), ("ldx", C.c_int64),
-                ("X2", C.c_void_p), ("ldx2", C.c_int64), ("split", C.c_int32), ("W", C.c_void_p), ("ldw", C.c_int64),
-                ("offset", C.c_void_p), ("scale", C.c_void_p), ("eps", C.c_float), ("relu", C.c_int32),
-                ("Y", C.c_void_p), ("ldy", C.c_int64), ("xhat", C.c_void_p), ("rstd", C.c_void_p),
-                ("drop", C.c_void_p), ("gidx", C.c_void_p), ("gidx2", C.c_void_p)]
 
 
 class Dropout(C.Structure):
@@ -88,9 +79,6 @@ SIGNATURES = {
     "sgcn_csplan_count": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, P, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_csplan_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P]),
-    "sgcn_csplan2_count": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
-                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "sgcn_csplan2_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P]),
     "sgcn_csplang_count": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_csplang_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P]),
@@ -119,7 +107,6 @@ SIGNATURES = {
                                 C.c_int64, P, C.c_int64, C.c_int32, P, P, P, P]),
     "sgcn_dense_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, C.c_int32,
                                      P, C.c_int64, P, P, C.c_float, C.c_int32, P, C.c_int64, P, P, P, P, P, P, P]),
-    "sgcn_dense2_fwd_f32": (C.c_int, [P, P, P]),
     "sgcn_dense_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P, P,
                                      C.c_int32, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, P, P, C.c_int64,
                                      P, P, P, P, P]),

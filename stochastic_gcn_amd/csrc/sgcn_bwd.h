@@ -1,4 +1,4 @@
-// Internal: the dense layer's backward as a value (shared by sgcn_gemm.hip and the step interpreter).
+// Internal: the dense layer's backward as a value (sgcn_gemm.hip).
 #pragma once
 #include <cstdint>
 
@@ -19,7 +19,4 @@ struct DenseBwdArgs {           // the arguments of sgcn_dense_bwd_f32
     float* g_tmp; float* ws;
     const int32_t* gidx;
 };
-// sgcn_gemm.hip: two consecutive layers' backward where the upper layer's dx is the lower layer's dy -- the lower
-// layer's LayerNorm / ReLU backward runs in the epilogue of the upper layer's input-gradient GEMM
-int dense_bwd_pair(const DenseBwdArgs& upper, const DenseBwdArgs& lower, void* stream, bool overlap);
 }  // namespace sgcn

@@ -34,12 +34,9 @@ int g_tune_cs_round = 0;
 int g_tune_cs_unroll = 0;
 int g_tune_cs_pace = 0;
 int g_tune_cs_slack = 0;
-int g_tune_cs_generic = 0;
 int g_tune_cs_noextra = 0;
 int g_tune_step_overlap = 1;
-int g_tune_cs_g2_plain = 0;
 int g_tune_cs_g2_wide = 0;
-int g_tune_cs_g2_unpacked = 0;
 int g_tune_cs_last_pct = 90;
 int g_tune_gemm_min_steps = 0;
 }  // namespace
@@ -52,12 +49,9 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_unroll")) return g_tune_cs_unroll;
     if (!strcmp(key, "cs_pace")) return g_tune_cs_pace;
     if (!strcmp(key, "cs_slack")) return g_tune_cs_slack;
-    if (!strcmp(key, "cs_generic")) return g_tune_cs_generic;
     if (!strcmp(key, "cs_noextra")) return g_tune_cs_noextra;
     if (!strcmp(key, "step_overlap")) return g_tune_step_overlap;
-    if (!strcmp(key, "cs_g2_plain")) return g_tune_cs_g2_plain;
     if (!strcmp(key, "cs_g2_wide")) return g_tune_cs_g2_wide;
-    if (!strcmp(key, "cs_g2_unpacked")) return g_tune_cs_g2_unpacked;
     if (!strcmp(key, "cs_last_pct")) return g_tune_cs_last_pct;
     if (!strcmp(key, "gemm_min_steps")) return g_tune_gemm_min_steps;
     return -1;
@@ -283,12 +277,9 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "spmm_slabmajor")) { g_tune_slabmajor = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_pace")) { SGCN_REQUIRE(value >= 0, "cs_pace >= 0"); g_tune_cs_pace = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_slack")) { SGCN_REQUIRE(value >= 0, "cs_slack >= 0"); g_tune_cs_slack = (int)value; return SGCN_OK; }
-    if (!strcmp(key, "cs_generic")) { g_tune_cs_generic = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_noextra")) { g_tune_cs_noextra = value != 0; return SGCN_OK; }
     if (!strcmp(key, "step_overlap")) { g_tune_step_overlap = value != 0; return SGCN_OK; }
-    if (!strcmp(key, "cs_g2_plain")) { g_tune_cs_g2_plain = value != 0; return SGCN_OK; }
     if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
-    if (!strcmp(key, "cs_g2_unpacked")) { g_tune_cs_g2_unpacked = value != 0; return SGCN_OK; }
     if (!strcmp(key, "gemm_min_steps")) { g_tune_gemm_min_steps = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_last_pct")) { SGCN_REQUIRE(value >= 0 && value <= 100, "cs_last_pct in [0, 100]"); g_tune_cs_last_pct = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }

@@ -22,13 +22,12 @@
 // the kernel sits on that line; the levers left are fewer fabric bytes (rows resident per XCD) and
 // graphs with locality (grouped plans, xcd_map).
 //
-// Kernels in this file:
+// Kernels in this file (what the product dispatches; the forms measured and dropped on the way -- plain and unpacked
+// two-group kernels, four lane groups per wave, the compiler-indexed generic form with 32-row tiles -- are kept as text
+// under profiles/experiments/ with their measurements in DESIGN.md 3.1b):
 //   cs_spmm16_kernel<U, EXTRA>     one 16-row tile per wavefront, pinned accumulators, up to 320 columns per pass
-//   cs_spmm16g2_kernel<U>          two 16-row bins per wavefront (half-wave execution masks), plain form
-//   cs_spmm16g2p_kernel<U, WIDE>   the same, software-pipelined and instruction-lean: what ColumnSweepCSR.choose_g
-//                                  selects for most widths (bench default at d = 602: 3.51 ms against 3.67)
-//   cs_spmm16g4p_kernel<U, WIDE>   four bins per wavefront: parity-green, instruction-bound (negative result)
-//   cs_spmm_kernel<R, VW, U>       generic compiler-indexed form (reference for the pinned ones; R = 32 tiles)
+//   cs_spmm16g2k_kernel<U, WIDE>   two 16-row bins per wavefront on 128-column passes, software-pipelined, packed FMAs:
+//                                  what ColumnSweepCSR.choose_g selects for most widths (bench default at d = 602)
 //   cs_fix_kernel<VW>              ordered sum of a split row's workspace slots
 #include "sgcn_dev.h"
 
@@ -223,360 +222,31 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     }
 }
 
-// ---- two lane groups per wavefront (plan->G == 2): plain form (the reference of the pipelined kernel below) ---
-// Lanes 0-31 hold the 16 x float4 accumulators of bin 0, lanes 32-63 those of bin 1 (same pinned registers
-// v[64:127], four planes of 16), one 128-column slab per pass.  A step applies ONE nonzero of each bin: the
-// two column words come from adjacent lanes of the coalesced entry load (v_readlane), a per-lane select
-// gives every lane ITS bin's column, one dwordx4 instruction gathers the 512-byte slab pieces of the two B
-// rows, and the indexed FMA group runs twice under the two half-wave execution masks (a pad entry gets an
-// empty mask and never touches an accumulator).
-// The idea: a wave holds 32 rows of a 128-column slab instead of 16 rows of a 304-column one, so B passes
-// through every XCD's L2 half as often per register byte, while the gather keeps the full-width rate (28.4 TB/s
-// measured for this shape in profiles/gather_ceiling).  This plain form is kept as the reference the pipelined
-// kernel below is tested against (knob cs_g2_plain); measured history on S-Reddit (profiles/g2_*):
-//  * no alignment of the two bins: 4.4 ms -- every B piece fetched 2.6 times per XCD and pass (1.6 with all
-//    waves clock-locked at a third of the speed).  profiles/l2_sweep_sim.py replays the plan through an LRU of
-//    the L2's size and gives the same numbers: the k-th entries of a wave's two bins sit 2,600 columns apart on
-//    average (p99 9,500) and the pace only governs bin 0, so the halves gather from two windows, not one;
-//  * bins aligned by the plan (sgcn_csplan2 `align` = 2048: 3-4 % pad steps): fetches compulsory (8.4 M lines
-//    per launch) whenever the clock is slow enough, but this kernel cannot follow a clock under ~270 ns per step
-//    (4.5 ms): it is latency- and issue-bound, see the pipelined form.
-template <int U>
-__global__ __launch_bounds__(kBlock) void cs_spmm16g2_kernel(CsArgs a) {
-    typedef Vec<4>::type VT;
-    constexpr int kShift = 28;
-    constexpr uint32_t kColMask = (1u << kShift) - 1u;
-    const int lane = threadIdx.x & 63;
-    const bool hi = lane >= 32;
-    const int li = lane & 31;
-    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
-    if (tile >= a.tile_end) return;
-    const int fbase = a.slab * 128;
-    const int f4 = fbase + li * 4;
-    const bool act = f4 < a.d;
-    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
-    const char* Bb = reinterpret_cast<const char*>(a.B);
-    const int64_t ldb_bytes = a.ldb * 4;
-    const uint32_t ldb32 = (uint32_t)ldb_bytes;               // the host checks the pitch fits 32 bits
 
-    typedef float accv_t __attribute__((ext_vector_type(16)));
-    accv_t ax = {}, ay = {}, az = {}, aw = {};
-
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t tnow = t0;
-    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
-    int step0 = 0;
-    for (int64_t p0 = start; p0 < end; p0 += kWave, step0 += kWave / 2) {
-        const int n = (int)min((int64_t)kWave, end - p0);          // entries in this chunk (even)
-        uint32_t mycr = 0;
-        float myv = 0.f;
-        if (lane < n) {
-            mycr = a.colrow[p0 + lane];
-            myv = a.val[p0 + lane];
-            uint32_t c = mycr & kColMask;
-            if (a.cscale && __float_as_int(myv) != (int)0x80000000) {
-                myv *= a.cscale[c];
-                if (__float_as_int(myv) == (int)0x80000000) myv = 0.f;      // a product that rounds to -0 is not a pad
-            }
-            if (a.gidx) { c = (uint32_t)a.gidx[c]; mycr = (mycr & ~kColMask) | c; }
-        }
-        const int nsteps = n / 2;
-        // m0 / m1: all-ones or zero, the half-wave's execution mask (wave-uniform: forced into SGPRs)
-        auto apply2 = [&](uint32_t cr0, float v0, int m0, uint32_t cr1, float v1, int m1, VT b) {
-            const int l0 = (int)(cr0 >> kShift), l1 = (int)(cr1 >> kShift);
-            asm volatile("s_mov_b32 exec_lo, %4\n\t"
-                         "s_mov_b32 exec_hi, 0\n\t"
-                         "s_set_gpr_idx_on %5, 0xc\n\t"
-                         "v_fma_f32 v64, %6, %10, v64\n\t"
-                         "v_fma_f32 v80, %6, %11, v80\n\t"
-                         "v_fma_f32 v96, %6, %12, v96\n\t"
-                         "v_fma_f32 v112, %6, %13, v112\n\t"
-                         "s_set_gpr_idx_off\n\t"
-                         "s_mov_b32 exec_lo, 0\n\t"
-                         "s_mov_b32 exec_hi, %7\n\t"
-                         "s_set_gpr_idx_on %8, 0xc\n\t"
-                         "v_fma_f32 v64, %9, %10, v64\n\t"
-                         "v_fma_f32 v80, %9, %11, v80\n\t"
-                         "v_fma_f32 v96, %9, %12, v96\n\t"
-                         "v_fma_f32 v112, %9, %13, v112\n\t"
-                         "s_set_gpr_idx_off\n\t"
-                         "s_mov_b64 exec, -1"
-                         : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw)
-                         : "s"(m0), "s"(l0), "s"(v0), "s"(m1), "s"(l1), "s"(v1), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
-        };
-        auto gather = [&](int j) -> VT {
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j) & kColMask;
-            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j + 1) & kColMask;
-            const uint32_t c = hi ? c1 : c0;
-            return *reinterpret_cast<const VT*>(Bb + (uint64_t)c * ldb32 + off4);         // one v_mad_u64_u32
-        };
-        auto fma2 = [&](int j, VT b) {
-            const uint32_t cr0 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j);
-            const uint32_t cr1 = (uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * j + 1);
-            const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), 2 * j));
-            const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), 2 * j + 1));
-            // pad entries (value bits 0x80000000) get an empty execution mask
-            const int m0 = __builtin_amdgcn_readfirstlane(__float_as_int(v0) == (int)0x80000000 ? 0 : -1);
-            const int m1 = __builtin_amdgcn_readfirstlane(__float_as_int(v1) == (int)0x80000000 ? 0 : -1);
-            apply2(cr0, v0, m0, cr1, v1, m1, b);
-        };
-        const int nb = nsteps / U;
-        for (int k = 0; k < nb; k++) {
-            const int jj = k * U;
-            if (a.cols_per_tick > 0.f) {
-                const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, 2 * jj) & kColMask);
-                float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
-                for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {   // bounded: never hangs
-                    __builtin_amdgcn_s_sleep(8);
-                    allowed = (float)(__builtin_amdgcn_s_memrealtime() - t0) * a.cols_per_tick + a.slack_cols;
-                }
-            }
-            VT bb[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) bb[u] = gather(jj + u);
-            if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-            for (int u = 0; u < U; u++) fma2(jj + u, bb[u]);
-        }
-        for (int j = nb * U; j < nsteps; j++) fma2(j, gather(j));
-    }
-
-    const int32_t* rows = a.tile_rows + tile * 32 + (hi ? 16 : 0);
-    const int32_t* slots = a.tile_slots + tile * 32 + (hi ? 16 : 0);
-    const int left = a.d - f4;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = rows[r];                       // differs between the two half-waves
-        const VT accv = {ax[r], ay[r], az[r], aw[r]};
-        if (row < 0 || !act) continue;
-        const int slot = slots[r];
-        if (slot >= 0) {
-            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
-        } else {
-            float* out = a.C + (int64_t)row * a.ldc;
-            const float rs = a.rscale ? a.rscale[row] : 1.0f;
-            VT res = accv * rs;
-            if (a.beta != 0.f) {
-                if (left >= 4) res += a.beta * vload<4>(out + f4);
-                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
-            }
-            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
-        }
-    }
-}
-
-// Software-pipelined, instruction-lean form of the two-group kernel (the default for G = 2 plans).
-// The plain form above (a) issues a batch of gathers, waits for ALL of them, applies them and only then issues
-// the next batch, (b) stalls every 32 steps on a dependent load of the next 64 plan entries, and (c) spends
-// ~20 VALU instructions per step, 12 of them moving plan entries from lanes to scalars (v_readlane) and
-// building addresses and masks; with 4 waves per SIMD that is 65 % of the SIMD's issue slots and the sweep
-// cannot be clocked under ~250 ns per step although the L2 would allow it (profiles/g2p_*).  Here:
-//  * the gathers of batch k+1 are in flight while batch k is applied (two register buffers of U float4), the
-//    pipeline runs across chunk boundaries, and the next chunk's entries are fetched a whole chunk ahead;
-//  * a lane gets ITS bin's column and value of a step by ds_bpermute (the LDS crossbar, no VALU slot), the
-//    row offset is one v_mad_u32_u24, the load uses the scalar-base + 32-bit-offset form;
-//  * the 64 local row ids of a chunk are packed into 8 scalars once per chunk (3 DPP ORs + 8 v_readlane) and
-//    picked per step by s_bfe; the chunk's pad mask is ONE v_cmp, tested per step by s_bitcmp;
+// ---- two lane groups per wavefront (plan->G == 2): the default for most operand widths ------------------------------
+// A tile is TWO bins of 16 virtual rows (sgcn_csplang_*): lanes 0-31 hold the accumulators of bin 0, lanes 32-63 those of
+// bin 1, each lane one float4 of a 128-column slab; ONE dwordx4 load per step gathers the 512-byte pieces of two
+// different B rows ("x4 on 2 rows" in profiles/gather_ceiling.json: 28 TB/s from L2) and a wave holds 32 rows instead of
+// 16 -- half the passes of B through every XCD per register byte.  The plan keeps the two bins' column positions within
+// `align` columns of each other (pads), so a wave gathers from ONE L2 window (profiles/l2_sweep_sim.py).
+//
+// History of the step (the earlier forms are kept as text under profiles/experiments/): plain form
+// 4.4 ms per S-Reddit SpMM; software-pipelined, 8 half-wave v_fma + 15 scalar + 2 ds_bpermute per step: 3.5 ms; THIS
+// form, 3.2 ms.  profiles/issue_probe.hip says what a step costs on the instruction side of gfx950: a v_fma_f32 occupies
+// its SIMD for 4.4 clocks WHATEVER the execution mask (a half-wave update is not cheaper than a full one), a
+// v_pk_fma_f32 for 5.0 (two columns per lane), a scalar instruction 1.05 clocks of the CU's one scalar unit, a
+// ds_bpermute 6 clocks of the CU's LDS pipeline (three times a ds_read_b64).  So a row's (x, y) and (z, w) live in
+// adjacent, even-aligned register pairs and a step is 4 packed FMAs + 2 v_readlane, 8 scalar instructions and ONE
+// ds_bpermute:
+//  * the gathers of batch k+1 are in flight while batch k is applied (two register buffers of U float4), across chunk
+//    boundaries; the next chunk's entries are fetched a whole chunk ahead;
+//  * a lane gets ITS bin's column of a step by ds_bpermute, the row offset is one v_mad_u32_u24, the load uses the
+//    scalar-base + 32-bit-offset form; the two values of a step come down by v_readlane into fixed scalar pairs;
+//  * the 64 accumulator offsets of a chunk are packed into 16 scalars once per chunk (2 DPP ORs + 16 v_readlane) and
+//    read as bytes; the chunk's pad mask is ONE v_cmp, tested per step by s_bitcmp + s_cselect_b64 on exec;
 //  * the clock comparison is integer scalar arithmetic.
-// 10 VALU instructions per step (8 of them the FMAs).  Requires every tile's entry count to be a multiple of
-// 64 (sgcn_csplan2_fill pads to that).  WIDE: K >= 2^24 or B beyond 4 GiB -- 64-bit row offsets.
-template <int U, bool WIDE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g2p_kernel(CsArgs a) {
-    typedef Vec<4>::type VT;
-    constexpr int kShift = 28;
-    constexpr uint32_t kColMask = (1u << kShift) - 1u;
-    constexpr int kSteps = kWave / 2;                 // steps per chunk of 64 entries
-    constexpr int kBatches = kSteps / U;
-    static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
-    const int lane = threadIdx.x & 63;
-    const bool hi = lane >= 32;
-    const int li = lane & 31;
-    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
-    if (tile >= a.tile_end) return;
-    const int fbase = a.slab * 128;
-    const int f4 = fbase + li * 4;
-    const bool act = f4 < a.d;
-    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
-    const char* Bb = reinterpret_cast<const char*>(a.B);
-    const uint32_t ldb32 = (uint32_t)(a.ldb * 4);
-    const int sel0 = hi ? 4 : 0;                      // ds_bpermute byte address of entry (2 j + bin) is sel0 + 8 j
-
-    typedef float accv_t __attribute__((ext_vector_type(16)));
-    accv_t ax = {}, ay = {}, az = {}, aw = {};
-
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    uint32_t tnow = t0;
-    // columns per tick in 16.16 fixed point (a launch lasts < 2^16 ticks of 10 ns; K / ticks < 2^15)
-    const uint32_t cpt16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.cols_per_tick * 65536.0f));
-    const uint32_t slack = (uint32_t)a.slack_cols;
-    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
-
-    // one chunk of plan entries: lane l holds entry l (even lanes bin 0, odd lanes bin 1 of step l / 2)
-    auto entries = [&](int64_t p, uint32_t& cr, float& v) {
-        cr = 0;
-        v = __int_as_float((int)0x80000000);                       // beyond the tile: pads on column 0
-        if (p < end) {
-            cr = a.colrow[p + lane];
-            v = a.val[p + lane];
-            uint32_t c = cr & kColMask;
-            if (a.cscale && __float_as_int(v) != (int)0x80000000) {
-                v *= a.cscale[c];
-                if (__float_as_int(v) == (int)0x80000000) v = 0.f;
-            }
-            if (a.gidx) { c = (uint32_t)a.gidx[c]; cr = (cr & ~kColMask) | c; }
-        }
-    };
-    // per-chunk scalars: the local row ids, 8 lanes x 4 bits per word, and the pad mask
-    struct Meta { uint32_t lr[8]; uint32_t pad_lo, pad_hi; };
-    auto meta = [&](uint32_t cr, float v) -> Meta {
-        Meta m;
-        int x = (int)((cr >> kShift) << (4 * (lane & 7)));
-        x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
-        x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
-        x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4 -> lane 8g+7 holds group g
-#pragma unroll
-        for (int g = 0; g < 8; g++) m.lr[g] = (uint32_t)__builtin_amdgcn_readlane(x, 8 * g + 7);
-        const uint64_t pm = __ballot(__float_as_int(v) == (int)0x80000000);
-        m.pad_lo = (uint32_t)pm; m.pad_hi = (uint32_t)(pm >> 32);
-        return m;
-    };
-    auto pace = [&](uint32_t crs, int j) {
-        if (cpt16 != 0) {
-            const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 2 * j) & kColMask;
-            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
-            for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
-                __builtin_amdgcn_s_sleep(8);
-                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
-            }
-        }
-    };
-    auto gather = [&](uint32_t crs, int j) -> VT {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 8 * j, (int)crs);   // my bin's column word
-        if constexpr (WIDE) {
-            return *reinterpret_cast<const VT*>(Bb + (uint64_t)(c & kColMask) * ldb32 + off4);
-        } else {                                       // u24 multiply: the row id above bit 24 is ignored by the instruction
-            const uint32_t off = __umul24(c, ldb32) + off4;
-            return *reinterpret_cast<const VT*>(Bb + off);
-        }
-    };
-#define SGCN_G2_FMA(PADWORD, BIT0, BIT1)                                                        \
-        asm volatile("s_bitcmp0_b32 %4, " #BIT0 "\n\t"                                          \
-                     "s_cselect_b32 exec_lo, -1, 0\n\t"                                         \
-                     "s_mov_b32 exec_hi, 0\n\t"                                                 \
-                     "s_set_gpr_idx_on %5, 0xc\n\t"                                             \
-                     "v_fma_f32 v64, %7, %8, v64\n\t"                                           \
-                     "v_fma_f32 v80, %7, %9, v80\n\t"                                           \
-                     "v_fma_f32 v96, %7, %10, v96\n\t"                                          \
-                     "v_fma_f32 v112, %7, %11, v112\n\t"                                        \
-                     "s_set_gpr_idx_off\n\t"                                                    \
-                     "s_bitcmp0_b32 %4, " #BIT1 "\n\t"                                          \
-                     "s_mov_b32 exec_lo, 0\n\t"                                                 \
-                     "s_cselect_b32 exec_hi, -1, 0\n\t"                                         \
-                     "s_set_gpr_idx_on %6, 0xc\n\t"                                             \
-                     "v_fma_f32 v64, %7, %8, v64\n\t"                                           \
-                     "v_fma_f32 v80, %7, %9, v80\n\t"                                           \
-                     "v_fma_f32 v96, %7, %10, v96\n\t"                                          \
-                     "v_fma_f32 v112, %7, %11, v112\n\t"                                        \
-                     "s_set_gpr_idx_off\n\t"                                                    \
-                     "s_mov_b64 exec, -1"                                                       \
-                     : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw) \
-                     : "s"(PADWORD), "s"(l0), "s"(l1), "v"(vv), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w) \
-                     : "scc")
-    // step j of the chunk (compile-time j): the value word of my bin by ds_bpermute, the two row ids by s_bfe, the pad
-    // bits 2j / 2j+1 of the chunk's mask by s_bitcmp
-    auto fma2 = [&](const Meta& m, float vs, auto jc, VT b) {
-        constexpr int j = decltype(jc)::value;
-        const float vv = __int_as_float(__builtin_amdgcn_ds_bpermute(sel0 + 8 * j, __float_as_int(vs)));
-        const int l0 = (int)((m.lr[j >> 2] >> ((j & 3) * 8)) & 15u);
-        const int l1 = (int)((m.lr[j >> 2] >> ((j & 3) * 8 + 4)) & 15u);
-        const uint32_t pw = j < 16 ? m.pad_lo : m.pad_hi;
-        constexpr int b0 = (2 * j) & 31;
-        if constexpr (b0 == 0) SGCN_G2_FMA(pw, 0, 1);
-        else if constexpr (b0 == 2) SGCN_G2_FMA(pw, 2, 3);
-        else if constexpr (b0 == 4) SGCN_G2_FMA(pw, 4, 5);
-        else if constexpr (b0 == 6) SGCN_G2_FMA(pw, 6, 7);
-        else if constexpr (b0 == 8) SGCN_G2_FMA(pw, 8, 9);
-        else if constexpr (b0 == 10) SGCN_G2_FMA(pw, 10, 11);
-        else if constexpr (b0 == 12) SGCN_G2_FMA(pw, 12, 13);
-        else if constexpr (b0 == 14) SGCN_G2_FMA(pw, 14, 15);
-        else if constexpr (b0 == 16) SGCN_G2_FMA(pw, 16, 17);
-        else if constexpr (b0 == 18) SGCN_G2_FMA(pw, 18, 19);
-        else if constexpr (b0 == 20) SGCN_G2_FMA(pw, 20, 21);
-        else if constexpr (b0 == 22) SGCN_G2_FMA(pw, 22, 23);
-        else if constexpr (b0 == 24) SGCN_G2_FMA(pw, 24, 25);
-        else if constexpr (b0 == 26) SGCN_G2_FMA(pw, 26, 27);
-        else if constexpr (b0 == 28) SGCN_G2_FMA(pw, 28, 29);
-        else SGCN_G2_FMA(pw, 30, 31);
-    };
-#undef SGCN_G2_FMA_DECL
-
-    uint32_t ccr, ncr;
-    float cv, nv;
-    entries(start, ccr, cv);
-    entries(start + kWave, ncr, nv);
-    Meta cm = meta(ccr, cv);
-    VT buf[2][U];
-    pace(ccr, 0);
-#pragma unroll
-    for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
-    if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    for (int64_t p0 = start; p0 < end; p0 += kWave) {
-        static_for<kBatches>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            // batch k+1 goes in flight (the first batch of the NEXT chunk after this chunk's last) ...
-            if constexpr (k + 1 < kBatches) {
-                pace(ccr, (k + 1) * U);
-#pragma unroll
-                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
-            } else {
-                pace(ncr, 0);
-#pragma unroll
-                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
-            }
-            if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            // ... while batch k is applied
-            static_for<U>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                fma2(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
-            });
-        });
-        ccr = ncr; cv = nv;
-        cm = meta(ccr, cv);
-        entries(p0 + 2 * kWave, ncr, nv);
-    }
-
-    const int32_t* rows = a.tile_rows + tile * 32 + (hi ? 16 : 0);
-    const int32_t* slots = a.tile_slots + tile * 32 + (hi ? 16 : 0);
-    const int left = a.d - f4;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = rows[r];
-        const VT accv = {ax[r], ay[r], az[r], aw[r]};
-        if (row < 0 || !act) continue;
-        const int slot = slots[r];
-        if (slot >= 0) {
-            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
-        } else {
-            float* out = a.C + (int64_t)row * a.ldc;
-            const float rs = a.rscale ? a.rscale[row] : 1.0f;
-            VT res = accv * rs;
-            if (a.beta != 0.f) {
-                if (left >= 4) res += a.beta * vload<4>(out + f4);
-                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
-            }
-            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
-        }
-    }
-}
-#undef SGCN_G2_FMA
-
-// Packed form of the pipelined two-group kernel (round 3; the default for G = 2 plans).  profiles/issue_probe.hip says what
-// a step costs on the instruction side of gfx950: a v_fma_f32 occupies its SIMD for 4.4 clocks WHATEVER the execution
-// mask (a half-wave update is not cheaper than a full one), a v_pk_fma_f32 for 5.0 (two columns per lane), a scalar
-// instruction 1.05 clocks of the CU's one scalar unit, a ds_bpermute 6 clocks of the CU's LDS pipeline (three times a
-// ds_read_b64).  The kernel above spends 8 FMAs + 15 scalar instructions + 2 ds_bpermute per step; this one keeps a row's
-// (x, y) and (z, w) in adjacent register pairs and spends 4 packed FMAs + 2 v_readlane, 8 scalar instructions and ONE
-// ds_bpermute.  Same plan, same entry order per accumulator, fused multiply-adds either way: bit-identical products.
+// Requires every tile's entry count to be a multiple of 64 (the plan pads to that).  WIDE: K >= 2^24 or B beyond 4 GiB
+// -- 64-bit row offsets.
 template <int U, bool WIDE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g2k_kernel(CsArgs a) {
     typedef Vec<4>::type VT;
@@ -664,7 +334,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // FMA takes a 64-bit scalar operand and, with op_sel_hi:[0,1,1], uses its low word for both columns); a pad's
     // execution mask is empty (s_bitcmp0 on the chunk's pad mask + ONE s_cselect_b64); the indexing mode is switched on
     // once per step and re-pointed for the second bin.  6 VALU (2 v_readlane + 4 v_pk_fma_f32) and 8 scalar instructions
-    // per step against 9 + 15 in the kernel above, and one ds_bpermute (the column word) instead of two.
+    // per step, and one ds_bpermute (the column word).
     auto fma2 = [&](const Meta& m, float vs, auto jc, VT b) {
         constexpr int j = decltype(jc)::value;
         const int l0 = (int)(m.lr[j >> 1] >> ((j & 1) * 16));
@@ -754,332 +424,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
-// Four lane groups per wavefront (plan->G == 4): lanes 16 g .. 16 g + 15 hold the 16 x float4 accumulators of bin g on a
-// 64-column slab -- 64 rows per wavefront, so the 4,096 resident wavefronts cover 262 k rows: S-Reddit in ONE round of
-// tiles, B streamed through every XCD once per 64-column pass.  Same structure as the two-group kernel above (pipelined
-// gathers, ds_bpermute operand selection, row ids packed per chunk, scalar clock arithmetic); a step applies four
-// entries: four indexed FMA groups under quarter-wave execution masks.
-// MEASURED on S-Reddit (profiles/g2_probe.py with G=4): 4.43 ms against 3.49 for two groups -- 10 launches of ~1,740
-// steps either way, but the time no longer follows the clock (4.45-4.6 ms from 220 to 280 ns per step): a step costs
-// ~255 ns of instruction issue, four times (execution-mask write, s_set_gpr_idx_on, four quarter-occupied FMAs,
-// s_set_gpr_idx_off) with four waves per SIMD.  The halved fabric traffic cannot be cashed in.  Opt-in
-// (`ColumnSweepCSR(G=4)`, `bench.py --cs-g 4`), parity-tested with the two-group kernel; a reproducible negative result.
-template <int U, bool WIDE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g4p_kernel(CsArgs a) {
-    typedef Vec<4>::type VT;
-    constexpr int kShift = 28;
-    constexpr uint32_t kColMask = (1u << kShift) - 1u;
-    constexpr int kSteps = kWave / 4;                 // steps per chunk of 64 entries (four bins per step)
-    constexpr int kBatches = kSteps / U;
-    static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
-    const int lane = threadIdx.x & 63;
-    const int q = lane >> 4;                          // my bin: lanes 16 q .. 16 q + 15
-    const int li = lane & 15;
-    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
-    if (tile >= a.tile_end) return;
-    const int fbase = a.slab * 64;
-    const int f4 = fbase + li * 4;
-    const bool act = f4 < a.d;
-    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
-    const char* Bb = reinterpret_cast<const char*>(a.B);
-    const uint32_t ldb32 = (uint32_t)(a.ldb * 4);
-    const int sel0 = q * 4;                           // ds_bpermute byte address of entry (4 j + bin) is sel0 + 16 j
-
-    typedef float accv_t __attribute__((ext_vector_type(16)));
-    accv_t ax = {}, ay = {}, az = {}, aw = {};
-
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    uint32_t tnow = t0;
-    // columns per tick in 16.16 fixed point (a launch lasts < 2^16 ticks of 10 ns; K / ticks < 2^15)
-    const uint32_t cpt16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.cols_per_tick * 65536.0f));
-    const uint32_t slack = (uint32_t)a.slack_cols;
-    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
-
-    // one chunk of plan entries: lane l holds entry l (even lanes bin 0, odd lanes bin 1 of step l / 2)
-    auto entries = [&](int64_t p, uint32_t& cr, float& v) {
-        cr = 0;
-        v = __int_as_float((int)0x80000000);                       // beyond the tile: pads on column 0
-        if (p < end) {
-            cr = a.colrow[p + lane];
-            v = a.val[p + lane];
-            uint32_t c = cr & kColMask;
-            if (a.cscale && __float_as_int(v) != (int)0x80000000) {
-                v *= a.cscale[c];
-                if (__float_as_int(v) == (int)0x80000000) v = 0.f;
-            }
-            if (a.gidx) { c = (uint32_t)a.gidx[c]; cr = (cr & ~kColMask) | c; }
-        }
-    };
-    // per-chunk scalars: the local row ids, 8 lanes x 4 bits per word, and the pad mask
-    struct Meta { uint32_t lr[8]; uint32_t pad_lo, pad_hi; };
-    auto meta = [&](uint32_t cr, float v) -> Meta {
-        Meta m;
-        int x = (int)((cr >> kShift) << (4 * (lane & 7)));
-        x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
-        x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
-        x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4 -> lane 8g+7 holds group g
-#pragma unroll
-        for (int g = 0; g < 8; g++) m.lr[g] = (uint32_t)__builtin_amdgcn_readlane(x, 8 * g + 7);
-        const uint64_t pm = __ballot(__float_as_int(v) == (int)0x80000000);
-        m.pad_lo = (uint32_t)pm; m.pad_hi = (uint32_t)(pm >> 32);
-        return m;
-    };
-    auto pace = [&](uint32_t crs, int j) {
-        if (cpt16 != 0) {
-            const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 4 * j) & kColMask;
-            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
-            for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
-                __builtin_amdgcn_s_sleep(8);
-                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
-            }
-        }
-    };
-    auto gather = [&](uint32_t crs, int j) -> VT {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 16 * j, (int)crs);  // my bin's column word
-        if constexpr (WIDE) {
-            return *reinterpret_cast<const VT*>(Bb + (uint64_t)(c & kColMask) * ldb32 + off4);
-        } else {                                       // u24 multiply: the row id above bit 24 is ignored by the instruction
-            const uint32_t off = __umul24(c, ldb32) + off4;
-            return *reinterpret_cast<const VT*>(Bb + off);
-        }
-    };
-#define SGCN_G4_FMA(PADWORD, B0, B1, B2, B3)                                                     \
-        asm volatile("s_bitcmp0_b32 %4, " #B0 "\n\t"                                            \
-                     "s_cselect_b32 exec_lo, 0xffff, 0\n\t"                                     \
-                     "s_mov_b32 exec_hi, 0\n\t"                                                 \
-                     "s_set_gpr_idx_on %5, 0xc\n\t"                                             \
-                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
-                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
-                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
-                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
-                     "s_set_gpr_idx_off\n\t"                                                    \
-                     "s_bitcmp0_b32 %4, " #B1 "\n\t"                                            \
-                     "s_cselect_b32 exec_lo, 0xffff0000, 0\n\t"                                 \
-                     "s_set_gpr_idx_on %6, 0xc\n\t"                                             \
-                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
-                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
-                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
-                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
-                     "s_set_gpr_idx_off\n\t"                                                    \
-                     "s_bitcmp0_b32 %4, " #B2 "\n\t"                                            \
-                     "s_mov_b32 exec_lo, 0\n\t"                                                 \
-                     "s_cselect_b32 exec_hi, 0xffff, 0\n\t"                                     \
-                     "s_set_gpr_idx_on %7, 0xc\n\t"                                             \
-                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
-                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
-                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
-                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
-                     "s_set_gpr_idx_off\n\t"                                                    \
-                     "s_bitcmp0_b32 %4, " #B3 "\n\t"                                            \
-                     "s_cselect_b32 exec_hi, 0xffff0000, 0\n\t"                                 \
-                     "s_set_gpr_idx_on %8, 0xc\n\t"                                             \
-                     "v_fma_f32 v64, %9, %10, v64\n\t"                                          \
-                     "v_fma_f32 v80, %9, %11, v80\n\t"                                          \
-                     "v_fma_f32 v96, %9, %12, v96\n\t"                                          \
-                     "v_fma_f32 v112, %9, %13, v112\n\t"                                        \
-                     "s_set_gpr_idx_off\n\t"                                                    \
-                     "s_mov_b64 exec, -1"                                                       \
-                     : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw) \
-                     : "s"(PADWORD), "s"(l0), "s"(l1), "s"(l2), "s"(l3), "v"(vv), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w) \
-                     : "scc")
-    // step j of the chunk (compile-time j): the value word of my bin by ds_bpermute, the four row ids by s_bfe (entries
-    // 4j..4j+3 = four nibbles of word j / 2), the pad bits 4j..4j+3 of the chunk's mask by s_bitcmp
-    auto fma2 = [&](const Meta& m, float vs, auto jc, VT b) {
-        constexpr int j = decltype(jc)::value;
-        const float vv = __int_as_float(__builtin_amdgcn_ds_bpermute(sel0 + 16 * j, __float_as_int(vs)));
-        const uint32_t w = m.lr[j >> 1] >> ((j & 1) * 16);
-        const int l0 = (int)(w & 15u), l1 = (int)((w >> 4) & 15u), l2 = (int)((w >> 8) & 15u), l3 = (int)((w >> 12) & 15u);
-        const uint32_t pw = j < 8 ? m.pad_lo : m.pad_hi;
-        constexpr int b0 = (4 * j) & 31;
-        if constexpr (b0 == 0) SGCN_G4_FMA(pw, 0, 1, 2, 3);
-        else if constexpr (b0 == 4) SGCN_G4_FMA(pw, 4, 5, 6, 7);
-        else if constexpr (b0 == 8) SGCN_G4_FMA(pw, 8, 9, 10, 11);
-        else if constexpr (b0 == 12) SGCN_G4_FMA(pw, 12, 13, 14, 15);
-        else if constexpr (b0 == 16) SGCN_G4_FMA(pw, 16, 17, 18, 19);
-        else if constexpr (b0 == 20) SGCN_G4_FMA(pw, 20, 21, 22, 23);
-        else if constexpr (b0 == 24) SGCN_G4_FMA(pw, 24, 25, 26, 27);
-        else SGCN_G4_FMA(pw, 28, 29, 30, 31);
-    };
-
-    uint32_t ccr, ncr;
-    float cv, nv;
-    entries(start, ccr, cv);
-    entries(start + kWave, ncr, nv);
-    Meta cm = meta(ccr, cv);
-    VT buf[2][U];
-    pace(ccr, 0);
-#pragma unroll
-    for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
-    if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    for (int64_t p0 = start; p0 < end; p0 += kWave) {
-        static_for<kBatches>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            // batch k+1 goes in flight (the first batch of the NEXT chunk after this chunk's last) ...
-            if constexpr (k + 1 < kBatches) {
-                pace(ccr, (k + 1) * U);
-#pragma unroll
-                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
-            } else {
-                pace(ncr, 0);
-#pragma unroll
-                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
-            }
-            if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            // ... while batch k is applied
-            static_for<U>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                fma2(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
-            });
-        });
-        ccr = ncr; cv = nv;
-        cm = meta(ccr, cv);
-        entries(p0 + 2 * kWave, ncr, nv);
-    }
-
-    const int32_t* rows = a.tile_rows + tile * 64 + q * 16;
-    const int32_t* slots = a.tile_slots + tile * 64 + q * 16;
-    const int left = a.d - f4;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = rows[r];
-        const VT accv = {ax[r], ay[r], az[r], aw[r]};
-        if (row < 0 || !act) continue;
-        const int slot = slots[r];
-        if (slot >= 0) {
-            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
-        } else {
-            float* out = a.C + (int64_t)row * a.ldc;
-            const float rs = a.rscale ? a.rscale[row] : 1.0f;
-            VT res = accv * rs;
-            if (a.beta != 0.f) {
-                if (left >= 4) res += a.beta * vload<4>(out + f4);
-                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
-            }
-            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
-        }
-    }
-}
-#undef SGCN_G4_FMA
-
-template <int R, int VW, int U>
-__global__ __launch_bounds__(kBlock) void cs_spmm_kernel(CsArgs a) {
-    typedef typename Vec<VW>::type VT;
-    constexpr int kShift = (R <= 16) ? 28 : 27;                 // local row id lives above the column
-    constexpr uint32_t kColMask = (1u << kShift) - 1u;
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
-    if (tile >= a.tile_end) return;
-    const int vi = a.slab * kWave + lane;
-    const bool act = vi < a.nvec;
-    const uint32_t loff = (uint32_t)min(vi, a.nvec - 1) * (uint32_t)(VW * 4);
-    const char* Bb = reinterpret_cast<const char*>(a.B);
-    const int64_t ldb_bytes = a.ldb * 4;
-
-    // R x VW accumulators as VW register vectors of R floats (one per vector component).  The
-    // row is selected by a wave-uniform DYNAMIC INDEX, which hipcc lowers to the gfx9 VGPR
-    // indexing mode (s_set_gpr_idx_on + v_mov): no branches and no register copies.  (A `switch`
-    // over named accumulators makes the structurizer shuffle v_mov_b64 copies at every merge,
-    // and a flat 64-float array goes to scratch -- both seen in the ISA.)
-    typedef float accv_t __attribute__((ext_vector_type(R)));
-    accv_t acc[VW];
-#pragma unroll
-    for (int e = 0; e < VW; e++) acc[e] = accv_t{};
-    // Clock-paced sweep: every wave of a launch starts within ~1 us and holds its column position
-    // to `elapsed * cols_per_tick` on the chip-wide constant 100 MHz counter (s_memrealtime), so
-    // all waves of an XCD gather from the same L2-sized window of B at the same time without
-    // exchanging a single message (counting nonzeros is not enough: a tile's position after k
-    // nonzeros jitters by ~N/(2 sqrt(nnz_tile)) columns, more than the window).
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t tnow = t0;
-    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
-    for (int64_t p0 = start; p0 < end; p0 += kWave) {
-        const int n = (int)min((int64_t)kWave, end - p0);
-        uint32_t mycr = 0;
-        float myv = 0.f;
-        if (lane < n) {
-            mycr = a.colrow[p0 + lane];
-            myv = a.val[p0 + lane];
-            uint32_t c = mycr & kColMask;
-            if (a.cscale) myv *= a.cscale[c];
-            if (a.gidx) { c = (uint32_t)a.gidx[c]; mycr = (mycr & ~kColMask) | c; }
-        }
-#define SGCN_CS_APPLY(cr, v, b)                                                            \
-    {                                                                                      \
-        const int lr_ = (int)((cr) >> kShift);                                             \
-        _Pragma("unroll") for (int e_ = 0; e_ < VW; e_++)                                  \
-            acc[e_][lr_] += (v) * velem<VW>((b), e_);                                      \
-    }
-        // batches of U nonzeros: U gathers in flight, then U accumulations
-        const int nb = n / U;                       // full batches
-        VT bufA[U];
-        // The clock read (s_memrealtime) is a long-latency scalar memory op: it is issued right
-        // after a batch's gathers and consumed before the NEXT batch, so its latency overlaps the
-        // loads instead of serialising every batch (the stale reading only adds look-ahead).
-        auto pace = [&](int jj) {
-            if (a.cols_per_tick > 0.f) {
-                const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj) & kColMask);
-                float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
-                for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {   // bounded: never hangs
-                    __builtin_amdgcn_s_sleep(8);
-                    allowed = (float)(__builtin_amdgcn_s_memrealtime() - t0) * a.cols_per_tick + a.slack_cols;
-                }
-            }
-        };
-        auto issue = [&](int jj, VT* buf) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
-                buf[u] = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
-            }
-            if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
-        };
-        auto apply = [&](int jj, const VT* buf) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
-                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), jj + u));
-                const VT b = buf[u];
-                SGCN_CS_APPLY(cr, v, b)
-            }
-        };
-        for (int k = 0; k < nb; k++) { pace(k * U); issue(k * U, bufA); apply(k * U, bufA); }
-        for (int j = nb * U; j < n; j++) {
-            const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, j);
-            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myv), j));
-            const VT b = *reinterpret_cast<const VT*>(Bb + (int64_t)(cr & kColMask) * ldb_bytes + loff);
-            SGCN_CS_APPLY(cr, v, b)
-        }
-#undef SGCN_CS_APPLY
-    }
-
-    if (!act) return;
-    const int32_t* rows = a.tile_rows + tile * R;
-    const int32_t* slots = a.tile_slots + tile * R;
-    const int left = a.d - vi * VW;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int row = rows[r];
-        if (row < 0) continue;
-        VT accv;
-#pragma unroll
-        for (int e = 0; e < VW; e++) {
-            if constexpr (VW == 1) accv = acc[0][r]; else accv[e] = acc[e][r];
-        }
-        const int slot = slots[r];
-        if (slot >= 0) {
-            vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accv);
-        } else {
-            float* out = a.C + (int64_t)row * a.ldc + (int64_t)vi * VW;
-            VT res = accv * (a.rscale ? a.rscale[row] : 1.0f);
-            if (a.beta != 0.f) {
-                if (left >= VW) res += a.beta * vload<VW>(out);
-                else for (int e = 0; e < left; e++) { if constexpr (VW == 1) res += a.beta * out[0]; else res[e] += a.beta * out[e]; }
-            }
-            if (left >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left);
-        }
-    }
-}
-
 // fix-up of split rows: ordered slot sum + epilogue (float4 path only)
 template <int VW>
 __global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix_t* fix, int64_t nfix) {
@@ -1110,69 +454,43 @@ using namespace sgcn;
 namespace {
 // What sgcn_spmm_cs_f32 dispatches for (plan, d) under the current knobs: passes over the feature
 // dimension, columns per pass, the fifth plane, gathers in flight -- and the kernel's name.
-struct CsVariant { int nslab, slab_floats, U; bool pinned, extra; const char* name; };
+struct CsVariant { int nslab, slab_floats, U; bool extra; const char* name; };
 
 CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
     CsVariant v{};
-    if (plan->G == 4) {             // four lane groups per wave: 64-column passes
-        v.nslab = ((d + 3) / 4 * 4 + 63) / 64;
-        v.slab_floats = 64;
-        v.pinned = true; v.extra = false;
-        v.U = 4;
-        v.name = "sgcn::cs_spmm16g4p_kernel<4, false>";
-        return v;
-    }
     if (plan->G == 2) {             // two lane groups per wave: 128-column passes, one dwordx4 per step
         v.nslab = ((d + 3) / 4 * 4 + 127) / 128;
         v.slab_floats = 128;
-        v.pinned = true; v.extra = false;
-        if (tune_get("cs_g2_plain") > 0) {
-            v.U = tune_get("cs_unroll") == 4 ? 4 : 8;
-            v.name = v.U == 4 ? "sgcn::cs_spmm16g2_kernel<4>" : "sgcn::cs_spmm16g2_kernel<8>";
-        } else if (tune_get("cs_g2_unpacked") > 0) {   // software-pipelined: two buffers of U gathers
-            v.U = 4;
-            v.name = "sgcn::cs_spmm16g2p_kernel<4, false>";     // <4, true> when B needs 64-bit row offsets
-        } else {                    // ... with packed FMAs (the default)
-            v.U = 4;
-            v.name = "sgcn::cs_spmm16g2k_kernel<4, false>";
-        }
+        v.extra = false;
+        v.U = 4;
+        v.name = "sgcn::cs_spmm16g2k_kernel<4, false>";     // <4, true> when B needs 64-bit row offsets
         return v;
     }
-    const int VW = plan->R <= 16 ? 4 : 2;
-    const int nvec = (d + VW - 1) / VW;
+    const int nvec = (d + 3) / 4;
     v.U = tune_get("cs_unroll") > 0 ? tune_get("cs_unroll") : 8;
     v.nslab = (nvec + kWave - 1) / kWave;
-    v.pinned = plan->R == 16 && tune_get("cs_generic") <= 0;
     v.slab_floats = 256;
-    if (v.pinned) {
-        // a pass costs the same whatever its width: cover d in ceil(d / 320) passes of
-        // (64 float4 + extra floats) instead of ceil(d / 256) passes of 64 float4
-        const int dp = (d + 3) / 4 * 4;
-        const int np = (dp + 319) / 320;
-        if (np < v.nslab && tune_get("cs_noextra") <= 0) {
-            v.nslab = np;
-            v.slab_floats = ((dp + np - 1) / np + 3) / 4 * 4;
-            v.extra = v.slab_floats > 256;
-        }
-        // EXTRA at U = 8 needs 142 VGPRs (3 waves/SIMD, breaks the 4096-tile residency): U = 4
-        if (v.extra) v.U = tune_get("cs_unroll") == 8 ? 8 : 4;
-        else v.U = v.U == 4 ? 4 : 8;
-        v.name = v.extra ? (v.U == 8 ? "sgcn::cs_spmm16_kernel<8, true>" : "sgcn::cs_spmm16_kernel<4, true>")
-                         : (v.U == 8 ? "sgcn::cs_spmm16_kernel<8, false>" : "sgcn::cs_spmm16_kernel<4, false>");
-    } else if (plan->R == 16) {
-        v.U = v.U == 4 ? 4 : 8;
-        v.name = v.U == 4 ? "sgcn::cs_spmm_kernel<16, 4, 4>" : "sgcn::cs_spmm_kernel<16, 4, 8>";
-    } else {
-        v.U = v.U == 4 ? 4 : 8;
-        v.name = v.U == 4 ? "sgcn::cs_spmm_kernel<32, 2, 4>" : "sgcn::cs_spmm_kernel<32, 2, 8>";
+    // a pass costs the same whatever its width: cover d in ceil(d / 320) passes of
+    // (64 float4 + extra floats) instead of ceil(d / 256) passes of 64 float4
+    const int dp = (d + 3) / 4 * 4;
+    const int np = (dp + 319) / 320;
+    if (np < v.nslab && tune_get("cs_noextra") <= 0) {
+        v.nslab = np;
+        v.slab_floats = ((dp + np - 1) / np + 3) / 4 * 4;
+        v.extra = v.slab_floats > 256;
     }
+    // EXTRA at U = 8 needs 142 VGPRs (3 waves/SIMD, breaks the 4096-tile residency): U = 4
+    if (v.extra) v.U = tune_get("cs_unroll") == 8 ? 8 : 4;
+    else v.U = v.U == 4 ? 4 : 8;
+    v.name = v.extra ? (v.U == 8 ? "sgcn::cs_spmm16_kernel<8, true>" : "sgcn::cs_spmm16_kernel<4, true>")
+                     : (v.U == 8 ? "sgcn::cs_spmm16_kernel<8, false>" : "sgcn::cs_spmm16_kernel<4, false>");
     return v;
 }
 }  // namespace
 
 extern "C" int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_t buflen) {
     SGCN_REQUIRE(plan && buf && buflen > 0 && d > 0, "spmm_cs_variant: bad argument");
-    SGCN_REQUIRE(plan->R == 16 || plan->R == 32, "spmm_cs_variant: R must be 16 or 32");
+    SGCN_REQUIRE(plan->R == 16 && (plan->G == 1 || plan->G == 2 || plan->G == 0), "spmm_cs_variant: 16-row bins, one or two lane groups");
     const CsVariant v = cs_variant(plan, d);
     int64_t round = plan->round_tiles > 0 ? plan->round_tiles : (tune_get("cs_round") > 0 ? tune_get("cs_round") : 4096);
     snprintf(buf, (size_t)buflen, "%s x %d launches (%d passes of %d columns x %lld rounds of %lld tiles)", v.name,
@@ -1187,13 +505,12 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
                                 float beta, void* stream) {
     SGCN_REQUIRE(plan && M >= 0 && K >= 0 && d >= 0, "spmm_cs: bad argument");
     if (M == 0 || d == 0) return SGCN_OK;
-    SGCN_REQUIRE(plan->R == 16 || plan->R == 32, "spmm_cs: R must be 16 or 32");
+    SGCN_REQUIRE(plan->R == 16 && (plan->G == 0 || plan->G == 1 || plan->G == 2),
+                 "spmm_cs: the plan must have 16-row bins and one or two lane groups per wavefront");
     SGCN_REQUIRE(plan->dev_tile_ptr && plan->dev_tile_rows && plan->dev_tile_slots && B && C,
                  "spmm_cs: null operand");
-    SGCN_REQUIRE(K < (1 << (plan->R <= 16 ? 28 : 27)), "spmm_cs: K too large for the packed column word");
-    // R = 16: float4 per lane (1 KiB row slabs).  R = 32: float2 per lane (512 B row slabs, twice
-    // the rows per wave: denser tiles, narrower L2 window) -- same 64 accumulator VGPRs.
-    const int VW = plan->R <= 16 ? 4 : 2;
+    SGCN_REQUIRE(K < (1 << 28), "spmm_cs: K too large for the packed column word");
+    const int VW = 4;               // float4 per lane (16-byte aligned rows)
     SGCN_REQUIRE(pick_vw(d, {B, C, plan->dev_ws}, {ldb, ldc}) >= VW,
                  "spmm_cs: rows must be %d-byte aligned (pitch multiple of %d floats covering d)", VW * 4, VW);
     hipStream_t st = (hipStream_t)stream;
@@ -1204,7 +521,6 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
     a.xcd_map = plan->xcd_map;
-    SGCN_REQUIRE((plan->G != 2 && plan->G != 4) || plan->R == 16, "spmm_cs: a G = 2 / 4 plan needs R = 16");
     SGCN_REQUIRE(plan->G != 2 || ldb * 4 < (1ll << 32), "spmm_cs: row pitch of B must fit 32 bits");
     if (plan->nfix > 0) {
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
@@ -1221,7 +537,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     const int slack = tune_get("cs_slack") > 0 ? tune_get("cs_slack") : 512;
     const CsVariant var = cs_variant(plan, d);
     const int nslab = var.nslab, U = var.U;
-    const bool pinned = var.pinned, extra = var.extra;
+    const bool extra = var.extra;
     a.slab_floats = var.slab_floats;
     for (int slab = 0; slab < nslab; slab++) {
         a.slab = slab;
@@ -1240,35 +556,16 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
                 a.cols_per_tick = (float)((double)K / (launch_ns / 10.0));   // 100 MHz: 10 ns per tick
             }
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
-#define SGCN_CS_LAUNCH(RR, VV, UU) hipLaunchKernelGGL((cs_spmm_kernel<RR, VV, UU>), dim3(blocks), dim3(kBlock), 0, st, a)
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
-            if (plan->G == 4) {
+            if (plan->G == 2) {
                 const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
                                   tune_get("cs_g2_wide") > 0;
-                if (wide) hipLaunchKernelGGL((cs_spmm16g4p_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else hipLaunchKernelGGL((cs_spmm16g4p_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-            } else if (plan->G == 2 && tune_get("cs_g2_plain") > 0) {
-                if (U == 4) hipLaunchKernelGGL((cs_spmm16g2_kernel<4>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else hipLaunchKernelGGL((cs_spmm16g2_kernel<8>), dim3(blocks), dim3(kBlock), 0, st, a);
-            } else if (plan->G == 2) {
-                const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
-                                  tune_get("cs_g2_wide") > 0;
-                if (tune_get("cs_g2_unpacked") > 0) {
-                    if (wide) hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                    else hipLaunchKernelGGL((cs_spmm16g2p_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-                } else {
-                    if (wide) hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                    else hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-                }
-            } else if (pinned) {
+                if (wide) hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+            } else {
                 if (extra) { if (U == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }
-            } else if (plan->R == 16) {         // generic (hipcc-lowered indexing) reference path
-                if (U == 4) SGCN_CS_LAUNCH(16, 4, 4); else SGCN_CS_LAUNCH(16, 4, 8);
-            } else {                            // 32-row tiles, float2 per lane
-                if (U == 4) SGCN_CS_LAUNCH(32, 2, 4); else SGCN_CS_LAUNCH(32, 2, 8);
             }
-#undef SGCN_CS_LAUNCH
 #undef SGCN_CS16
         }
     }
@@ -1276,8 +573,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     if (plan->nfix > 0) {
         const int64_t nfblk = (int64_t)((a.nvec + kBlock - 1) / kBlock) * plan->nfix;
         SGCN_REQUIRE(nfblk < (1ll << 31), "spmm_cs: too many split rows");
-        if (VW == 4) hipLaunchKernelGGL(cs_fix_kernel<4>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
-        else hipLaunchKernelGGL(cs_fix_kernel<2>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
+        hipLaunchKernelGGL(cs_fix_kernel<4>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
         SGCN_HIP_TRY(hipGetLastError());
     }
     return SGCN_OK;

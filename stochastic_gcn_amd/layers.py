@@ -14,7 +14,7 @@ TF autodiff derives) keep every sparse product on our HIP kernels in both direct
 Dense GEMMs / LayerNorm / ReLU / dropout are the "downstream dense" part:
 one fused fp32 MFMA launch per dense layer forward (dropout on the operand load + GEMM + LayerNorm
 + ReLU, ops.dense_fwd), two GEMM launches backward (ops.gemm with the dropout mask recomputed /
-applied in the epilogue); rocBLAS only above ops.GEMM_LIBRARY_THRESHOLD.
+applied in the epilogue), at every size: there is no library GEMM on the product path.
 """
 import torch
 
@@ -53,7 +53,7 @@ def dot(x, y, sparse=False):
     """Wrapper for matmul (sparse vs dense), as gcn/layers.py:31-37."""
     if sparse:
         return ops.spmm(x, y)
-    return torch.mm(x, y)
+    return ops.gemm(x, y)
 
 
 class SparseInput(object):

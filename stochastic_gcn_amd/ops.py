@@ -446,11 +446,13 @@ class ColumnSweepCSR(object):
         DESIGN.md 3.1b."""
         a = a.tocsr()
         self.G = int(G)
-        if self.G not in (1, 2, 4):
-            raise ValueError("G must be 1, 2 or 4")
+        if R != 16:
+            raise ValueError("the column-sweep kernels keep 16-row bins (R = 16)")
+        if self.G not in (1, 2):
+            raise ValueError("G must be 1 or 2 (four lane groups per wave were instruction-bound: profiles/experiments/)")
         if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
-                raise ValueError("G = 2 / 4 plans are ungrouped and use 16-row bins")
+                raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
             self._init_g2(a, device, T, round_tiles, int(align))
             return
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
@@ -748,10 +750,9 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
 
 
 # ---- fp32 MFMA GEMM / fused dense layer (sgcn_gemm.hip) ------------------------------------------
-# Above this many multiply-adds a GEMM is no longer launch-latency-bound and the library GEMM
-# (rocBLAS via torch, "plain library GEMM") is the better tool; below it our one-launch kernels
-# (and the fused GEMM+LayerNorm+ReLU) win on launch count and dispatch cost.
-GEMM_LIBRARY_THRESHOLD = 512 * 1024 * 1024
+# Every dense product of the model runs on this library's own kernel, whatever its size (round 3: the size-keyed
+# rocBLAS path above 512 M multiply-adds -- Exact-mode and large evaluation batches -- is gone: one code path; the
+# kernel is a plain tiled GEMM with split-K, so a 233 k-row operand is just more workgroups).
 
 
 _GEMM_WS = {}
@@ -776,10 +777,6 @@ def dense_bwd(dy, y, ctx, scale, relu, x, W, dW, doffset=None, dscale=None, need
         x, gidx = x.src, x.idx
     n, N, K = int(dy.shape[0]), int(dy.shape[1]), int(x.shape[1])
     norm = ctx is not None
-    if drop is None and gidx is None and n * N * K >= GEMM_LIBRARY_THRESHOLD:       # library-sized: three steps
-        g = ln_act_bwd(dy, y, ctx, scale, relu, doffset, dscale) if (norm or relu) else dy
-        gemm(x, g, out=dW, trans_a=True, accumulate=True)
-        return gemm(g, W, trans_b=True) if need_dx else None
     gp, ldg = _rows2d(dy, "dy")
     xp, ldx = _rows2d(x, "x")
     wp, ldw = _rows2d(W, "W")
@@ -854,15 +851,6 @@ def dropout(x, drop, out=None):
 def gemm(A, B, out=None, trans_a=False, trans_b=False, accumulate=False, drop_a=None, drop_c=None):
     """out = op(A) @ op(B) (+ out)   (sgcn_gemm_f32; exact fp32 on the matrix cores).
     drop_a: the stored A is a dropout input (masked while loaded); drop_c: mask the output."""
-    if drop_a is None and drop_c is None and \
-            A.shape[0] * A.shape[1] * (B.shape[0] if trans_b else B.shape[1]) >= GEMM_LIBRARY_THRESHOLD:
-        a = A.t() if trans_a else A
-        b = B.t() if trans_b else B
-        if out is None:
-            return torch.mm(a, b)
-        if accumulate:
-            return out.addmm_(a, b)
-        return torch.mm(a, b, out=out)
     ap, lda = _rows2d(A, "A")
     bp, ldb = _rows2d(B, "B")
     M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
@@ -915,9 +903,6 @@ def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
     n1 = int(x.shape[0] if gidx is None else gidx.shape[0])
     K, N = int(x.shape[1]), int(W.shape[1])
     M = n1 + (0 if x2 is None else int(x2.shape[0] if gidx2 is None else gidx2.shape[0]))
-    if x2 is None and drop is None and gidx is None and M * K * N >= GEMM_LIBRARY_THRESHOLD:
-        return ln_act_fwd(torch.mm(x, W), offset, scale, relu, eps) if (offset is not None or relu) \
-            else (torch.mm(x, W), None)
     xp, ldx = _rows2d(x, "x")
     x2p, ldx2 = _rows2d(x2, "x2") if x2 is not None else (None, 0)
     wp, ldw = _rows2d(W, "W")
@@ -932,49 +917,3 @@ def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
                                  float(eps), int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), dr,
                                  _ptr(ws), _ptr(gidx), _ptr(gidx2), _stream()))
     return y, ((xhat, rstd) if norm else None)
-
-
-def dense2_fwd(x, W1, off1, sc1, relu1, W2, off2, sc2, relu2, eps=1e-9, x2=None, drop1=None, drop2=None):
-    """Two chained dense layers of the same rows in ONE launch (sgcn_dense2_fwd_f32):
-    y1 = act1(LN1([drop1(x) ; x2] @ W1)), y2 = act2(LN2([drop2(y1[:n1]) ; y1[n1:]] @ W2)).
-    Returns (y1, ctx1, y2, ctx2) -- what two dense_fwd calls return, equal to them to fp32 rounding."""
-    gidx = gidx2 = None
-    if isinstance(x2, GatheredRows):
-        x2, gidx2 = x2.src, x2.idx
-    if isinstance(x, GatheredRows):
-        x, gidx = x.src, x.idx
-    n1 = int(x.shape[0] if gidx is None else gidx.shape[0])
-    K, N1, N2 = int(x.shape[1]), int(W1.shape[1]), int(W2.shape[1])
-    M = n1 + (0 if x2 is None else int(x2.shape[0] if gidx2 is None else gidx2.shape[0]))
-    dev = x.device
-    y1 = torch.empty((M, N1), dtype=torch.float32, device=dev)
-    y2 = torch.empty((M, N2), dtype=torch.float32, device=dev)
-    ctx = []
-    layers = []
-    keep = []
-    for (Wk, off, sc, relu, y, Kk, Nk, first) in ((W1, off1, sc1, relu1, y1, K, N1, True), (W2, off2, sc2, relu2, y2, N1, N2, False)):
-        norm = off is not None
-        xhat = torch.empty((M, Nk), dtype=torch.float32, device=dev) if norm else None
-        rstd = torch.empty((M,), dtype=torch.float32, device=dev) if norm else None
-        ctx.append((xhat, rstd) if norm else None)
-        drop = drop1 if first else drop2
-        ds = drop.struct(Kk, rows=n1) if drop is not None else None
-        keep.append(ds)
-        L = _ffi.DenseLayer()
-        L.M, L.N, L.K = M, Nk, Kk
-        if first:
-            L.X, L.ldx = _rows2d(x, "x")
-            L.X2, L.ldx2 = _rows2d(x2, "x2") if x2 is not None else (None, 0)
-            L.gidx, L.gidx2 = _ptr(gidx), _ptr(gidx2)
-        else:
-            L.X, L.ldx = y1.data_ptr(), N1
-            L.X2, L.ldx2 = (y1.data_ptr() + n1 * N1 * 4, N1) if x2 is not None else (None, 0)
-        L.split = n1
-        L.W, L.ldw = _rows2d(Wk, "W")
-        L.offset, L.scale, L.eps, L.relu = _ptr(off), _ptr(sc), float(eps), int(bool(relu))
-        L.Y, L.ldy = y.data_ptr(), Nk
-        L.xhat, L.rstd = _ptr(xhat), _ptr(rstd)
-        L.drop = C.cast(C.pointer(ds), C.c_void_p) if ds is not None else None
-        layers.append(L)
-    check(lib.sgcn_dense2_fwd_f32(C.byref(layers[0]), C.byref(layers[1]), _stream()))
-    return y1, ctx[0], y2, ctx[1]

@@ -12,8 +12,7 @@ slot table from the sampler's descriptor (three NumPy operations) and (3) makes 
 
 Intermediates live in a preallocated arena sized from the flags' row bounds (|field l| <= batch *
 prod(1 + degree)); a minibatch that does not fit, a feed-dict that is not a PackedBatch, or a layer
-stack outside the supported set (sparse input features, hidden width > 128 with LayerNorm, the
-library-GEMM size class) falls back to the eager path, which stays the reference implementation: both
+stack outside the supported set (sparse input features, hidden width > 128 with LayerNorm) falls back to the eager path, which stays the reference implementation: both
 run the same kernels with the same arguments and are bit-identical (tests/test_step_program_gpu.py).
 """
 import ctypes as C
@@ -29,7 +28,7 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DENSE_FWD_PAIR=18, DENSE_FWD_CE=19, DENSE_BWD_PAIR=20, DW_FLUSH=21, GRAD_STORE=22)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22)       # 18-20: retired (include/sgcn.h)
 MAX_ARGS = 48
 GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
@@ -268,8 +267,6 @@ class StepProgram(object):
             r1 = x.rows
         Kd, N = x.cols, W.cols
         M = r1 if x2 is None else r1 + r2
-        if M.cap * Kd * N >= ops.GEMM_LIBRARY_THRESHOLD:
-            raise Unsupported("library-sized GEMM")
         self._ws_need = max(self._ws_need, GEMM_WS_BOUND)
         y = self._alloc(M, N)
         norm = off is not None
@@ -288,8 +285,6 @@ class StepProgram(object):
             x, gidx = x.src, x.idx
         n, N, Kd = dy.rows, dy.cols, x.cols
         norm = ctx is not None
-        if site is None and gidx == NULL and n.cap * N * Kd >= ops.GEMM_LIBRARY_THRESHOLD:
-            raise Unsupported("library-sized GEMM")
         pre = norm or bool(relu)
         # LayerNorm-backward partials grow with the rows (monotonic: evaluated at the capacity); the split-K scratch
         # of either GEMM is bounded whatever the batch
@@ -525,77 +520,7 @@ class StepProgram(object):
                                         K(nh.cols), self._p(nh), K(nh.ld)])
 
     # ---- build the ctypes program ------------------------------------------------------------------
-    def _pair_dense_fwd(self, lst):
-        """Peephole: a DENSE_FWD whose output is the next DENSE_FWD's operand, in place and on the same rows,
-        becomes DENSE_FWD_PAIR -- the two run as one sgcn_dense2_fwd_f32 (the library re-checks the chain
-        at run time and refuses a pair that is not one)."""
-        F = OP['DENSE_FWD']
-        null = (0, -1, 0)
-        fused = 0
-        k = 0
-        while k + 1 < len(lst):
-            (oa, a), (ob, b) = lst[k], lst[k + 1]
-            ok = oa == F and ob == F
-            if ok:
-                a, b = [tuple(int(v) for v in t) for t in a], [tuple(int(v) for v in t) for t in b]
-                const = lambda t: t[1] < 0          # noqa: E731
-                ok = (b[0] == a[0] and b[2] == a[1] and b[3] == a[14] and b[4] == a[15] and b[25] == null and b[26] == null
-                      and const(a[1]) and const(b[1]) and a[1][2] <= 128 and b[1][2] <= 128 and const(a[14]) and const(a[15]))
-                if ok and b[5] != null:             # second operand: the rows of Y from `split` on
-                    ld4 = 4 * a[15][2]
-                    sp = b[7]
-                    ok = b[6] == a[15] and b[5] == (ld4 * sp[0] if sp[1] >= 0 else 0, sp[1], a[14][2] + (ld4 * sp[2] if sp[1] >= 0 else ld4 * sp[2]))
-            if ok:
-                lst[k] = (OP['DENSE_FWD_PAIR'], lst[k][1])
-                fused += 1
-                k += 2
-            else:
-                k += 1
-        return fused
-
-    def _fuse_loss(self, lst):
-        """Peephole: a plain DENSE_FWD (no LayerNorm, no ReLU, one operand) whose output is the logits of the
-        following SOFTMAX_CE becomes DENSE_FWD_CE: the loss runs in the GEMM's epilogue (bit-identical)."""
-        F, CE = OP['DENSE_FWD'], OP['SOFTMAX_CE']
-        null = (0, -1, 0)
-        n = 0
-        for k in range(len(lst) - 1):
-            (oa, a), (ob, b) = lst[k], lst[k + 1]
-            if oa != F or ob != CE or (k > 0 and lst[k - 1][0] == OP['DENSE_FWD_PAIR']):      # (second half of a pair)
-                continue
-            a, b = [tuple(int(v) for v in t) for t in a], [tuple(int(v) for v in t) for t in b]
-            if (a[5] == null and a[10] == null and a[11] == null and a[13] == null and a[25] == null and a[26] == null
-                    and a[1][1] < 0 and a[1][2] <= 128 and b[0] == a[14] and b[1] == a[15] and b[4] == a[0] and b[5] == a[1]):
-                lst[k] = (OP['DENSE_FWD_CE'], lst[k][1])
-                n += 1
-        return n
-
-    def _pair_dense_bwd(self, lst):
-        """Peephole: a DENSE_BWD whose dx is the dy of the next DENSE_BWD (the layer below, <= 128 wide, with a
-        LayerNorm or ReLU to back-propagate through) becomes DENSE_BWD_PAIR."""
-        B = OP['DENSE_BWD']
-        null = (0, -1, 0)
-        n = 0
-        k = 0
-        while k + 1 < len(lst):
-            (oa, a), (ob, b) = lst[k], lst[k + 1]
-            ok = oa == B and ob == B
-            if ok:
-                a, b = [tuple(int(v) for v in t) for t in a], [tuple(int(v) for v in t) for t in b]
-                ok = (a[19] != null and b[3] == a[19] and b[4] == a[20] and b[0] == a[0] and b[1] == a[2] and a[2][1] < 0
-                      and a[2][2] <= 128 and (b[9] != null or b[10] != null) and b[26] != null and b[5] != null)
-            if ok:
-                lst[k] = (OP['DENSE_BWD_PAIR'], lst[k][1])
-                n += 1
-                k += 2
-            else:
-                k += 1
-        return n
-
     def _finalize(self):
-        self.n_bwd_pairs = self._pair_dense_bwd(self.ops_fb) if FLAGS.fuse_bwd else 0
-        self.n_pairs = self._pair_dense_fwd(self.ops_fb) if FLAGS.fuse_dense else 0
-        self.n_loss_fused = self._fuse_loss(self.ops_fb) if FLAGS.fuse_loss else 0
         self._key_slots = {li: self._n_meta + i for i, li in enumerate(self._key_layers)}
         self.lr_slot = self._n_meta + len(self._key_layers)
         self.nslots = self.lr_slot + 1

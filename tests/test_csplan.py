@@ -102,7 +102,7 @@ def test_label_propagation_finds_planted_communities_and_nothing_else():
 
 @pytest.mark.parametrize("align", [0, 40])
 def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
-    """sgcn_csplan2_*: interleaved entries (2*step + bin), pads marked by the value bits 0x80000000, 32 row slots
+    """sgcn_csplang_* (two lane groups): interleaved entries (2*step + bin), pads marked by the value bits 0x80000000, 32 row slots
     per tile, whole launches; with align > 0 the two bins of a tile stay within `align` columns of each other."""
     rng = np.random.RandomState(5)
     a = sp.random(900, 700, density=0.04, random_state=rng, format='csr', dtype=np.float32)
@@ -114,7 +114,7 @@ def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
     M = a.shape[0]
     for rnd in (0, 8):
         nt, ne, nf, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplan2_count(rowptr.ctypes.data, col.ctypes.data, M, 64, rnd, align, C.byref(nt), C.byref(ne),
+        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, 64, rnd, align, 2, C.byref(nt), C.byref(ne),
                                      C.byref(nf), C.byref(ns)))
         if rnd:
             assert nt.value % rnd == 0
@@ -122,7 +122,7 @@ def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
         cr, vo = np.empty(ne.value, np.int32), np.empty(ne.value, np.float32)
         tr, ts = np.empty(nt.value * 32, np.int32), np.empty(nt.value * 32, np.int32)
         fx = np.empty((nf.value, 3), np.int32)
-        check(lib.sgcn_csplan2_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, 64, rnd, align, tp.ctypes.data,
+        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, 64, rnd, align, 2, tp.ctypes.data,
                                     cr.ctypes.data, vo.ctypes.data, tr.ctypes.data, ts.ctypes.data, fx.ctypes.data))
         assert tp[-1] == ne.value and nf.value >= 1 and (np.diff(tp) % 2 == 0).all()
         u = cr.view(np.uint32)

@@ -302,7 +302,7 @@ def test_spmm_column_sweep_vs_oracle(dev, M, K, d, pad):
     a = rand_csr(M, K, 0.08, M + d, long_rows=[(0, min(K, 300)), (M // 2, min(K, 150))])
     rng = np.random.RandomState(d)
     B = rng.standard_normal((K, d + pad)).astype(np.float32)
-    A = ops.ColumnSweepCSR(a, dev, R=(32 if d % 2 == 0 and M > 100 else 16), T=32)
+    A = ops.ColumnSweepCSR(a, dev, T=32)
     assert A.nfix >= 1
     Bd = T(B, dev)[:, :d]
     ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
@@ -337,8 +337,7 @@ def test_column_sweep_full_size_matches_row_gather(dev):
 
 @pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6), (500, 500, 256, 0),
                                          (64, 64, 130, 2), (90, 70, 30, 2), (5000, 3000, 602, 6)])
-@pytest.mark.parametrize("G", [2, 4])
-def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G):
+def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G=2):
     """G = 2 plan (two 16-row bins per wavefront, 128-column passes, half-wave execution masks): the product,
     its fusions and beta against the oracle; bit-identical reruns and paces."""
     from stochastic_gcn_amd import ops
@@ -365,12 +364,11 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G):
     assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
     if pad:
         np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
-    assert ("g2k" if G == 2 else "g4p") in A.variant(d)       # G = 2: the packed-FMA kernel is the default
-    # the pipelined kernel (default), its 64-bit-offset form and (G = 2) the plain two-group kernel apply every
-    # bin's entries in the same order: bit-identical products
+    assert "g2k" in A.variant(d)
+    # the kernel and its 64-bit-offset form apply every bin's entries in the same order: bit-identical products
     from stochastic_gcn_amd._ffi import lib
     try:
-        for knob in (b"cs_g2_wide", b"cs_g2_unpacked", b"cs_g2_plain") if G == 2 else (b"cs_g2_wide",):
+        for knob in (b"cs_g2_wide",):
             lib.sgcn_tune(knob, 1)
             assert torch.equal(ops.spmm_cs(A, Bd), out)
             o3 = T(c0, dev)
@@ -379,8 +377,6 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G):
             lib.sgcn_tune(knob, 0)
     finally:
         lib.sgcn_tune(b"cs_g2_wide", 0)
-        lib.sgcn_tune(b"cs_g2_plain", 0)
-        lib.sgcn_tune(b"cs_g2_unpacked", 0)
 
 
 def test_two_lane_group_full_size_vs_oracle_rows(dev):
@@ -486,10 +482,9 @@ def test_grouped_column_sweep_equals_plain_plan_and_oracle(dev, d, pad):
                                    (64, 128, 128), (31, 7, 33),
                                    # weight-gradient shapes of the Reddit step: split-K (4..8 output tiles, long K)
                                    (128, 128, 1021), (256, 128, 512), (128, 41, 512), (1204, 128, 1021), (5, 3, 4000)])
-def test_gemm_all_transposes_vs_numpy(dev, M, N, K, monkeypatch):
+def test_gemm_all_transposes_vs_numpy(dev, M, N, K):
     """fp32 MFMA GEMM vs float64 NumPy; asymmetric operands (a swapped row/col map must fail)."""
     from stochastic_gcn_amd import ops
-    monkeypatch.setattr(ops, "GEMM_LIBRARY_THRESHOLD", 1 << 62)        # always our kernel
     rng = np.random.RandomState(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     B = rng.standard_normal((K, N)).astype(np.float32)
@@ -764,69 +759,6 @@ def test_csr_transpose_index_is_the_stable_transpose(dev, n, f, per):
     assert tp.cpu().numpy().tolist() == [0] * 8 and tr_.numel() == 0
 
 
-# ---- two chained dense layers in one launch (sgcn_dense2_fwd_f32) ------------------------------------------
-@pytest.mark.parametrize("n1,n2,K,N1,N2,norm1,norm2,relu2,keep,gather", [
-    (1021, 1021, 1204, 128, 128, True, True, True, 0.8, True),     # the two CVD layers below the aggregator
-    (512, 0, 256, 128, 41, True, False, False, 0.8, False),        # the two layers above it
-    (37, 5, 50, 32, 7, True, True, False, 0.5, False),
-    (1, 0, 3, 41, 16, False, True, True, 1.0, False),
-    (300, 300, 130, 96, 128, False, False, True, 0.9, True),
-    (5000, 0, 64, 128, 128, True, True, True, 0.8, False)])
-def test_dense2_fwd_equals_two_dense_fwd_and_the_oracle(dev, n1, n2, K, N1, N2, norm1, norm2, relu2, keep, gather):
-    """One launch for two dense layers of the same rows: stacked dropout / clean streams, row gather and dropout
-    on layer 1's operand, layer 2's dropout on the stored Y1 -- against two sgcn_dense_fwd_f32 calls (same
-    arithmetic, different K split: fp32 rounding) and against the NumPy oracle."""
-    from stochastic_gcn_amd import ops
-    from oracle import model_np as mnp
-    rng = np.random.RandomState(n1 + K + N2)
-    src = rng.standard_normal((n1 + n2 + 50, K)).astype(np.float32)
-    W1 = (rng.standard_normal((K, N1)) / np.sqrt(K)).astype(np.float32)
-    W2 = (rng.standard_normal((N1, N2)) / np.sqrt(N1)).astype(np.float32)
-    o1, s1 = 0.1 * rng.standard_normal((1, N1)).astype(np.float32), (1 + 0.1 * rng.standard_normal((1, N1))).astype(np.float32)
-    o2, s2 = 0.1 * rng.standard_normal((1, N2)).astype(np.float32), (1 + 0.1 * rng.standard_normal((1, N2))).astype(np.float32)
-    i1 = rng.permutation(n1 + n2 + 50)[:n1].astype(np.int32)
-    i2 = rng.permutation(n1 + n2 + 50)[:n2].astype(np.int32)
-    sd = T(src, dev)
-    if gather:
-        x = ops.GatheredRows(sd, T(i1, dev))
-        x2 = ops.GatheredRows(sd, T(i2, dev)) if n2 else None
-    else:
-        x = T(src[i1], dev)
-        x2 = T(src[i2], dev) if n2 else None
-    d1 = ops.Drop(keep, 77) if keep < 1.0 else None
-    d2 = ops.Drop(keep, 91) if keep < 1.0 else None
-    args1 = (T(W1, dev), T(o1, dev) if norm1 else None, T(s1, dev) if norm1 else None, True)
-    args2 = (T(W2, dev), T(o2, dev) if norm2 else None, T(s2, dev) if norm2 else None, relu2)
-    y1, c1, y2, c2 = ops.dense2_fwd(x, *args1, *args2, x2=x2, drop1=d1, drop2=d2)
-    # two separate launches
-    r1, rc1 = ops.dense_fwd(x, *args1, x2=x2, drop=d1)
-    r2, rc2 = ops.dense_fwd(r1[:n1], *args2, x2=r1[n1:] if n2 else None, drop=d2)
-    tol = 2e-5
-    assert onp.rel_err(y1.cpu().numpy(), r1.cpu().numpy()) <= tol
-    assert onp.rel_err(y2.cpu().numpy(), r2.cpu().numpy()) <= tol
-    for c, rc in ((c1, rc1), (c2, rc2)):
-        assert (c is None) == (rc is None)
-        if c is not None:
-            assert onp.rel_err(c[0].cpu().numpy(), rc[0].cpu().numpy()) <= 1e-4      # xhat amplifies by rstd
-            assert onp.rel_err(c[1].cpu().numpy(), rc[1].cpu().numpy()) <= tol
-    assert torch.equal(ops.dense2_fwd(x, *args1, *args2, x2=x2, drop1=d1, drop2=d2)[2], y2)     # deterministic
-    # oracle
-    X = np.concatenate([src[i1], src[i2]]) if n2 else src[i1]
-    if d1 is not None:
-        X = X.copy(); X[:n1] = mnp.dropout_fwd(X[:n1], keep, mnp.hash_mask(77, X[:n1].shape, keep))
-    h = (X @ W1).astype(np.float32)
-    if norm1:
-        h, _ = mnp.layer_norm_fwd(h, o1, s1)
-    h = np.maximum(h, 0)
-    assert onp.rel_err(y1.cpu().numpy(), h) <= TOL
-    if d2 is not None:
-        h = h.copy(); h[:n1] = mnp.dropout_fwd(h[:n1], keep, mnp.hash_mask(91, h[:n1].shape, keep))
-    z = (h @ W2).astype(np.float32)
-    if norm2:
-        z, _ = mnp.layer_norm_fwd(z, o2, s2)
-    if relu2:
-        z = np.maximum(z, 0)
-    assert onp.rel_err(y2.cpu().numpy(), z) <= TOL
 
 
 def test_column_sweep_plan_cache_round_trip_both_group_counts(dev, tmp_path):
@@ -850,4 +782,7 @@ def test_column_sweep_plan_cache_round_trip_both_group_counts(dev, tmp_path):
         assert not hit3 and other.G == 3 - G
         b = a.copy(); b.data = b.data * 2
         assert not ops.ColumnSweepCSR.cached(b, dev, path, G=G)[1]              # another matrix: rebuilt
+        with open(path, "r+b") as f:                                            # a truncated / corrupt cache file is a
+            f.truncate(1000)                                                    # cache miss, not a crash at startup
+        assert not ops.ColumnSweepCSR.cached(a, dev, path, G=G)[1]
     assert [ops.ColumnSweepCSR.choose_g(d) for d in (32, 128, 256, 320, 602, 640)] == [2, 2, 2, 1, 2, 2]

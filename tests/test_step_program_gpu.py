@@ -11,13 +11,13 @@ import model_cases as mc
 pytestmark = pytest.mark.gpu
 
 
-def _model(case, params, native, fuse=False, epi=False, group=True):
+def _model(case, params, native, group=True):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.vrgcn import VRGCN
     from stochastic_gcn_amd.plaingcn import PlainGCN
     FLAGS.reset()
     FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
-    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], fuse_dense=fuse, fuse_loss=epi, fuse_bwd=epi, group_dw=group, lean_sync=group)
+    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], group_dw=group, lean_sync=group)
     cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
     fl = case['flags']
     m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
@@ -26,11 +26,11 @@ def _model(case, params, native, fuse=False, epi=False, group=True):
     return m
 
 
-def _run(case, native, steps, slot, fuse=False, epi=False, group=True):
+def _run(case, native, steps, slot, group=True):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.scheduler import StagingSlot
     params = mc.make_oracle_model(case, seed=3).params
-    m = _model(case, {k: v.copy() for k, v in params.items()}, native, fuse, epi, group)
+    m = _model(case, {k: v.copy() for k, v in params.items()}, native, group)
     sch = mc.make_scheduler(case, 1)
     slots = [StagingSlot(pin=True) for _ in range(3)] if slot else None
     losses = []
@@ -49,18 +49,15 @@ SUPPORTED = ['reddit_cvd_pp', 'reddit_cv_pp', 'cvd_pp_L3', 'cv_nopp_L2', 'ns_nop
 
 
 @pytest.mark.parametrize("name", SUPPORTED)
-@pytest.mark.parametrize("slot,epi,group", [(False, False, True), (True, False, True), (True, True, True), (True, False, False),
-                                            (False, True, False)])
-def test_program_is_bit_identical_to_the_eager_path(name, slot, epi, group):
-    """epi: with --fuse_loss --fuse_bwd (the loss and the lower layer's LayerNorm backward in GEMM epilogues: same
-    arithmetic, same summation blocks) the program is STILL bit-identical to the eager path.
-    group: the layers' weight-gradient GEMMs recorded and issued as ONE grouped launch + ONE reduction launch, gradients
+@pytest.mark.parametrize("slot,group", [(False, True), (True, True), (True, False), (False, False)])
+def test_program_is_bit_identical_to_the_eager_path(name, slot, group):
+    """group: the layers' weight-gradient GEMMs recorded and issued as ONE grouped launch + ONE reduction launch, gradients
     STORED (no memset), loss statistics in the optimizer's launch, history scatter after the optimizer (the defaults:
     --group_dw --lean_sync) or everything layer by layer / on the auxiliary stream -- the same tiles, K slices and
     order of additions either way."""
     case = mc.build_case(name)
     a, la = _run(case, False, 5, slot)
-    b, lb = _run(case, True, 5, slot, epi=epi, group=group)
+    b, lb = _run(case, True, 5, slot, group=group)
     progs = getattr(b, '_programs', {})
     assert progs and all(p is not None for p in progs.values()), getattr(b, '_program_note', 'no program was compiled')
     assert not getattr(a, '_programs', {})
@@ -76,31 +73,7 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot, epi, group):
     assert sum(1 for o, _ in prog.ops_fb if o == OP['DW_FLUSH']) == (1 if group else 0)
     assert sum(1 for o, _ in prog.ops_fb if o == OP['GRAD_STORE']) == (1 if group else 0)
     assert sum(1 for o, _ in prog.ops_fb if o == OP['AUX_MEMSET0']) == (0 if group else 1)
-    assert prog.n_loss_fused == (1 if epi else 0)
-    if name.startswith('reddit_'):           # LayerNorm backwards in the epilogue of the GEMM above (Dense4 -> Dense3, ADD2 -> ADD1)
-        assert prog.n_bwd_pairs == (2 if epi else 0), prog.n_bwd_pairs
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
-
-
-@pytest.mark.parametrize("name,pairs", [('reddit_cvd_pp', 2), ('reddit_cv_pp', 2), ('cvd_pp_L3', 0), ('is_pp', 0), ('ns_nopp_L2', 0)])
-def test_fused_dense_pairs_agree_with_the_eager_path_to_rounding(name, pairs):
-    """--fuse_dense (default): consecutive dense layers of the same rows run as ONE launch (DENSE_FWD_PAIR ->
-    sgcn_dense2_fwd_f32).  Same arithmetic, the K sums cut inside the workgroup instead of across workgroups:
-    loss and accuracy agree to fp32 rounding over consecutive steps; the weights after 5 Adam steps agree except
-    where a gradient is rounding noise around zero (Adam divides by its own magnitude there)."""
-    case = mc.build_case(name)
-    a, la = _run(case, False, 5, False)
-    b, lb = _run(case, True, 5, False, fuse=True)
-    prog = next(iter(b._programs.values()))
-    assert prog is not None and prog.n_pairs >= pairs, (prog.n_pairs if prog else None)
-    for (l1, a1), (l2, a2) in zip(la, lb):
-        assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l1)))
-        assert abs(float(a1) - float(a2)) <= 2.0 / case['cfg']['batch']
-    d = (a.theta - b.theta).abs()
-    assert float((d > 1e-5).float().mean()) < 2e-3 and float(d.max()) < 0.05
-    for ha, hb in zip(a.history, b.history):
-        assert float((ha[0] - hb[0]).abs().max()) <= 1e-4 * max(1.0, float(ha[0].abs().max()))
-    print("%s: %d ops per step, %d dense pairs" % (name, prog.n_all, prog.n_pairs))
 
 
 def test_dropout_zero_and_weight_decay_variants():

@@ -174,3 +174,36 @@ def test_evaluation_through_the_step_program_equals_the_eager_path():
     assert res[True][0] == res[False][0], (res[True][0], res[False][0])      # ... and gave the same numbers
     assert torch.equal(res[True][1], res[False][1]) and float(res[True][1].abs().sum()) > 0
     assert res[True][0][0] != res[True][0][1]         # the second sweep read the history the first one wrote
+
+
+def test_no_library_gemm_on_the_product_path(monkeypatch):
+    """the size-keyed rocBLAS path (torch.mm above 512 M multiply-adds: Exact mode, large
+    evaluation batches) is gone.  With every torch matmul entry point booby-trapped, the Reddit recipe (CVD+PP,
+    program and eager) and an Exact configuration whose dense layers see ALL 6,000 vertices at once -- 6,000 x 64 x 96
+    and the like, and an evaluation batch of 6,000 -- still train and evaluate: every dense product ran on
+    sgcn_gemm.hip."""
+    import torch
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+
+    def trap(*a, **k):
+        raise AssertionError("a library GEMM (torch.mm / addmm / matmul) was reached on the product path")
+    for name in ("mm", "addmm", "matmul", "bmm"):
+        monkeypatch.setattr(torch, name, trap)
+    monkeypatch.setattr(torch.Tensor, "addmm_", trap)
+    monkeypatch.setattr(torch.Tensor, "mm", trap)
+    monkeypatch.setattr(torch.Tensor, "matmul", trap)
+    monkeypatch.setattr(torch.Tensor, "__matmul__", trap)
+    base = dict(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+                hidden1=64, num_fc_layers=2, learning_rate=0.01, seed=1, prefetch=2)
+    for flags in (dict(cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, batch_size=256, test_batch_size=512),
+                  dict(cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, batch_size=256, test_batch_size=512, native_step=False),
+                  dict(cv=False, degree=10000, test_degree=10000, batch_size=6000, test_batch_size=6000, preprocess=False,
+                       num_fc_layers=1)):
+        FLAGS.reset()
+        FLAGS.update(**dict(base, **flags))
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Trainer(data=_data(), verbose=False)
+            tr.train_epoch()
+            cost, acc = tr.evaluate(tr.val_d)[:2]
+        assert np.isfinite(cost) and 0.0 <= acc <= 1.0
