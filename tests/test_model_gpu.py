@@ -294,23 +294,29 @@ def test_full_size_reddit_cvd_pp_steps_match_oracle():
     """BASELINE config 3 at FULL size (S-Reddit: N = 232,965, 602 features, reddit.config flags +
     --cv --cvd --degree=1, batch 512): THREE CONSECUTIVE training steps, device vs NumPy oracle, each
     side on its own weights, Adam moments and history throughout -- the PP product, every layer
-    activation, loss, gradients, Adam-updated weights and the 119 MB history.  Nothing the device
-    computed is fed into the oracle's forward or backward pass.
+    activation, loss, gradients, Adam-updated weights and the 119 MB history.  NOTHING the device
+    computed enters the oracle: not its forward pass, not its backward pass, not its weights (round 2
+    still took 14 % of the Adam-updated weights from the device).
 
     Two things are ill-conditioned at this size and are handled explicitly instead of by loose
-    tolerances:
+    tolerances or by steering the oracle:
     (1) with ~330k ReLU inputs per step a few land within fp32 rounding of 0 and their gate switches
         a gradient contribution on or off -- the device's gradient is required to lie in the oracle's
         gradient INTERVAL over all assignments of those gates (_gate_interval);
     (2) Adam's first steps are sign-like (lr * g / (|g| + 3e-7)), so a weight's update is DETERMINED
         at fp32 only where |g| is above its noise floor and where the entry's BUDGET -- Adam's
         sensitivity (|d update / d g| <= lr / (|g| + 3e-7), doubled) times the width of its gate
-        interval; an ambiguous gate moves a whole weight column's gradient by ~1/sqrt(rows) -- stays
-        small.  Determined weights are compared at PARAM_TOL plus their budget and never touched.  The undetermined rest -- where two correct fp32 implementations may differ by
-        a fraction of lr -- is checked against Adam's own bound (|update| <= ~lr per step) and then
-        taken from the device, because left alone those entries (and only those) make ANY two fp32
-        runs drift apart by 5e-3 on step-3 activations (measured); their share is printed and
-        bounded."""
+        interval -- stays small.  Determined weights are compared at PARAM_TOL plus their budget.  The
+        undetermined rest -- where two correct fp32 implementations may differ by a fraction of lr --
+        is checked against Adam's own bound (|update| <= ~lr per step) and then LEFT ALONE on both
+        sides.  What that does to the NEXT step is measured on the oracle alone, with a TWIN: a second
+        oracle instance that takes the same steps on its own weights, moments and history, except that
+        its gradients carry noise of 1e-5 of each tensor's max-norm before Adam sees them -- the level
+        at which the device's gradients agree with the oracle's (measured: 9e-6), i.e. the twin is "an
+        implementation that meets the gradient parity claim".  The relative distance D of the twin's
+        layer activations from the oracle's is how far two such implementations drift apart through
+        Adam's sign-like first steps; steps 2 and 3 compare activations at TOL + 3 D and gradients at
+        GRAD_TOL + 3 D (step 1: D = 0, i.e. the plain tolerances).  D is printed and bounded."""
     from stochastic_gcn_amd import synthetic, ops
     from stochastic_gcn_amd.scheduler import PyScheduler
     from oracle import model_np as mnp
@@ -325,6 +331,7 @@ def test_full_size_reddit_cvd_pp_steps_match_oracle():
                 labels=labels, ph=ph)
     probe = mnp.Model(fl, 2, True, True, True, feats, nbr, n, 41, {})
     om = mnp.Model(fl, 2, True, True, True, feats, nbr, n, 41, mnp.init_params(probe.specs, 1))
+    twin = mnp.Model(fl, 2, True, True, True, feats, nbr, n, 41, {k: v.copy() for k, v in om.params.items()})
     dm = _make_device_model(case, {k: v.copy() for k, v in om.params.items()})
     dev = torch.device('cuda:0')
     # the PP product itself at full size: both HIP SpMM kernels vs SciPy
@@ -336,52 +343,97 @@ def test_full_size_reddit_cvd_pp_steps_match_oracle():
     assert onp.rel_err(pp.cpu().numpy(), nbr) <= TOL
     del pp, Xd
     sch = PyScheduler(train_adj, labels, 1, [1], ph, 1, data=tr.copy(), cv=True)
-    well, budget = {}, {}
-    n_amb, n_und, n_w, worst = 0, 0, 0, dict(act=0.0, grad_excess=0.0, param=0.0)
+    prng = np.random.RandomState(99)
+    n_amb, n_und, n_w, worst, drift, drift_g = 0, 0, 0, dict(act=0.0, grad_excess=0.0, param=0.0), [], []
     for step in range(3):
         feed = sch.minibatch(512)
         feed[ph['dropout']] = 0.2
-        masks = _masks(dm, 0.8)
+        step_id = dm.dropout_step                            # the dropout keys of THIS step (the device advances its counter)
+        mk = lambda: mnp.HashMasks(dm.dropout_seed, step_id, 0.8)          # noqa: E731
         outs = dm.run_one_step(None, feed)
         d_acts, dg = [_np(a) for a in dm.activations[1:]], dm.get_grads()
-        # the oracle's step, taken apart so that the gradient interval can be computed before Adam moves on
+        masks = mk()
         logits, o_acts = om.forward(feed, ph, 0.2, masks)
         assert masks.calls == 4
+        # the twin's step (oracle alone: the device is not consulted), and how far it has drifted
+        t_logits, t_acts = twin.forward(feed, ph, 0.2, mk())
+        D = 0.0
+        for pa, oa in zip(t_acts, o_acts):
+            for pp_, oo in (zip(pa, oa) if isinstance(oa, tuple) else [(pa, oa)]):
+                D = max(D, onp.rel_err(pp_, oo))
+        drift.append(D)
+        _, _, _, t_dlogits = twin.loss_and_grad(t_logits, feed[ph['labels']])
+        t_grads = twin.backward(t_dlogits)
         o_loss, o_acc, _, dlogits = om.loss_and_grad(logits, feed[ph['labels']])
         lo, hi, k_amb = _gate_interval(om, dlogits)
         n_amb += k_amb
         o_grads = om.backward(dlogits)               # the oracle's own gates
+        Dg = max(onp.rel_err(t_grads[k], o_grads[k]) for k in o_grads)          # the twin's gradient drift (0 at step 1)
+        drift_g.append(Dg)
+        twin.adam_step({k: (g + 1e-5 * np.abs(g).max() * prng.standard_normal(g.shape)).astype(np.float32) for k, g in t_grads.items()})
+        twin.update_history(feed, ph)
         om.adam_step(o_grads)
         om.update_history(feed, ph)
         for da, oa in zip(d_acts, o_acts):
             for dd, oo in (zip(da, oa) if isinstance(oa, tuple) else [(da, oa)]):
-                e = onp.rel_err(dd, oo); worst['act'] = max(worst['act'], e)
-                assert e <= TOL, (step, e)
-        assert abs(outs[1] - float(o_loss)) <= 1e-4 * max(1.0, abs(float(o_loss)))
-        for k, g in o_grads.items():
-            tol = GRAD_TOL * np.abs(g).max()
-            excess = max(float((lo[k] - dg[k]).max()), float((dg[k] - hi[k]).max()), 0.0) / np.abs(g).max()
-            worst['grad_excess'] = max(worst['grad_excess'], excess)
-            assert np.all(dg[k] >= lo[k] - tol) and np.all(dg[k] <= hi[k] + tol), (step, k, excess)
-            budget[k] = 2.0 * fl['learning_rate'] * (hi[k] - lo[k]) / (np.abs(g) + 3e-7)
-            well[k] = np.abs(g) > 1e-6
+                e = onp.rel_err(dd, oo); worst['act'] = max(worst['act'], e - 3 * D)
+                assert e <= TOL + 3 * D, (step, e, D)
+        assert abs(outs[1] - float(o_loss)) <= (1e-4 + 3 * D) * max(1.0, abs(float(o_loss)))
         dp = dm.get_params()
-        for k, v in om.params.items():
+        for k, g in o_grads.items():
+            tol = (GRAD_TOL + 3 * Dg) * np.abs(g).max()
+            excess = max(float((lo[k] - dg[k]).max()), float((dg[k] - hi[k]).max()), 0.0) / np.abs(g).max()
+            worst['grad_excess'] = max(worst['grad_excess'], excess - 3 * Dg)
+            assert np.all(dg[k] >= lo[k] - tol) and np.all(dg[k] <= hi[k] + tol), (step, k, excess, Dg)
+            v = om.params[k]
             wmax = np.abs(v).max()
-            det = well[k] & (budget[k] <= 10 * PARAM_TOL * wmax)
+            budget = 2.0 * fl['learning_rate'] * (hi[k] - lo[k]) / (np.abs(g) + 3e-7)
+            det = (np.abs(g) > 1e-6) & (budget <= 10 * PARAM_TOL * wmax)
             err = np.abs(dp[k] - v)
-            e = float((err - budget[k])[det].max() / wmax); worst['param'] = max(worst['param'], e)
-            assert e <= PARAM_TOL, (step, k, e)
-            # undetermined entries: inside Adam's own bound (each side moved them by at most ~lr per step)
-            assert err[~det].max(initial=0.0) <= 2.5 * fl['learning_rate'] * (step + 1), (step, k)
-            v[~det] = dp[k][~det]
-            n_und += int((~det).sum()); n_w += det.size
+            if step == 0:        # one Adam step from identical weights: the determined entries must agree
+                e = float((err - budget)[det].max(initial=0.0) / wmax); worst['param'] = max(worst['param'], e)
+                assert e <= PARAM_TOL, (step, k, e)
+                n_und += int((~det).sum()); n_w += det.size
+            # every entry: inside Adam's own bound (each side moved it by at most ~lr per step); nothing is copied
+            assert err.max(initial=0.0) <= 2.5 * fl['learning_rate'] * (step + 1), (step, k)
         idx = feed[ph['fields'][0]]
         assert onp.rel_err(dm.history[0][0][torch.from_numpy(idx).long().to(dev)].cpu().numpy(),
-                           om.history[0][idx]) <= TOL
-    assert onp.rel_err(dm.history[0][0].cpu().numpy(), om.history[0]) <= TOL
-    print("full-size parity, 3 unsynchronised steps: %d ambiguous ReLU gates (|pre| < %.0e); worst rel err  "
-          "activations %.1e  grad outside the gate interval %.1e  determined weights %.1e; %.2f %% of the "
-          "weight updates undetermined at fp32 (taken from the device after the Adam-bound check)"
-          % (n_amb, BAND, worst['act'], worst['grad_excess'], worst['param'], 100.0 * n_und / max(n_w, 1)))
-    assert n_und <= 0.25 * n_w
+                           om.history[0][idx]) <= TOL + 3 * D
+    assert onp.rel_err(dm.history[0][0].cpu().numpy(), om.history[0]) <= TOL + 3 * max(drift)
+    print("full-size parity, 3 unsynchronised steps, nothing fed from the device: %d ambiguous ReLU gates (|pre| < %.0e); "
+          "twin drift per step: activations %s gradients %s; worst rel err beyond 3 x drift: activations %.1e  gradient "
+          "outside the gate interval %.1e; step-1 determined weights %.1e, %.2f %% of the first weight updates undetermined at "
+          "fp32 (left alone on both sides)"
+          % (n_amb, BAND, ["%.1e" % d for d in drift], ["%.1e" % d for d in drift_g], worst['act'], worst['grad_excess'],
+             worst['param'], 100.0 * n_und / max(n_w, 1)))
+    # step 1 is the strict one (no drift yet); the later steps are bounded by what Adam's sign-like first updates do to ANY
+    # two implementations that agree on gradients to 1e-5 (the twin): a few per cent by step 3
+    assert drift[0] == 0.0 and drift_g[0] == 0.0 and max(drift) <= 0.1 and n_und <= 0.25 * n_w
+    # ---- the history path across steps, STRICT: the same three-step run with the learning rate at 0 ----------------
+    # (weights stay put on both sides, so nothing is ill-conditioned; the control-variate history is not: step k's
+    # aggregator reads the rows steps < k scattered, on each side from its own 119 MB history)
+    from stochastic_gcn_amd.flags import FLAGS
+    fl0 = dict(fl, learning_rate=0.0)
+    om0 = mnp.Model(fl0, 2, True, True, True, feats, nbr, n, 41, mnp.init_params(probe.specs, 1))
+    dm0 = _make_device_model(dict(case, flags=fl0), {k: v.copy() for k, v in om0.params.items()})
+    assert FLAGS.learning_rate == 0.0
+    sch0 = PyScheduler(train_adj, labels, 1, [1], ph, 1, data=tr.copy(), cv=True)
+    worst0, touched = 0.0, 0
+    for step in range(3):
+        feed = sch0.minibatch(512)
+        feed[ph['dropout']] = 0.2
+        step_id = dm0.dropout_step
+        outs = dm0.run_one_step(None, feed)
+        d_acts = [_np(a) for a in dm0.activations[1:]]
+        o_loss, _, _, o_acts, _ = om0.run_one_step(feed, ph, 0.2, mnp.HashMasks(dm0.dropout_seed, step_id, 0.8))
+        for da, oa in zip(d_acts, o_acts):
+            for dd, oo in (zip(da, oa) if isinstance(oa, tuple) else [(da, oa)]):
+                e = onp.rel_err(dd, oo); worst0 = max(worst0, e)
+                assert e <= TOL, ("lr = 0", step, e)
+        assert abs(outs[1] - float(o_loss)) <= 1e-4 * max(1.0, abs(float(o_loss)))
+        touched += len(feed[ph['fields'][0]])
+    for k, v in om0.params.items():
+        np.testing.assert_array_equal(dm0.get_params()[k], v)               # (nothing moved)
+    assert onp.rel_err(dm0.history[0][0].cpu().numpy(), om0.history[0]) <= TOL and float(np.abs(om0.history[0]).sum()) > 0
+    print("full-size history path, 3 unsynchronised steps at learning rate 0 (%d history rows written, read back by later "
+          "steps): worst activation rel err %.1e" % (touched, worst0))
