@@ -437,3 +437,48 @@ def test_full_size_reddit_cvd_pp_steps_match_oracle():
     assert onp.rel_err(dm0.history[0][0].cpu().numpy(), om0.history[0]) <= TOL and float(np.abs(om0.history[0]).sum()) > 0
     print("full-size history path, 3 unsynchronised steps at learning rate 0 (%d history rows written, read back by later "
           "steps): worst activation rel err %.1e" % (touched, worst0))
+
+
+@pytest.mark.parametrize("mode,degree", [("NS", 20), ("Exact", 10000)])
+def test_full_size_non_pp_two_hops_match_oracle(mode, degree):
+    """SURVEY.md 8f f-4 AT SCALE (it existed only as a probe): the full S-Reddit graph (N = 232,965, 602
+    features), NO preprocessing, two sampled hops -- neighbour sampling with degree 20 (512 -> ~10 k -> ~106 k vertices,
+    ~200 k sampled edges: the true "sampled SpMM" regime of K1) and Exact (degree 10000: the receptive field is most of
+    the graph, all 154 k training vertices, 2.9 M edges in the input-side hop) -- PlainGCN, graphsage concat, LayerNorm, dropout 0.2: one training
+    step, device vs NumPy oracle.  Forward (every layer activation, loss, accuracy) at 1e-4.  Gradients: with 13-30 M
+    ReLU inputs a few hundred land within fp32 rounding of zero and their gates are not determined (the enumeration of
+    the batch-512 CVD test would need hundreds of backward passes here), so they are compared at 2e-4 of each tensor's
+    max-norm (measured: 6e-6 / 6e-5)."""
+    from stochastic_gcn_amd import synthetic
+    from stochastic_gcn_amd.scheduler import PyScheduler
+    from oracle import model_np as mnp
+    n, train_adj, _, _, _, _, labels, tr, _, _ = synthetic.reddit_like(with_features=False)
+    rng = np.random.RandomState(0)
+    feats = rng.standard_normal((n, 602)).astype(np.float32)
+    fl = mnp.make_flags(normalization='graphsage', weight_decay=0.0, dropout=0.2, layer_norm=True, hidden1=128,
+                        num_fc_layers=1, cv=False, cvd=False, degree=degree, preprocess=False, num_layers=2)
+    ph = mc.placeholders(2, 41)
+    case = dict(cfg=dict(model='plain', n=n, classes=41), flags=fl, adj=train_adj, feats=feats, nbr=feats, labels=labels, ph=ph)
+    probe = mnp.Model(fl, 2, False, False, False, feats, feats, n, 41, {})
+    om = mnp.Model(fl, 2, False, False, False, feats, feats, n, 41, mnp.init_params(probe.specs, 1))
+    dm = _make_device_model(case, {k: v.copy() for k, v in om.params.items()})
+    sch = PyScheduler(train_adj, labels, 2, [degree, degree], ph, 1, data=tr.copy(), cv=False)
+    feed = sch.minibatch(512)
+    feed[ph['dropout']] = 0.2
+    sizes = [int(feed[ph['fields'][l]].shape[0]) for l in range(3)]
+    edges = [int(feed[ph['adj'][l]][1].shape[0]) for l in range(2)]
+    assert sizes[2] == 512 and sizes[0] > (100000 if mode == "Exact" else 50000) and edges[0] > (2_000_000 if mode == "Exact" else 150_000)
+    masks = _masks(dm, 0.8)
+    outs = dm.run_one_step(None, feed)
+    d_acts, dg = [_np(a) for a in dm.activations[1:]], dm.get_grads()
+    o_loss, o_acc, _, o_acts, o_grads = om.run_one_step(feed, ph, 0.2, masks)
+    worst = 0.0
+    for da, oa in zip(d_acts, o_acts):
+        for dd, oo in (zip(da, oa) if isinstance(oa, tuple) else [(da, oa)]):
+            e = onp.rel_err(dd, oo); worst = max(worst, e)
+            assert e <= TOL, (mode, e)
+    assert abs(outs[1] - float(o_loss)) <= 1e-4 * max(1.0, abs(float(o_loss))) and abs(outs[2] - float(o_acc)) <= 1e-6
+    gw = max(onp.rel_err(dg[k], g) for k, g in o_grads.items())
+    assert gw <= 2e-4, (mode, gw)
+    print("full-size %s, no PP, 2 hops: fields %s, sampled edges %s; worst rel err activations %.1e, gradients %.1e"
+          % (mode, sizes, edges, worst, gw))
