@@ -715,9 +715,23 @@ def main(argv=None):
             t_model = miss_b / (gc["miss"] * 1e12) + hit_b / (gc["hit"] * 1e12)
             out["roofline"]["gather_ceiling"]["ms_model_for_profiled_traffic"] = t_model * 1e3
             out["roofline"]["frac_of_traffic_model"] = t_model / (fwd_ms * 1e-3)
+    def emit():
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
     if world > 1 and sh is None and not args.no_strong:
         # the weak line above is ~N x by construction (every rank its own graph + a 0.84 MB all-reduce); the
-        # informative numbers of a multi-GPU run are these
+        # informative numbers of a multi-GPU run are these.  A watchdog bounds a wedged collective (RCCL has not run on
+        # hardware yet): the weak line is still printed.
+        import threading
+
+        def bail_strong():
+            out["strong"] = {"error": "timed out after %d s" % args.epoch_timeout}
+            emit()
+            os._exit(0)
+        sdog = threading.Timer(args.epoch_timeout, bail_strong)
+        sdog.daemon = True
+        sdog.start()
         try:
             adj0 = full_adj if rank == 0 else make_graph(args, 0)[1]
             del A
@@ -726,14 +740,11 @@ def main(argv=None):
             out["strong"]["grad_allreduce_ms"] = ar_ms
         except Exception as e:
             out["strong"] = {"error": repr(e)}
+        sdog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(full_adj, d, args.cpu_sample_rows)
         if data10 is not None:
             out["cpu_baseline"]["sampler"] = sampler_baseline(data10)
-
-    def emit():
-        if rank == 0:
-            print(json.dumps(out), flush=True)
 
     if not args.no_epoch and data10 is not None and sh is None:
         # the minibatch training epoch, on every rank (vertex-range shards, RCCL gradient
