@@ -341,6 +341,44 @@ int sgcn_l2_penalty_f32(const float* dev_theta, int64_t lo, int64_t hi, float wd
 int sgcn_adam_f32(float* dev_theta, const float* dev_grad, float* dev_m, float* dev_v, int64_t n,
                   float lr_t, float beta1, float beta2, float eps, void* stream);
 
+/* ---- deterministic dropout (--det_dropout; gcn/layers.py:141-202, 236-248, 320-349, 425-428): the element-wise and
+ * row-wise pieces of the moment-propagation variant, forward and backward (autodiff of the reference's formulas).  The
+ * variant's matrix products are sgcn_gemm_f32 / sgcn_spmm_csr_f32.  All arrays dense with pitch d unless a pitch is given. */
+/* var_out = var / keep + (1 / keep - 1) mu^2 (var NULL: 0)                                   layers.py:168-176 */
+int sgcn_det_pre_f32(const float* dev_mu, const float* dev_var, int64_t n, float keep, float* dev_var_out, void* stream);
+/* d_mu += g 2 (1 / keep - 1) mu;  d_var = g / keep (d_var nullable) */
+int sgcn_det_pre_bwd_f32(const float* dev_mu, const float* dev_g, int64_t n, float keep, float* dev_d_mu, float* dev_d_var,
+                         void* stream);
+int sgcn_square_f32(const float* dev_x, int64_t n, float c, float* dev_y, void* stream);                 /* y = c x^2 */
+int sgcn_addmul_f32(float* dev_acc, const float* dev_a, const float* dev_b, int64_t n, float c, void* stream); /* acc += c a b */
+/* var2 = var1 scale^2 / variance, variance of the mean stream's row recovered from its rstd = rsqrt(variance + eps)  :184-188 */
+int sgcn_det_lnvar_fwd_f32(const float* dev_var1, const float* dev_rstd, const float* dev_scale, int32_t n, int32_t d, float eps,
+                           float* dev_var2, void* stream);
+/* d_var1 = g scale^2 / V;  d_mu1 += dV 2 (mu1 - mean) / d;  dscale += column sums of g var1 2 scale / V.  tmp: n * d floats */
+int sgcn_det_lnvar_bwd_f32(const float* dev_g, const float* dev_var1, const float* dev_xhat, const float* dev_rstd,
+                           const float* dev_scale, int32_t n, int32_t d, float eps, float* dev_d_var1, float* dev_d_mu1,
+                           float* dev_dscale, float* dev_tmp, void* stream);
+/* ReLU by moment matching of a Gaussian (mu, var) -> (mean, variance) of max(x, 0)                        :190-202 */
+int sgcn_det_relu_fwd_f32(const float* dev_mu, const float* dev_var, int64_t n, float* dev_mu_out, float* dev_var_out, void* stream);
+int sgcn_det_relu_bwd_f32(const float* dev_mu, const float* dev_var, const float* dev_g_mu, const float* dev_g_var, int64_t n,
+                          float* dev_d_mu, float* dev_d_var, void* stream);
+/* x = mu + eps sqrt(var + 1e-10), eps ~ N(0, 1) a pure function of (key, element index): Box-Muller on two fmix32 hashes
+ * (tf.random_normal in the reference, :427: a stateful generator nothing outside TensorFlow can replay).  d_mu = g. */
+int sgcn_gauss_sample_f32(const float* dev_mu, const float* dev_var, int64_t n, uint32_t key, float* dev_x, void* stream);
+int sgcn_gauss_sample_bwd_f32(const float* dev_var, const float* dev_g, int64_t n, uint32_t key, float* dev_d_var, void* stream);
+/* operands of the control-variate aggregator on (mu, var), :320-349: delta_mu = mu - Hm[if], ds = sqrt(var) - sqrt(Hv[if]),
+ * ds2 = ds^2, msig2 = 2 ds sqrt(Hv[if]); sbar = sqrt(Hv[if]) */
+int sgcn_det_agg_prep_f32(const float* dev_mu, const float* dev_var, const float* dev_Hm, const float* dev_Hv, int64_t ldh,
+                          const int32_t* dev_ifield, int32_t n0, int32_t d, float* dev_delta_mu, float* dev_ds2, float* dev_msig2,
+                          float* dev_ds, float* dev_sbar, void* stream);
+/* d_var = (2 ds g_ds2 + 2 sbar g_msig2) / (2 sqrt(var)) (+ add[r] for rows r < add_rows: the self half of a concat aggregator) */
+int sgcn_det_agg_prep_bwd_f32(const float* dev_var, const float* dev_ds, const float* dev_sbar, const float* dev_g_ds2,
+                              const float* dev_g_msig2, int32_t n0, int32_t d, const float* dev_add, int64_t ldadd,
+                              int32_t add_rows, float* dev_d_var, void* stream);
+/* y = relu(raw) + eps;   out = raw > 0 ? g : 0 */
+int sgcn_relu_eps_f32(const float* dev_raw, int64_t ldr, int32_t n, int32_t d, float eps, float* dev_y, int64_t ldy, void* stream);
+int sgcn_gate_f32(const float* dev_raw, int64_t ldr, const float* dev_g, int64_t ldg, int32_t n, int32_t d, float* dev_out, void* stream);
+
 /* ======================================================================================
  * Host neighbour sampler (stays on host: BASELINE.json north_star)
  *   replaces class Scheduler gcn/scheduler.h:6-28, gcn/scheduler.cpp:11-189

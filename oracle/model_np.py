@@ -22,6 +22,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import oracle_np as onp
+from . import det_np
 
 f32 = np.float32
 
@@ -52,7 +53,9 @@ def layer_specs(flags, L_after_pp, preprocess, cvd, input_dim, output_dim, spars
             sparse_in = sparse_mm if l == 0 else False
             last = L_after_pp == 0 and l + 1 == nfc
             out_dim = output_dim if last else H
-            if cvd:
+            if flags['det_dropout']:                                # gcn/models.py:275-282
+                specs.append(('det', 'dense%d' % cnt, in_dim, H, sparse_in, flags['layer_norm']))
+            elif cvd:
                 specs.append(('add', 'dense%d' % cnt, in_dim, H, sparse_in, flags['layer_norm']))
             else:
                 specs.append(('dropout',))
@@ -67,7 +70,9 @@ def layer_specs(flags, L_after_pp, preprocess, cvd, input_dim, output_dim, spars
             last = l2 + 1 == nfc and l + 1 == L_after_pp
             out_dim = output_dim if last else H
             norm = False if last else flags['layer_norm']
-            if cvd and l + 1 != L_after_pp:
+            if flags['det_dropout'] and l + 1 != L_after_pp:        # gcn/models.py:312-318
+                specs.append(('det', 'dense%d' % cnt, in_dim, out_dim, False, norm))
+            elif cvd and l + 1 != L_after_pp:
                 specs.append(('add', 'dense%d' % cnt, in_dim, out_dim, False, norm))
             else:
                 if not flags['reverse']:
@@ -84,11 +89,11 @@ def init_params(specs, seed):
     rng = np.random.RandomState(seed)
     params = {}
     for s in specs:
-        if s[0] in ('add', 'dense'):
+        if s[0] in ('add', 'dense', 'det'):
             name, fin, fout = s[1], s[2], s[3]
             lim = np.sqrt(6.0 / (fin + fout))
             params[name + '/weights'] = rng.uniform(-lim, lim, (fin, fout)).astype(f32)
-            norm = s[5] if s[0] == 'add' else s[6]
+            norm = s[6] if s[0] == 'dense' else s[5]
             if norm:
                 params[name + '/offset'] = np.zeros((1, fout), f32)
                 params[name + '/scale'] = np.ones((1, fout), f32)
@@ -154,6 +159,12 @@ class HashMasks(object):
         self.calls += 1
         return hash_mask(dropout_key(self.seed, int(tag[1:]), self.step), tuple(shape), self.keep)
 
+    def noise(self, tag, shape):
+        """N(0, 1) of the Gaussian re-sampling in front of a det-dropout model's last Dropout (layer index + 4096
+        keeps its stream apart from the layer's dropout mask)."""
+        from . import det_np
+        return det_np.gauss_noise(dropout_key(self.seed, int(tag[1:]) + 4096, self.step), tuple(shape))
+
 
 def dropout_fwd(x, keep_prob, mask):
     """tf.nn.dropout: x * mask / keep_prob with mask in {0,1}."""
@@ -208,6 +219,10 @@ class Model(object):
         # zero-initialised N x dims history per aggregator layer (gcn/vrgcn.py:23-36)
         self.history = [np.zeros((num_data, agg0 if i == 0 else H), f32) for i in range(self.L)] \
             if self.cv else []
+        # det-dropout keeps (mean, variance) histories: n_history = 2 (gcn/vrgcn.py:28)
+        self.history_var = [np.zeros_like(h) for h in self.history] if flags['det_dropout'] else []
+        if flags['det_dropout'] and (self.cvd or flags['reverse'] or self.sparse_mm or self.L == 0):
+            raise ValueError("det_dropout: the reference has no working cvd / reverse / sparse-input / one-layer form")
         self.adam_t = 0
         self.adam_m = {k: np.zeros_like(v) for k, v in params.items()}
         self.adam_v = {k: np.zeros_like(v) for k, v in params.items()}
@@ -247,6 +262,19 @@ class Model(object):
                 out = (np.maximum(xs_n, 0).astype(f32), np.maximum(mus_n, 0).astype(f32))
                 tape.append(('add', s, xd, m, keep, ctx, xs_n))
                 act = out
+            elif kind == 'det':                                    # DetDropoutFC, gcn/layers.py:141-202
+                _, name, fin, fout, sparse_in, norm = s
+                off = self.params[name + '/offset'] if norm else None
+                sc = self.params[name + '/scale'] if norm else None
+                act, ctx = det_np.fc_fwd(act, self.params[name + '/weights'], off, sc, keep)
+                tape.append(('det', s, ctx))
+            elif kind == 'dropout' and isinstance(act, tuple) and not self.cvd:   # gcn/layers.py:425-428
+                mu_, var_ = act
+                eps_ = masks.noise('L%d' % li, mu_.shape)
+                x_ = det_np.sample_fwd(mu_, var_, eps_)
+                m = masks('L%d' % li, x_.shape) if dropout > 0 else None
+                act = dropout_fwd(x_, keep, m)
+                tape.append(('gauss', m, keep, var_, eps_))
             elif kind == 'dropout':
                 if self.cvd and isinstance(act, tuple):            # gcn/layers.py:423-425
                     h = act[0]
@@ -279,7 +307,18 @@ class Model(object):
             elif kind == 'agg':
                 l = s[1]
                 adj = onp.coo_to_csr(feed[ph['adj'][l]])
-                if self.cv:
+                if isinstance(act, tuple) and not self.cvd:        # (mu, var): gcn/layers.py:236-248, 320-349
+                    if self.cv:
+                        fadj = onp.coo_to_csr(feed[ph['fadj'][l]])
+                        madj = onp.coo_to_csr(feed[ph['madj'][l]])
+                        new_hist[l] = act                          # self.new_history = (mu, var), :341
+                        act, ctx = det_np.vr_agg_fwd(adj, fadj, madj, act[0], act[1], self.history[l],
+                                                     self.history_var[l], feed[ph['fields'][l]],
+                                                     feed[ph['ffields'][l]], concat)
+                    else:
+                        act, ctx = det_np.plain_agg_fwd(adj, act[0], act[1], concat)
+                    tape.append(('detagg', ctx, self.cv))
+                elif self.cv:
                     fadj = onp.coo_to_csr(feed[ph['fadj'][l]])
                     ifield, ffield = feed[ph['fields'][l]], feed[ph['ffields'][l]]
                     scale = feed[ph['scales'][l]]
@@ -331,7 +370,7 @@ class Model(object):
 
     def _wd_names(self):
         for s in self.specs:
-            if s[0] == 'add':
+            if s[0] in ('add', 'det'):
                 return [k for k in (s[1] + '/weights', s[1] + '/offset', s[1] + '/scale') if k in self.params]
             if s[0] == 'dense':
                 return [s[1] + '/weights']       # MyLayerNorm vars are not in Dense.vars
@@ -366,6 +405,24 @@ class Model(object):
                 else:
                     grads[name + '/weights'] += (xin.T @ g).astype(f32)
                     g = (g @ W.T).astype(f32)
+            elif kind == 'det':
+                _, s, ctx = rec
+                name, norm = s[1], s[5]
+                g, dW, doff, dsc = det_np.fc_bwd(g, ctx)
+                grads[name + '/weights'] += dW
+                if norm:
+                    grads[name + '/offset'] += doff
+                    grads[name + '/scale'] += dsc
+                if g[1] is None:                                   # plain (first-layer) input
+                    g = g[0]
+            elif kind == 'gauss':
+                _, m, keep, var_, eps_ = rec
+                if m is not None:
+                    g = (g * (m * f32(1.0 / keep))).astype(f32)
+                g = det_np.sample_bwd(g, var_, eps_)
+            elif kind == 'detagg':
+                _, ctx, cv = rec
+                g = det_np.vr_agg_bwd(g, ctx) if cv else det_np.plain_agg_bwd(g, ctx)
             elif kind == 'dropout':
                 _, m, keep, _ = rec
                 if g is not None and m is not None:
@@ -422,7 +479,11 @@ class Model(object):
         """tf.scatter_update(history, fields[l], new_history) after the optimizer step
         (gcn/models.py:160-166,186-194)."""
         for l, nh in self._new_hist.items():
-            onp.scatter_rows(self.history[l], feed[ph['fields'][l]], nh)
+            if isinstance(nh, tuple):
+                onp.scatter_rows(self.history[l], feed[ph['fields'][l]], nh[0])
+                onp.scatter_rows(self.history_var[l], feed[ph['fields'][l]], nh[1])
+            else:
+                onp.scatter_rows(self.history[l], feed[ph['fields'][l]], nh)
 
     def run_one_step(self, feed, ph, dropout, masks):
         logits, acts = self.forward(feed, ph, dropout if self.is_training else 0.0, masks)

@@ -110,6 +110,20 @@ SIGNATURES = {
     "sgcn_dense_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P, P,
                                      C.c_int32, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, P, P, C.c_int64,
                                      P, P, P, P, P]),
+    "sgcn_det_pre_f32": (C.c_int, [P, P, C.c_int64, C.c_float, P, P]),
+    "sgcn_det_pre_bwd_f32": (C.c_int, [P, P, C.c_int64, C.c_float, P, P, P]),
+    "sgcn_square_f32": (C.c_int, [P, C.c_int64, C.c_float, P, P]),
+    "sgcn_addmul_f32": (C.c_int, [P, P, P, C.c_int64, C.c_float, P]),
+    "sgcn_det_lnvar_fwd_f32": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_float, P, P]),
+    "sgcn_det_lnvar_bwd_f32": (C.c_int, [P, P, P, P, P, C.c_int32, C.c_int32, C.c_float, P, P, P, P, P]),
+    "sgcn_det_relu_fwd_f32": (C.c_int, [P, P, C.c_int64, P, P, P]),
+    "sgcn_det_relu_bwd_f32": (C.c_int, [P, P, P, P, C.c_int64, P, P, P]),
+    "sgcn_gauss_sample_f32": (C.c_int, [P, P, C.c_int64, C.c_uint32, P, P]),
+    "sgcn_gauss_sample_bwd_f32": (C.c_int, [P, P, C.c_int64, C.c_uint32, P, P]),
+    "sgcn_det_agg_prep_f32": (C.c_int, [P, P, P, P, C.c_int64, P, C.c_int32, C.c_int32, P, P, P, P, P, P]),
+    "sgcn_det_agg_prep_bwd_f32": (C.c_int, [P, P, P, P, P, C.c_int32, C.c_int32, P, C.c_int64, C.c_int32, P, P]),
+    "sgcn_relu_eps_f32": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, C.c_float, P, C.c_int64, P]),
+    "sgcn_gate_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
     "sgcn_dropout_f32": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, C.c_int64, P]),
     "sgcn_softmax_ce_f32": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64,
                                       P, C.c_int64, P, P, P]),

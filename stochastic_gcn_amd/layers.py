@@ -111,12 +111,20 @@ class Dropout(Layer):
         super(Dropout, self).__init__(**kw)
         self.keep_prob_fn, self.cvd = keep_prob_fn, cvd
         self.fuse_next = False      # models.py: the consumer is a Dense layer that applies the mask itself
+        self.noise_key_fn = None    # models.py: () -> key of this layer's normal deviates at the current step
 
     def forward(self, inputs):
         keep = self.keep_prob_fn()
-        self._drop, self._sparse, self._fused = self.drop_site(keep), False, False
+        self._drop, self._sparse, self._fused, self._gauss = self.drop_site(keep), False, False, None
         if self.cvd and isinstance(inputs, tuple):
             inputs = inputs[0]                          # keeps only dropout(h), :423-425
+        elif isinstance(inputs, tuple):
+            # det-dropout (mu, var): draw x ~ N(mu, var + 1e-10), then ordinary dropout (:425-428).  The normal
+            # deviates are a counter hash like the masks (layer index + 4096 keeps the two streams apart)
+            mu, var = inputs
+            key = self.noise_key_fn() if self.noise_key_fn else ops.dropout_key(FLAGS.seed, self.index + 4096, 0)
+            self._gauss = (var, key)
+            inputs = ops.gauss_sample(mu, var, key)
         if isinstance(inputs, SparseInput):
             self._sparse = True
             if self._drop is None:
@@ -138,9 +146,12 @@ class Dropout(Layer):
         return pending.materialize()
 
     def backward(self, g):
-        if g is None or self._sparse or self._drop is None or self._fused:
-            return g                  # fused: the consumer's dx GEMM already applied the mask
-        return ops.dropout(g, self._drop)
+        if not (g is None or self._sparse or self._drop is None or self._fused):
+            g = ops.dropout(g, self._drop)        # (fused: the consumer's dx GEMM already applied the mask)
+        if self._gauss is not None and g is not None:
+            var, key = self._gauss
+            return g, ops.gauss_sample_bwd(var, g, key)
+        return g
 
 
 class Dense(Layer):
@@ -273,17 +284,97 @@ class AugmentedDropoutDense(Layer):
                              self.grads.get('scale'), need_dx=self.need_dx, drop=self._drop)
 
 
+class DetDropoutFC(Layer):
+    """gcn/layers.py:141-202: X -> Dropout -> Linear -> LayerNorm -> ReLU with the dropout noise integrated out: the
+    layer maps (mean, variance) to (mean, variance).  The two linear maps are ops.gemm (mu W and var_in (1.2 W^2), the
+    factor being the reference's own `* 1.2  # TODO hack`), the mean stream's LayerNorm is the ordinary fused kernel,
+    everything else is sgcn_det.hip; the backward is the hand-derived one the oracle pins against autograd."""
+    LN_EPS = 1e-10
+
+    def __init__(self, keep_prob_fn, input_dim, output_dim, sparse_inputs=False, norm=True, **kw):
+        super(DetDropoutFC, self).__init__(**kw)
+        if sparse_inputs:
+            raise NotImplementedError("det_dropout on sparse input features (the reference marks it TODO, "
+                                      "gcn/layers.py:145)")
+        self.keep_prob_fn, self.input_dim, self.output_dim, self.norm = keep_prob_fn, input_dim, output_dim, norm
+
+    def param_shapes(self):
+        s = [('weights', (self.input_dim, self.output_dim), 'glorot')]
+        if self.norm:
+            s += [('offset', (1, self.output_dim), 'zeros'), ('scale', (1, self.output_dim), 'ones')]
+        return s
+
+    def wd_vars(self):
+        return [n for n, _, _ in self.param_shapes()]
+
+    def forward(self, inputs):
+        mu, var = inputs if isinstance(inputs, tuple) else (dense_of(inputs), None)
+        keep = self.keep_prob_fn()
+        W = self.vars['weights']
+        var_in = ops.det_pre(mu, var, keep)
+        W2 = ops.square(W, 1.2)
+        mu1, var1 = ops.gemm(mu, W), ops.gemm(var_in, W2)
+        ctx = None
+        if self.norm:
+            mu2, ctx = ops.ln_act_fwd(mu1, self.vars['offset'], self.vars['scale'], False, eps=self.LN_EPS)
+            var2 = ops.det_lnvar_fwd(var1, ctx[1], self.vars['scale'], self.LN_EPS)
+        else:
+            mu2, var2 = mu1, var1
+        self._saved = (mu, var is not None, var_in, W2, var1, mu2, var2, ctx, keep)
+        return ops.det_relu_fwd(mu2, var2)
+
+    def backward(self, g):
+        mu, had_var, var_in, W2, var1, mu2, var2, ctx, keep = self._saved
+        W = self.vars['weights']
+        g_mu, g_var = ops.det_relu_bwd(mu2, var2, g[0].contiguous(), g[1].contiguous())
+        if self.norm:
+            sc = self.vars['scale']
+            g_mu1 = ops.ln_act_bwd(g_mu, mu2, ctx, sc, False, self.grads['offset'], self.grads['scale'])
+            g_var = ops.det_lnvar_bwd(g_var, var1, ctx[0], ctx[1], sc, self.LN_EPS, g_mu1, self.grads['scale'])
+            g_mu = g_mu1
+        # dW = mu^T d_mu1 + 2.4 W (.) (var_in^T d_var1)
+        ops.gemm(mu, g_mu, out=self.grads['weights'], trans_a=True, accumulate=True)
+        ops.addmul(self.grads['weights'], W, ops.gemm(var_in, g_var, trans_a=True), 2.4)
+        if not self.need_dx:
+            return None
+        d_mu = ops.gemm(g_mu, W, trans_b=True)
+        d_var = ops.det_pre_bwd(mu, ops.gemm(g_var, W2, trans_b=True), keep, d_mu, had_var)
+        return (d_mu, d_var) if had_var else d_mu
+
+
+def _squared(A):
+    """tf.square(adj) of a DeviceCSR (and of its transpose): same structure and launch plan, squared values."""
+    A2 = ops.DeviceCSR(A.shape, A.rowptr, A.col, ops.square(A.val), A.plan)
+    if A.transpose is not None:
+        T = A.transpose
+        A2.transpose = ops.DeviceCSR(T.shape, T.rowptr, T.col, ops.square(T.val), T.plan)
+    return A2
+
+
 class PlainAggregator(Layer):
-    """gcn/layers.py:214-257 (non-det-dropout branch): Z = A.H, or concat(H[:n1], A.H)."""
+    """gcn/layers.py:214-257: Z = A.H, or concat(H[:n1], A.H); on (mu, var): A.mu and A^2.var."""
 
     def __init__(self, model, l, **kw):
         super(PlainAggregator, self).__init__(**kw)
         self.model, self.l = model, l
 
     def forward(self, x):
-        x = dense_of(x)
         A = self.model.cur.adj[self.l]
         concat = FLAGS.normalization != 'gcn'
+        self._det = isinstance(x, tuple)
+        if self._det:                                   # (mu, var): A mu and A^2 var, gcn/layers.py:236-248
+            mu, var = x
+            n1, d = A.shape[0], mu.shape[1]
+            self._A, self._A2, self._concat, self._d = A, _squared(A), concat, d
+            if not concat:
+                return ops.spmm(A, mu), ops.spmm(self._A2, var)
+            om = torch.empty((n1, 2 * d), dtype=torch.float32, device=mu.device)
+            ov = torch.empty((n1, 2 * d), dtype=torch.float32, device=mu.device)
+            om[:, :d], ov[:, :d] = mu[:n1], var[:n1]
+            ops.spmm(A, mu, out=om[:, d:])
+            ops.spmm(self._A2, var, out=ov[:, d:])
+            return om, ov
+        x = dense_of(x)
         n1, d = A.shape[0], x.shape[1]
         self._A, self._concat, self._d = A, concat, d
         if not concat:
@@ -295,6 +386,12 @@ class PlainAggregator(Layer):
 
     def backward(self, g):
         A, d = self._A, self._d
+        if self._det:
+            A2, n1 = self._A2, A.shape[0]
+            if not self._concat:
+                return ops.spmm(A.transpose, g[0]), ops.spmm(A2.transpose, g[1])
+            return (ops.spmm(A.transpose, g[0][:, d:], add=g[0][:, :d], add_rows=n1),
+                    ops.spmm(A2.transpose, g[1][:, d:], add=g[1][:, :d], add_rows=n1))
         if not self._concat:
             return ops.spmm(A.transpose, g)
         # dX = A^T g_nbr + [g_self ; 0]: the self term rides in the SpMM epilogue (one launch)
@@ -314,6 +411,9 @@ class VRAggregator(Layer):
         A, P = cur.adj[l], cur.fadj[l]
         concat = FLAGS.normalization != 'gcn'
         hist = self.model.history[l][0]
+        self._det = isinstance(inputs, tuple) and not self.cvd
+        if self._det:
+            return self._forward_det(inputs, cur, A, P, concat)
         if self.cvd:
             h, mu = (dense_of(t) for t in inputs)
             out_h, out_mu = ops.vr_aggregate(A, P, h, mu, hist, cur.fields[l], cur.ffields[l],
@@ -330,9 +430,55 @@ class VRAggregator(Layer):
         self._d = (inputs[0] if self.cvd else inputs).shape[1]
         return out
 
+    def _forward_det(self, inputs, cur, A, P, concat):
+        """gcn/layers.py:320-349: the control-variate estimator on (mu, var) with a mean and a variance history:
+            mu_nbr  = A (mu - Hm[if]) + P Hm[ff]
+            var_nbr = relu(A^2 ds^2 + P^2 Hv[ff] + 2 M (ds . sbar)) + 1e-10,  ds = sqrt(var) - sbar, sbar = sqrt(Hv[if])
+        M = the adjacency pattern with the sampler's medg weights.  Seven SpMMs on the general kernel (the history rows are
+        read through the index, never gathered) around two element-wise launches."""
+        l = self.l
+        mu, var = inputs
+        Hm, Hv = self.model.history[l]
+        ifield, ffield = cur.fields[l], cur.ffields[l]
+        n1, d = A.shape[0], mu.shape[1]
+        A2, P2, M = _squared(A), _squared(P), cur.madj[l]
+        delta_mu, ds2, msig2, ds, sbar = ops.det_agg_prep(mu, var, Hm, Hv, ifield)
+        w = 2 * d if concat else d
+        om = torch.empty((n1, w), dtype=torch.float32, device=mu.device)
+        ov = torch.empty((n1, w), dtype=torch.float32, device=mu.device)
+        nb = om[:, d:] if concat else om
+        ops.spmm(A, delta_mu, out=nb)
+        ops.spmm(P, Hm, gidx=ffield, out=nb, beta=1.0)
+        raw = ops.spmm(A2, ds2)
+        ops.spmm(P2, Hv, gidx=ffield, out=raw, beta=1.0)
+        ops.spmm(M, msig2, out=raw, beta=1.0)
+        ops.relu_eps(raw, 1e-10, out=ov[:, d:] if concat else ov)
+        if concat:
+            om[:, :d], ov[:, :d] = mu[:n1], var[:n1]
+        self.new_history = [mu, var]
+        self._A, self._concat, self._d = A, concat, d
+        self._saved = (A2, M, var, ds, sbar, raw)
+        return om, ov
+
+    def _backward_det(self, g):
+        A, d, n1 = self._A, self._d, self._A.shape[0]
+        A2, M, var, ds, sbar, raw = self._saved
+        gm, gv = (g[0][:, d:], g[1][:, d:]) if self._concat else g
+        gv = ops.gate(raw, gv)
+        if self._concat:
+            d_mu = ops.spmm(A.transpose, gm, add=g[0][:, :d], add_rows=n1)
+        else:
+            d_mu = ops.spmm(A.transpose, gm)
+        g_ds2, g_msig2 = ops.spmm(A2.transpose, gv), ops.spmm(M.transpose, gv)
+        d_var = ops.det_agg_prep_bwd(var, ds, sbar, g_ds2, g_msig2, add=g[1][:, :d] if self._concat else None,
+                                     add_rows=n1 if self._concat else 0)
+        return d_mu, d_var
+
     def backward(self, g):
         """d/dh of h_nbr = (A (h - mu)) * s + mu_nbr  ->  A^T (s (.) g_nbr); mu and the history
         carry no gradient (stop_gradient gcn/layers.py:412, non-trainable gcn/vrgcn.py:31-32)."""
+        if self._det:
+            return self._backward_det(g)
         A, d = self._A, self._d
         if not self._concat:
             return ops.spmm(A.transpose, g, cscale=self._s)

@@ -27,7 +27,7 @@ import torch
 
 from . import ops
 from .flags import FLAGS
-from .layers import (AugmentedDropoutDense, Dense, Dropout, SparseInput)
+from .layers import (AugmentedDropoutDense, Dense, DetDropoutFC, Dropout, SparseInput)
 from .scheduler import PackedBatch, build_plan
 
 
@@ -347,6 +347,8 @@ class GCN(Model):
         for i, layer in enumerate(self.layers):
             layer.index = i
             layer.key_fn = (lambda idx=i: ops.dropout_key(self.dropout_seed, idx, self.dropout_step))
+            if isinstance(layer, _Dropout):
+                layer.noise_key_fn = (lambda idx=i: ops.dropout_key(self.dropout_seed, idx + 4096, self.dropout_step))
             if isinstance(layer, _Dropout) and i + 1 < len(self.layers):
                 nxt = self.layers[i + 1]
                 layer.fuse_next = isinstance(nxt, _Dense) and not nxt.sparse_inputs
@@ -359,6 +361,11 @@ class GCN(Model):
         return 1.0 - self.dropout
 
     def _build(self):
+        if FLAGS.det_dropout and (self.cvd or FLAGS.reverse or self.L == 0):
+            # the reference builds these stacks but cannot run them: with --cvd the aggregator reads (mu, var) as (h, mu)
+            # (gcn/layers.py:299), with --reverse / one layer a Dense layer or the loss receives the tuple
+            raise NotImplementedError("det_dropout with cvd / reverse / a single pre-processed layer has no working form "
+                                      "in the reference")
         dim_s = 1 if FLAGS.normalization == 'gcn' else 2
         cnt = 0
         self.layer_comp = []
@@ -370,8 +377,9 @@ class GCN(Model):
                 last_layer = self.L == 0 and l + 1 == FLAGS.num_fc_layers
                 output_dim = self.output_dim if last_layer else FLAGS.hidden1
                 layer_norm = False if last_layer else FLAGS.layer_norm
-                if FLAGS.det_dropout:
-                    raise NotImplementedError("det_dropout is out of scope (SURVEY.md §2)")
+                if FLAGS.det_dropout:                                   # gcn/models.py:275-282
+                    self.layers.append(DetDropoutFC(kp, input_dim, FLAGS.hidden1, sparse_inputs=sparse_inputs,
+                                                    norm=FLAGS.layer_norm, name='dense%d' % cnt))
                 elif self.cvd:
                     self.layers.append(AugmentedDropoutDense(kp, input_dim, FLAGS.hidden1,
                                                              sparse_inputs=sparse_inputs,
@@ -391,8 +399,8 @@ class GCN(Model):
                 last_layer = l2 + 1 == FLAGS.num_fc_layers and l + 1 == self.L
                 output_dim = self.output_dim if last_layer else FLAGS.hidden1
                 layer_norm = False if last_layer else FLAGS.layer_norm
-                if FLAGS.det_dropout and l + 1 != self.L:
-                    raise NotImplementedError("det_dropout is out of scope (SURVEY.md §2)")
+                if FLAGS.det_dropout and l + 1 != self.L:               # gcn/models.py:312-318
+                    self.layers.append(DetDropoutFC(kp, input_dim, output_dim, norm=layer_norm, name='dense%d' % cnt))
                 elif self.cvd and l + 1 != self.L:
                     self.layers.append(AugmentedDropoutDense(kp, input_dim, output_dim,
                                                              norm=layer_norm, name='dense%d' % cnt))
@@ -497,6 +505,8 @@ class GCN(Model):
             cur = DevFeed.from_packed(feed_dict, self.device)
         else:
             cur = DevFeed(feed_dict, self.placeholders, self.L, cv, self.device)
+        if FLAGS.det_dropout and cv:
+            cur.madj = [self._madj(feed_dict, l) for l in range(self.L)]
         f0 = cur.fields[0]
         if self.sparse_input and self.sparse_mm:
             sl = ops.csr_slice(self.features_dev, cur.host_fields[0], rows_dev=f0, with_coo_rows=True)
@@ -504,6 +514,16 @@ class GCN(Model):
         else:       # gathered by the first dense layer's GEMMs, or on demand (ops.GatheredRows)
             cur.inputs = ops.GatheredRows(self.features_dev, f0)
         return cur
+
+    def _madj(self, feed_dict, l):
+        """The det-dropout aggregator's third matrix (placeholders['madj'], gcn/train.py:92): the minibatch adjacency's
+        pattern carrying the sampler's medg weights (gcn/scheduler.cpp:164), with its transpose for the backward."""
+        if isinstance(feed_dict, PackedBatch):
+            a, w = feed_dict.csr(l, 0), feed_dict._f(*feed_dict._medg[l])
+        else:
+            a, w = feed_dict[('csr', self.placeholders['adj'][l])], feed_dict[self.placeholders['madj'][l]][1]
+        m = sp.csr_matrix((np.asarray(w, np.float32), np.asarray(a.col), np.asarray(a.rowptr)), shape=tuple(a.shape))
+        return ops.DeviceCSR.from_scipy(m, self.device, with_plan=True, with_transpose=True)
 
     def forward(self, cur):
         self.cur = cur

@@ -917,3 +917,136 @@ def dense_fwd(x, W, offset, scale, relu, eps=1e-9, x2=None, drop=None):
                                  float(eps), int(bool(relu)), y.data_ptr(), N, _ptr(xhat), _ptr(rstd), dr,
                                  _ptr(ws), _ptr(gidx), _ptr(gidx2), _stream()))
     return y, ((xhat, rstd) if norm else None)
+
+
+# ---- deterministic dropout: element-/row-wise pieces (sgcn_det.hip; gcn/layers.py:141-202, 236-248, 320-349, 425-428) ----
+def _flat(x, name):
+    """(pointer, element count) of a contiguous fp32 device array (tensor or DevArray)."""
+    if isinstance(x, torch.Tensor):
+        _dev(x, torch.float32, name)
+        if not x.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+    return x.data_ptr(), int(x.numel())
+
+
+def _like(x):
+    return torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+
+
+def det_pre(mu, var, keep):
+    """Variance of dropout(x) / keep for x ~ (mu, var): var / keep + (1 / keep - 1) mu^2 (var None: plain input)."""
+    mp, n = _flat(mu, "mu")
+    out = _like(mu)
+    check(lib.sgcn_det_pre_f32(mp, _flat(var, "var")[0] if var is not None else None, n, float(keep), out.data_ptr(), _stream()))
+    return out
+
+
+def det_pre_bwd(mu, g, keep, d_mu, want_var):
+    """d_mu += g 2 (1 / keep - 1) mu; returns d_var = g / keep (or None)."""
+    mp, n = _flat(mu, "mu")
+    d_var = _like(mu) if want_var else None
+    check(lib.sgcn_det_pre_bwd_f32(mp, _flat(g, "g")[0], n, float(keep), _flat(d_mu, "d_mu")[0], _ptr(d_var), _stream()))
+    return d_var
+
+
+def square(x, c=1.0):
+    """c * x^2 element-wise (tf.square of a weight matrix / of an adjacency's values)."""
+    xp, n = _flat(x, "x")
+    out = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    check(lib.sgcn_square_f32(xp, n, float(c), out.data_ptr(), _stream()))
+    return out
+
+
+def addmul(acc, a, b, c=1.0):
+    """acc += c * a * b element-wise."""
+    ap, n = _flat(a, "a")
+    check(lib.sgcn_addmul_f32(_flat(acc, "acc")[0], ap, _flat(b, "b")[0], n, float(c), _stream()))
+    return acc
+
+
+def det_lnvar_fwd(var1, rstd, scale, eps):
+    n, d = int(var1.shape[0]), int(var1.shape[1])
+    out = _like(var1)
+    check(lib.sgcn_det_lnvar_fwd_f32(_flat(var1, "var1")[0], _ptr(rstd), _ptr(scale), n, d, float(eps), out.data_ptr(), _stream()))
+    return out
+
+
+def det_lnvar_bwd(g, var1, xhat, rstd, scale, eps, d_mu1, dscale):
+    """Returns d_var1; adds the variance stream's share to d_mu1 and dscale."""
+    n, d = int(var1.shape[0]), int(var1.shape[1])
+    d_var1, tmp = _like(var1), _like(var1)
+    check(lib.sgcn_det_lnvar_bwd_f32(_flat(g, "g")[0], _flat(var1, "var1")[0], _ptr(xhat), _ptr(rstd), _ptr(scale), n, d, float(eps),
+                                     d_var1.data_ptr(), _flat(d_mu1, "d_mu1")[0], _ptr(dscale), tmp.data_ptr(), _stream()))
+    return d_var1
+
+
+def det_relu_fwd(mu, var):
+    mp, n = _flat(mu, "mu")
+    mo, vo = _like(mu), _like(mu)
+    check(lib.sgcn_det_relu_fwd_f32(mp, _flat(var, "var")[0], n, mo.data_ptr(), vo.data_ptr(), _stream()))
+    return mo, vo
+
+
+def det_relu_bwd(mu, var, g_mu, g_var):
+    mp, n = _flat(mu, "mu")
+    d_mu, d_var = _like(mu), _like(mu)
+    check(lib.sgcn_det_relu_bwd_f32(mp, _flat(var, "var")[0], _flat(g_mu, "g_mu")[0], _flat(g_var, "g_var")[0], n,
+                                    d_mu.data_ptr(), d_var.data_ptr(), _stream()))
+    return d_mu, d_var
+
+
+def gauss_sample(mu, var, key):
+    mp, n = _flat(mu, "mu")
+    x = _like(mu)
+    check(lib.sgcn_gauss_sample_f32(mp, _flat(var, "var")[0], n, int(key) & 0xFFFFFFFF, x.data_ptr(), _stream()))
+    return x
+
+
+def gauss_sample_bwd(var, g, key):
+    vp, n = _flat(var, "var")
+    d_var = _like(var)
+    check(lib.sgcn_gauss_sample_bwd_f32(vp, _flat(g, "g")[0], n, int(key) & 0xFFFFFFFF, d_var.data_ptr(), _stream()))
+    return d_var
+
+
+def det_agg_prep(mu, var, Hm, Hv, ifield):
+    """(delta_mu, ds2, msig2, ds, sbar) of the control-variate aggregator on (mu, var)."""
+    n0, d = int(mu.shape[0]), int(mu.shape[1])
+    hp, ldh = _rows2d(Hm, "Hm")
+    vp, ldv = _rows2d(Hv, "Hv")
+    if ldh != ldv:
+        raise ValueError("the two histories must share a pitch")
+    outs = [_like(mu) for _ in range(5)]
+    check(lib.sgcn_det_agg_prep_f32(_flat(mu, "mu")[0], _flat(var, "var")[0], hp, vp, ldh, _ptr(_dev(ifield, torch.int32, "ifield")),
+                                    n0, d, *[o.data_ptr() for o in outs], _stream()))
+    return outs
+
+
+def det_agg_prep_bwd(var, ds, sbar, g_ds2, g_msig2, add=None, add_rows=0):
+    n0, d = int(var.shape[0]), int(var.shape[1])
+    d_var = _like(var)
+    ap, ldadd = _rows2d(add, "add") if add is not None else (None, 0)
+    check(lib.sgcn_det_agg_prep_bwd_f32(_flat(var, "var")[0], _ptr(ds), _ptr(sbar), _flat(g_ds2, "g_ds2")[0], _flat(g_msig2, "g_msig2")[0],
+                                        n0, d, ap, ldadd, int(add_rows), d_var.data_ptr(), _stream()))
+    return d_var
+
+
+def relu_eps(raw, eps, out=None):
+    """relu(raw) + eps (out may be a column block of a wider array)."""
+    rp, ldr = _rows2d(raw, "raw")
+    n, d = int(raw.shape[0]), int(raw.shape[1])
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=raw.device)
+    op, ldo = _rows2d(out, "out")
+    check(lib.sgcn_relu_eps_f32(rp, ldr, n, d, float(eps), op, ldo, _stream()))
+    return out
+
+
+def gate(raw, g):
+    """g where raw > 0, else 0 (dense result; g may be a column block)."""
+    rp, ldr = _rows2d(raw, "raw")
+    gp, ldg = _rows2d(g, "g")
+    n, d = int(raw.shape[0]), int(raw.shape[1])
+    out = torch.empty((n, d), dtype=torch.float32, device=raw.device)
+    check(lib.sgcn_gate_f32(rp, ldr, gp, ldg, n, d, out.data_ptr(), _stream()))
+    return out

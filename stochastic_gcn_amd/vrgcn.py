@@ -17,11 +17,10 @@ class VRGCN(GCN):
         self.history = []
         for i in range(self.L):
             dims = self.agg0_dim if i == 0 else FLAGS.hidden1
-            if FLAGS.det_dropout:
-                raise NotImplementedError("det_dropout is out of scope (SURVEY.md §2)")
-            self.history.append([torch.zeros((self.num_data, dims), dtype=torch.float32,
-                                             device=self.device)])
-            print('History size = {} GB'.format(self.num_data * dims * 4 / 1024.0 / 1024.0 / 1024.0))
+            n_history = 2 if FLAGS.det_dropout else 1        # (mean, variance) under det-dropout, gcn/vrgcn.py:28
+            self.history.append([torch.zeros((self.num_data, dims), dtype=torch.float32, device=self.device)
+                                 for _ in range(n_history)])
+            print('History size = {} GB'.format(self.num_data * dims * 4 * n_history / 1024.0 / 1024.0 / 1024.0))
 
     def _build_aggregators(self):
         for l in range(self.L):

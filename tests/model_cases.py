@@ -23,6 +23,14 @@ class MaskSource(object):
         self.rec.append(m)
         return m
 
+    def noise(self, tag, shape):
+        """N(0, 1) draws for the Gaussian re-sampling of a det-dropout model, recorded / replayed like the masks."""
+        if self.replaying:
+            return self(tag, shape)
+        z = self.rng.standard_normal(shape).astype(np.float32)
+        self.rec.append(z)
+        return z
+
     def replay(self):
         self.replaying, self.pos = True, 0
         return self
@@ -97,6 +105,29 @@ CASES = {
 }
 
 
+# --det_dropout (moment propagation, gcn/layers.py:141-202,236-248,320-349,425-428): no golden vectors (the variant
+# came after the fixtures; its oracle is pinned by float64 autograd, tests/test_model_oracle.py), so not in CASES
+DET_CASES = {
+    # CV + PP, three layers: DetDropoutFC -> VR aggregator on (mu, var) with two histories -> DetDropoutFC on a tuple
+    # -> second aggregator -> Gaussian re-sampling + dropout -> Dense
+    'det_cv_pp_L3': dict(n=900, avg=10, f=20, classes=4, sparse=False, model='vr', batch=40,
+                         flags=dict(normalization='graphsage', dropout=0.3, layer_norm=True, hidden1=16, cv=True,
+                                    degree=2, preprocess=True, num_layers=3, det_dropout=True, weight_decay=1e-3)),
+    # the Reddit recipe with two FC layers per block
+    'det_cv_pp_fc2': dict(n=1200, avg=12, f=24, classes=5, sparse=False, model='vr', batch=48,
+                          flags=dict(normalization='graphsage', dropout=0.2, layer_norm=True, hidden1=16,
+                                     num_fc_layers=2, cv=True, degree=1, preprocess=True, det_dropout=True)),
+    # neighbour sampling, no PP: the first aggregator sees plain features, the second one (mu, var); no LayerNorm
+    'det_ns_nopp_L2': dict(n=900, avg=10, f=20, classes=4, sparse=False, model='plain', batch=40,
+                           flags=dict(normalization='gcn', dropout=0.5, hidden1=16, degree=3, preprocess=False,
+                                      det_dropout=True)),
+    # CV without PP, gcn normalisation
+    'det_cv_nopp_L2': dict(n=900, avg=10, f=20, classes=4, sparse=False, model='vr', batch=40,
+                           flags=dict(normalization='gcn', dropout=0.3, hidden1=16, cv=True, degree=2,
+                                      preprocess=False, det_dropout=True, layer_norm=True)),
+}
+
+
 def make_scheduler(case, seed=1, data=None):
     """The product's sampler for a case (bit-exact against the reference C++, tests/test_sampler.py)."""
     from stochastic_gcn_amd.scheduler import PyScheduler
@@ -137,7 +168,7 @@ REDDIT_MID = dict(n=12000, avg=40, f=96, classes=41, sparse=False, model='vr', b
 
 
 def build_case(name, seed=0):
-    c = CASES[name] if isinstance(name, str) else name
+    c = (CASES.get(name) or DET_CASES[name]) if isinstance(name, str) else name
     fl = mnp.make_flags(**c['flags'])
     rng = np.random.RandomState(seed)
     adj = _graph(c['n'], c['avg'], seed + 1, fl['normalization'])

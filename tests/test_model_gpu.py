@@ -49,7 +49,7 @@ def _masks(dmodel, keep):
     return mnp.HashMasks(dmodel.dropout_seed, dmodel.dropout_step, keep)
 
 
-@pytest.mark.parametrize("name", sorted(mc.CASES))
+@pytest.mark.parametrize("name", sorted(mc.CASES) + sorted(mc.DET_CASES))
 def test_training_steps_match_oracle(name):
     from stochastic_gcn_amd.scheduler import PyScheduler
     case = mc.build_case(name)
@@ -96,7 +96,44 @@ def test_training_steps_match_oracle(name):
         for l, h in enumerate(omodel.history):
             e = onp.rel_err(dmodel.history[l][0].cpu().numpy(), h)
             assert e <= TOL, (name, step, 'history', l, e)
+        for l, h in enumerate(omodel.history_var):          # det-dropout: the variance history (gcn/vrgcn.py:28)
+            e = onp.rel_err(dmodel.history[l][1].cpu().numpy(), h)
+            assert e <= TOL, (name, step, 'history_var', l, e)
     print("%s: worst activation rel err %.2e" % (name, worst))
+
+
+def test_det_dropout_packed_batches_take_the_same_path():
+    """A det-dropout model is not compiled into a step program (its layers are outside the program's op set): packed
+    minibatches -- what the training loop produces -- run eagerly, the third adjacency rebuilt from the packed medg
+    weights, and give the numbers of the reference-format feed."""
+    from stochastic_gcn_amd.flags import FLAGS
+    case = mc.build_case('det_cv_pp_L3')
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    om = mc.make_oracle_model(case, seed=3)
+    res = []
+    for packed in (False, True):
+        dm = _make_device_model(case, {k: v.copy() for k, v in om.params.items()})
+        sch = mc.make_scheduler(case, 1)
+        losses = []
+        for step in range(3):
+            if packed:
+                pb = sch.minibatch_packed(c['batch'], FLAGS.plan_t, None)
+                pb.dropout = fl['dropout']
+                out = dm.run_one_step(None, pb)
+            else:
+                feed = sch.minibatch(c['batch'])
+                feed[ph['dropout']] = fl['dropout']
+                out = dm.run_one_step(None, feed)
+            losses.append(out[1])
+        assert getattr(dm, '_programs', None) is None or all(v is None for v in dm._programs.values())
+        res.append((losses, dm.get_params(), [h.cpu().numpy() for hs in dm.history for h in hs]))
+    # (the two feeds carry different launch plans -- long rows are split differently -- so sums differ in their last bits)
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-5)
+    for k in res[0][1]:
+        assert onp.rel_err(res[0][1][k], res[1][1][k]) < 1e-4, k
+    for a, b in zip(res[0][2], res[1][2]):
+        assert onp.rel_err(a, b) < 1e-5
+    assert len(res[0][2]) == 4 and all(np.abs(h).max() > 0 for h in res[0][2])     # two histories per layer, both written
 
 
 GOLD = None

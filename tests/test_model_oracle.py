@@ -53,6 +53,55 @@ def autograd_forward(model, feed, ph, dropout, masks, params_t):
                 xs = _ln(xs, params_t[name + '/offset'], params_t[name + '/scale'])
                 mus = _ln(mus, params_t[name + '/offset'], params_t[name + '/scale'])
             act = (torch.relu(xs), torch.relu(mus).detach())          # tf.stop_gradient(mu)
+        elif kind == 'det':                                           # gcn/layers.py:141-202, verbatim formulas
+            _, name, fin, fout, sparse_in, norm = s
+            W = params_t[name + '/weights']
+            if isinstance(act, tuple):
+                mu, var = act
+                var = (var + mu ** 2) / keep - mu ** 2
+            else:
+                mu, var = act, (1 - keep) / keep * act ** 2
+            mu, var = mu @ W, (var @ W ** 2) * 1.2
+            if norm:
+                mean = mu.mean(dim=1, keepdim=True)
+                variance = ((mu - mean) ** 2).mean(dim=1, keepdim=True)
+                sc, off = params_t[name + '/scale'], params_t[name + '/offset']
+                mu = (mu - mean) / torch.sqrt(variance + 1e-10) * sc + off
+                var = var * (sc ** 2 / variance)
+            ncdf = lambda x: 0.5 * torch.erfc(-x / np.sqrt(2.0))           # noqa: E731
+            sigma = torch.sqrt(var)
+            alpha = -mu / sigma
+            phi = torch.exp(-0.5 * alpha ** 2) / np.sqrt(2 * np.pi)
+            Phi, Z = ncdf(alpha), ncdf(-alpha) + 1e-10
+            m_ = mu + sigma * phi / Z
+            mu = Z * m_
+            var = torch.relu(var * (1 + alpha * phi / Z - (phi / Z) ** 2)) + 1e-10
+            act = (mu, Z * var + Z * Phi * mu ** 2)
+        elif kind == 'dropout' and isinstance(act, tuple) and not model.cvd:    # gcn/layers.py:425-428
+            mu, var = act
+            x = mu + _t(masks.noise('x', tuple(var.shape))) * torch.sqrt(var + 1e-10)
+            m = masks('x', tuple(x.shape)) if dropout > 0 else None
+            act = x * _t(m) / keep if m is not None else x
+        elif kind == 'agg' and isinstance(act, tuple) and not model.cvd:        # gcn/layers.py:236-248, 320-349
+            l = s[1]
+            adj = onp.coo_to_csr(feed[ph['adj'][l]])
+            A, n1 = _sp(adj), adj.shape[0]
+            A2 = _sp(adj.multiply(adj).tocsr())
+            mu, var = act
+            if model.cv:
+                fadj, madj = onp.coo_to_csr(feed[ph['fadj'][l]]), onp.coo_to_csr(feed[ph['madj'][l]])
+                P, P2, M = _sp(fadj), _sp(fadj.multiply(fadj).tocsr()), _sp(madj)
+                Hm, Hv = _t(model.history[l]), _t(model.history_var[l])
+                ifield = torch.tensor(feed[ph['fields'][l]].astype(np.int64))
+                ffield = torch.tensor(feed[ph['ffields'][l]].astype(np.int64))
+                sbar = torch.sqrt(Hv[ifield])
+                ds = torch.sqrt(var) - sbar
+                mu_n = torch.sparse.mm(A, mu - Hm[ifield]) + torch.sparse.mm(P, Hm[ffield])
+                var_n = torch.sparse.mm(A2, ds ** 2) + torch.sparse.mm(P2, Hv[ffield]) + 2 * torch.sparse.mm(M, ds * sbar)
+                var_n = torch.relu(var_n) + 1e-10
+            else:
+                mu_n, var_n = torch.sparse.mm(A, mu), torch.sparse.mm(A2, var)
+            act = (torch.cat([mu[:n1], mu_n], 1), torch.cat([var[:n1], var_n], 1)) if concat else (mu_n, var_n)
         elif kind == 'dropout':
             if model.cvd and isinstance(act, tuple):
                 act = act[0]
@@ -93,7 +142,7 @@ def autograd_forward(model, feed, ph, dropout, masks, params_t):
     return act
 
 
-@pytest.mark.parametrize("name", sorted(mc.CASES))
+@pytest.mark.parametrize("name", sorted(mc.CASES) + sorted(mc.DET_CASES))
 def test_oracle_backward_matches_autograd(name):
     from stochastic_gcn_amd.scheduler import PyScheduler
     case = mc.build_case(name)
@@ -108,6 +157,8 @@ def test_oracle_backward_matches_autograd(name):
             om.params[k] = (1 + 0.1 * rng.standard_normal(om.params[k].shape)).astype(np.float32)
     for h in om.history:
         h[:] = rng.uniform(-1, 1, h.shape)
+    for h in om.history_var:
+        h[:] = rng.uniform(0.05, 1, h.shape)
     sch = mc.make_scheduler(case, 1)
     feed = sch.minibatch(c['batch'])
     masks = mc.MaskSource(7, 1.0 - fl['dropout'])
