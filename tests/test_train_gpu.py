@@ -207,3 +207,13 @@ def test_no_library_gemm_on_the_product_path(monkeypatch):
             tr.train_epoch()
             cost, acc = tr.evaluate(tr.val_d)[:2]
         assert np.isfinite(cost) and 0.0 <= acc <= 1.0
+
+
+def test_det_dropout_model_trains_through_the_driver():
+    """--det_dropout (moment propagation instead of sampled dropout, gcn/train.py:55) with the CV estimator's two
+    histories per layer: the driver trains it (eager layers, packed minibatches) and it learns the planted labels."""
+    tr, accs = _train(dict(cv=True, cvd=False, det_dropout=True, test_cv=True, degree=2, test_degree=2, dropout=0.2,
+                           num_layers=3), 8)
+    assert all(len(h) == 2 for h in tr.train_model.history)
+    assert all(float(h.abs().max()) > 0 for hs in tr.train_model.history for h in hs)
+    assert np.isfinite(accs).all() and accs[-1] > 0.45 and accs[-1] > accs[0], accs
