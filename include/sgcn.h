@@ -452,9 +452,12 @@ int64_t sgcn_sched_packed_meta_len(int32_t L);
 
 /* ---- native prefetch thread: the sampler of a whole epoch off the interpreter ------------------
  * sgcn_prefetch_start copies the epoch's id slices (batch b = host_ids[offsets[b] : offsets[b+1]]) and
- * starts one C++ thread per sampler.  With ONE sampler the thread packs batch 0, 1, ... in order --
- * the same sample sequence as calling sgcn_sched_batch_packed in a loop; with N samplers (the
- * NON-PARITY fast mode: independent RNG streams) thread k packs batches k, k + N, ... and the consumer
+ * starts the producer threads.  With ONE sampler the batches are sampled 0, 1, ... in order -- the same
+ * sample sequence as calling sgcn_sched_batch_packed in a loop -- either by one thread that also packs them
+ * (n_packers = 0) or by a core thread (random draws, the CSR permutation, the rows' neighbour lists) feeding
+ * n_packers > 0 packer threads (numbering of the full-neighbour field, transposes, plans, layout, the copy into
+ * the slot): the same bits with only the core on the critical path (ABI v7).  With N samplers (the NON-PARITY
+ * fast mode: independent RNG streams; n_packers must be 0) thread k packs batches k, k + N, ... and the consumer
  * still receives them in batch order.  Each batch goes into a free staging slot (host_slot_words[i]: cap
  * 4-byte words, pinned by the caller, laid out [max(n_i32,1) ints | max(n_f32,1) floats]).  The
  * sampler handle must not be used by anyone else until sgcn_prefetch_stop.
@@ -469,12 +472,13 @@ int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32
                         const int32_t* host_ids, const int64_t* host_offsets, int32_t L,
                         const int32_t* host_degrees, const float* host_labels, int32_t n_classes,
                         int32_t plan_T, int32_t n_slots, void* const* host_slot_words,
-                        const int64_t* host_slot_caps, int32_t lag, sgcn_prefetch_t** out);
+                        const int64_t* host_slot_caps, int32_t lag, int32_t n_packers, sgcn_prefetch_t** out);
 int sgcn_prefetch_next(sgcn_prefetch_t* p, int32_t* slot, int64_t* host_meta, int64_t* n_i32,
                        int64_t* n_f32, const void** spill);
 int sgcn_prefetch_release(sgcn_prefetch_t* p, int32_t slot);
-/* producer-side seconds so far: [waiting for a free slot, sampling + packing, copying to slots] */
-int sgcn_prefetch_stats(sgcn_prefetch_t* p, double* out3);
+/* producer-side seconds so far: [waiting for a free slot, sampling + packing (with packers: packing, summed over them),
+ * copying to slots, the core thread's sampling (with packers; else 0)] */
+int sgcn_prefetch_stats(sgcn_prefetch_t* p, double* out4);
 void sgcn_prefetch_stop(sgcn_prefetch_t* p);
 int sgcn_sched_packed_copy(sgcn_sched_t* s, int32_t* dst_i32, float* dst_f32);
 

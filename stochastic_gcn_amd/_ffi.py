@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 6          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 7          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -151,7 +151,7 @@ SIGNATURES = {
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_sched_packed_meta_len": (C.c_int64, [C.c_int32]),
     "sgcn_prefetch_start": (C.c_int, [P, C.c_int32, C.c_int32, P, P, C.c_int32, P, P, C.c_int32, C.c_int32,
-                                      C.c_int32, P, P, C.c_int32, C.POINTER(C.c_void_p)]),
+                                      C.c_int32, P, P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "sgcn_prefetch_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), P, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
     "sgcn_prefetch_release": (C.c_int, [C.c_void_p, C.c_int32]),

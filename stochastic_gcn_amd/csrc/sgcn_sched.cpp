@@ -33,6 +33,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -100,12 +101,254 @@ private:
 };
 
 // ---- neighbour sampler ------------------------------------------------------------------------
+// Two halves.  The CORE is the reference's sequential state machine: the Mersenne twister, the private CSR it
+// permutes, the first-seen table of the sampled field.  Its output per hop is a Hop whose full-neighbour lists
+// still hold VERTEX ids.  The PACKER is a pure function of a Hop sequence: first-seen numbering of those lists
+// (the reference's second table, scheduler.cpp:167-179), the transposed CSR, the launch plans, the packed
+// layout.  One thread running both reproduces `Scheduler::expand` call by call; the prefetcher runs the core on
+// one thread and packers on others (sgcn_prefetch, below) -- same bits, the core alone on the critical path.
+
+// growable array WITHOUT value-initialisation (std::vector::resize zero-fills: 400 KB per Reddit batch)
+template <class T> struct Buf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0, cap = 0;
+    T* data() { return p.get(); }
+    const T* data() const { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        const size_t nc = std::max(c, cap * 2 + 64);
+        std::unique_ptr<T[]> q(new T[nc]);
+        if (n) memcpy(q.get(), p.get(), n * sizeof(T));
+        p.swap(q);
+        cap = nc;
+    }
+    T* grow(size_t k) { reserve(n + k); T* r = p.get() + n; n += k; return r; }     // uninitialised tail
+    void push_back(T v) { if (n == cap) reserve(n + 1); p[n++] = v; }
+    void assign(const T* b, size_t k) { n = 0; reserve(k); if (k) memcpy(p.get(), b, k * sizeof(T)); n = k; }
+    void fill(size_t k, T v) { n = 0; reserve(k); std::fill(p.get(), p.get() + k, v); n = k; }
+    void shrink(size_t k) { n = k; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
+struct Hop {
+    Buf<int32_t> field;                      // the receptive field after the hop (= the layer's input rows)
+    Buf<int32_t> edg_s, edg_t, edg_p;        // sampled edges: COO row, column (position in `field`), CSR offsets
+    Buf<float> scales, edg_w, medg_w;
+    Buf<int32_t> fedg_s, fedg_t, fedg_p;     // every neighbour of every output row; fedg_t: vertex ids until relabelled
+    Buf<float> fedg_w;
+    int rc = SGCN_OK;
+    bool relabelled = false;
+    char err[160] = {0};
+    void clear() {
+        field.clear(); edg_s.clear(); edg_t.clear(); edg_p.clear(); scales.clear(); edg_w.clear(); medg_w.clear();
+        fedg_s.clear(); fedg_t.clear(); fedg_p.clear(); fedg_w.clear();
+        rc = SGCN_OK; relabelled = false; err[0] = 0;
+    }
+};
+
+// First-seen numbering of the full-neighbour lists (scheduler.cpp:167-179): vertex ids -> positions in `ffield`.
+class Relabeller {
+public:
+    explicit Relabeller(int32_t n) : fslot_((size_t)n, -1) {}
+
+    void run(Buf<int32_t>& t, Buf<int32_t>& ffield) {
+        const size_t ne = t.size();
+        ffield.clear();
+        ffield.reserve(ne + 16);
+        out_ = ffield.data();
+        cnt_ = 0;
+        if (avx512_) run_avx512(t.data(), ne);
+        else for (size_t e = 0; e < ne; e++) t[e] = place(t[e]);
+        ffield.shrink((size_t)cnt_);
+        // entries are stamped (fbase_ + position): advancing the base un-marks this hop's field without touching
+        // its ~43 k scattered table entries again
+        fbase_ += cnt_;
+        if (fbase_ > (1 << 30)) { std::fill(fslot_.begin(), fslot_.end(), -1); fbase_ = 0; }
+    }
+
+private:
+    int32_t place(int32_t v) {
+        int32_t& s = fslot_[(size_t)v];
+        if (s < fbase_) {
+            s = fbase_ + cnt_;
+            out_[cnt_++] = v;
+        }
+        return s - fbase_;
+    }
+#if defined(__x86_64__)
+    // 16 entries per step (AVX-512: gather the table entries, give the unseen vertices consecutive positions in
+    // list order with an expand, scatter the new stamps, append the new vertices with a compress-store).  Same
+    // first-seen numbering as the scalar loop: the entries of a vector are applied "at once", which differs from
+    // one-by-one only if a vertex occurs twice among the unseen lanes -- detected with vpconflictd and handed to
+    // the scalar loop.  (This numbering was 2/3 of the sampler's time: 50 k table lookups per Reddit batch.)
+    __attribute__((target("avx512f,avx512cd")))
+    void run_avx512(int32_t* t, size_t ne) {
+        int32_t next = 0;
+        const __m512i base = _mm512_set1_epi32(fbase_);
+        const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        const __m512i neg = _mm512_sub_epi32(_mm512_setzero_si512(), _mm512_add_epi32(iota, _mm512_set1_epi32(1)));
+        for (size_t k = 0; k < ne; k += 16) {
+            const __mmask16 m = ne - k >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << (ne - k)) - 1u);
+            const __m512i v = _mm512_maskz_loadu_epi32(m, t + k);
+            __m512i sl = _mm512_mask_i32gather_epi32(_mm512_set1_epi32(-1), m, v, fslot_.data(), 4);
+            const __mmask16 fresh = _mm512_mask_cmplt_epi32_mask(m, sl, base);
+            if (fresh) {
+                const __m512i conf = _mm512_conflict_epi32(_mm512_mask_mov_epi32(neg, fresh, v));
+                if (_mm512_mask_test_epi32_mask(fresh, conf, conf)) {      // a repeated unseen vertex: one by one
+                    cnt_ = next;
+                    for (size_t q = k; q < std::min(ne, k + 16); q++) t[q] = place(t[q]);
+                    next = cnt_;
+                    continue;
+                }
+                const __m512i ids = _mm512_maskz_expand_epi32(fresh, _mm512_add_epi32(iota, _mm512_set1_epi32(next)));
+                const __m512i stamped = _mm512_add_epi32(ids, base);
+                _mm512_mask_i32scatter_epi32(fslot_.data(), fresh, v, stamped, 4);
+                _mm512_mask_compressstoreu_epi32(out_ + next, fresh, v);
+                next += __builtin_popcount((unsigned)fresh);
+                sl = _mm512_mask_mov_epi32(sl, fresh, stamped);
+            }
+            _mm512_mask_storeu_epi32(t + k, m, _mm512_sub_epi32(sl, base));
+        }
+        cnt_ = next;
+    }
+    const bool avx512_ = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && !getenv("SGCN_NO_AVX512");
+#else
+    void run_avx512(int32_t* t, size_t ne) { for (size_t e = 0; e < ne; e++) t[e] = place(t[e]); }   // never taken
+    const bool avx512_ = false;
+#endif
+    std::vector<int32_t> fslot_;
+    int32_t fbase_ = 0, cnt_ = 0;          // stamp base: an entry >= fbase_ is a position in this hop's ffield
+    int32_t* out_ = nullptr;
+};
+
+// ---- packed minibatch (one call = PyScheduler.batch, gcn/_scheduler.pyx:55-127) ----------
+// Lays every array the device step needs into two growable staging vectors (int32 / fp32), each sub-array
+// 16-byte aligned: fields, ffields, scales, labels[fields[-1]], and per layer the CSR of adj, adj^T and fadj
+// with their row plans.  `meta` receives (offset, length) descriptors, layer 0 = input-most layer (the reversal
+// of gcn/_scheduler.pyx:121-126).  No Python objects are touched: the call runs without the GIL.
+class Packer {
+public:
+    enum { kCsrDesc = 11 };   // nrows ncols nnz rowptr col val seg nseg fix nfix nslots
+    explicit Packer(int32_t n) : relabel_(n) {}
+    static int64_t meta_len(int32_t L) { return 4 + 2 * (L + 1) + 2 * L + 2 * L + 3 + 2 * L + 3 * L * kCsrDesc; }
+
+    void relabel(Hop& h) {
+        if (h.relabelled) return;
+        relabel_.run(h.fedg_t, ffield);
+        h.relabelled = true;
+    }
+    // CSR of A^T (A = the hop's sampled adjacency, n_out x |field|): stable counting sort by column, so within a
+    // transposed row entries keep ascending output-row order (deterministic).
+    void transpose(const Hop& h) {
+        const size_t n_in = h.field.size(), ne = h.edg_t.size();
+        tedg_p.fill(n_in + 1, 0);
+        for (size_t e = 0; e < ne; e++) tedg_p[(size_t)h.edg_t[e] + 1]++;
+        for (size_t c = 0; c < n_in; c++) tedg_p[c + 1] += tedg_p[c];
+        tedg_t.clear(); tedg_t.grow(ne);
+        tedg_w.clear(); tedg_w.grow(ne);
+        cur_.assign(tedg_p.data(), n_in);
+        for (size_t e = 0; e < ne; e++) {
+            const int32_t q = cur_[(size_t)h.edg_t[e]]++;
+            tedg_t[(size_t)q] = h.edg_s[e];
+            tedg_w[(size_t)q] = h.edg_w[e];
+        }
+    }
+
+    // hops[l] = the l-th expansion (hops[0] grew the batch itself).  Relabels the hops in place.
+    int pack(int32_t n, const int32_t* ids, Hop* hops, int32_t L, bool cv, const float* labels, int32_t n_classes,
+             int32_t plan_T, int64_t* meta, int64_t meta_cap, int64_t* n_i32, int64_t* n_f32) {
+        const int64_t need = meta_len(L);
+        if (meta_cap < need) return fail(SGCN_ERR_INVALID, "batch_packed: meta too small (%lld < %lld)",
+                                         (long long)meta_cap, (long long)need);
+        pi_.clear(); pf_.clear();
+        std::fill(meta, meta + need, 0);
+        meta[0] = L; meta[1] = cv ? 1 : 0; meta[2] = n_classes;
+        int64_t* fields_d = meta + 4;                    // (L+1) x (off,len)
+        int64_t* scales_d = fields_d + 2 * (L + 1);      // L x (off,len)
+        int64_t* ffields_d = scales_d + 2 * L;           // L x (off,len)
+        int64_t* labels_d = ffields_d + 2 * L;           // off, rows, cols
+        int64_t* medg_d = labels_d + 3;                  // L x (off,len)
+        int64_t* csr_d = medg_d + 2 * L;                 // L x 3 x kCsrDesc  (adj, adjT, fadj)
+        put_i(ids, (size_t)n, fields_d + 2 * L);         // fields[L] = the batch itself
+        int rc = SGCN_OK;
+        for (int32_t l = 0; l < L; l++) {
+            Hop& h = hops[l];
+            const int32_t slot = L - 1 - l;              // position after the reversal
+            if (h.rc != SGCN_OK) rc = fail(h.rc, "%s", h.err);
+            const int32_t n1 = (int32_t)h.edg_p.size() - 1, n0 = (int32_t)h.field.size();
+            put_i(h.field.data(), h.field.size(), fields_d + 2 * slot);
+            put_f(h.scales.data(), h.scales.size(), scales_d + 2 * slot);
+            put_f(h.medg_w.data(), h.medg_w.size(), medg_d + 2 * slot);
+            transpose(h);
+            put_csr(csr_d + (3 * slot + 0) * kCsrDesc, n1, n0, h.edg_p, h.edg_t, h.edg_w, plan_T);
+            put_csr(csr_d + (3 * slot + 1) * kCsrDesc, n0, n1, tedg_p, tedg_t, tedg_w, plan_T);
+            if (cv) {
+                relabel(h);
+                put_i(ffield.data(), ffield.size(), ffields_d + 2 * slot);
+                put_csr(csr_d + (3 * slot + 2) * kCsrDesc, n1, (int32_t)ffield.size(), h.fedg_p, h.fedg_t, h.fedg_w, plan_T);
+            }
+        }
+        if (labels && n_classes > 0) {                   // labels[fields[-1]]  (_scheduler.pyx:138)
+            labels_d[0] = (int64_t)pf_.size(); labels_d[1] = n; labels_d[2] = n_classes;
+            float* dst = pf_.grow((size_t)n * (size_t)n_classes);
+            for (int32_t i = 0; i < n; i++)
+                memcpy(dst + (size_t)i * n_classes, labels + (int64_t)ids[i] * n_classes, sizeof(float) * (size_t)n_classes);
+            pad_f();
+        }
+        *n_i32 = (int64_t)pi_.size();
+        *n_f32 = (int64_t)pf_.size();
+        return rc;
+    }
+    void copy_out(int32_t* di, float* df) const {
+        if (di && !pi_.empty()) memcpy(di, pi_.data(), pi_.size() * sizeof(int32_t));
+        if (df && !pf_.empty()) memcpy(df, pf_.data(), pf_.size() * sizeof(float));
+    }
+
+    Buf<int32_t> ffield, tedg_p, tedg_t;     // of the hop last relabelled / transposed (the view API reads them)
+    Buf<float> tedg_w;
+
+private:
+    void pad_i() { while (pi_.size() & 3) pi_.push_back(0); }
+    void pad_f() { while (pf_.size() & 3) pf_.push_back(0.f); }
+    void put_i(const int32_t* v, size_t k, int64_t* d) {
+        d[0] = (int64_t)pi_.size(); d[1] = (int64_t)k;
+        if (k) memcpy(pi_.grow(k), v, k * sizeof(int32_t));
+        pad_i();
+    }
+    void put_f(const float* v, size_t k, int64_t* d) {
+        d[0] = (int64_t)pf_.size(); d[1] = (int64_t)k;
+        if (k) memcpy(pf_.grow(k), v, k * sizeof(float));
+        pad_f();
+    }
+    void put_csr(int64_t* d, int32_t nrows, int32_t ncols, const Buf<int32_t>& rowptr, const Buf<int32_t>& col,
+                 const Buf<float>& val, int32_t plan_T) {
+        int64_t tmp[2];
+        d[0] = nrows; d[1] = ncols; d[2] = (int64_t)col.size();
+        put_i(rowptr.data(), rowptr.size(), tmp); d[3] = tmp[0];
+        put_i(col.data(), col.size(), tmp); d[4] = tmp[0];
+        put_f(val.data(), val.size(), tmp); d[5] = tmp[0];
+        int64_t nslots = 0;
+        plan_build(rowptr.data(), nrows, plan_T, seg_, fix_, nslots);
+        put_i(seg_.data(), seg_.size(), tmp); d[6] = tmp[0]; d[7] = (int64_t)seg_.size() / 4;
+        put_i(fix_.data(), fix_.size(), tmp); d[8] = tmp[0]; d[9] = (int64_t)fix_.size() / 3;
+        d[10] = nslots;
+    }
+    Relabeller relabel_;
+    Buf<int32_t> pi_, cur_;
+    Buf<float> pf_;
+    std::vector<int32_t> seg_, fix_;
+};
+
 class NeighbourSampler {
 public:
     NeighbourSampler(const float* w, const int32_t* idx, const int32_t* ptr, int32_t n,
                      int32_t nnz, bool cv, bool is)
         : n_(n), cv_(cv), is_(is), nbr_(idx, idx + nnz), wgt_(w, w + nnz), ptr_(ptr, ptr + n),
-          slot_(n, -1), fslot_(n, -1), importance_(n, 1.0f) {
+          slot_(n, -1), importance_(n, 1.0f), packer_(n) {
         ptr_.push_back(nnz);  // the reference trusts only the first n offsets (scheduler.cpp:16,20)
         if (is_) {
             // column-wise squared weight mass on top of 1e-6   (scheduler.cpp:18,22-25)
@@ -114,238 +357,138 @@ public:
                 for (int32_t p = ptr[r]; p < ptr[r + 1]; p++) importance_[idx[p]] += w[p] * w[p];
         }
     }
+    int32_t num_vertices() const { return n_; }
+    bool cv() const { return cv_; }
 
     void seed(int32_t s) { rng_.reseed((uint32_t)s); }
 
-    void start_batch(int32_t n, const int32_t* ids) { field_.assign(ids, ids + n); }
+    void start_batch(int32_t n, const int32_t* ids) { field_.assign(ids, (size_t)n); }
 
-    int expand(int32_t degree) {
+    // ---- the core: one hop of the receptive field into `h` (full-neighbour lists as vertex ids) ----------------
+    int expand_core(int32_t degree, Hop& h, bool want_coo) {
         const size_t n_out = field_.size();
-        clear_outputs();
+        h.clear();
         // output rows are the first |field| entries of the next field   (scheduler.cpp:50-52)
-        next_ = field_;
-        for (size_t i = 0; i < next_.size(); i++) slot_[next_[i]] = (int32_t)i;
-        edg_p_.push_back(0);
-        fedg_p_.push_back(0);
+        h.field.assign(field_.data(), n_out);
+        for (size_t i = 0; i < n_out; i++) slot_[(size_t)field_[i]] = (int32_t)i;
+        h.edg_p.push_back(0);
+        h.fedg_p.push_back(0);
+        h.rc = is_ ? expand_importance(degree, h) : expand_uniform(degree, n_out, h, want_coo);
+        if (h.rc != SGCN_OK) snprintf(h.err, sizeof(h.err), "%s", error_slot());
+        for (size_t i = 0; i < h.field.size(); i++) slot_[(size_t)h.field[i]] = -1;
+        field_.assign(h.field.data(), h.field.size());
+        return h.rc;
+    }
+    // the L hops of a minibatch (gcn/_scheduler.pyx:60-66)
+    int sample_batch(int32_t n, const int32_t* ids, int32_t L, const int32_t* degrees, std::vector<Hop>& hops) {
+        if ((int32_t)hops.size() < L) hops.resize((size_t)L);
+        start_batch(n, ids);
+        int rc = SGCN_OK;
+        for (int32_t l = 0; l < L; l++) {
+            const int r = expand_core(degrees[L - l - 1], hops[(size_t)l], false);    // the packed layout is CSR only
+            if (r != SGCN_OK) rc = r;
+        }
+        return rc;
+    }
 
-        int rc = is_ ? expand_importance(degree) : expand_uniform(degree, n_out);
-
-        field_.swap(next_);
-        for (int32_t v : field_) slot_[v] = -1;
-        // fslot_ entries are stamped (fbase_ + position): advancing the base un-marks this hop's
-        // full-neighbour field without touching its ~43 k scattered table entries again
-        fbase_ += (int32_t)ffield_.size();
-        if (fbase_ > (1 << 30)) { std::fill(fslot_.begin(), fslot_.end(), -1); fbase_ = 0; }
+    // ---- the reference's call-by-call interface: expand, then read the arrays ----------------------------------
+    int expand(int32_t degree) {
+        const int rc = expand_core(degree, cur_, true);
+        if (cv_) packer_.relabel(cur_);
+        else packer_.ffield.clear();
         transpose_ready_ = false;
         return rc;
     }
-
-    // CSR of A^T (A = last sampled adjacency, n_out x |field|): stable counting sort by column,
-    // so within a transposed row entries keep ascending output-row order (deterministic).
     void build_transpose() {
         if (transpose_ready_) return;
-        const size_t n_in = field_.size(), ne = edg_t_.size();
-        tedg_p_.assign(n_in + 1, 0);
-        for (size_t e = 0; e < ne; e++) tedg_p_[edg_t_[e] + 1]++;
-        for (size_t c = 0; c < n_in; c++) tedg_p_[c + 1] += tedg_p_[c];
-        tedg_t_.resize(ne);
-        tedg_w_.resize(ne);
-        std::vector<int32_t> cur(tedg_p_.begin(), tedg_p_.end() - 1);
-        for (size_t e = 0; e < ne; e++) {
-            int32_t q = cur[edg_t_[e]]++;
-            tedg_t_[q] = edg_s_[e];
-            tedg_w_[q] = edg_w_[e];
-        }
+        packer_.transpose(cur_);
         transpose_ready_ = true;
     }
-
-    const std::vector<int32_t>* ivec(int which) {
+    bool ivec(int which, const int32_t** p, int64_t* len) {
+        const Buf<int32_t>* b = nullptr;
         switch (which) {
-            case SGCN_SCHED_FIELD: return &field_;
-            case SGCN_SCHED_FFIELD: return &ffield_;
-            case SGCN_SCHED_EDG_S: return &edg_s_;
-            case SGCN_SCHED_EDG_T: return &edg_t_;
-            case SGCN_SCHED_FEDG_S: return &fedg_s_;
-            case SGCN_SCHED_FEDG_T: return &fedg_t_;
-            case SGCN_SCHED_EDG_P: return &edg_p_;
-            case SGCN_SCHED_FEDG_P: return &fedg_p_;
-            case SGCN_SCHED_ADJ_I: return &nbr_;
-            case SGCN_SCHED_TEDG_P: build_transpose(); return &tedg_p_;
-            case SGCN_SCHED_TEDG_T: build_transpose(); return &tedg_t_;
-            default: return nullptr;
+            case SGCN_SCHED_FIELD: *p = field_.data(); *len = (int64_t)field_.size(); return true;
+            case SGCN_SCHED_FFIELD: b = &packer_.ffield; break;
+            case SGCN_SCHED_EDG_S: b = &cur_.edg_s; break;
+            case SGCN_SCHED_EDG_T: b = &cur_.edg_t; break;
+            case SGCN_SCHED_FEDG_S: b = &cur_.fedg_s; break;
+            case SGCN_SCHED_FEDG_T: b = &cur_.fedg_t; break;
+            case SGCN_SCHED_EDG_P: b = &cur_.edg_p; break;
+            case SGCN_SCHED_FEDG_P: b = &cur_.fedg_p; break;
+            case SGCN_SCHED_ADJ_I: *p = nbr_.data(); *len = (int64_t)nbr_.size(); return true;
+            case SGCN_SCHED_TEDG_P: build_transpose(); b = &packer_.tedg_p; break;
+            case SGCN_SCHED_TEDG_T: build_transpose(); b = &packer_.tedg_t; break;
+            default: return false;
         }
+        *p = b->data(); *len = (int64_t)b->size();
+        return true;
     }
-    const std::vector<float>* fvec(int which) {
+    bool fvec(int which, const float** p, int64_t* len) {
+        const Buf<float>* b = nullptr;
         switch (which) {
-            case SGCN_SCHED_SCALES: return &scales_;
-            case SGCN_SCHED_EDG_W: return &edg_w_;
-            case SGCN_SCHED_MEDG_W: return &medg_w_;
-            case SGCN_SCHED_FEDG_W: return &fedg_w_;
-            case SGCN_SCHED_ADJ_W: return &wgt_;
-            case SGCN_SCHED_TEDG_W: build_transpose(); return &tedg_w_;
-            default: return nullptr;
+            case SGCN_SCHED_SCALES: b = &cur_.scales; break;
+            case SGCN_SCHED_EDG_W: b = &cur_.edg_w; break;
+            case SGCN_SCHED_MEDG_W: b = &cur_.medg_w; break;
+            case SGCN_SCHED_FEDG_W: b = &cur_.fedg_w; break;
+            case SGCN_SCHED_ADJ_W: *p = wgt_.data(); *len = (int64_t)wgt_.size(); return true;
+            case SGCN_SCHED_TEDG_W: build_transpose(); b = &packer_.tedg_w; break;
+            default: return false;
         }
+        *p = b->data(); *len = (int64_t)b->size();
+        return true;
     }
 
-    // ---- packed minibatch (one call = PyScheduler.batch, gcn/_scheduler.pyx:55-127) ----------
-    // Runs the L expansions and lays every array the device step needs into two growable
-    // staging vectors (int32 / fp32), each sub-array 16-byte aligned: fields, ffields, scales,
-    // labels[fields[-1]], and per layer the CSR of adj, adj^T and fadj with their row plans.
-    // `meta` receives (offset, length) descriptors, layer 0 = input-most layer (the reversal of
-    // gcn/_scheduler.pyx:121-126).  No Python objects are touched: the call runs without the GIL.
-    enum { kCsrDesc = 11 };   // nrows ncols nnz rowptr col val seg nseg fix nfix nslots
+    // one thread: core, then the own packer
     int pack_batch(int32_t n, const int32_t* ids, int32_t L, const int32_t* degrees,
                    const float* labels, int32_t n_classes, int32_t plan_T, int64_t* meta,
                    int64_t meta_cap, int64_t* n_i32, int64_t* n_f32) {
-        const int64_t need = meta_len(L);
-        if (meta_cap < need) return fail(SGCN_ERR_INVALID, "batch_packed: meta too small (%lld < %lld)",
-                                         (long long)meta_cap, (long long)need);
-        pi_.clear(); pf_.clear();
-        std::fill(meta, meta + need, 0);
-        struct CooOff { bool& f; bool old; ~CooOff() { f = old; } } coo_off{want_coo_, want_coo_};
-        want_coo_ = false;                               // the packed layout is CSR only
-        meta[0] = L; meta[1] = cv_ ? 1 : 0; meta[2] = n_classes;
-        start_batch(n, ids);
-        int64_t* fields_d = meta + 4;                    // (L+1) x (off,len)
-        int64_t* scales_d = fields_d + 2 * (L + 1);      // L x (off,len)
-        int64_t* ffields_d = scales_d + 2 * L;           // L x (off,len)
-        int64_t* labels_d = ffields_d + 2 * L;           // off, rows, cols
-        int64_t* medg_d = labels_d + 3;                  // L x (off,len)
-        int64_t* csr_d = medg_d + 2 * L;                 // L x 3 x kCsrDesc  (adj, adjT, fadj)
-        put_i(field_, fields_d + 2 * L);                 // fields[L] = the batch itself
-        int rc = SGCN_OK;
-        for (int32_t l = 0; l < L; l++) {
-            const int32_t slot = L - 1 - l;              // position after the reversal
-            const int r = expand(degrees[L - l - 1]);    // gcn/_scheduler.pyx:66
-            if (r != SGCN_OK) rc = r;
-            const int32_t n1 = (int32_t)edg_p_.size() - 1, n0 = (int32_t)field_.size();
-            put_i(field_, fields_d + 2 * slot);
-            put_f(scales_, scales_d + 2 * slot);
-            put_f(medg_w_, medg_d + 2 * slot);
-            build_transpose();
-            put_csr(csr_d + (3 * slot + 0) * kCsrDesc, n1, n0, edg_p_, edg_t_, edg_w_, plan_T);
-            put_csr(csr_d + (3 * slot + 1) * kCsrDesc, n0, n1, tedg_p_, tedg_t_, tedg_w_, plan_T);
-            if (cv_) {
-                put_i(ffield_, ffields_d + 2 * slot);
-                put_csr(csr_d + (3 * slot + 2) * kCsrDesc, n1, (int32_t)ffield_.size(), fedg_p_,
-                        fedg_t_, fedg_w_, plan_T);
-            }
-        }
-        if (labels && n_classes > 0) {                   // labels[fields[-1]]  (_scheduler.pyx:138)
-            labels_d[0] = (int64_t)pf_.size(); labels_d[1] = n; labels_d[2] = n_classes;
-            for (int32_t i = 0; i < n; i++) {
-                const float* src = labels + (int64_t)ids[i] * n_classes;
-                pf_.insert(pf_.end(), src, src + n_classes);
-            }
-            pad_f();
-        }
-        *n_i32 = (int64_t)pi_.size();
-        *n_f32 = (int64_t)pf_.size();
-        return rc;
+        if (meta_cap < Packer::meta_len(L))
+            return fail(SGCN_ERR_INVALID, "batch_packed: meta too small (%lld < %lld)", (long long)meta_cap,
+                        (long long)Packer::meta_len(L));
+        sample_batch(n, ids, L, degrees, hops_);
+        return packer_.pack(n, ids, hops_.data(), L, cv_, labels, n_classes, plan_T, meta, meta_cap, n_i32, n_f32);
     }
-    static int64_t meta_len(int32_t L) { return 4 + 2 * (L + 1) + 2 * L + 2 * L + 3 + 2 * L + 3 * L * kCsrDesc; }
-    void packed_copy(int32_t* di, float* df) const {
-        if (di && !pi_.empty()) memcpy(di, pi_.data(), pi_.size() * sizeof(int32_t));
-        if (df && !pf_.empty()) memcpy(df, pf_.data(), pf_.size() * sizeof(float));
-    }
+    static int64_t meta_len(int32_t L) { return Packer::meta_len(L); }
+    void packed_copy(int32_t* di, float* df) const { packer_.copy_out(di, df); }
 
 private:
-    void clear_outputs() {
-        ffield_.clear(); scales_.clear();
-        edg_s_.clear(); edg_t_.clear(); edg_w_.clear(); medg_w_.clear(); edg_p_.clear();
-        fedg_s_.clear(); fedg_t_.clear(); fedg_w_.clear(); fedg_p_.clear();
-    }
     // position of vertex v in the growing next field (appending it on first sight)
-    int32_t place(int32_t v) {
-        int32_t& s = slot_[v];
+    int32_t place(int32_t v, Hop& h) {
+        int32_t& s = slot_[(size_t)v];
         if (s < 0) {
-            s = (int32_t)next_.size();
-            next_.push_back(v);
+            s = (int32_t)h.field.size();
+            h.field.push_back(v);
         }
         return s;
     }
-    int32_t fplace(int32_t v) {
-        int32_t& s = fslot_[v];
-        if (s < fbase_) {
-            s = fbase_ + (int32_t)ffield_.size();
-            ffield_.push_back(v);
-        }
-        return s - fbase_;
-    }
-
-#if defined(__x86_64__)
-    // fplace() over a whole neighbour list, 16 entries per step (AVX-512: gather the table entries, give the
-    // unseen vertices consecutive positions in list order with an expand, scatter the new stamps, append the
-    // new vertices with a compress-store).  Same first-seen numbering as the scalar loop: the entries of a
-    // vector are applied "at once", which differs from one-by-one only if a vertex occurs twice among the
-    // unseen lanes -- detected with vpconflictd and handed to the scalar loop.  This loop was 2/3 of the
-    // sampler's time (50 k table lookups per Reddit batch).
-    __attribute__((target("avx512f,avx512cd")))
-    void fplace_row_avx512(const int32_t* cols, int32_t deg, int32_t* ft) {
-        const size_t old = ffield_.size();
-        ffield_.resize(old + (size_t)deg);                 // room for the worst case; trimmed below
-        int32_t* fnew = ffield_.data();
-        int32_t next = (int32_t)old;
-        const __m512i base = _mm512_set1_epi32(fbase_);
-        const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-        for (int32_t k = 0; k < deg; k += 16) {
-            const __mmask16 m = deg - k >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << (deg - k)) - 1u);
-            const __m512i v = _mm512_maskz_loadu_epi32(m, cols + k);
-            __m512i sl = _mm512_mask_i32gather_epi32(_mm512_set1_epi32(-1), m, v, fslot_.data(), 4);
-            const __mmask16 fresh = _mm512_mask_cmplt_epi32_mask(m, sl, base);
-            if (fresh) {
-                const __m512i conf = _mm512_conflict_epi32(_mm512_mask_mov_epi32(_mm512_sub_epi32(_mm512_setzero_si512(), _mm512_add_epi32(iota, _mm512_set1_epi32(1))), fresh, v));
-                if (_mm512_mask_test_epi32_mask(fresh, conf, conf)) {      // a repeated unseen vertex: one by one
-                    ffield_.resize((size_t)next);
-                    for (int32_t q = k; q < std::min(deg, k + 16); q++) ft[q] = fplace(cols[q]);
-                    next = (int32_t)ffield_.size();
-                    ffield_.resize(old + (size_t)deg);
-                    fnew = ffield_.data();
-                    continue;
-                }
-                const __m512i ids = _mm512_maskz_expand_epi32(fresh, _mm512_add_epi32(iota, _mm512_set1_epi32(next)));
-                const __m512i stamped = _mm512_add_epi32(ids, base);
-                _mm512_mask_i32scatter_epi32(fslot_.data(), fresh, v, stamped, 4);
-                _mm512_mask_compressstoreu_epi32(fnew + next, fresh, v);
-                next += __builtin_popcount((unsigned)fresh);
-                sl = _mm512_mask_mov_epi32(sl, fresh, stamped);
-            }
-            _mm512_mask_storeu_epi32(ft + k, m, _mm512_sub_epi32(sl, base));
-        }
-        ffield_.resize((size_t)next);
-    }
-#else
-    void fplace_row_avx512(const int32_t* cols, int32_t deg, int32_t* ft) {          // never taken: avx512_ is false
-        for (int32_t k = 0; k < deg; k++) ft[k] = fplace(cols[k]);
-    }
-#endif
 
     // Uniform sampling w/o replacement, optional control-variate extras (scheduler.cpp:125-180)
-    int expand_uniform(int32_t degree, size_t n_out) {
+    int expand_uniform(int32_t degree, size_t n_out, Hop& h, bool want_coo) {
         // The batch's rows are scattered over a CSR of hundreds of MB (shuffled train ids): every row
         // starts with two DRAM misses (neighbour ids, weights).  The ids are known up front, so the rows a
         // few iterations ahead are prefetched -- the row pointer first (it is needed to form the address),
-        // then the first lines of both arrays; the hardware prefetcher follows the rest of a row.
+        // then the lines of both arrays (rows are too short to train the hardware prefetcher).
         constexpr size_t kAheadPtr = 16, kAhead = 8;
+        constexpr int kLines = 16;
         for (size_t i = 0; i < n_out; i++) {
             if (i + kAheadPtr < n_out) __builtin_prefetch(ptr_.data() + field_[i + kAheadPtr], 0, 1);
             if (i + kAhead < n_out) {
-                const int32_t pv = ptr_[field_[i + kAhead]];
-                const int32_t pdeg = ptr_[field_[i + kAhead] + 1] - pv;
+                const int32_t pv = ptr_[(size_t)field_[i + kAhead]];
+                const int32_t pdeg = ptr_[(size_t)field_[i + kAhead] + 1] - pv;
                 const char* c0 = reinterpret_cast<const char*>(nbr_.data() + pv);
                 const char* w0 = reinterpret_cast<const char*>(wgt_.data() + pv);
-                const int lines = std::min(4, (pdeg * 4 + 63) / 64);
+                const int lines = std::min(kLines, (pdeg * 4 + 63) / 64);
                 for (int q = 0; q < lines; q++) { __builtin_prefetch(c0 + 64 * q, 1, 1); __builtin_prefetch(w0 + 64 * q, 1, 1); }
             }
             const int32_t v = field_[i];
-            int32_t* cols = nbr_.data() + ptr_[v];
-            float* vals = wgt_.data() + ptr_[v];
-            const int32_t deg = ptr_[v + 1] - ptr_[v];
+            int32_t* cols = nbr_.data() + ptr_[(size_t)v];
+            float* vals = wgt_.data() + ptr_[(size_t)v];
+            const int32_t deg = ptr_[(size_t)v + 1] - ptr_[(size_t)v];
             const int32_t take = std::min(deg, degree);
             // amplification deg/take in fp32; isolated rows amplify by 1  (scheduler.cpp:132-133)
             const float amp = deg == 0 ? 1.0f : (float)deg / (float)take;
             // 1/sqrt(amp): fp32 sqrt, fp64 reciprocal, stored fp32        (scheduler.cpp:134)
-            scales_.push_back((float)(1.0 / (double)std::sqrt(amp)));
+            h.scales.push_back((float)(1.0 / (double)std::sqrt(amp)));
 
             for (int32_t k = 0; k < take; k++) {
                 // pick a position in [k, deg) and move it to the front segment; the product
@@ -356,130 +499,92 @@ private:
                 std::swap(cols[k], cols[j]);
                 std::swap(vals[k], vals[j]);
                 const float w = vals[k] * amp;
-                edg_s_.push_back((int32_t)i);
-                edg_t_.push_back(place(cols[k]));
-                edg_w_.push_back(w);
-                if (cv_) medg_w_.push_back(vals[k] * w);
+                h.edg_s.push_back((int32_t)i);
+                h.edg_t.push_back(place(cols[k], h));
+                h.edg_w.push_back(w);
+                if (cv_) h.medg_w.push_back(vals[k] * w);
             }
-            edg_p_.push_back((int32_t)edg_t_.size());
+            h.edg_p.push_back((int32_t)h.edg_t.size());
 
             if (cv_) {
-                // every neighbour, in the row's current (post-swap) order   (scheduler.cpp:167-179);
-                // bulk-grown and filled through raw pointers: this loop is half of the sampler's time
-                const size_t base = fedg_t_.size();
-                fedg_t_.resize(base + (size_t)deg);
-                fedg_w_.resize(base + (size_t)deg);
-                int32_t* ft = fedg_t_.data() + base;
-                if (avx512_) fplace_row_avx512(cols, deg, ft);
-                else for (int32_t k = 0; k < deg; k++) ft[k] = fplace(cols[k]);
-                if (deg) memcpy(fedg_w_.data() + base, vals, (size_t)deg * sizeof(float));
-                if (want_coo_) fedg_s_.insert(fedg_s_.end(), (size_t)deg, (int32_t)i);
-                fedg_p_.push_back((int32_t)fedg_t_.size());
+                // every neighbour, in the row's current (post-swap) order   (scheduler.cpp:167-179): the vertex
+                // ids now, their first-seen positions when a packer relabels the hop
+                if (deg) {
+                    memcpy(h.fedg_t.grow((size_t)deg), cols, (size_t)deg * sizeof(int32_t));
+                    memcpy(h.fedg_w.grow((size_t)deg), vals, (size_t)deg * sizeof(float));
+                    if (want_coo) std::fill_n(h.fedg_s.grow((size_t)deg), (size_t)deg, (int32_t)i);
+                }
+                h.fedg_p.push_back((int32_t)h.fedg_t.size());
             }
         }
-        if (!cv_) fedg_p_.assign(n_out + 1, 0);
+        if (!cv_) h.fedg_p.fill(n_out + 1, 0);
         return SGCN_OK;
     }
 
     // Importance sampling of the joint neighbourhood (scheduler.cpp:63-123)
-    int expand_importance(int32_t degree) {
+    int expand_importance(int32_t degree, Hop& h) {
         const size_t n_out = field_.size();
         std::vector<int32_t> cand;
         std::vector<float> prob;
         std::vector<char> seen((size_t)n_, 0);
         std::vector<int32_t> hits((size_t)n_, 0);
         float mass = 0.f;
-        for (int32_t v : field_)
-            for (int32_t p = ptr_[v]; p < ptr_[v + 1]; p++) {
-                const int32_t t = nbr_[p];
-                if (!seen[t]) {
-                    seen[t] = 1;
+        for (size_t i = 0; i < n_out; i++) {
+            const int32_t v = field_[i];
+            for (int32_t p = ptr_[(size_t)v]; p < ptr_[(size_t)v + 1]; p++) {
+                const int32_t t = nbr_[(size_t)p];
+                if (!seen[(size_t)t]) {
+                    seen[(size_t)t] = 1;
                     cand.push_back(t);
-                    mass += importance_[t];
-                    prob.push_back(importance_[t]);
+                    mass += importance_[(size_t)t];
+                    prob.push_back(importance_[(size_t)t]);
                 }
             }
+        }
         if (prob.empty()) {
-            edg_p_.assign(n_out + 1, 0);
-            fedg_p_.assign(n_out + 1, 0);
+            h.edg_p.fill(n_out + 1, 0);
+            h.fedg_p.fill(n_out + 1, 0);
             return fail(SGCN_ERR_EMPTY_PROB, "Prob is empty");
         }
         FenwickMultinomial mult(prob.data(), (int)prob.size());
         const int32_t draws = (int32_t)std::min(n_out * (size_t)degree, cand.size());
         for (int32_t k = 0; k < draws; k++) {
-            const int32_t t = cand[mult.draw()];
-            hits[t]++;
-            place(t);
+            const int32_t t = cand[(size_t)mult.draw()];
+            hits[(size_t)t]++;
+            place(t, h);
         }
         int rc = SGCN_OK;
         for (size_t i = 0; i < n_out; i++) {
             const int32_t v = field_[i];
-            for (int32_t p = ptr_[v]; p < ptr_[v + 1]; p++) {
-                const int32_t t = nbr_[p];
-                if (!hits[t]) continue;
+            for (int32_t p = ptr_[(size_t)v]; p < ptr_[(size_t)v + 1]; p++) {
+                const int32_t t = nbr_[(size_t)p];
+                if (!hits[(size_t)t]) continue;
                 // ((hits*w)*mass) / (importance*draws), all fp32, left to right (scheduler.cpp:107-108)
-                const float num = ((float)hits[t] * wgt_[p]) * mass;
-                const float den = importance_[t] * (float)draws;
+                const float num = ((float)hits[(size_t)t] * wgt_[(size_t)p]) * mass;
+                const float den = importance_[(size_t)t] * (float)draws;
                 const float w = num / den;
-                edg_s_.push_back((int32_t)i);
-                edg_t_.push_back(slot_[t]);
-                edg_w_.push_back(w);
+                h.edg_s.push_back((int32_t)i);
+                h.edg_t.push_back(slot_[(size_t)t]);
+                h.edg_w.push_back(w);
                 if (std::isnan(w)) rc = fail(SGCN_ERR_NAN, "nan");
             }
-            edg_p_.push_back((int32_t)edg_t_.size());
+            h.edg_p.push_back((int32_t)h.edg_t.size());
         }
-        fedg_p_.assign(n_out + 1, 0);
+        h.fedg_p.fill(n_out + 1, 0);
         return rc;
     }
 
-    void pad_i() { while (pi_.size() & 3) pi_.push_back(0); }
-    void pad_f() { while (pf_.size() & 3) pf_.push_back(0.f); }
-    void put_i(const std::vector<int32_t>& v, int64_t* d) {
-        d[0] = (int64_t)pi_.size(); d[1] = (int64_t)v.size();
-        pi_.insert(pi_.end(), v.begin(), v.end());
-        pad_i();
-    }
-    void put_f(const std::vector<float>& v, int64_t* d) {
-        d[0] = (int64_t)pf_.size(); d[1] = (int64_t)v.size();
-        pf_.insert(pf_.end(), v.begin(), v.end());
-        pad_f();
-    }
-    void put_csr(int64_t* d, int32_t nrows, int32_t ncols, const std::vector<int32_t>& rowptr,
-                 const std::vector<int32_t>& col, const std::vector<float>& val, int32_t plan_T) {
-        int64_t tmp[2];
-        d[0] = nrows; d[1] = ncols; d[2] = (int64_t)col.size();
-        put_i(rowptr, tmp); d[3] = tmp[0];
-        put_i(col, tmp); d[4] = tmp[0];
-        put_f(val, tmp); d[5] = tmp[0];
-        int64_t nslots = 0;
-        plan_build(rowptr.data(), nrows, plan_T, seg_, fix_, nslots);
-        put_i(seg_, tmp); d[6] = tmp[0]; d[7] = (int64_t)seg_.size() / 4;
-        put_i(fix_, tmp); d[8] = tmp[0]; d[9] = (int64_t)fix_.size() / 3;
-        d[10] = nslots;
-    }
-
-    std::vector<int32_t> pi_, seg_, fix_;
-    std::vector<float> pf_;
     int32_t n_;
     bool cv_, is_, transpose_ready_ = false;
-    bool want_coo_ = true;     // the COO source-row array of the full edges (only the view API needs it)
     std::vector<int32_t> nbr_;   // private, permuted in place
     std::vector<float> wgt_;
     std::vector<int32_t> ptr_;
-    std::vector<int32_t> slot_, fslot_;
-    int32_t fbase_ = 0;                    // stamp base of fslot_: an entry >= fbase_ is a position in this hop's ffield_
-#if defined(__x86_64__)
-    const bool avx512_ = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && !getenv("SGCN_NO_AVX512");
-#else
-    const bool avx512_ = false;
-#endif
+    std::vector<int32_t> slot_;
     std::vector<float> importance_;
-    std::vector<int32_t> field_, next_, ffield_;
-    std::vector<float> scales_;
-    std::vector<int32_t> edg_s_, edg_t_, edg_p_, fedg_s_, fedg_t_, fedg_p_;
-    std::vector<float> edg_w_, medg_w_, fedg_w_;
-    std::vector<int32_t> tedg_p_, tedg_t_;
-    std::vector<float> tedg_w_;
+    Buf<int32_t> field_;         // the current receptive field (input of the next hop)
+    Hop cur_;                    // the call-by-call interface's hop
+    std::vector<Hop> hops_;      // pack_batch's hops
+    Packer packer_;
     Mt19937 rng_;
 };
 
@@ -521,81 +626,169 @@ static bool numa_cpus_of_caller(cpu_set_t* set) {
     return false;
 }
 
-// ---- native prefetch thread --------------------------------------------------------------------
-// The sampler of an epoch as a C++ thread: it walks the epoch's id slices in order (so the sample
-// sequence is the synchronous loop's, bit for bit), packs each minibatch and copies it into the
-// next free pinned staging slot.  No Python runs on this thread: a Python producer thread has to
+// ---- native prefetch threads ------------------------------------------------------------------
+// The sampler of an epoch as C++ threads: the epoch's id slices are walked in order (so the sample
+// sequence is the synchronous loop's, bit for bit), each minibatch is packed and copied into the
+// next free pinned staging slot.  No Python runs on these threads: a Python producer thread has to
 // re-take the interpreter lock after every foreign call, and against a launching thread that
 // releases and re-takes it every ~20 us that costs ~0.25 ms per batch (measured: 0.5 ms per batch
 // next to 0.26 ms alone) -- enough to make the sampler the bottleneck of the epoch.
+//
+// Three shapes:
+//   * one sampler, no packers: one thread samples and packs (rounds 1-2);
+//   * one sampler + P packers (round 3, the default): the sampler's CORE (random draws, the in-place permutation,
+//     the rows' neighbour lists) runs on one thread and hands each batch's hops to one of P packer threads (numbering
+//     of the full-neighbour field, transposes, plans, layout, copy into the slot).  The core is the only sequential
+//     part and less than half of the work; the output is the single thread's, bit for bit;
+//   * N samplers: N independent streams (NOT the reference's sample sequence: the non-parity fast mode).
 struct sgcn_prefetch {
     struct Ready { int32_t batch = 0, slot = 0; int64_t n_i = 0, n_f = 0; std::vector<int64_t> meta; std::unique_ptr<std::vector<int32_t>> spill; };
+    struct Raw { int32_t batch = 0; std::vector<sgcn::Hop> hops; };
     std::vector<sgcn_sched*> ss;                   // one sampler per producer thread
     std::vector<int32_t> ids; std::vector<int64_t> off;
     int32_t L = 0, n_classes = 0, plan_T = 0, lag = 2;
     std::vector<int32_t> degrees; const float* labels = nullptr;
     std::vector<void*> slot_words; std::vector<int64_t> slot_caps;
     int64_t meta_len = 0;
-    std::mutex mu; std::condition_variable cv_free, cv_ready;
+    std::mutex mu; std::condition_variable cv_free, cv_ready, cv_raw;
     std::deque<int32_t> free_slots;
     std::vector<Ready> ready; std::vector<char> is_ready;       // indexed by batch
     int32_t next_batch = 0;                                      // the batch the consumer takes next
     std::vector<std::unique_ptr<std::vector<int32_t>>> spills;   // batches that outgrew their slot
     bool stop = false; int32_t running = 0; int error = 0; std::string error_msg;
-    double t_wait = 0, t_pack = 0, t_copy = 0;       // producer seconds: waiting for a slot / packing / copying
+    double t_wait = 0, t_pack = 0, t_copy = 0, t_sample = 0;     // producer seconds: waiting for a slot / packing / copying / the core
     std::vector<std::thread> ths;
+    // pipelined shape
+    std::vector<std::unique_ptr<sgcn::Packer>> packers;
+    std::vector<std::unique_ptr<Raw>> raw_pool;
+    std::deque<Raw*> raw_free, raw_ready;
+    bool core_done = false;
 
-    // Thread k builds batches k, k + N, k + 2N, ...  A batch may take a slot only inside the window
-    // of batches the consumer will ask for next: with `window` = slots the consumer never holds,
-    // the batches in the window can all be staged at once, so the one the consumer is waiting for
-    // can never be starved of a slot by later ones.
-    void run(int32_t k) {
-        const int32_t nb = (int32_t)off.size() - 1, N = (int32_t)ss.size();
-        const int32_t window = std::max<int32_t>(1, (int32_t)slot_words.size() - lag - 1);
-        using clk = std::chrono::steady_clock;
-        for (int32_t b = k; b < nb; b += N) {
-            int32_t slot;
-            const auto c0 = clk::now();
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_free.wait(lk, [&] { return stop || error || (b < next_batch + window && !free_slots.empty()); });
-                if (stop || error) break;
-                slot = free_slots.front(); free_slots.pop_front();
-            }
-            const auto c1 = clk::now();
-            Ready r; r.batch = b; r.slot = slot; r.meta.assign((size_t)meta_len, 0);
-            const int rc = ss[(size_t)k]->impl.pack_batch((int32_t)(off[b + 1] - off[b]), ids.data() + off[b], L,
-                                                          degrees.data(), labels, n_classes, plan_T, r.meta.data(),
-                                                          meta_len, &r.n_i, &r.n_f);
-            if (rc != SGCN_OK) {
-                std::lock_guard<std::mutex> lk(mu);
-                error = rc; error_msg = sgcn::error_slot();
-                break;
-            }
-            const int64_t ni = std::max<int64_t>(r.n_i, 1), nf = std::max<int64_t>(r.n_f, 1);
-            int32_t* dst;
-            if (ni + nf <= slot_caps[(size_t)slot]) dst = static_cast<int32_t*>(slot_words[(size_t)slot]);
-            else {                       // rare: the batch outgrew the slot -> heap buffer, slot stays unused
-                r.spill.reset(new std::vector<int32_t>((size_t)(ni + nf)));
-                dst = r.spill->data();
-            }
-            const auto c2 = clk::now();
-            ss[(size_t)k]->impl.packed_copy(dst, reinterpret_cast<float*>(dst + ni));
-            const auto c3 = clk::now();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                ready[(size_t)b] = std::move(r);
-                is_ready[(size_t)b] = 1;
-                t_wait += std::chrono::duration<double>(c1 - c0).count();
-                t_pack += std::chrono::duration<double>(c2 - c1).count();
-                t_copy += std::chrono::duration<double>(c3 - c2).count();
-            }
-            cv_ready.notify_all();
+    using clk = std::chrono::steady_clock;
+    static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+    // A batch may take a slot only inside the window of batches the consumer will ask for next: with `window` = slots
+    // the consumer never holds, the batches in the window can all be staged at once, so the one the consumer is waiting
+    // for can never be starved of a slot by later ones.
+    int32_t window() const { return std::max<int32_t>(1, (int32_t)slot_words.size() - lag - 1); }
+    bool take_slot(int32_t b, int32_t* slot) {
+        std::unique_lock<std::mutex> lk(mu);
+        const int32_t w = window();
+        cv_free.wait(lk, [&] { return stop || error || (b < next_batch + w && !free_slots.empty()); });
+        if (stop || error) return false;
+        *slot = free_slots.front(); free_slots.pop_front();
+        return true;
+    }
+    int32_t* dest(Ready& r, int64_t ni, int64_t nf) {
+        if (ni + nf <= slot_caps[(size_t)r.slot]) return static_cast<int32_t*>(slot_words[(size_t)r.slot]);
+        r.spill.reset(new std::vector<int32_t>((size_t)(ni + nf)));   // rare: the batch outgrew the slot -> heap buffer
+        return r.spill->data();
+    }
+    void publish(Ready&& r, double tw, double tp, double tc) {
+        const int32_t b = r.batch;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready[(size_t)b] = std::move(r);
+            is_ready[(size_t)b] = 1;
+            t_wait += tw; t_pack += tp; t_copy += tc;
         }
+        cv_ready.notify_all();
+    }
+    void set_error(int rc) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!error) { error = rc; error_msg = sgcn::error_slot(); }
+    }
+    void producer_exit() {
         std::lock_guard<std::mutex> lk(mu);
         running--;
         cv_ready.notify_all();
         cv_free.notify_all();
+        cv_raw.notify_all();
+    }
+
+    // Thread k builds batches k, k + N, k + 2N, ... with its own sampler (core and packer on the same thread).
+    void run(int32_t k) {
+        const int32_t nb = (int32_t)off.size() - 1, N = (int32_t)ss.size();
+        for (int32_t b = k; b < nb; b += N) {
+            const auto c0 = clk::now();
+            Ready r; r.batch = b;
+            if (!take_slot(b, &r.slot)) break;
+            const auto c1 = clk::now();
+            r.meta.assign((size_t)meta_len, 0);
+            const int rc = ss[(size_t)k]->impl.pack_batch((int32_t)(off[b + 1] - off[b]), ids.data() + off[b], L,
+                                                          degrees.data(), labels, n_classes, plan_T, r.meta.data(),
+                                                          meta_len, &r.n_i, &r.n_f);
+            if (rc != SGCN_OK) { set_error(rc); break; }
+            const int64_t ni = std::max<int64_t>(r.n_i, 1), nf = std::max<int64_t>(r.n_f, 1);
+            int32_t* dst = dest(r, ni, nf);
+            const auto c2 = clk::now();
+            ss[(size_t)k]->impl.packed_copy(dst, reinterpret_cast<float*>(dst + ni));
+            const auto c3 = clk::now();
+            publish(std::move(r), secs(c0, c1), secs(c1, c2), secs(c2, c3));
+        }
+        producer_exit();
+    }
+
+    // The core thread of the pipelined shape: batches in order, each into a Raw from the pool.
+    void run_core() {
+        const int32_t nb = (int32_t)off.size() - 1;
+        for (int32_t b = 0; b < nb; b++) {
+            Raw* raw;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_raw.wait(lk, [&] { return stop || error || !raw_free.empty(); });
+                if (stop || error) break;
+                raw = raw_free.front(); raw_free.pop_front();
+            }
+            const auto c0 = clk::now();
+            raw->batch = b;
+            (void)ss[0]->impl.sample_batch((int32_t)(off[b + 1] - off[b]), ids.data() + off[b], L, degrees.data(), raw->hops);
+            const auto c1 = clk::now();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                raw_ready.push_back(raw);
+                t_sample += secs(c0, c1);
+            }
+            cv_raw.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        core_done = true;
+        cv_raw.notify_all();
+    }
+    void run_packer(int32_t j) {
+        sgcn::Packer& pk = *packers[(size_t)j];
+        const bool cv = ss[0]->impl.cv();
+        for (;;) {
+            Raw* raw;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_raw.wait(lk, [&] { return stop || error || !raw_ready.empty() || core_done; });
+                if (stop || error || raw_ready.empty()) break;
+                raw = raw_ready.front(); raw_ready.pop_front();       // batches arrive in order: the oldest first
+            }
+            const int32_t b = raw->batch;
+            const auto c0 = clk::now();
+            Ready r; r.batch = b;
+            if (!take_slot(b, &r.slot)) break;
+            const auto c1 = clk::now();
+            r.meta.assign((size_t)meta_len, 0);
+            const int32_t n = (int32_t)(off[b + 1] - off[b]);
+            const int rc = pk.pack(n, ids.data() + off[b], raw->hops.data(), L, cv, labels, n_classes, plan_T, r.meta.data(),
+                                   meta_len, &r.n_i, &r.n_f);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                raw_free.push_back(raw);
+            }
+            cv_raw.notify_all();
+            if (rc != SGCN_OK) { set_error(rc); break; }
+            const int64_t ni = std::max<int64_t>(r.n_i, 1), nf = std::max<int64_t>(r.n_f, 1);
+            int32_t* dst = dest(r, ni, nf);
+            const auto c2 = clk::now();
+            pk.copy_out(dst, reinterpret_cast<float*>(dst + ni));
+            const auto c3 = clk::now();
+            publish(std::move(r), secs(c0, c1), secs(c1, c2), secs(c2, c3));
+        }
+        producer_exit();
     }
 };
 
@@ -604,7 +797,7 @@ struct sgcn_mult { sgcn::FenwickMultinomial impl; };
 extern "C" {
 
 const char* sgcn_last_error(void) { return sgcn::error_slot(); }
-int sgcn_abi_version(void) { return 6; }
+int sgcn_abi_version(void) { return 7; }
 
 int sgcn_sched_create(const float* w, const int32_t* idx, const int32_t* ptr, int32_t num_data,
                       int32_t num_edges, int32_t L, int32_t cv, int32_t is, sgcn_sched_t** out) {
@@ -634,17 +827,11 @@ int sgcn_sched_expand(sgcn_sched_t* s, int32_t degree) {
     return s->impl.expand(degree);
 }
 int sgcn_sched_view_i32(sgcn_sched_t* s, int32_t which, const int32_t** ptr, int64_t* len) {
-    const std::vector<int32_t>* v = s ? s->impl.ivec(which) : nullptr;
-    if (!v || !ptr || !len) return sgcn::fail(SGCN_ERR_INVALID, "view_i32: bad selector %d", which);
-    *ptr = v->data();
-    *len = (int64_t)v->size();
+    if (!s || !ptr || !len || !s->impl.ivec(which, ptr, len)) return sgcn::fail(SGCN_ERR_INVALID, "view_i32: bad selector %d", which);
     return SGCN_OK;
 }
 int sgcn_sched_view_f32(sgcn_sched_t* s, int32_t which, const float** ptr, int64_t* len) {
-    const std::vector<float>* v = s ? s->impl.fvec(which) : nullptr;
-    if (!v || !ptr || !len) return sgcn::fail(SGCN_ERR_INVALID, "view_f32: bad selector %d", which);
-    *ptr = v->data();
-    *len = (int64_t)v->size();
+    if (!s || !ptr || !len || !s->impl.fvec(which, ptr, len)) return sgcn::fail(SGCN_ERR_INVALID, "view_f32: bad selector %d", which);
     return SGCN_OK;
 }
 
@@ -673,9 +860,9 @@ int64_t sgcn_sched_packed_meta_len(int32_t L) { return sgcn::NeighbourSampler::m
 int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32_t n_batches,
                         const int32_t* ids, const int64_t* offsets, int32_t L, const int32_t* degrees,
                         const float* labels, int32_t n_classes, int32_t plan_T, int32_t n_slots,
-                        void* const* slot_words, const int64_t* slot_caps, int32_t lag,
+                        void* const* slot_words, const int64_t* slot_caps, int32_t lag, int32_t n_packers,
                         sgcn_prefetch_t** out) {
-    if (!samplers || n_samplers < 1 || !out || n_batches < 0 || !offsets || (n_batches > 0 && !ids) || L < 0 ||
+    if (!samplers || n_samplers < 1 || n_packers < 0 || (n_packers > 0 && n_samplers != 1) || !out || n_batches < 0 || !offsets || (n_batches > 0 && !ids) || L < 0 ||
         (L > 0 && !degrees) || n_slots < 1 || !slot_words || !slot_caps || lag < 0 || lag + 1 >= n_slots)
         return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: bad argument");
     for (int32_t i = 0; i < n_samplers; i++)
@@ -695,14 +882,28 @@ int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32
             p->free_slots.push_back(i);
         }
         sgcn_prefetch* raw = p.get();
-        p->running = n_samplers;
         cpu_set_t node_cpus;
         const bool pin = numa_cpus_of_caller(&node_cpus);      // keep the producers next to the CSR copy
-        for (int32_t k = 0; k < n_samplers; k++)
-            p->ths.emplace_back([raw, k, pin, node_cpus] {
+        auto spawn = [&](std::function<void()> body) {
+            p->ths.emplace_back([body, pin, node_cpus] {
                 if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_cpus);
-                raw->run(k);
+                body();
             });
+        };
+        if (n_packers == 0) {
+            p->running = n_samplers;
+            for (int32_t k = 0; k < n_samplers; k++) spawn([raw, k] { raw->run(k); });
+        } else {
+            const int32_t nv = samplers[0]->impl.num_vertices();
+            for (int32_t j = 0; j < n_packers; j++) p->packers.emplace_back(new sgcn::Packer(nv));
+            for (int32_t j = 0; j < 2 * n_packers + 1; j++) {       // hops in flight: one per packer + what the core runs ahead
+                p->raw_pool.emplace_back(new sgcn_prefetch::Raw);
+                p->raw_free.push_back(p->raw_pool.back().get());
+            }
+            p->running = n_packers;
+            spawn([raw] { raw->run_core(); });
+            for (int32_t j = 0; j < n_packers; j++) spawn([raw, j] { raw->run_packer(j); });
+        }
         *out = p.release();
     } catch (const std::exception& e) {
         return sgcn::fail(SGCN_ERR_INVALID, "prefetch_start: %s", e.what());
@@ -754,12 +955,12 @@ int sgcn_prefetch_release(sgcn_prefetch_t* p, int32_t slot) {
     return SGCN_OK;
 }
 
-/* Producer-side seconds so far: out[0] waiting for a free slot, out[1] sampling + packing,
- * out[2] copying into the staging slots. */
+/* Producer-side seconds so far: out[0] waiting for a free slot, out[1] sampling + packing (pipelined shape: packing,
+ * summed over the packers), out[2] copying into the staging slots, out[3] the core thread's sampling (pipelined shape). */
 int sgcn_prefetch_stats(sgcn_prefetch_t* p, double* out) {
     if (!p || !out) return sgcn::fail(SGCN_ERR_INVALID, "prefetch_stats: bad argument");
     std::lock_guard<std::mutex> lk(p->mu);
-    out[0] = p->t_wait; out[1] = p->t_pack; out[2] = p->t_copy;
+    out[0] = p->t_wait; out[1] = p->t_pack; out[2] = p->t_copy; out[3] = p->t_sample;
     return SGCN_OK;
 }
 
@@ -770,6 +971,7 @@ void sgcn_prefetch_stop(sgcn_prefetch_t* p) {
         p->stop = true;
     }
     p->cv_free.notify_all();
+    p->cv_raw.notify_all();
     for (auto& t : p->ths)
         if (t.joinable()) t.join();
     delete p;

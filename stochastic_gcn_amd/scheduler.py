@@ -413,8 +413,13 @@ class NativePrefetcher(object):
     staging slots; a slot goes back to the producers ``lag`` batches after it was handed out, once
     the H2D copy the consumer recorded on it has completed."""
 
-    def __init__(self, sch, batches, plan_T=0, depth=2, pin=True, lag=2):
+    def __init__(self, sch, batches, plan_T=0, depth=2, pin=True, lag=2, packers=None):
         schs = list(sch) if isinstance(sch, (list, tuple)) else [sch]
+        if packers is None:       # one sampler: its core on one thread, the packing on three others (same bits)
+            packers = 3 if len(schs) == 1 else 0
+        if len(schs) > 1:
+            packers = 0
+        self.packers = int(packers)
         for s_ in schs:
             s_._packed_setup()
         sch = schs[0]
@@ -423,7 +428,7 @@ class NativePrefetcher(object):
         ids = np.ascontiguousarray(np.concatenate(batches) if batches else np.zeros(0), dtype=np.int32)
         off = np.zeros(len(batches) + 1, dtype=np.int64)
         np.cumsum([len(b) for b in batches], out=off[1:])
-        n_slots = max(1, depth) * len(schs) + 1 + lag
+        n_slots = max(1, depth) * max(len(schs), self.packers) + 1 + lag
         words = int(getattr(sch, "_slot_words", 0) or (1 << 20))
         pool = getattr(sch, "_slot_pool", None)
         if pool is None or len(pool) != n_slots or pool[0].cap < words or pool[0].pin != pin:
@@ -438,7 +443,7 @@ class NativePrefetcher(object):
         self._h = C.c_void_p()
         check(lib.sgcn_prefetch_start(handles, len(schs), len(batches), ids.ctypes.data, off.ctypes.data, self.L,
                                       sch._deg32_ptr, sch._lab32_ptr, sch._lab32_cols, int(plan_T), n_slots,
-                                      ptrs, caps, int(lag), C.byref(self._h)))
+                                      ptrs, caps, int(lag), self.packers, C.byref(self._h)))
         self._keep = schs
         self.pending = []
         self.max_words = 0
@@ -470,9 +475,9 @@ class NativePrefetcher(object):
 
     def close(self):
         if self._h is not None:
-            st = (C.c_double * 3)()
+            st = (C.c_double * 4)()
             lib.sgcn_prefetch_stats(self._h, st)
-            self.stats = dict(wait_slot_s=st[0], pack_s=st[1], copy_s=st[2])
+            self.stats = dict(wait_slot_s=st[0], pack_s=st[1], copy_s=st[2], sample_s=st[3], packers=self.packers)
             lib.sgcn_prefetch_stop(self._h)
             self._h = None
             if self.max_words > self.slots[0].cap:      # size the next epoch's slots for what we saw

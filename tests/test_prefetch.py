@@ -63,9 +63,9 @@ def test_single_sampler_prefetcher_is_the_sequential_sequence():
 
 
 def test_native_prefetcher_is_the_sequential_sequence_and_survives_small_slots():
-    """The C++ sampler thread (sgcn_prefetch_*) yields exactly the batches the synchronous loop
-    yields -- also when a batch outgrows its staging slot (spill path) and when the consumer
-    stops early."""
+    """The C++ sampler threads (sgcn_prefetch_*) yield exactly the batches the synchronous loop yields -- one thread
+    sampling and packing (packers = 0) or the sampler's core on one thread feeding 1-3 packer threads -- also when a
+    batch outgrows its staging slot (spill path) and when the consumer stops early."""
     from stochastic_gcn_amd.scheduler import NativePrefetcher
     a, labels = _graph()
     deg = np.array([2, 3], dtype=np.int32)
@@ -73,10 +73,11 @@ def test_native_prefetcher_is_the_sequential_sequence_and_survives_small_slots()
     batches = epoch_batches(ids, 40, 17)
     seq = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
     ref = [seq.batch_packed(b) for b in batches]
-    for words in (1 << 20, 300):                          # roomy slots / every batch spills
-        sch = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
+    for words, packers in ((1 << 20, 0), (300, 0), (1 << 20, 1), (1 << 20, 2), (300, 2), (1 << 20, 3), (1 << 20, None)):
+        sch = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)      # roomy slots / every batch spills
         sch._slot_words = words
-        pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False)
+        pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False, packers=packers)
+        assert pre.packers == (3 if packers is None else packers)
         for r in ref:
             pb = pre.next()
             assert (pb.n_i, pb.n_f) == (r.n_i, r.n_f)
@@ -86,13 +87,15 @@ def test_native_prefetcher_is_the_sequential_sequence_and_survives_small_slots()
         assert pre.next() is None and pre.next() is None
         if words == 300:
             assert sch._slot_words > 300                  # the next epoch gets bigger slots
-    # early stop: the thread is joined without draining the epoch
-    sch = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
-    pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False)
-    assert pre.next() is not None
-    pre.close()
-    # and the sampler is usable again afterwards
-    assert sch.batch_packed(batches[0]) is not None
+        assert set(pre.stats) >= {'wait_slot_s', 'pack_s', 'copy_s', 'sample_s'} and (pre.stats['sample_s'] > 0) == (pre.packers > 0)
+    # early stop: the threads are joined without draining the epoch
+    for packers in (0, 2):
+        sch = PyScheduler(a, labels, 2, deg, PH, 5, cv=True)
+        pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False, packers=packers)
+        assert pre.next() is not None
+        pre.close()
+        # and the sampler is usable again afterwards
+        assert sch.batch_packed(batches[0]) is not None
 
 
 def test_native_multi_sampler_delivers_valid_batches_in_order():
@@ -130,12 +133,12 @@ def test_native_prefetcher_stress_no_deadlock():
     rng = np.random.RandomState(0)
     schs = [PyScheduler(a, labels, 1, deg, PH, 5 + k, cv=True) for k in range(4)]
     ids = np.arange(a.shape[0], dtype=np.int32)
-    for it in range(60):
+    for it in range(120):
         nb = int(rng.randint(0, 25))
         batches = epoch_batches(ids, int(rng.randint(1, 40)), nb)
         n = int(rng.randint(1, 5))
         pre = NativePrefetcher(schs[:n] if n > 1 else schs[0], batches, 0, depth=int(rng.randint(1, 4)), pin=False,
-                               lag=int(rng.randint(0, 3)))
+                               lag=int(rng.randint(0, 3)), packers=int(rng.randint(0, 4)))
         take = nb if rng.rand() < 0.5 else int(rng.randint(0, nb + 1))
         for i in range(take):
             pb = pre.next()
