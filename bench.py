@@ -359,6 +359,17 @@ def sampler_baseline(data10):
     while k < 150 and sch.minibatch_packed(512) is not None:
         k += 1
     res["sgcn_packed_ms_per_batch"] = (time.time() - t0) / max(k, 1) * 1e3
+    # the same batches from the prefetcher (core thread + 3 packer threads, bit-identical): producer throughput
+    from stochastic_gcn_amd.scheduler import NativePrefetcher
+    ids = np.random.RandomState(0).permutation(tr).astype(np.int32)
+    batches = [ids[i:i + 512] for i in range(0, len(ids) - 511, 512)][:150]
+    for _ in range(2):
+        pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False)
+        t0, k = time.time(), 0
+        while pre.next() is not None:
+            k += 1
+        res["sgcn_prefetch_ms_per_batch"] = (time.time() - t0) / max(k, 1) * 1e3
+    res["sgcn_prefetch_threads"] = "1 core + %d packers" % pre.packers
     try:
         from oracle import ref_binding as rb
         if rb.available():

@@ -26,6 +26,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -656,6 +657,9 @@ struct sgcn_prefetch {
     int32_t next_batch = 0;                                      // the batch the consumer takes next
     std::vector<std::unique_ptr<std::vector<int32_t>>> spills;   // batches that outgrew their slot
     bool stop = false; int32_t running = 0; int error = 0; std::string error_msg;
+    std::unique_ptr<std::atomic<char>[]> ready_flag;             // is_ready mirrored for the consumer's short spin before it blocks
+    std::atomic<int32_t> taken_raw{0};
+    std::atomic<int32_t> raw_count{0};                           // hops handed over by the core so far (same, for the packers)
     double t_wait = 0, t_pack = 0, t_copy = 0, t_sample = 0;     // producer seconds: waiting for a slot / packing / copying / the core
     std::vector<std::thread> ths;
     // pipelined shape
@@ -665,6 +669,17 @@ struct sgcn_prefetch {
     bool core_done = false;
 
     using clk = std::chrono::steady_clock;
+    // A blocked thread wakes 50-100 us after its condition variable is signalled (futex + scheduler), which is a whole
+    // batch of this pipeline: whoever is about to block polls the thing it waits for for a few tens of microseconds first.
+    template <class F> static void spin_for(F&& ready, double us) {
+        const auto t0 = clk::now();
+        while (!ready()) {
+#if defined(__x86_64__)
+            for (int i = 0; i < 32; i++) _mm_pause();
+#endif
+            if (std::chrono::duration<double, std::micro>(clk::now() - t0).count() > us) return;
+        }
+    }
     static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 
     // A batch may take a slot only inside the window of batches the consumer will ask for next: with `window` = slots
@@ -692,6 +707,7 @@ struct sgcn_prefetch {
             is_ready[(size_t)b] = 1;
             t_wait += tw; t_pack += tp; t_copy += tc;
         }
+        ready_flag[(size_t)b].store(1, std::memory_order_release);
         cv_ready.notify_all();
     }
     void set_error(int rc) {
@@ -749,6 +765,7 @@ struct sgcn_prefetch {
                 raw_ready.push_back(raw);
                 t_sample += secs(c0, c1);
             }
+            raw_count.fetch_add(1, std::memory_order_release);
             cv_raw.notify_all();
         }
         std::lock_guard<std::mutex> lk(mu);
@@ -761,10 +778,13 @@ struct sgcn_prefetch {
         for (;;) {
             Raw* raw;
             {
+                const int32_t seen = taken_raw.load(std::memory_order_relaxed);
+                spin_for([&] { return raw_count.load(std::memory_order_acquire) > seen; }, 40.0);
                 std::unique_lock<std::mutex> lk(mu);
                 cv_raw.wait(lk, [&] { return stop || error || !raw_ready.empty() || core_done; });
                 if (stop || error || raw_ready.empty()) break;
                 raw = raw_ready.front(); raw_ready.pop_front();       // batches arrive in order: the oldest first
+                taken_raw.fetch_add(1, std::memory_order_relaxed);
             }
             const int32_t b = raw->batch;
             const auto c0 = clk::now();
@@ -877,6 +897,8 @@ int sgcn_prefetch_start(sgcn_sched_t* const* samplers, int32_t n_samplers, int32
         p->meta_len = sgcn::NeighbourSampler::meta_len(L);
         p->ready.resize((size_t)n_batches);
         p->is_ready.assign((size_t)n_batches, 0);
+        p->ready_flag.reset(new std::atomic<char>[(size_t)std::max(n_batches, 1)]);
+        for (int32_t i = 0; i < n_batches; i++) p->ready_flag[(size_t)i].store(0, std::memory_order_relaxed);
         for (int32_t i = 0; i < n_slots; i++) {
             p->slot_words.push_back(slot_words[i]); p->slot_caps.push_back(slot_caps[i]);
             p->free_slots.push_back(i);
@@ -919,6 +941,9 @@ int sgcn_prefetch_next(sgcn_prefetch_t* p, int32_t* slot, int64_t* meta, int64_t
     if (!p || !slot || !meta || !n_i || !n_f || !spill) return sgcn::fail(SGCN_ERR_INVALID, "prefetch_next: bad argument");
     sgcn_prefetch::Ready r;
     {
+        const int32_t b0 = p->next_batch;              // only this (the consumer) thread writes it
+        if (b0 < (int32_t)p->ready.size())
+            sgcn_prefetch::spin_for([&] { return p->ready_flag[(size_t)b0].load(std::memory_order_acquire) != 0; }, 40.0);
         std::unique_lock<std::mutex> lk(p->mu);
         const int32_t b = p->next_batch;
         if (b >= (int32_t)p->ready.size()) return 1;
