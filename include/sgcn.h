@@ -449,6 +449,9 @@ int sgcn_sched_batch_packed_into(sgcn_sched_t* s, int32_t n, const int32_t* host
                                  int64_t meta_cap, void* host_words, int64_t cap_words,
                                  int64_t* n_i32, int64_t* n_f32);
 int64_t sgcn_sched_packed_meta_len(int32_t L);
+/* the packed batch's fadj plan uses segments of max(plan_T, SGCN_AGG_PLAN_T) nonzeros: sgcn_vr_aggregate_* give a whole
+ * workgroup to a segment (8 lane groups x 16 history rows in flight per lane = one round for 128 nonzeros) (ABI v7) */
+#define SGCN_AGG_PLAN_T 128
 
 /* ---- native prefetch thread: the sampler of a whole epoch off the interpreter ------------------
  * sgcn_prefetch_start copies the epoch's id slices (batch b = host_ids[offsets[b] : offsets[b+1]]) and

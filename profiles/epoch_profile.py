@@ -80,7 +80,7 @@ def gaps(src):
           % (len(dur), span / 1e3, dur.sum() / 1e3, 100 * dur.sum() / span, gap.sum() / 1e3))
     print("gap between consecutive kernels: median %.2f us, mean %.2f us, p90 %.2f us, share of gaps > 4 us: %.1f %%"
           % (np.median(gap), gap.mean(), np.percentile(gap, 90), 100 * (gap > 4).mean()))
-    adam = [i for i in range(lo, len(rows)) if "adam_kernel" in names[i]]
+    adam = [i for i in range(lo, len(rows)) if "adam_" in names[i]]
     if len(adam) > 2:
         per = np.diff(st[adam]) / 1e3
         print("step period (adam to adam): median %.1f us; kernels per step %.1f"
@@ -112,7 +112,7 @@ def timeline(src, n=70):
     cols = [r[1] for r in t.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     rows = list(t.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")))
-    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+    adam = [i for i, r in enumerate(rows) if "adam_" in r[0]]
     a, b = adam[len(adam) // 2], adam[len(adam) // 2 + 1]
     t0 = rows[a][2]
     print("columns:", cols)

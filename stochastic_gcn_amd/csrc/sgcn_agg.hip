@@ -43,12 +43,12 @@ __device__ __forceinline__ void store_masked(float* p, typename Vec<VW>::type v,
     else vstore_head<VW>(p, v, left);
 }
 
-// Sampled-adjacency part + epilogue for one (row, vector) given the finished P-sum.
+// Sampled-adjacency part of one (row, vector): acc1 = A (mu - Hbar[ifield]) | A x,  acc2 = A (h - mu) | A Hbar[ifield]
 template <int G, int VW>
-__device__ __forceinline__ void agg_finish(const AggArgs& a, int row, int vi, int lig, bool act,
-                                           typename Vec<VW>::type accP) {
+__device__ __forceinline__ void agg_apart(const AggArgs& a, int row, int vi, int lig, bool act,
+                                          typename Vec<VW>::type& acc1, typename Vec<VW>::type& acc2) {
     typedef typename Vec<VW>::type VT;
-    VT acc1 = vzero<VW>(), acc2 = vzero<VW>();
+    acc1 = vzero<VW>(); acc2 = vzero<VW>();
     const int start = uniform_i<G>(a.a_rowptr[row]), end = uniform_i<G>(a.a_rowptr[row + 1]);
     const int64_t voff = (int64_t)vi * VW;
     for (int p0 = start; p0 < end; p0 += G) {
@@ -77,7 +77,15 @@ __device__ __forceinline__ void agg_finish(const AggArgs& a, int row, int vi, in
             }
         }
     }
+}
+
+// The three sums combined in the reference's order, and the (self | neighbour) concat written in place.
+template <int VW>
+__device__ __forceinline__ void agg_epilogue(const AggArgs& a, int row, int vi, bool act, typename Vec<VW>::type accP,
+                                             typename Vec<VW>::type acc1, typename Vec<VW>::type acc2) {
+    typedef typename Vec<VW>::type VT;
     if (!act) return;
+    const int64_t voff = (int64_t)vi * VW;
     const int left = a.d - vi * VW;
     float* oh = a.out_h + (int64_t)row * a.ldo;
     if (a.cvd) {
@@ -97,14 +105,31 @@ __device__ __forceinline__ void agg_finish(const AggArgs& a, int row, int vi, in
     }
 }
 
+// Sampled-adjacency part + epilogue for one (row, vector) given the finished P-sum.
+template <int G, int VW>
+__device__ __forceinline__ void agg_finish(const AggArgs& a, int row, int vi, int lig, bool act,
+                                           typename Vec<VW>::type accP) {
+    typename Vec<VW>::type acc1, acc2;
+    agg_apart<G, VW>(a, row, vi, lig, act, acc1, acc2);
+    agg_epilogue<VW>(a, row, vi, act, accP, acc1, acc2);
+}
+
+// One WORKGROUP per plan segment (= one output row unless the row is longer than the plan's T): the workgroup's
+// NG = 256 / G lane groups take consecutive chunks of the segment's nonzeros, every lane keeps up to U row pieces of
+// the history in flight, and the NG partial sums are added in group order through LDS (fixed order: deterministic).
+// A Reddit CVD batch is 512 rows of ~100 history rows (512 B each, scattered over a 119 MB history): with one lane
+// group per 64-nonzero segment (rounds 1-2) 2 MB were in flight and the pass took 15 us + 6 us for the fix-up
+// kernel every row then needed; this form has the whole 26 MB requested at once and needs the fix-up only for the rows
+// longer than T = 128 (one round of 8 groups x U = 16; a longer segment would make the launch wait for its extra rounds:
+// T = 1,024 measured 29-34 us, set by the one hub row half of the batches contain).
 template <int G, int VW, int U>
-__global__ __launch_bounds__(kBlock) void agg_seg_kernel(AggArgs a) {
+__global__ __launch_bounds__(kBlock) void agg_row_kernel(AggArgs a) {
     typedef typename Vec<VW>::type VT;
-    constexpr int GPB = kBlock / G;
-    const int lig = threadIdx.x & (G - 1);
-    const int slab = (int)(blockIdx.x / a.nsegblk);
-    const int64_t s = (blockIdx.x % a.nsegblk) * GPB + threadIdx.x / G;
-    if (s >= a.nseg) return;
+    constexpr int NG = kBlock / G, NP = NG - 1;       // NP groups share the P-sum, the last one walks the sampled adjacency
+    __shared__ float part[NG + 1][G * VW];
+    const int lig = threadIdx.x & (G - 1), gq = threadIdx.x / G;
+    const int slab = (int)(blockIdx.x / a.nseg);
+    const int64_t s = blockIdx.x % a.nseg;
     int row, start, end, slot;
     if (a.seg) {
         const sgcn_seg_t sg = a.seg[s];
@@ -116,39 +141,51 @@ __global__ __launch_bounds__(kBlock) void agg_seg_kernel(AggArgs a) {
     end = uniform_i<G>(end); slot = uniform_i<G>(slot);
     const int vi = slab * G + lig;
     const bool act = vi < a.nvec;
+    const bool finish_here = slot < 0 && !a.accP_out;              // an unsplit row of the fused pass
     const float* Hl = a.H + (int64_t)vi * VW;
 
-    VT accP = vzero<VW>();
-    for (int p0 = start; p0 < end; p0 += G) {
-        const int n = min(G, end - p0);
-        int myrow = 0;
-        float myval = 0.f;
-        if (lig < n) {
-            myrow = a.ffield[a.f_col[p0 + lig]];
-            myval = a.f_val[p0 + lig];
-        }
-        int j = 0;
-        for (; j + U <= n; j += U) {
-            VT b[U];
-            float v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int c = bcast_i<G>(myrow, j + u);
-                v[u] = bcast_f<G>(myval, j + u);
-                b[u] = act ? vload<VW>(Hl + (int64_t)c * a.ldh) : vzero<VW>();
+    if (gq < NP) {
+        const int chunk = (end - start + NP - 1) / NP;
+        const int gs = start + gq * chunk, ge = min(end, gs + chunk);
+        VT accP = vzero<VW>();
+        for (int p0 = gs; p0 < ge; p0 += G) {
+            const int n = min(G, ge - p0);
+            int myrow = 0;
+            float myval = 0.f;
+            if (lig < n) {
+                myrow = a.ffield[a.f_col[p0 + lig]];
+                myval = a.f_val[p0 + lig];
             }
+            for (int j = 0; j < n; j += U) {
+                VT b[U];
+                float v[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) accP += v[u] * b[u];
+                for (int u = 0; u < U; u++) {
+                    const bool in = j + u < n;
+                    const int c = bcast_i<G>(myrow, in ? j + u : 0);
+                    v[u] = in ? bcast_f<G>(myval, j + u) : 0.f;
+                    b[u] = (act && in) ? vload<VW>(Hl + (int64_t)c * a.ldh) : vzero<VW>();
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) accP += v[u] * b[u];
+            }
         }
-        for (; j < n; j++) {
-            const int c = bcast_i<G>(myrow, j);
-            const float v = bcast_f<G>(myval, j);
-            if (act) accP += v * vload<VW>(Hl + (int64_t)c * a.ldh);
-        }
+        vstore<VW>(&part[gq][lig * VW], accP);
+    } else if (finish_here) {
+        // beside the P-sum instead of after it: its index chain (rowptr -> column -> ifield -> rows) is as long as the P-sum's
+        VT acc1, acc2;
+        agg_apart<G, VW>(a, row, vi, lig, act, acc1, acc2);
+        vstore<VW>(&part[NP][lig * VW], acc1);
+        vstore<VW>(&part[NG][lig * VW], acc2);
     }
+    __syncthreads();
+    if (gq != 0) return;
+    VT accP = vload<VW>(&part[0][lig * VW]);
+#pragma unroll
+    for (int q = 1; q < NP; q++) accP += vload<VW>(&part[q][lig * VW]);
     if (slot >= 0) { if (act) vstore<VW>(a.ws + (int64_t)slot * a.ldw + (int64_t)vi * VW, accP); }
     else if (a.accP_out) { if (act) vstore<VW>(a.accP_out + (int64_t)row * a.ldw + (int64_t)vi * VW, accP); }
-    else agg_finish<G, VW>(a, row, vi, lig, act, accP);
+    else agg_epilogue<VW>(a, row, vi, act, accP, vload<VW>(&part[NP][lig * VW]), vload<VW>(&part[NG][lig * VW]));
 }
 
 template <int G, int VW>
@@ -212,11 +249,11 @@ static int launch_agg_post(int G, const AggArgs& a, int32_t n1, hipStream_t st) 
 template <int VW>
 static int launch_agg(int G, const AggArgs& a, const sgcn_plan_t* plan, hipStream_t st) {
     const int nslab = (a.nvec + G - 1) / G;
-    const int64_t nblocks = a.nsegblk * nslab;
+    const int64_t nblocks = a.nseg * nslab;                      // one workgroup per (segment, feature slab)
     SGCN_REQUIRE(nblocks < (1ll << 31), "vr_aggregate: grid too large");
 #define SGCN_AGG_CASE(GG)                                                                          \
     case GG: {                                                                                     \
-        hipLaunchKernelGGL((agg_seg_kernel<GG, VW, 4>), dim3((unsigned)nblocks), dim3(kBlock), 0,  \
+        hipLaunchKernelGGL((agg_row_kernel<GG, VW, 16>), dim3((unsigned)nblocks), dim3(kBlock), 0,  \
                            st, a);                                                                 \
         if (plan && plan->nfix > 0) {                                                              \
             const int64_t nfblk = (plan->nfix + (kBlock / GG) - 1) / (kBlock / GG);               \

@@ -290,7 +290,10 @@ public:
             if (cv) {
                 relabel(h);
                 put_i(ffield.data(), ffield.size(), ffields_d + 2 * slot);
-                put_csr(csr_d + (3 * slot + 2) * kCsrDesc, n1, (int32_t)ffield.size(), h.fedg_p, h.fedg_t, h.fedg_w, plan_T);
+                // the full-neighbour matrix is consumed by the aggregator, one WORKGROUP per plan segment (sgcn_agg.hip):
+                // 128 nonzeros = one round of the workgroup's 8 lane groups x 16 loads in flight
+                put_csr(csr_d + (3 * slot + 2) * kCsrDesc, n1, (int32_t)ffield.size(), h.fedg_p, h.fedg_t, h.fedg_w,
+                        std::max(plan_T, (int32_t)SGCN_AGG_PLAN_T));
             }
         }
         if (labels && n_classes > 0) {                   // labels[fields[-1]]  (_scheduler.pyx:138)

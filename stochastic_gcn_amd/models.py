@@ -33,6 +33,8 @@ from .scheduler import PackedBatch, build_plan
 
 from .scheduler import CSR_DESC as _CSR_DESC          # noqa: E402
 
+AGG_PLAN_T = 128       # include/sgcn.h SGCN_AGG_PLAN_T: the aggregator gives a workgroup to a plan segment of the fadj matrix
+
 
 class _LazyHostFields(object):
     """``cur.host_fields[l]`` for a packed batch without touching NumPy unless somebody asks (only
@@ -105,7 +107,7 @@ class DevFeed(object):
             if cv:
                 ff_slots.append(add_i(feed_dict[ph['ffields'][l]]))
                 p = feed_dict[('csr', ph['fadj'][l])]
-                entry['f'] = self._pack_csr(p, add_i, add_f, plan_T, transpose=False)
+                entry['f'] = self._pack_csr(p, add_i, add_f, max(plan_T, AGG_PLAN_T), transpose=False)
             csr_slots.append(entry)
 
         ibuf = np.concatenate(ints) if ints else np.zeros(0, np.int32)

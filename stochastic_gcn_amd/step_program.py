@@ -325,6 +325,11 @@ class StepProgram(object):
         # Work that depends on nothing this step computes goes to the auxiliary stream first, beside the
         # dense layers: zeroing the gradient buffer, and every control-variate aggregator's history-only sum
         # P . Hbar[ffield] (the dominant gather of the step) -- sgcn_vr_aggregate_pre_f32.
+        # the library's auxiliary stream is used only on request: with the weight gradients grouped and the memset /
+        # statistics / scatter gone from it (group_dw, lean_sync) the two events around the aggregator's history half cost
+        # more than the overlap returns
+        from . import _ffi
+        _ffi.tune('step_overlap', int(bool(FLAGS.agg_overlap) or not (FLAGS.lean_sync and FLAGS.group_dw)))
         local_hist = m.history_hook is None
         # the history scatter: beside the step on the auxiliary stream (one event pair, a barrier on the compute queue), or
         # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
@@ -338,8 +343,9 @@ class StepProgram(object):
             else:
                 self._emit('AUX_MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
         accP = {}
+        two_phase = bool(FLAGS.agg_overlap)
         for layer in m.layers:
-            if isinstance(layer, VRAggregator):
+            if two_phase and isinstance(layer, VRAggregator):
                 l = layer.l
                 bf = self._csr(l, 2)
                 hist = m.history[l][0]
@@ -418,9 +424,15 @@ class StepProgram(object):
                     sptr = self._fp(self._pb.o_scales + 2 * l)
                     if d != int(hist.shape[1]):
                         raise Unsupported("aggregator width differs from its history")
-                    self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
-                                               self._p(h), self._p(mu), K(h.ld), self._p(H), K(H.ld), self._field_ptr(l), sptr,
-                                               self._p(out_h), self._p(out_mu), K(width), K(1), K(int(concat)), self._p(accP[l])])
+                    if two_phase:
+                        self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
+                                                   self._p(h), self._p(mu), K(h.ld), self._p(H), K(H.ld), self._field_ptr(l), sptr,
+                                                   self._p(out_h), self._p(out_mu), K(width), K(1), K(int(concat)), self._p(accP[l])])
+                    else:
+                        self._emit('VR_AGG', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), self._ip(bf + 3), self._ip(bf + 4),
+                                              self._fp(bf + 5), n1.op(), self.rows[l].op(), self._n(bf + 1), K(d), self._p(h), self._p(mu),
+                                              K(h.ld), self._p(H), K(H.ld), self._field_ptr(l), self._ip(self._pb.o_ffields + 2 * l), sptr,
+                                              self._p(out_h), self._p(out_mu), K(width), K(1), K(int(concat))] + self._plan(bf, d))
                     if local_hist and not self._hist_last:
                         self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                                         K(mu.cols), self._p(mu), K(mu.ld)])
@@ -434,9 +446,15 @@ class StepProgram(object):
                     out_h = self._alloc(n1, width)
                     if d != int(hist.shape[1]):
                         raise Unsupported("aggregator width differs from its history")
-                    self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
-                                               self._p(x), NULL, K(x.ld), self._p(H), K(H.ld), self._field_ptr(l), NULL,
-                                               self._p(out_h), NULL, K(width), K(0), K(int(concat)), self._p(accP[l])])
+                    if two_phase:
+                        self._emit('VR_AGG_POST', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), n1.op(), self.rows[l].op(), K(d),
+                                                   self._p(x), NULL, K(x.ld), self._p(H), K(H.ld), self._field_ptr(l), NULL,
+                                                   self._p(out_h), NULL, K(width), K(0), K(int(concat)), self._p(accP[l])])
+                    else:
+                        self._emit('VR_AGG', [self._ip(ba + 3), self._ip(ba + 4), self._fp(ba + 5), self._ip(bf + 3), self._ip(bf + 4),
+                                              self._fp(bf + 5), n1.op(), self.rows[l].op(), self._n(bf + 1), K(d), self._p(x), NULL,
+                                              K(x.ld), self._p(H), K(H.ld), self._field_ptr(l), self._ip(self._pb.o_ffields + 2 * l), NULL,
+                                              self._p(out_h), NULL, K(width), K(0), K(int(concat))] + self._plan(bf, d))
                     if local_hist and not self._hist_last:
                         self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                                         K(x.cols), self._p(x), K(x.ld)])

@@ -230,9 +230,8 @@ class Trainer(object):
         if par.world > torch.cuda.device_count():
             # several ranks time-slice ONE GPU (the gloo smoke configuration): every cross-stream event of
             # the step program's auxiliary stream then costs a context switch between the processes
-            # (measured: 95 ms per step instead of 1.2) -- run the program's launches on one stream
-            from . import _ffi
-            _ffi.tune('step_overlap', 0)
+            # (measured: 95 ms per step instead of 1.2) -- keep the program's launches on one stream
+            FLAGS.update(agg_overlap=False)
         self.log = log = print if (par.rank == 0 and verbose) else (lambda *a, **k: None)
 
         (num_data, train_adj, full_adj, features, train_features, test_features, labels,

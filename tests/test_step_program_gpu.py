@@ -17,7 +17,7 @@ def _model(case, params, native, group=True):
     from stochastic_gcn_amd.plaingcn import PlainGCN
     FLAGS.reset()
     FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
-    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], group_dw=group, lean_sync=group)
+    FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], group_dw=group, lean_sync=group, agg_overlap=not group)
     cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
     fl = case['flags']
     m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
@@ -52,9 +52,9 @@ SUPPORTED = ['reddit_cvd_pp', 'reddit_cv_pp', 'cvd_pp_L3', 'cv_nopp_L2', 'ns_nop
 @pytest.mark.parametrize("slot,group", [(False, True), (True, True), (True, False), (False, False)])
 def test_program_is_bit_identical_to_the_eager_path(name, slot, group):
     """group: the layers' weight-gradient GEMMs recorded and issued as ONE grouped launch + ONE reduction launch, gradients
-    STORED (no memset), loss statistics in the optimizer's launch, history scatter after the optimizer (the defaults:
-    --group_dw --lean_sync) or everything layer by layer / on the auxiliary stream -- the same tiles, K slices and
-    order of additions either way."""
+    STORED (no memset), loss statistics in the optimizer's launch, history scatter after the optimizer, the aggregator fused
+    (the defaults: --group_dw --lean_sync --noagg_overlap) or everything layer by layer / on the auxiliary stream -- the same
+    tiles, K slices and order of additions either way."""
     case = mc.build_case(name)
     a, la = _run(case, False, 5, slot)
     b, lb = _run(case, True, 5, slot, group=group)
@@ -73,6 +73,10 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot, group):
     assert sum(1 for o, _ in prog.ops_fb if o == OP['DW_FLUSH']) == (1 if group else 0)
     assert sum(1 for o, _ in prog.ops_fb if o == OP['GRAD_STORE']) == (1 if group else 0)
     assert sum(1 for o, _ in prog.ops_fb if o == OP['AUX_MEMSET0']) == (0 if group else 1)
+    # the control-variate aggregator: fused on the step's stream (default), or its history half first on the auxiliary stream
+    n_agg = sum(1 for l in b.layers if type(l).__name__ == 'VRAggregator')
+    assert sum(1 for o, _ in prog.ops_fb if o == OP['VR_AGG']) == (n_agg if group else 0)
+    assert sum(1 for o, _ in prog.ops_fb if o == OP['VR_AGG_PRE']) == (0 if group else n_agg)
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
 
 
