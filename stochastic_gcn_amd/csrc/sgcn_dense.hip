@@ -250,12 +250,20 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
 // Adam with the step's loss / accuracy statistics riding along: workgroups [0, gridDim.x - 1) are adam_kernel, the LAST one
 // is softmax_stats_kernel / sigmoid_stats_kernel (same code, same summation order -> the same bits).  Nothing in a step
 // reads the statistics before the optimizer has run, so they need neither a launch nor a stream of their own.
+// ... and the history scatter (tf.scatter_update after the optimizer, gcn/models.py:160-166): rows of the step's activations
+// into the resident history, independent of the weights -- up to two of them as further workgroups of the same launch.
+struct TailScatter {
+    float* H[2]; int64_t ldh[2]; const int32_t* idx[2]; int32_t n[2], d[2]; const float* src[2]; int64_t lds[2];
+    int32_t first[3];            // workgroups [first[j], first[j + 1]) after the Adam + statistics workgroups copy job j's rows
+    int32_t jobs;
+};
+constexpr int kTailRowsPerBlock = kBlock / 32;      // 32 lanes x float4 per 128 columns of a row
+
 __global__ __launch_bounds__(kBlock) void adam_stats_kernel(float* __restrict__ theta, const float* __restrict__ grad,
                                                             float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                             float lr_t, float b1, float b2, float eps,
                                                             const float* __restrict__ rowstat, int32_t rows, int32_t c,
-                                                            int32_t softmax, float* __restrict__ stats) {
-    const int nb = (int)gridDim.x - 1;
+                                                            int32_t softmax, float* __restrict__ stats, int32_t nb, TailScatter sc) {
     if ((int)blockIdx.x < nb) {
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)nb * kBlock) {
             const float g = grad[i];
@@ -266,6 +274,20 @@ __global__ __launch_bounds__(kBlock) void adam_stats_kernel(float* __restrict__ 
         }
         return;
     }
+    if ((int)blockIdx.x > nb) {                      // history rows: one 32-lane group per row, float4 per lane and 128 columns
+        const int b = (int)blockIdx.x - nb - 1;
+        const int j = (sc.jobs > 1 && b >= sc.first[1]) ? 1 : 0;
+        const int64_t i = (int64_t)(b - sc.first[j]) * kTailRowsPerBlock + threadIdx.x / 32;
+        if (i >= sc.n[j]) return;
+        const int64_t ri = sc.idx[j][i];
+        if (ri < 0) return;                          // negative row id: padding slot, nothing to write
+        const float* src = sc.src[j] + i * sc.lds[j];
+        float* dst = sc.H[j] + ri * sc.ldh[j];
+        for (int cq = (threadIdx.x & 31) * 4; cq < sc.d[j]; cq += 128)
+            *reinterpret_cast<float4*>(dst + cq) = *reinterpret_cast<const float4*>(src + cq);
+        return;
+    }
+    if (rows <= 0) return;                           // no statistics parked
     __shared__ float red[2][kBlock];
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < rows; i += kBlock) { a += rowstat[i]; b += rowstat[rows + i]; }
@@ -373,18 +395,39 @@ int stats_flush(void* stream) {
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }
+// history scatters parked for the optimizer's launch (sgcn_step_run: SCATTER_ROWS ops that directly follow ADAM)
+namespace { TailScatter& pending_scatter() { static TailScatter t{}; return t; } }
+// true when the job can ride (whole float4 columns, 16-byte aligned rows); false: the caller launches it itself
+bool scatter_park(float* H, int64_t ldh, const int32_t* idx, int32_t n, int32_t d, const float* src, int64_t lds) {
+    TailScatter& t = pending_scatter();
+    if (t.jobs >= 2 || n <= 0 || d <= 0 || d % 4 || ldh % 4 || lds % 4 || !aligned16(H) || !aligned16(src) || !idx) return false;
+    const int j = t.jobs++;
+    t.H[j] = H; t.ldh[j] = ldh; t.idx[j] = idx; t.n[j] = n; t.d[j] = d; t.src[j] = src; t.lds[j] = lds;
+    if (j == 0) t.first[0] = 0;
+    t.first[j + 1] = t.first[j] + (n + kTailRowsPerBlock - 1) / kTailRowsPerBlock;
+    return true;
+}
 int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                     float eps, void* stream) {
     PendingStats& p = pending_stats();
-    if (!p.armed || n <= 0) {
+    TailScatter sc = pending_scatter();
+    pending_scatter().jobs = 0;
+    if ((!p.armed && sc.jobs == 0) || n <= 0) {
         const int rc = stats_flush(stream);
-        return rc != SGCN_OK ? rc : sgcn_adam_f32(theta, grad, m, v, n, lr_t, beta1, beta2, eps, stream);
+        if (rc != SGCN_OK) return rc;
+        for (int j = 0; j < sc.jobs; j++) {
+            const int r2 = sgcn_scatter_rows_f32(sc.H[j], sc.ldh[j], sc.idx[j], sc.n[j], sc.d[j], sc.src[j], sc.lds[j], stream);
+            if (r2 != SGCN_OK) return r2;
+        }
+        return n > 0 ? sgcn_adam_f32(theta, grad, m, v, n, lr_t, beta1, beta2, eps, stream) : SGCN_OK;
     }
+    const bool st = p.armed != 0;
     p.armed = 0;
     SGCN_REQUIRE(theta && grad && m && v, "adam: null operand");
     const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
-    hipLaunchKernelGGL(adam_stats_kernel, dim3(blocks + 1), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m, v, n, lr_t,
-                       beta1, beta2, eps, p.rowstat, p.n, p.c, p.softmax, p.stats);
+    const unsigned extra = sc.jobs ? (unsigned)sc.first[sc.jobs] : 0u;
+    hipLaunchKernelGGL(adam_stats_kernel, dim3(blocks + 1 + extra), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m, v, n, lr_t,
+                       beta1, beta2, eps, st ? p.rowstat : nullptr, st ? p.n : 0, p.c, p.softmax, p.stats, (int32_t)blocks, sc);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }

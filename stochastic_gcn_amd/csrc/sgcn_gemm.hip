@@ -73,6 +73,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     const int kend = min(g.K, kbeg + g.kchunk);
     f16acc acc = {};
     float ra[4], rb[16];
+    // the LayerNorm parameters of the fused epilogue: requested now, used ~10 us later (a load issued inside the
+    // epilogue's row loop costs every row a trip to the L2: 4 us of the 12.6 this kernel took on the step's 2,036 x 128 layer)
+    float ep_scale[2] = {1.f, 1.f}, ep_offset[2] = {0.f, 0.f};
+    if (g.epi == 2) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = (threadIdx.x & 63) + e * kWave;
+            if (c < g.N) { ep_scale[e] = g.scale[c]; ep_offset[e] = g.offset[c]; }
+        }
+    }
 
     // four consecutive floats at p (the run is contiguous in every operand layout): one 16-byte
     // load when the host verified alignment and the run is fully in range, else guarded scalars
@@ -225,11 +235,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         const float rs = rsqrtf(wsum(q) / (float)g.N + g.eps);
         if (lane == 0) g.rstd[row] = rs;
         float* hr = g.xhat + (int64_t)row * g.N;
-        for (int c = lane; c < g.N; c += kWave) {
-            const float h = (Cs[rr][c] - mean) * rs;
-            hr[c] = h;
-            const float v = h * g.scale[c] + g.offset[c];
-            yr[c] = g.relu ? fmaxf(v, 0.f) : v;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            if (c < g.N) {
+                const float h = (Cs[rr][c] - mean) * rs;
+                hr[c] = h;
+                const float v = h * ep_scale[e] + ep_offset[e];
+                yr[c] = g.relu ? fmaxf(v, 0.f) : v;
+            }
         }
     }
 }
@@ -340,6 +354,14 @@ __global__ __launch_bounds__(kBlock) void splitk_ln_act_kernel(const float* __re
     if (row >= g.M) return;
     const int64_t mn = (int64_t)g.M * g.N;
     float v[2];                                   // N <= 128: two columns per lane
+    float sc[2] = {1.f, 1.f}, of[2] = {0.f, 0.f};   // requested with the partial tiles, not after the row statistics
+    if (g.epi == 2) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            if (c < g.N) { sc[e] = g.scale[c]; of[e] = g.offset[c]; }
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const int c = lane + e * kWave;
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void splitk_ln_act_kernel(const float* __re
             if (c < g.N) {
                 const float h = (v[e] - mean) * rs;
                 g.xhat[row * g.N + c] = h;
-                const float y = h * g.scale[c] + g.offset[c];
+                const float y = h * sc[e] + of[e];
                 yr[c] = g.relu ? fmaxf(y, 0.f) : y;
             }
         }

@@ -36,6 +36,7 @@ void stats_defer(int on);                // sgcn_dense.hip: the loss kernel's st
 int stats_flush(void* stream);
 int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                     float eps, void* stream);
+bool scatter_park(float* H, int64_t ldh, const int32_t* idx, int32_t n, int32_t d, const float* src, int64_t lds);
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap);
 }  // namespace sgcn
@@ -101,17 +102,23 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         bool on; void* st;
         ~Guard() { if (on) sgcn::dw_group_abort(); sgcn::grad_store_mode(0); sgcn::stats_defer(0); sgcn::stats_flush(st); }
     } guard{grouped, stream};
+    auto eval_args = [&](const sgcn_step_op_t& o, Args& a) {
+        a.n = o.nargs; a.pos = 0;
+        for (int j = 0; j < o.nargs; j++) {
+            const int32_t s = o.slot[j];
+            if (s >= nslots) return false;
+            a.v[j] = (s < 0 ? 0 : o.mul[j] * slots[s]) + o.add[j];
+        }
+        return true;
+    };
+    int32_t skip_until = 0;
     for (int32_t k = 0; k < nops; k++) {
         const sgcn_step_op_t& op = ops[k];
         if (op.nargs < 0 || op.nargs > SGCN_STEP_MAX_ARGS)
             return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d has %d arguments", k, op.nargs);
+        if (k < skip_until) continue;        // a history scatter that rode in the optimizer's launch
         Args a;
-        a.n = op.nargs; a.pos = 0;
-        for (int j = 0; j < op.nargs; j++) {
-            const int32_t s = op.slot[j];
-            if (s >= nslots) return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d reads slot %d of %d", k, s, nslots);
-            a.v[j] = (s < 0 ? 0 : op.mul[j] * slots[s]) + op.add[j];
-        }
+        if (!eval_args(ops[k], a)) return sgcn::fail(SGCN_ERR_INVALID, "step_run: op %d reads a slot beyond %d", k, nslots);
         int rc = SGCN_OK;
         sgcn_dropout_t dr;
         sgcn_plan_t pl;
@@ -220,6 +227,20 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             float* th = a.p<float>(); const float* g = a.p<const float>(); float* m = a.p<float>(); float* v = a.p<float>();
             const int64_t n = a.next();
             const float lr = a.f(), b1 = a.f(), b2 = a.f(), eps = a.f();
+            // history scatters that directly follow the optimizer (the reference orders them after it by a control dependency
+            // only, gcn/models.py:186-194) touch nothing it touches: they ride in its launch as further workgroups
+            int32_t nxt = k + 1;
+            for (; nxt < nops && nxt <= k + 2 && ops[nxt].op == SGCN_OP_SCATTER_ROWS && ops[nxt].nargs >= 0 &&
+                   ops[nxt].nargs <= SGCN_STEP_MAX_ARGS; nxt++) {
+                Args b;
+                if (!eval_args(ops[nxt], b)) break;
+                float* H = b.p<float>(); const int64_t ldh = b.next();
+                const int32_t* r = b.p<const int32_t>(); const int32_t rn = b.i(), rd = b.i();
+                const float* src = b.p<const float>(); const int64_t lds = b.next();
+                if (rn == 0 || rd == 0) continue;                  // nothing to write: counts as done
+                if (!H || !r || !src || !sgcn::scatter_park(H, ldh, r, rn, rd, src, lds)) break;
+            }
+            skip_until = nxt;
             rc = sgcn::adam_with_stats(th, g, m, v, n, lr, b1, b2, eps, stream);
             break;
         }
