@@ -322,7 +322,6 @@ class Trainer(object):
         total_pred, total_labs, stats = [], [], []
         t_test = time()
         N = len(data)
-        k = 0
         chunks = [data[st:min(st + FLAGS.test_batch_size, N)] for st in range(0, N, FLAGS.test_batch_size)]
         if FLAGS.native_prefetch and (FLAGS.prefetch > 0 or len(self.eval_schs) > 1):
             pre = NativePrefetcher(self.eval_schs if len(self.eval_schs) > 1 else self.eval_sch, chunks,
@@ -331,10 +330,15 @@ class Trainer(object):
             pre = ParallelPrefetcher(self.eval_schs, chunks, FLAGS.plan_t, self.eval_slots, max(FLAGS.prefetch, 1))
         else:
             pre = None
-        for chunk in chunks:
-            batch = pre.next() if pre else \
-                self.eval_sch.batch_packed(chunk, FLAGS.plan_t, self.eval_slots[k % len(self.eval_slots)])
-            k += 1
+        def fetch(i):
+            return pre.next() if pre else \
+                self.eval_sch.batch_packed(chunks[i], FLAGS.plan_t, self.eval_slots[i % len(self.eval_slots)])
+        nxt = fetch(0) if chunks else None
+        for k in range(len(chunks)):
+            batch = nxt
+            nxt = fetch(k + 1) if k + 1 < len(chunks) else None
+            if nxt is not None and pre is not None:      # its H2D copy starts one batch early (train_epoch)
+                self.test_model.stage(nxt)
             los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
             stats.append(torch.stack([los, acc]) * prd.shape[0])
             total_pred.append(prd)
@@ -375,10 +379,20 @@ class Trainer(object):
         outs = None
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+        def fetch(it):
+            return pre.next() if pre else next_minibatch(train_sch, FLAGS.batch_size, slots[it % len(slots)])
+        t1 = time()
+        nxt = fetch(1) if n_steps > 0 else None
+        tsch += time() - t1
         for it in range(1, n_steps + 1):
+            batch = nxt
             t1 = time()
-            batch = pre.next() if pre else next_minibatch(train_sch, FLAGS.batch_size, slots[it % len(slots)])
+            # one batch of lookahead: the NEXT minibatch's H2D copy is started before this step is queued, so that by
+            # the time its own step is queued the copy has completed and the step needs no device-side wait for it
+            nxt = fetch(it + 1) if it < n_steps else None
             tsch += time() - t1
+            if nxt is not None and pre is not None:
+                train_model.stage(nxt)
             batch.dropout = FLAGS.dropout
             # no host sync inside the epoch: loss / accuracy stay on the device
             outs = train_model.run_one_step(self.sess, batch, sync=False)
