@@ -164,8 +164,9 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  *   0 = unpaced), cs_slack (columns), cs_noextra (no fifth fp32 accumulator plane), cs_g2_wide (G = 2 plans: force the
  *   64-bit row offsets), cs_last_pct (default 90: clock of a last pass that covers <= 3/4 of a slab, in percent of the
  *   plan's pace; 0 = off) : column-sweep kernels
- *   step_overlap (default 1): in sgcn_step_run, the history-only half of the aggregator (and, without --group_dw /
- *   --lean_sync, weight-gradient GEMMs, memset, scatter, statistics) on an auxiliary stream
+ *   step_overlap (library default 1; the step program sets it from its flags, 0 unless --agg_overlap or a non-lean mode):
+ *   in sgcn_step_run the AUX_* / VR_AGG_PRE ops (and, without --group_dw / --lean_sync, weight-gradient GEMMs and loss
+ *   statistics) go to an auxiliary stream
  *   gemm_min_steps: K-steps a split-K slice keeps at least (default 3) */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */
