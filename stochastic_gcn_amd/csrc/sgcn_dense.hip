@@ -105,6 +105,44 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
     ln_param_reduce_cols32(partial, nblk, d, doffset, dscale, (int)blockIdx.x);
 }
 
+// The input gradient of the LAST dense layer, dx = dlogits . W^T (no LayerNorm, no ReLU behind the logits), as a tail of
+// the loss kernel's row pass: the wave that has just produced a row's dlogits (one per lane, c <= 64) multiplies them into
+// the K x c weight matrix -- 2 x 41 fused multiply-adds per lane on a 512 x 41 batch -- instead of a 16-workgroup MFMA launch
+// of its own (7.8 us of the step's chain for 5 MFLOP).  k ascending from zero in one fmaf chain: the same bits as the GEMM
+// (sgcn_gemm.hip: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain), dropout mask of the layer's input included.
+struct CeDx { const float* W; int64_t ldw; int32_t K; float* dx; int64_t lddx; DropArgs drop; };
+
+// W is staged in LDS by the whole workgroup first (coalesced; lane j then reads its row W[j][0..c) with stride c floats --
+// odd for the class counts that occur, so conflict-free -- instead of 64 different cache lines per load instruction)
+__device__ __forceinline__ void ce_dx_stage(const CeDx& t, int c, float* wl) {
+    for (int i = threadIdx.x; i < t.K * c; i += kBlock) wl[i] = t.W[(int64_t)(i / c) * t.ldw + (i % c)];
+    __syncthreads();
+}
+__device__ __forceinline__ void ce_dx_tail(const CeDx& t, const float* wl, int64_t row, int lane, int c, float mydz) {
+    // k is wave-uniform: the dlogit comes through v_readlane (a scalar operand), not the LDS crossbar; the weights of eight
+    // k are read before they are used so that the LDS latency is paid once per eight, and two output columns run side by side
+    auto dzk = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydz), k)); };
+    for (int j0 = 0; j0 < t.K; j0 += 2 * kWave) {
+        const int ja = j0 + lane, jb = j0 + kWave + lane;
+        const bool oka = ja < t.K, okb = jb < t.K;
+        const float* wa = wl + (oka ? ja : 0) * c;
+        const float* wb = wl + (okb ? jb : 0) * c;
+        float acca = 0.f, accb = 0.f;
+        int k = 0;
+        for (; k + 8 <= c; k += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = wa[k + u]; b[u] = wb[k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const float d = dzk(k + u); acca = fmaf(d, a[u], acca); accb = fmaf(d, b[u], accb); }
+        }
+        for (; k < c; k++) { const float d = dzk(k); acca = fmaf(d, wa[k], acca); accb = fmaf(d, wb[k], accb); }
+        if (t.drop.on) { acca *= drop_factor(t.drop, (int)row, oka ? ja : 0); accb *= drop_factor(t.drop, (int)row, okb ? jb : 0); }
+        if (oka) t.dx[row * t.lddx + ja] = acca;
+        if (okb) t.dx[row * t.lddx + jb] = accb;
+    }
+}
+
 // One wavefront per row, as many workgroups as rows need (a single-workgroup version spent
 // 277 us on 512 x 41 logits: ~40 dependent cross-lane shuffles per row, 128 rows per wave).
 // Per-row CE and hit flags go to `rowstat`; softmax_stats_kernel adds them in a fixed order
@@ -112,9 +150,11 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
 __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
     int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
-    float* __restrict__ rowstat /* [2][n] */) {
+    float* __restrict__ rowstat /* [2][n] */, CeDx tail) {
+    extern __shared__ float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (tail.K > 0) ce_dx_stage(tail, c, ce_lds);
     if (row >= n) return;
     const float inv_n = 1.0f / (float)n;
     const float* zr = z + row * ldz;
@@ -137,15 +177,17 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     for (int k = lane; k < c; k += kWave) { se += __expf(zr[k] - m); sl += lr[k]; }
     se = wave_sum(se); sl = wave_sum(sl);
     const float lse = m + __logf(se);
-    float l = 0.f;
+    float l = 0.f, mydz = 0.f;
     for (int k = lane; k < c; k += kWave) {
         const float logp = zr[k] - lse, p = __expf(logp);
         l -= lr[k] * logp;
-        if (dz) dz[row * lddz + k] = (p * sl - lr[k]) * inv_n;
+        mydz = (p * sl - lr[k]) * inv_n;
+        if (dz) dz[row * lddz + k] = mydz;
         if (pred) pred[row * ldp + k] = p;
     }
     l = wave_sum(l);
     if (lane == 0) { rowstat[row] = l; rowstat[n + row] = (am == alm) ? 1.f : 0.f; }
+    if (tail.K > 0) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
 }
 
 // stats = {sum_i CE_i, #correct, mean CE, accuracy}: one workgroup, fixed summation order
@@ -173,23 +215,27 @@ __global__ __launch_bounds__(kBlock) void softmax_stats_kernel(const float* __re
 __global__ __launch_bounds__(kBlock) void sigmoid_ce_kernel(
     const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
     int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
-    float* __restrict__ rowstat /* [2][n] */) {
+    float* __restrict__ rowstat /* [2][n] */, CeDx tail) {
+    extern __shared__ float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (tail.K > 0) ce_dx_stage(tail, c, ce_lds);
     if (row >= n) return;
     const float inv = 1.0f / ((float)n * (float)c);
-    float l = 0.f, hit = 0.f;
+    float l = 0.f, hit = 0.f, mydz = 0.f;
     for (int k = lane; k < c; k += kWave) {
         const float x = z[row * ldz + k], y = lab[row * ldl + k];
         const float e = __expf(-fabsf(x));
         l += fmaxf(x, 0.f) - x * y + log1pf(e);
         const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
         hit += ((x > 0.f) == (y > 0.5f)) ? 1.f : 0.f;
-        if (dz) dz[row * lddz + k] = (p - y) * inv;
+        mydz = (p - y) * inv;
+        if (dz) dz[row * lddz + k] = mydz;
         if (pred) pred[row * ldp + k] = p;
     }
     l = wave_sum(l); hit = wave_sum(hit);
     if (lane == 0) { rowstat[row] = l; rowstat[n + row] = hit; }
+    if (tail.K > 0) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
 }
 
 // stats = {sum CE, #correct elements, mean CE, accuracy} over n*c elements, fixed summation order
@@ -433,17 +479,27 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
 }
 // The loss kernels with the statistics reduction (loss / accuracy sums: nothing in the step depends on them
 // before the optimizer's join) on the auxiliary stream when `overlap`: one kernel less on the step's chain.
+// dx_W != nullptr: the loss kernel also writes dx[n x dx_K] = dlogits . W^T (* the dropout mask) -- the caller has checked
+// c <= 64 and that a dlogits buffer is given
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream,
-            bool overlap) {
+            bool overlap, const float* dx_W, int64_t dx_ldw, int32_t dx_K, float* dx, int64_t lddx,
+            const sgcn_dropout_t* dx_drop) {
+    CeDx tail{};
+    if (dx_W && dx && dx_K > 0) {
+        SGCN_REQUIRE(c <= kWave && dx_ldw >= c && lddx >= dx_K && (int64_t)dx_K * c * 4 <= 48 * 1024, "ce: bad dx tail");
+        tail = CeDx{dx_W, dx_ldw, dx_K, dx, lddx, drop_args(dx_drop)};
+        SGCN_REQUIRE(!tail.drop.on || tail.drop.width == dx_K, "ce: dropout width must be the layer's input width");
+    }
     SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "%s: bad operand", softmax ? "softmax_ce" : "sigmoid_ce");
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = tail.K > 0 ? (size_t)tail.K * c * sizeof(float) : 0;
     if (softmax)
-        hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, logits, ldz, labels, ldl,
-                           n, c, dlogits, lddz, pred, ldp, rowstat);
+        hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), lds, st, logits, ldz, labels, ldl,
+                           n, c, dlogits, lddz, pred, ldp, rowstat, tail);
     else
-        hipLaunchKernelGGL(sigmoid_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, st, logits, ldz, labels, ldl,
-                           n, c, dlogits, lddz, pred, ldp, rowstat);
+        hipLaunchKernelGGL(sigmoid_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), lds, st, logits, ldz, labels, ldl,
+                           n, c, dlogits, lddz, pred, ldp, rowstat, tail);
     if (pending_stats().on) {            // parked for the optimizer's launch
         PendingStats& p = pending_stats();
         p.armed = 1; p.softmax = softmax ? 1 : 0; p.rowstat = rowstat; p.n = n; p.c = c; p.stats = stats;
@@ -468,13 +524,13 @@ extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float
                                    int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
                                    float* pred, int64_t ldp, float* stats, float* rowstat,
                                    void* stream) {
-    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false);
+    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr);
 }
 
 extern "C" int sgcn_sigmoid_ce_f32(const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n,
                                    int32_t c, float* dlogits, int64_t lddz, float* pred, int64_t ldp,
                                    float* stats, float* rowstat, void* stream) {
-    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false);
+    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr);
 }
 
 extern "C" int sgcn_l2_penalty_f32(const float* theta, int64_t lo, int64_t hi, float wd, float* grad,

@@ -38,7 +38,8 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
                     float eps, void* stream);
 bool scatter_park(float* H, int64_t ldh, const int32_t* idx, int32_t n, int32_t d, const float* src, int64_t lds);
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
-            float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap);
+            float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap,
+            const float* dx_W, int64_t dx_ldw, int32_t dx_K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop);
 }  // namespace sgcn
 
 namespace {
@@ -111,7 +112,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         }
         return true;
     };
-    int32_t skip_until = 0;
+    int32_t skip_until = 0, dx_done_at = -1;
     for (int32_t k = 0; k < nops; k++) {
         const sgcn_step_op_t& op = ops[k];
         if (op.nargs < 0 || op.nargs > SGCN_STEP_MAX_ARGS)
@@ -176,7 +177,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
                                  std::max(sgcn_gemm_ws_floats(K, N, n), sgcn_gemm_ws_floats(n, K, N));
             if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: backward scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
             rc = sgcn::dense_bwd_overlapped(n, N, K, dy, lddy, y, ldy, xhat, rstd, sc, relu, x, ldx, W, ldw, dW, lddw, doff,
-                                            dsc, dx, lddx, d, gtmp, need ? ws : nullptr, gidx, stream);
+                                            dsc, k == dx_done_at ? nullptr : dx, lddx, d, gtmp, need ? ws : nullptr, gidx, stream);
             break;
         }
         case SGCN_OP_DW_FLUSH:
@@ -219,8 +220,35 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             float* dz = a.p<float>(); const int64_t lddz = a.next();
             float* pred = a.p<float>(); const int64_t ldp = a.next();
             float* stats = a.p<float>(); float* rowstat = a.p<float>();
+            // The backward of the LAST dense layer follows at once (it has neither LayerNorm nor ReLU): its input gradient
+            // dx = dlogits . W^T is a tail of the loss kernel's row pass (sgcn_dense.hip ce_dx_tail), that op then only
+            // records its weight-gradient GEMM
+            const float* tW = nullptr; int64_t tldw = 0, tlddx = 0; int32_t tK = 0; float* tdx = nullptr;
+            sgcn_dropout_t tdr; const sgcn_dropout_t* tdrop = nullptr;
+            if (dz && c <= 64 && k + 1 < nops && ops[k + 1].op == SGCN_OP_DENSE_BWD && ops[k + 1].nargs >= 0 &&
+                ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
+                Args b;
+                if (eval_args(ops[k + 1], b)) {
+                    const int32_t bn = b.i(), bN = b.i(), bK = b.i();
+                    const float* bdy = b.p<const float>(); const int64_t blddy = b.next();
+                    (void)b.p<const float>(); (void)b.next();                                  // y, ldy
+                    const float* bxhat = b.p<const float>(); (void)b.p<const float>();          // xhat, rstd
+                    const float* bsc = b.p<const float>(); const int32_t brelu = b.i();
+                    (void)b.p<const float>(); (void)b.next();                                  // x, ldx
+                    const float* bW = b.p<const float>(); const int64_t bldw = b.next();
+                    (void)b.p<float>(); (void)b.next(); (void)b.p<float>(); (void)b.p<float>();  // dW, lddw, doff, dsc
+                    float* bdx = b.p<float>(); const int64_t blddx = b.next();
+                    const sgcn_dropout_t* bd = b.drop(&tdr);
+                    if (bn == n && bN == c && bdy == dz && blddy == lddz && !bxhat && !bsc && !brelu && bdx && bW && bK > 0 &&
+                        (int64_t)bK * c * 4 <= 48 * 1024) {
+                        tW = bW; tldw = bldw; tK = bK; tdx = bdx; tlddx = blddx; tdrop = bd;
+                        dx_done_at = k + 1;
+                    }
+                }
+            }
             // the loss / accuracy sums run beside the backward pass (joined before L2_PENALTY / ADAM)
-            rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream, overlap);
+            rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream, overlap,
+                               tW, tldw, tK, tdx, tlddx, tdrop);
             break;
         }
         case SGCN_OP_ADAM: {
