@@ -110,14 +110,68 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
 // the K x c weight matrix -- 2 x 41 fused multiply-adds per lane on a 512 x 41 batch -- instead of a 16-workgroup MFMA launch
 // of its own (7.8 us of the step's chain for 5 MFLOP).  k ascending from zero in one fmaf chain: the same bits as the GEMM
 // (sgcn_gemm.hip: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain), dropout mask of the layer's input included.
-struct CeDx { const float* W; int64_t ldw; int32_t K; float* dx; int64_t lddx; DropArgs drop; };
+struct CeDx { const float* W; int64_t ldw; int32_t K; float* dx; int64_t lddx; DropArgs drop;
+              // ... and the last layer's FORWARD as a head of the same pass: logits = dropout(x) . W for x = hx[row][0..K),
+              // K <= 128, with the K-step / K-group order of additions of the launch it replaces (kg groups of alternating
+              // 32-wide K-steps, partial sums added in group order: sgcn_gemm.hip gemm_body)
+              const float* hx; int64_t ldhx; int32_t kg; DropArgs hdrop; float* zout; int64_t ldzo; };
 
 // W is staged in LDS by the whole workgroup first (coalesced; lane j then reads its row W[j][0..c) with stride c floats --
 // odd for the class counts that occur, so conflict-free -- instead of 64 different cache lines per load instruction)
 __device__ __forceinline__ void ce_dx_stage(const CeDx& t, int c, float* wl) {
-    for (int i = threadIdx.x; i < t.K * c; i += kBlock) wl[i] = t.W[(int64_t)(i / c) * t.ldw + (i % c)];
+    // the matrix was written by the previous step's optimizer: every round of loads is a trip past the L2 (~2 us), so a
+    // thread requests ALL of its share (<= 48 values: 48 KB / 256 threads) before it stores any
+    constexpr int kMax = 48;
+    const int total = t.K * c;
+    if (t.ldw == c) {                       // the weights are contiguous in the flat parameter buffer: a flat copy
+        float v[kMax];
+#pragma unroll
+        for (int u = 0; u < kMax; u++) {
+            const int i = threadIdx.x + u * kBlock;
+            v[u] = i < total ? t.W[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kMax; u++) {
+            const int i = threadIdx.x + u * kBlock;
+            if (i < total) wl[i] = v[u];
+        }
+    } else {                                // (a pitched matrix: one integer division per element -- not on the step's path)
+        for (int i = threadIdx.x; i < total; i += kBlock) wl[i] = t.W[(int64_t)(i / c) * t.ldw + (i % c)];
+    }
     __syncthreads();
 }
+// lane cc < c returns logit cc of `row`
+__device__ __forceinline__ float ce_head(const CeDx& t, const float* wl, int64_t row, int lane, int c, float x0, float x1) {
+    if (t.hdrop.on) { x0 *= drop_factor(t.hdrop, (int)row, lane); x1 *= drop_factor(t.hdrop, (int)row, lane + kWave); }
+    const int cc = lane < c ? lane : 0;
+    float acc[2] = {0.f, 0.f};
+    for (int s0 = 0; s0 * 32 < t.K; s0++) {
+        const int g = t.kg > 1 ? (s0 & 1) : 0;
+        float a = acc[g];
+        const float xs = s0 < 2 ? x0 : x1;          // a 32-wide K-step never straddles the two halves of the row
+        const int kb = s0 * 32, lb = kb & (kWave - 1);
+        const float* wk = wl + kb * c + cc;
+        if (kb + 32 <= t.K) {                         // a whole K-step: straight-line
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = wk[(q * 8 + u) * c];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    a = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + q * 8 + u)), w[u], a);
+            }
+        } else {                                      // the ragged last one
+            for (int kk = 0; kb + kk < t.K; kk++)
+                a = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + kk)), wk[kk * c], a);
+        }
+        acc[g] = a;
+    }
+    const float z = t.kg > 1 ? acc[0] + acc[1] : acc[0];
+    if (lane < c && t.zout) t.zout[row * t.ldzo + lane] = z;
+    return z;
+}
+
 __device__ __forceinline__ void ce_dx_tail(const CeDx& t, const float* wl, int64_t row, int lane, int c, float mydz) {
     // k is wave-uniform: the dlogit comes through v_readlane (a scalar operand), not the LDS crossbar; the weights of eight
     // k are read before they are used so that the LDS latency is paid once per eight, and two output columns run side by side
@@ -154,16 +208,28 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     extern __shared__ float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const bool head = tail.hx != nullptr;            // c <= 64: logit k lives in lane k
+    // everything the row pass reads from memory is requested before the weight matrix is staged (one round trip, not four)
+    const bool live = row < n;
+    const float* lr = lab + (live ? row : 0) * ldl;
+    const float lab0 = (live && lane < c) ? lr[lane] : 0.f;
+    float hx0 = 0.f, hx1 = 0.f;
+    if (head && live) {
+        const float* xr = tail.hx + row * tail.ldhx;
+        hx0 = lane < tail.K ? xr[lane] : 0.f; hx1 = lane + kWave < tail.K ? xr[lane + kWave] : 0.f;
+    }
     if (tail.K > 0) ce_dx_stage(tail, c, ce_lds);
-    if (row >= n) return;
+    if (!live) return;
     const float inv_n = 1.0f / (float)n;
+    const float myz = head ? ce_head(tail, ce_lds, row, lane, c, hx0, hx1) : 0.f;
     const float* zr = z + row * ldz;
-    const float* lr = lab + row * ldl;
+    auto zv = [&](int k) { return head ? myz : zr[k]; };
+    auto lv = [&](int k) { return k < kWave ? lab0 : lr[k]; };     // k == lane in the first trip of every loop below
     float m = -INFINITY, lm = -INFINITY;
     int am = 0, alm = 0;
     for (int k = lane; k < c; k += kWave) {
-        if (zr[k] > m) { m = zr[k]; am = k; }
-        if (lr[k] > lm) { lm = lr[k]; alm = k; }
+        if (zv(k) > m) { m = zv(k); am = k; }
+        if (lv(k) > lm) { lm = lv(k); alm = k; }
     }
     // wave arg-max with lowest-index tie break (np.argmax / tf.argmax semantics)
 #pragma unroll
@@ -174,20 +240,20 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
         if (ol > lm || (ol == lm && ola < alm)) { lm = ol; alm = ola; }
     }
     float se = 0.f, sl = 0.f;
-    for (int k = lane; k < c; k += kWave) { se += __expf(zr[k] - m); sl += lr[k]; }
+    for (int k = lane; k < c; k += kWave) { se += __expf(zv(k) - m); sl += lv(k); }
     se = wave_sum(se); sl = wave_sum(sl);
     const float lse = m + __logf(se);
     float l = 0.f, mydz = 0.f;
     for (int k = lane; k < c; k += kWave) {
-        const float logp = zr[k] - lse, p = __expf(logp);
-        l -= lr[k] * logp;
-        mydz = (p * sl - lr[k]) * inv_n;
+        const float logp = zv(k) - lse, p = __expf(logp);
+        l -= lv(k) * logp;
+        mydz = (p * sl - lv(k)) * inv_n;
         if (dz) dz[row * lddz + k] = mydz;
         if (pred) pred[row * ldp + k] = p;
     }
     l = wave_sum(l);
     if (lane == 0) { rowstat[row] = l; rowstat[n + row] = (am == alm) ? 1.f : 0.f; }
-    if (tail.K > 0) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
+    if (tail.dx) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
 }
 
 // stats = {sum_i CE_i, #correct, mean CE, accuracy}: one workgroup, fixed summation order
@@ -219,12 +285,21 @@ __global__ __launch_bounds__(kBlock) void sigmoid_ce_kernel(
     extern __shared__ float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const bool head = tail.hx != nullptr;
+    const bool live = row < n;
+    const float lab0 = (live && lane < c) ? lab[row * ldl + lane] : 0.f;      // requested before the weights are staged
+    float hx0 = 0.f, hx1 = 0.f;
+    if (head && live) {
+        const float* xr = tail.hx + row * tail.ldhx;
+        hx0 = lane < tail.K ? xr[lane] : 0.f; hx1 = lane + kWave < tail.K ? xr[lane + kWave] : 0.f;
+    }
     if (tail.K > 0) ce_dx_stage(tail, c, ce_lds);
-    if (row >= n) return;
+    if (!live) return;
     const float inv = 1.0f / ((float)n * (float)c);
+    const float myz = head ? ce_head(tail, ce_lds, row, lane, c, hx0, hx1) : 0.f;
     float l = 0.f, hit = 0.f, mydz = 0.f;
     for (int k = lane; k < c; k += kWave) {
-        const float x = z[row * ldz + k], y = lab[row * ldl + k];
+        const float x = head ? myz : z[row * ldz + k], y = k < kWave ? lab0 : lab[row * ldl + k];
         const float e = __expf(-fabsf(x));
         l += fmaxf(x, 0.f) - x * y + log1pf(e);
         const float p = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
@@ -235,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void sigmoid_ce_kernel(
     }
     l = wave_sum(l); hit = wave_sum(hit);
     if (lane == 0) { rowstat[row] = l; rowstat[n + row] = hit; }
-    if (tail.K > 0) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
+    if (tail.dx) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
 }
 
 // stats = {sum CE, #correct elements, mean CE, accuracy} over n*c elements, fixed summation order
@@ -479,19 +554,31 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
 }
 // The loss kernels with the statistics reduction (loss / accuracy sums: nothing in the step depends on them
 // before the optimizer's join) on the auxiliary stream when `overlap`: one kernel less on the step's chain.
-// dx_W != nullptr: the loss kernel also writes dx[n x dx_K] = dlogits . W^T (* the dropout mask) -- the caller has checked
-// c <= 64 and that a dlogits buffer is given
+// W != nullptr: the loss kernel works on the last dense layer's K x c weight matrix too --
+//   dx != nullptr:  it also writes dx[n x K] = dlogits . W^T (* the dropout mask of the layer's input);
+//   hx != nullptr:  it computes the logits itself, dropout(hx)[n x K] . W (kg = the K-groups of the launch it replaces),
+//                   writing them to `logits`.
+// The caller has checked c <= 64, K <= 128 for the head, and that a dlogits buffer is given for the tail.
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream,
-            bool overlap, const float* dx_W, int64_t dx_ldw, int32_t dx_K, float* dx, int64_t lddx,
-            const sgcn_dropout_t* dx_drop) {
+            bool overlap, const float* W, int64_t ldw, int32_t K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop,
+            const float* hx, int64_t ldhx, int32_t kg, const sgcn_dropout_t* h_drop) {
     CeDx tail{};
-    if (dx_W && dx && dx_K > 0) {
-        SGCN_REQUIRE(c <= kWave && dx_ldw >= c && lddx >= dx_K && (int64_t)dx_K * c * 4 <= 48 * 1024, "ce: bad dx tail");
-        tail = CeDx{dx_W, dx_ldw, dx_K, dx, lddx, drop_args(dx_drop)};
-        SGCN_REQUIRE(!tail.drop.on || tail.drop.width == dx_K, "ce: dropout width must be the layer's input width");
+    if (W && K > 0 && (dx || hx)) {
+        SGCN_REQUIRE(c <= kWave && ldw >= c && (int64_t)K * c * 4 <= 48 * 1024, "ce: bad fused last layer");
+        tail.W = W; tail.ldw = ldw; tail.K = K;
+        if (dx) {
+            SGCN_REQUIRE(lddx >= K, "ce: bad dx pitch");
+            tail.dx = dx; tail.lddx = lddx; tail.drop = drop_args(dx_drop);
+            SGCN_REQUIRE(!tail.drop.on || tail.drop.width == K, "ce: dropout width must be the layer's input width");
+        }
+        if (hx) {
+            SGCN_REQUIRE(K <= 2 * kWave && ldhx >= K && kg >= 1 && kg <= 2, "ce: bad fused head");
+            tail.hx = hx; tail.ldhx = ldhx; tail.kg = kg; tail.hdrop = drop_args(h_drop);
+            tail.zout = const_cast<float*>(logits); tail.ldzo = ldz;
+            SGCN_REQUIRE(!tail.hdrop.on || tail.hdrop.width == K, "ce: dropout width must be the layer's input width");
+        }
     }
-    SGCN_REQUIRE(n > 0 && c > 0 && logits && labels && stats && rowstat, "%s: bad operand", softmax ? "softmax_ce" : "sigmoid_ce");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = tail.K > 0 ? (size_t)tail.K * c * sizeof(float) : 0;
     if (softmax)
@@ -524,13 +611,13 @@ extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float
                                    int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
                                    float* pred, int64_t ldp, float* stats, float* rowstat,
                                    void* stream) {
-    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr);
+    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr);
 }
 
 extern "C" int sgcn_sigmoid_ce_f32(const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n,
                                    int32_t c, float* dlogits, int64_t lddz, float* pred, int64_t ldp,
                                    float* stats, float* rowstat, void* stream) {
-    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr);
+    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr);
 }
 
 extern "C" int sgcn_l2_penalty_f32(const float* theta, int64_t lo, int64_t hi, float wd, float* grad,

@@ -458,6 +458,18 @@ static GemmPlan prepare_gemm(GemmArgs& g, float* ws) {
     return p;
 }
 
+// K slicing and K-groups a forward dense layer of this shape would get (sgcn_dense.hip's fused output head reproduces
+// the launch's order of additions, so it asks)
+namespace sgcn {
+void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K;
+    float dummy;
+    const GemmPlan p = prepare_gemm(g, sgcn_gemm_ws_floats(M, N, K) > 0 ? &dummy : nullptr);
+    *S = p.S; *kgroups = p.kgroups;
+}
+}  // namespace sgcn
+
 static void launch_prepared(const GemmArgs& g, const GemmPlan& p, int ta, int tb, hipStream_t st) {
     if (!ta && !tb) launch_kg<false, false>(g, p.grid, p.kgroups, st);
     else if (ta && !tb) launch_kg<true, false>(g, p.grid, p.kgroups, st);

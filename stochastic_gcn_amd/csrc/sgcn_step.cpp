@@ -39,7 +39,9 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
 bool scatter_park(float* H, int64_t ldh, const int32_t* idx, int32_t n, int32_t d, const float* src, int64_t lds);
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap,
-            const float* dx_W, int64_t dx_ldw, int32_t dx_K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop);
+            const float* W, int64_t ldw, int32_t K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop,
+            const float* hx, int64_t ldhx, int32_t kg, const sgcn_dropout_t* h_drop);
+void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups);       // sgcn_gemm.hip
 }  // namespace sgcn
 
 namespace {
@@ -84,6 +86,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         return sgcn::fail(SGCN_ERR_INVALID, "step_run: bad argument");
     bool memset_on_aux = false;
     const bool overlap = sgcn_tune_get("step_overlap") != 0;
+    const int fuse = (int)sgcn_tune_get("step_fuse");
     bool grouped = false, store = false, l2 = false;
     int ce_at = -1, adam_at = -1;
     for (int32_t k = 0; k < nops; k++) {
@@ -113,6 +116,8 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         return true;
     };
     int32_t skip_until = 0, dx_done_at = -1;
+    struct Head { bool on = false, has_drop = false; int32_t at = -1, K = 0, kg = 1; const float* x = nullptr; int64_t ldx = 0;
+                  const float* W = nullptr; int64_t ldw = 0; sgcn_dropout_t drop{}; } head;
     for (int32_t k = 0; k < nops; k++) {
         const sgcn_step_op_t& op = ops[k];
         if (op.nargs < 0 || op.nargs > SGCN_STEP_MAX_ARGS)
@@ -150,6 +155,27 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             const sgcn_dropout_t* d = a.drop(&dr);
             float* ws = a.p<float>(); const int64_t ws_cap = a.next();
             const int32_t* g1 = a.p<const int32_t>(); const int32_t* g2 = a.p<const int32_t>();
+            // The output layer (no LayerNorm, no ReLU, <= 64 classes, <= 128 inputs) directly in front of the loss: its
+            // 5-MFLOP product becomes the head of the loss kernel's row pass (sgcn_dense.hip ce_head) instead of a launch
+            head.on = false;
+            if ((fuse & 1) && !off && !sc && !relu && !X2 && !g1 && N <= 64 && K <= 128 && (int64_t)K * N * 4 <= 48 * 1024 && k + 1 < nops &&
+                (ops[k + 1].op == SGCN_OP_SOFTMAX_CE || ops[k + 1].op == SGCN_OP_SIGMOID_CE) && ops[k + 1].nargs >= 0 &&
+                ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
+                Args b;
+                int S = 0, kgq = 0;
+                sgcn::gemm_fwd_shape(M, N, K, &S, &kgq);
+                if (S == 1 && kgq <= 2 && eval_args(ops[k + 1], b)) {
+                    const float* bz = b.p<const float>(); const int64_t bldz = b.next();
+                    (void)b.p<const float>(); (void)b.next();
+                    const int32_t bn = b.i(), bc = b.i();
+                    if (bz == Y && bldz == ldy && bn == M && bc == N) {
+                        head.on = true; head.at = k + 1; head.x = X; head.ldx = ldx; head.W = W; head.ldw = ldw; head.K = K;
+                        head.kg = kgq; head.has_drop = d != nullptr;
+                        if (d) head.drop = *d;
+                        break;                       // nothing launched: the loss op computes the logits
+                    }
+                }
+            }
             // the eager wrapper (ops.dense_fwd): split-K scratch only where the library asks for it
             const int64_t need = N <= 128 ? sgcn_gemm_ws_floats(M, N, K) : 0;
             if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
@@ -225,7 +251,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             // records its weight-gradient GEMM
             const float* tW = nullptr; int64_t tldw = 0, tlddx = 0; int32_t tK = 0; float* tdx = nullptr;
             sgcn_dropout_t tdr; const sgcn_dropout_t* tdrop = nullptr;
-            if (dz && c <= 64 && k + 1 < nops && ops[k + 1].op == SGCN_OP_DENSE_BWD && ops[k + 1].nargs >= 0 &&
+            if ((fuse & 2) && dz && c <= 64 && k + 1 < nops && ops[k + 1].op == SGCN_OP_DENSE_BWD && ops[k + 1].nargs >= 0 &&
                 ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
                 Args b;
                 if (eval_args(ops[k + 1], b)) {
@@ -247,8 +273,12 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
                 }
             }
             // the loss / accuracy sums run beside the backward pass (joined before L2_PENALTY / ADAM)
+            const bool hd = head.on && head.at == k;
+            if (hd && tW && (tW != head.W || tK != head.K || tldw != head.ldw)) { tW = nullptr; tdx = nullptr; dx_done_at = -1; }   // not the same layer
             rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream, overlap,
-                               tW, tldw, tK, tdx, tlddx, tdrop);
+                               hd ? head.W : tW, hd ? head.ldw : tldw, hd ? head.K : tK, tdx, tlddx, tdrop,
+                               hd ? head.x : nullptr, hd ? head.ldx : 0, hd ? head.kg : 1, (hd && head.has_drop) ? &head.drop : nullptr);
+            head.on = false;
             break;
         }
         case SGCN_OP_ADAM: {
