@@ -184,3 +184,24 @@ def test_dense_scratch_is_sized_for_the_row_capacity():
         for N in (16, 41, 128):
             for K in (24, 128, 1204):
                 assert lib.sgcn_gemm_ws_floats(M, N, K) <= GEMM_WS_BOUND and lib.sgcn_gemm_ws_floats(K, N, M) <= GEMM_WS_BOUND
+
+
+@pytest.mark.parametrize("fuse", [0, 1, 2])
+def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
+    """sgcn_step_run folds the output layer into the loss kernel's row pass (its forward product as the head, its input
+    gradient as the tail: knob step_fuse, default 3 -- what every other test of this file runs); with the fusion partly or
+    wholly off the same program issues the separate launches, and every variant gives the eager path's bits."""
+    from stochastic_gcn_amd import _ffi
+    case = mc.build_case('reddit_cvd_pp')
+    a, la = _run(case, False, 4, False)
+    _ffi.tune('step_fuse', fuse)
+    try:
+        b, lb = _run(case, True, 4, False)
+    finally:
+        _ffi.tune('step_fuse', 3)
+    assert all(p is not None for p in b._programs.values())
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m)
+    for ha, hb in zip(a.history, b.history):
+        assert torch.equal(ha[0], hb[0])
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
