@@ -397,6 +397,155 @@ __global__ __launch_bounds__(kBlock) void splitk_ln_act_kernel(const float* __re
     }
 }
 
+
+// ---- a split-K layer's reduce + epilogue AND the dense layer that follows it, as one row pass ----------------------------
+// The step's first layer (2,036 x 1,204 -> 128) is cut over K to fill the chip, so its LayerNorm + ReLU already run in a
+// one-wavefront-per-row kernel (splitk_ln_act_kernel above).  The layer behind it is 2,036 x 128 -> 128: an MFMA launch of
+// its own took 13.3 us of the step's chain, of which the arithmetic is under one.  Here the wave that has just finished a
+// row of layer 1 keeps it in registers (two columns per lane), applies layer 2's dropout mask, and multiplies it into
+// layer 2's weight matrix, staged in LDS once per workgroup -- x_k through v_readlane, two output columns per lane -- in
+// exactly the launch's order of additions (32-wide K-steps alternating between its K-groups, the groups' partial sums
+// added in group order), then layer 2's own LayerNorm / ReLU epilogue with gemm_body's arithmetic.  Same bits as the two
+// launches + the reduce it replaces (tests/test_step_program_gpu.py); profiles/rowmlp_probe.hip is the stand-alone form.
+struct RowDense {
+    const float* W; int64_t ldw; int32_t N, kg;
+    const float* offset; const float* scale; float eps; int32_t relu, epi;
+    DropArgs drop;
+    float* Y; int64_t ldy; float* xhat; float* rstd;
+};
+
+__global__ __launch_bounds__(kBlock) void splitk_ln_dense_kernel(const float* __restrict__ ws, int32_t S, GemmArgs g, RowDense d) {
+    extern __shared__ float wl[];                 // layer 2's weights, [K2 = g.N][d.N]
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const bool live = row < g.M;
+    const int K2 = g.N, total = K2 * d.N;
+    // everything the pass reads from memory is requested before anything is used
+    constexpr int kMax = 64;                      // 128 x 128 floats / 256 threads
+    float wv[kMax];
+#pragma unroll
+    for (int u = 0; u < kMax; u++) {
+        const int i = threadIdx.x + u * kBlock;
+        wv[u] = i < total ? d.W[i] : 0.f;
+    }
+    float sc1[2] = {1.f, 1.f}, of1[2] = {0.f, 0.f}, sc2[2] = {1.f, 1.f}, of2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int c = lane + e * kWave;
+        if (g.epi == 2 && c < g.N) { sc1[e] = g.scale[c]; of1[e] = g.offset[c]; }
+        if (d.epi == 2 && c < d.N) { sc2[e] = d.scale[c]; of2[e] = d.offset[c]; }
+    }
+    const int64_t mn = (int64_t)g.M * g.N;
+    float v[2] = {0.f, 0.f};
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            float s = 0.f;
+            if (c < g.N)
+                for (int z = 0; z < S; z++) s += ws[(int64_t)z * mn + row * g.N + c];
+            v[e] = s;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kMax; u++) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < total) wl[i] = wv[u];
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- layer 1's epilogue (splitk_ln_act_kernel)
+    float x[2];
+    float* yr = g.C + row * g.ldc;
+    if (g.epi == 2) {
+        const float mean = wsum(v[0] + v[1]) / (float)g.N;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) if (lane + e * kWave < g.N) { const float t = v[e] - mean; q += t * t; }
+        const float rs = rsqrtf(wsum(q) / (float)g.N + g.eps);
+        if (lane == 0) g.rstd[row] = rs;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            x[e] = 0.f;
+            if (c < g.N) {
+                const float h = (v[e] - mean) * rs;
+                g.xhat[row * g.N + c] = h;
+                const float y = h * sc1[e] + of1[e];
+                x[e] = g.relu ? fmaxf(y, 0.f) : y;
+                yr[c] = x[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            x[e] = 0.f;
+            if (c < g.N) { x[e] = (g.epi == 1 && g.relu) ? fmaxf(v[e], 0.f) : v[e]; yr[c] = x[e]; }
+        }
+    }
+    // ---- layer 2: dropout on the operand, then the product in the MFMA launch's order
+    if (d.drop.on) { x[0] *= drop_factor(d.drop, (int)row, lane); x[1] *= drop_factor(d.drop, (int)row, lane + kWave); }
+    const int c0 = lane < d.N ? lane : 0, c1 = lane + kWave < d.N ? lane + kWave : 0;
+    float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+    for (int s0 = 0; s0 * 32 < K2; s0++) {
+        const int gi = d.kg > 1 ? (s0 & 1) : 0;
+        const float xs = s0 < 2 ? x[0] : x[1];    // a 32-wide K-step never straddles the two halves of the row
+        const int kb = s0 * 32, lb = kb & (kWave - 1);
+        const float* wk = wl + kb * d.N;
+        float p0 = a0[gi], p1 = a1[gi];
+        if (kb + 32 <= K2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float w0[8], w1[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { w0[u] = wk[(q * 8 + u) * d.N + c0]; w1[u] = wk[(q * 8 + u) * d.N + c1]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + q * 8 + u));
+                    p0 = fmaf(xv, w0[u], p0); p1 = fmaf(xv, w1[u], p1);
+                }
+            }
+        } else {
+            for (int kk = 0; kb + kk < K2; kk++) {
+                const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + kk));
+                p0 = fmaf(xv, wk[kk * d.N + c0], p0); p1 = fmaf(xv, wk[kk * d.N + c1], p1);
+            }
+        }
+        a0[gi] = p0; a1[gi] = p1;
+    }
+    const float z[2] = {d.kg > 1 ? a0[0] + a0[1] : a0[0], d.kg > 1 ? a1[0] + a1[1] : a1[0]};
+    // ---- layer 2's epilogue (gemm_body)
+    float* y2 = d.Y + row * d.ldy;
+    if (d.epi != 2) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            if (c < d.N) y2[c] = (d.epi == 1 && d.relu) ? fmaxf(z[e], 0.f) : z[e];
+        }
+        return;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) if (lane + e * kWave < d.N) s += z[e];
+    const float mean = wsum(s) / (float)d.N;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) if (lane + e * kWave < d.N) { const float t = z[e] - mean; q += t * t; }
+    const float rs = rsqrtf(wsum(q) / (float)d.N + d.eps);
+    if (lane == 0) d.rstd[row] = rs;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int c = lane + e * kWave;
+        if (c < d.N) {
+            const float h = (z[e] - mean) * rs;
+            d.xhat[row * d.N + c] = h;
+            const float y = h * sc2[e] + of2[e];
+            y2[c] = d.relu ? fmaxf(y, 0.f) : y;
+        }
+    }
+}
+
 }  // namespace sgcn
 
 using namespace sgcn;
@@ -520,6 +669,49 @@ extern "C" int sgcn_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_
     if (g.drop_c.on) ws = nullptr;           // the output mask is applied in the GEMM's own epilogue
     return launch_gemm(g, trans_a, trans_b, ws, (hipStream_t)stream);
 }
+
+
+// Layer 1 (cut over K: partial tiles) and the dense layer on its output as GEMM + ONE row pass.  *fused = 0: the shapes do
+// not allow it, nothing was launched.
+namespace sgcn {
+int dense_fwd_pair(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx, const float* X2, int64_t ldx2, int32_t split,
+                   const float* W, int64_t ldw, const float* offset, const float* scale, float eps, int32_t relu, float* Y,
+                   int64_t ldy, float* xhat, float* rstd, const sgcn_dropout_t* drop, float* ws, const int32_t* gidx,
+                   const int32_t* gidx2, int32_t N2, const float* W2, int64_t ldw2, const float* offset2, const float* scale2,
+                   float eps2, int32_t relu2, float* Y2, int64_t ldy2, float* xhat2, float* rstd2, const sgcn_dropout_t* drop2,
+                   void* stream, int* fused) {
+    *fused = 0;
+    if (M <= 0 || N <= 0 || N > kTN || N2 <= 0 || N2 > kTN || !ws || !W2 || !Y2 || ldw2 != N2 || ldy != N) return SGCN_OK;
+    const int norm = (offset && scale) ? 1 : 0, norm2 = (offset2 && scale2) ? 1 : 0;
+    if ((norm && !(xhat && rstd)) || (norm2 && !(xhat2 && rstd2))) return SGCN_OK;
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+    g.M = M; g.N = N; g.K = K; g.offset = offset; g.scale = scale; g.eps = eps; g.relu = relu;
+    g.xhat = xhat; g.rstd = rstd; g.epi = norm ? 2 : (relu ? 1 : 0);
+    g.A2 = X2; g.lda2 = ldx2; g.a_split = split;
+    g.a_gidx = gidx; g.a_gidx2 = gidx2;
+    g.drop_a = drop_args(drop);
+    const GemmPlan p = prepare_gemm(g, ws);
+    int S2 = 0, kg2 = 0;
+    gemm_fwd_shape(M, N2, N, &S2, &kg2);
+    if (p.S <= 1 || S2 != 1 || kg2 > 2 || (size_t)N * N2 * sizeof(float) > 64 * 1024) return SGCN_OK;
+    SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
+    RowDense d{};
+    d.W = W2; d.ldw = ldw2; d.N = N2; d.kg = kg2; d.offset = offset2; d.scale = scale2; d.eps = eps2; d.relu = relu2;
+    d.epi = norm2 ? 2 : (relu2 ? 1 : 0);
+    d.drop = drop_args(drop2);
+    SGCN_REQUIRE(!d.drop.on || d.drop.width == N, "dense_fwd: the second layer's dropout width must be its input width");
+    d.Y = Y2; d.ldy = ldy2; d.xhat = xhat2; d.rstd = rstd2;
+    hipStream_t st = (hipStream_t)stream;
+    launch_prepared(g, p, 0, 0, st);
+    g.epi = p.epi;
+    const unsigned rb = (unsigned)((g.M + (kBlock / kWave) - 1) / (kBlock / kWave));
+    hipLaunchKernelGGL(splitk_ln_dense_kernel, dim3(rb), dim3(kBlock), (size_t)N * N2 * sizeof(float), st, g.ws, p.S, g, d);
+    SGCN_HIP_TRY(hipGetLastError());
+    *fused = 1;
+    return SGCN_OK;
+}
+}  // namespace sgcn
 
 extern "C" int sgcn_dense_fwd_f32(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
                                   const float* X2, int64_t ldx2, int32_t split,

@@ -42,6 +42,12 @@ int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels,
             const float* W, int64_t ldw, int32_t K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop,
             const float* hx, int64_t ldhx, int32_t kg, const sgcn_dropout_t* h_drop);
 void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups);       // sgcn_gemm.hip
+int dense_fwd_pair(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx, const float* X2, int64_t ldx2, int32_t split,
+                   const float* W, int64_t ldw, const float* offset, const float* scale, float eps, int32_t relu, float* Y,
+                   int64_t ldy, float* xhat, float* rstd, const sgcn_dropout_t* drop, float* ws, const int32_t* gidx,
+                   const int32_t* gidx2, int32_t N2, const float* W2, int64_t ldw2, const float* offset2, const float* scale2,
+                   float eps2, int32_t relu2, float* Y2, int64_t ldy2, float* xhat2, float* rstd2, const sgcn_dropout_t* drop2,
+                   void* stream, int* fused);
 }  // namespace sgcn
 
 namespace {
@@ -179,6 +185,41 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             // the eager wrapper (ops.dense_fwd): split-K scratch only where the library asks for it
             const int64_t need = N <= 128 ? sgcn_gemm_ws_floats(M, N, K) : 0;
             if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
+            // A layer that is cut over K (its epilogue is a row pass already) with a narrow dense layer on ALL of its output
+            // rows right behind it: that layer rides in the row pass (sgcn_gemm.hip splitk_ln_dense_kernel)
+            if ((fuse & 4) && need > 0 && k + 1 < nops && ops[k + 1].op == SGCN_OP_DENSE_FWD && ops[k + 1].nargs >= 0 &&
+                ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
+                Args b;
+                if (eval_args(ops[k + 1], b)) {
+                    const int32_t M2 = b.i(), N2 = b.i(), K2 = b.i();
+                    const float* Xb = b.p<const float>(); const int64_t ldxb = b.next();
+                    const float* X2b = b.p<const float>(); const int64_t ldx2b = b.next();
+                    const int32_t split2 = b.i();
+                    const float* W2 = b.p<const float>(); const int64_t ldw2 = b.next();
+                    const float* off2 = b.p<const float>(); const float* sc2 = b.p<const float>();
+                    const float eps2 = b.f(); const int32_t relu2 = b.i();
+                    float* Y2 = b.p<float>(); const int64_t ldy2 = b.next();
+                    float* xhat2 = b.p<float>(); float* rstd2 = b.p<float>();
+                    sgcn_dropout_t dr2;
+                    const sgcn_dropout_t* d2 = b.drop(&dr2);
+                    (void)b.p<float>(); const int64_t ws_cap2 = b.next();
+                    const int32_t* g1b = b.p<const int32_t>(); const int32_t* g2b = b.p<const int32_t>();
+                    // (an output layer in front of the loss is better off as the loss kernel's head: one pass fewer)
+                    const bool is_head = (fuse & 1) && !off2 && !sc2 && !relu2 && !X2b && N2 <= 64 && k + 2 < nops &&
+                                         (ops[k + 2].op == SGCN_OP_SOFTMAX_CE || ops[k + 2].op == SGCN_OP_SIGMOID_CE);
+                    const bool whole = !is_head && Xb == Y && ldxb == ldy && !g1b && !g2b && M2 == M && K2 == N &&
+                                       (X2b ? (X2b == Y + (int64_t)split2 * ldy && ldx2b == ldy) : true) &&
+                                       (!d2 || d2->rows == split2 || !X2b);
+                    if (whole && ws_cap2 >= 0) {
+                        int fusedq = 0;
+                        rc = sgcn::dense_fwd_pair(M, N, K, X, ldx, X2, ldx2, split, W, ldw, off, sc, eps, relu, Y, ldy, xhat, rstd, d,
+                                                  ws, g1, g2, N2, W2, ldw2, off2, sc2, eps2, relu2, Y2, ldy2, xhat2, rstd2, d2,
+                                                  stream, &fusedq);
+                        if (rc != SGCN_OK) break;
+                        if (fusedq) { skip_until = k + 2; break; }
+                    }
+                }
+            }
             rc = sgcn_dense_fwd_f32(M, N, K, X, ldx, X2, ldx2, split, W, ldw, off, sc, eps, relu, Y, ldy, xhat, rstd, d,
                                     need ? ws : nullptr, g1, g2, stream);
             break;
