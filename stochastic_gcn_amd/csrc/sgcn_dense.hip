@@ -54,25 +54,65 @@ __global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
 }
 
 // dx = LN-backward(dy masked by y > 0); per-block column partials of d(offset), d(scale).
+//
+// Optional tail (LnBwdDx, d <= 128, K <= 256): the layer's INPUT gradient dxo[row][j] = sum_k g[row][k] W[j][k] (* the dropout
+// mask of the layer's input) in the same row pass -- the wave keeps the row of g it has just produced in registers (two
+// columns per lane), the K x d weight matrix is staged in LDS once per workgroup, transposed with an odd pitch so that both
+// the staging writes and the per-lane reads are conflict-free, and lane j accumulates in exactly the order of the 32 x 128
+// MFMA launch it replaces (32-wide K-steps alternating between its K-groups, the groups' sums added in group order): the
+// same bits, one launch and one round trip of g through memory fewer (9.7 us of the step's chain, twice per step).
+struct LnBwdDx { const float* W; int32_t K, kg; DropArgs drop; float* dxo; int64_t lddxo; };
+
 constexpr int kBwdRowsPerWave = 1;     // one row per wave: 4x the workgroups, a quarter of the dependent chain (the step is GPU-latency-bound)
 __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
     const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ scale,
     int32_t n, int32_t d, int32_t norm, int32_t relu, float* __restrict__ dx, int64_t lddx,
-    float* __restrict__ partial /* [gridDim.x][2][d] */) {
-    extern __shared__ float lds[];      // [4 waves][2][d]
+    float* __restrict__ partial /* [gridDim.x][2][d] */, LnBwdDx t) {
+    extern __shared__ float lds[];      // [4 waves][2][d] (LayerNorm), then the tail's weights [d][K + 1]
     const int lane = threadIdx.x & 63, wave = threadIdx.x / kWave;
     const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kBwdRowsPerWave;
     float* my = lds + (size_t)wave * 2 * d;
+    float* wt = lds + (norm ? (size_t)8 * d : 0);
+    const int kp = t.K + 1;
+    if (t.W) {                          // stage W^T: element i = j * d + k of the contiguous K x d matrix -> wt[k][j]
+        // every round of loads is a trip past the L2 (~2 us), so a thread requests its whole share -- up to 32 float4 for
+        // the 256 x 128 matrix -- before it stores any (d % 4 == 0 and a 16-byte aligned matrix: checked by the host)
+        const int total4 = t.K * d / 4;
+        const float inv_d = 1.0f / (float)d;
+        constexpr int kU = 32;
+        float4 v[kU];
+        const float4* W4 = reinterpret_cast<const float4*>(t.W);
+#pragma unroll
+        for (int u = 0; u < kU; u++) { const int i4 = threadIdx.x + u * kBlock; if (i4 < total4) v[u] = W4[i4]; }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int i4 = threadIdx.x + u * kBlock;
+            if (i4 < total4) {
+                const int i = i4 * 4;
+                const int j = (int)(((float)i + 0.5f) * inv_d), k = i - j * d;       // exact: i < 2^15, d <= 128
+                float* w = wt + k * kp + j;
+                w[0] = v[u].x; w[kp] = v[u].y; w[2 * kp] = v[u].z; w[3 * kp] = v[u].w;
+            }
+        }
+    }
     if (norm) for (int c = lane; c < 2 * d; c += kWave) my[c] = 0.f;
+    float gk[2] = {0.f, 0.f};           // the row of g this wave produced (tail: d <= 128)
+    bool have = false;
+    int64_t myrow = 0;
     for (int k = 0; k < kBwdRowsPerWave; k++) {
         const int64_t row = row0 + k;
         if (row >= n) break;
+        have = true; myrow = row;
         const float* gr = dy + row * lddy;
         const float* yr = y + row * ldy;
         float* dr = dx + row * lddx;
         if (!norm) {
-            for (int c = lane; c < d; c += kWave) dr[c] = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
+            for (int c = lane; c < d; c += kWave) {
+                const float g = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
+                dr[c] = g;
+                if (c < 2 * kWave) gk[c / kWave] = g;
+            }
             continue;
         }
         const float* hr = xhat + row * (int64_t)d;
@@ -82,21 +122,76 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
             const float h = hr[c];
             my[c] += g;               // d(offset) column sum (lane-private columns: no race)
             my[d + c] += g * h;       // d(scale)
-            const float t = g * scale[c];
-            s1 += t;
-            s2 += t * h;
+            const float t2 = g * scale[c];
+            s1 += t2;
+            s2 += t2 * h;
         }
         const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d, r = rstd[row];
         for (int c = lane; c < d; c += kWave) {
             const float g = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
-            dr[c] = r * (g * scale[c] - m1 - hr[c] * m2);
+            const float o = r * (g * scale[c] - m1 - hr[c] * m2);
+            dr[c] = o;
+            if (c < 2 * kWave) gk[c / kWave] = o;
         }
     }
-    if (!norm) return;
+    if (!norm && !t.W) return;
     __syncthreads();
-    float* out = partial + (size_t)blockIdx.x * 2 * d;
-    for (int c = threadIdx.x; c < 2 * d; c += kBlock)
-        out[c] = (lds[c] + lds[2 * d + c]) + (lds[4 * d + c] + lds[6 * d + c]);
+    if (norm) {
+        float* out = partial + (size_t)blockIdx.x * 2 * d;
+        for (int c = threadIdx.x; c < 2 * d; c += kBlock)
+            out[c] = (lds[c] + lds[2 * d + c]) + (lds[4 * d + c] + lds[6 * d + c]);
+    }
+    if (!t.W || !have) return;
+    // ---- the tail: four output columns per lane
+    float acc[4][2];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { acc[e][0] = 0.f; acc[e][1] = 0.f; }
+    int jj[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) jj[e] = lane + e * kWave < t.K ? lane + e * kWave : 0;
+    for (int s0 = 0; s0 * 32 < d; s0++) {
+        const int gi = t.kg > 1 ? (s0 & 1) : 0;
+        const float xs = s0 < 2 ? gk[0] : gk[1];
+        const int kb = s0 * 32, lb = kb & (kWave - 1);
+        const int kn = min(32, d - kb);
+        const float* wk = wt + kb * kp;
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) p[e] = acc[e][gi];
+        if (kn == 32) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float w[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) w[u][e] = wk[(q * 8 + u) * kp + jj[e]];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + q * 8 + u));
+#pragma unroll
+                    for (int e = 0; e < 4; e++) p[e] = fmaf(xv, w[u][e], p[e]);
+                }
+            }
+        } else {
+            for (int kk = 0; kk < kn; kk++) {
+                const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + kk));
+#pragma unroll
+                for (int e = 0; e < 4; e++) p[e] = fmaf(xv, wk[kk * kp + jj[e]], p[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e][gi] = p[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int j = lane + e * kWave;
+        if (j < t.K) {
+            float v = t.kg > 1 ? acc[e][0] + acc[e][1] : acc[e][0];
+            if (t.drop.on) v *= drop_factor(t.drop, (int)myrow, j);
+            t.dxo[myrow * t.lddxo + j] = v;
+        }
+    }
 }
 
 // doffset[c] += sum_b partial[b][0][c]; dscale[c] += sum_b partial[b][1][c]   (fixed order)
@@ -463,7 +558,8 @@ extern "C" int64_t sgcn_ln_act_bwd_ws_floats(int32_t n, int32_t d) {
 int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xhat,
                             const float* rstd, const float* scale, int32_t n, int32_t d, int32_t relu,
                             float* dx, int64_t lddx, float* doffset, float* dscale, float* ws,
-                            bool reduce_params, int32_t* nblk, hipStream_t st) {
+                            bool reduce_params, int32_t* nblk, hipStream_t st, const float* tail_W, int32_t tail_K,
+                            int32_t tail_kg, const sgcn_dropout_t* tail_drop, float* tail_dx, int64_t tail_lddx) {
     SGCN_REQUIRE(n >= 0 && d >= 0, "ln_act_bwd: negative size");
     if (nblk) *nblk = 0;
     if (n == 0 || d == 0) return SGCN_OK;
@@ -471,10 +567,25 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
     SGCN_REQUIRE(dy && y && dx && (!norm || (xhat && rstd && doffset && dscale && ws)),
                  "ln_act_bwd: null operand");
     SGCN_REQUIRE(!norm || (size_t)d * 8 * sizeof(float) <= 64 * 1024, "ln_act_bwd: d too large for LDS");
+    LnBwdDx t{};
+    size_t lds = norm ? (size_t)d * 8 * sizeof(float) : 0;
+    if (tail_W) {
+        SGCN_REQUIRE(tail_dx && d <= 2 * kWave && d % 4 == 0 && aligned16(tail_W) && tail_K > 0 && tail_K <= 4 * kWave &&
+                     tail_lddx >= tail_K && tail_kg >= 1 && tail_kg <= 2, "ln_act_bwd: bad input-gradient tail");
+        t.W = tail_W; t.K = tail_K; t.kg = tail_kg; t.drop = drop_args(tail_drop); t.dxo = tail_dx; t.lddxo = tail_lddx;
+        SGCN_REQUIRE(!t.drop.on || t.drop.width == tail_K, "ln_act_bwd: dropout width must be the layer's input width");
+        lds += (size_t)d * (tail_K + 1) * sizeof(float);
+        SGCN_REQUIRE(lds <= 160 * 1024, "ln_act_bwd: weights too large for LDS");
+        static size_t raised = 0;          // > 64 KB of dynamic LDS needs the attribute
+        if (lds > 64 * 1024 && lds > raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_act_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = 160 * 1024;
+        }
+    }
     const int rows_per_block = 4 * kBwdRowsPerWave;
     const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(ln_act_bwd_kernel, dim3(blocks), dim3(kBlock), norm ? (size_t)d * 8 * sizeof(float) : 0,
-                       st, dy, lddy, y, ldy, xhat, rstd, scale, n, d, norm, relu, dx, lddx, ws);
+    hipLaunchKernelGGL(ln_act_bwd_kernel, dim3(blocks), dim3(kBlock), lds, st, dy, lddy, y, ldy, xhat, rstd, scale, n, d, norm,
+                       relu, dx, lddx, ws, t);
     if (nblk) *nblk = norm ? (int32_t)blocks : 0;
     if (norm && reduce_params)
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + kLnRedCols - 1) / kLnRedCols), dim3(256), 0, st, ws,

@@ -164,6 +164,7 @@ __device__ __forceinline__ void ln_param_reduce_cols32(const float* __restrict__
 int ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xhat,
                       const float* rstd, const float* scale, int32_t n, int32_t d, int32_t relu, float* dx,
                       int64_t lddx, float* doffset, float* dscale, float* ws, bool reduce_params, int32_t* nblk,
-                      hipStream_t st);
+                      hipStream_t st, const float* tail_W = nullptr, int32_t tail_K = 0, int32_t tail_kg = 1,
+                      const sgcn_dropout_t* tail_drop = nullptr, float* tail_dx = nullptr, int64_t tail_lddx = 0);
 
 }  // namespace sgcn

@@ -952,11 +952,25 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
     const float* g = a.dy;
     int64_t ldg = a.lddy;
     int32_t nblk = 0;
+    bool dx_in_row_pass = false;
+    int dx_kg = 1;
     if (a.scale || a.relu) {
         SGCN_REQUIRE(a.g_tmp && a.y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
         SGCN_REQUIRE(!a.scale || a.ws, "dense_bwd: LayerNorm backward needs the workspace");
+        // the input gradient dx = g . W^T in the same row pass where the launch it replaces would have run as ONE chain per
+        // output (no split over K) in two K-groups at most: sgcn_dense.hip LnBwdDx; knob step_fuse bit 3
+        if (a.dx && (tune_get("step_fuse") & 8) && a.N <= 128 && a.N % 4 == 0 && a.K <= 256 && a.ldw == a.N && aligned16(a.W) &&
+            (size_t)(8 * a.N + a.N * (a.K + 1)) * sizeof(float) <= 160 * 1024) {
+            int S = 0, kgq = 0;
+            const sgcn_dropout_t* dr = a.drop;
+            if (dr && dr->keep >= 1.0f) dr = nullptr;
+            if (dr) { S = 1; GemmArgs q{}; q.M = a.n; q.N = a.K; q.K = a.N; kgq = prepare_gemm(q, nullptr).kgroups; }   // a masked output is never split
+            else gemm_fwd_shape(a.n, a.K, a.N, &S, &kgq);
+            if (S == 1 && kgq <= 2) dx_in_row_pass = true, dx_kg = kgq;
+        }
         const int rc = ln_act_bwd_launch(a.dy, a.lddy, a.y, a.ldy, a.xhat, a.rstd, a.scale, a.n, a.N, a.relu, a.g_tmp, a.N,
-                                         a.doffset, a.dscale, s.ws_ln, /*reduce_params=*/false, &nblk, st);
+                                         a.doffset, a.dscale, s.ws_ln, /*reduce_params=*/false, &nblk, st,
+                                         dx_in_row_pass ? a.W : nullptr, a.K, dx_kg, a.drop, a.dx, a.lddx);
         if (rc != SGCN_OK) return rc;
         g = a.g_tmp; ldg = a.N;
     }
@@ -995,7 +1009,7 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
                            a.doffset, a.dscale, g_grad_store ? 0 : 1);
         SGCN_HIP_TRY(hipGetLastError());
     }
-    if (!a.dx) return SGCN_OK;
+    if (!a.dx || dx_in_row_pass) return SGCN_OK;
     // dx[n x K] = g[n x N] . W^T              (W stored [K x N]: trans_b)
     return sgcn_gemm_f32(0, 1, a.n, a.K, a.N, g, ldg, a.W, a.ldw, a.dx, a.lddx, 0, s.ws_gemm, nullptr, a.drop, stream);
 }
