@@ -84,36 +84,50 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         }
     }
 
-    // four consecutive floats at p (the run is contiguous in every operand layout): one 16-byte
-    // load when the host verified alignment and the run is fully in range, else guarded scalars
-    auto ld4 = [&](const float* p, bool vec, bool rowok, int first, int limit, float* out) {
-        if (vec && rowok && first + 3 < limit) {
-            const float4 v = *reinterpret_cast<const float4*>(p);
-            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    // four consecutive floats rowp[first .. first + 4) of a row whose start `rowp` is always addressable (the caller clamps the
+    // row): elements at or past `limit`, and everything when !rowok, read as zero.  Straight-line -- the address is clamped
+    // and the result selected -- so that the five loads of a K-step are all in flight before any of them is waited for.
+    // (Rounds 1-2 guarded each load with a branch; the compiler put a full wait behind every one of them: a trip to the L2
+    // per LOAD, five per K-step.  `vec`: the host verified 16-byte aligned rows and a run length that is a multiple of 4,
+    // so a float4 is either all in range or all out.)
+    auto ld4 = [&](const float* rowp, bool vec, bool rowok, int first, int limit, float* out) {
+        if (vec) {
+            const bool ok = rowok && first + 3 < limit;
+            const float4 v = *reinterpret_cast<const float4*>(rowp + (ok ? first : 0));
+            out[0] = ok ? v.x : 0.f; out[1] = ok ? v.y : 0.f; out[2] = ok ? v.z : 0.f; out[3] = ok ? v.w : 0.f;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) out[e] = (rowok && first + e < limit) ? p[e] : 0.f;
+            for (int e = 0; e < 4; e++) {
+                const bool ok = rowok && first + e < limit;
+                const float v = rowp[ok ? first + e : 0];
+                out[e] = ok ? v : 0.f;
+            }
         }
     };
+    // (!TA) the thread's A row is the same in every K-step: its address -- an index load away when the rows are gathered --
+    // is formed once, not once per step in front of the load that needs it
+    const float* arow = nullptr;
+    if (!TA) {
+        const int row = min(m0 + (tid >> 3), g.M - 1);
+        if (g.A2 && row >= g.a_split) {
+            const int r2 = row - g.a_split;
+            arow = g.A2 + (int64_t)(g.a_gidx2 ? g.a_gidx2[r2] : r2) * g.lda2;
+        } else {
+            arow = g.A + (int64_t)(g.a_gidx ? g.a_gidx[row] : row) * g.lda;
+        }
+    }
     auto fetch = [&](int k0) {
         if (!TA) {          // A is [M x K]: thread reads 4 consecutive k of one row
             const int i = tid >> 3, kq = (tid & 7) * 4, row = m0 + i;
-            const float* ar;
-            if (g.A2 && row >= g.a_split) {
-                const int r2 = row - g.a_split;
-                ar = g.A2 + (int64_t)((g.a_gidx2 && row < g.M) ? g.a_gidx2[r2] : r2) * g.lda2;
-            } else {
-                ar = g.A + (int64_t)((g.a_gidx && row < g.M) ? g.a_gidx[row] : row) * g.lda;
-            }
-            ld4(ar + k0 + kq, g.vec_a, row < g.M, k0 + kq, kend, ra);
+            ld4(arow, g.vec_a, row < g.M, k0 + kq, kend, ra);
             if (g.drop_a.on) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) ra[e] *= drop_factor(g.drop_a, row, k0 + kq + e);   // stored A = x[row][k]
             }
         } else {            // A is [K x M]: thread reads 4 consecutive m of one k
-            const int kk = tid >> 3, iq = (tid & 7) * 4, k = k0 + kk;
-            const int64_t ak = (g.a_gidx && k < kend) ? g.a_gidx[k] : k;         // stored row k of x
-            ld4(g.A + ak * g.lda + m0 + iq, g.vec_a, k < kend, m0 + iq, g.M, ra);
+            const int kk = tid >> 3, iq = (tid & 7) * 4, k = k0 + kk, kc = min(k, kend - 1);
+            const int64_t ak = g.a_gidx ? g.a_gidx[kc] : kc;                      // stored row k of x
+            ld4(g.A + ak * g.lda, g.vec_a, k < kend, m0 + iq, g.M, ra);
             if (g.drop_a.on) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) ra[e] *= drop_factor(g.drop_a, k, m0 + iq + e);     // stored A = x[k][row]
@@ -123,13 +137,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int kk = (tid >> 5) + 8 * r, jq = (tid & 31) * 4, k = k0 + kk;
-                ld4(g.B + (int64_t)k * g.ldb + n0 + jq, g.vec_b, k < kend, n0 + jq, g.N, rb + r * 4);
+                ld4(g.B + (int64_t)min(k, kend - 1) * g.ldb, g.vec_b, k < kend, n0 + jq, g.N, rb + r * 4);
             }
         } else {            // B is [N x K]: 4 consecutive k of one column
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int j = (tid >> 3) + 32 * r, kq = (tid & 7) * 4, col = n0 + j;
-                ld4(g.B + (int64_t)col * g.ldb + k0 + kq, g.vec_b, col < g.N, k0 + kq, kend, rb + r * 4);
+                ld4(g.B + (int64_t)min(col, g.N - 1) * g.ldb, g.vec_b, col < g.N, k0 + kq, kend, rb + r * 4);
             }
         }
     };
@@ -585,10 +599,11 @@ static void launch_kg(const GemmArgs& g, dim3 grid, int kgroups, hipStream_t st)
 // what launch_gemm decides before it launches: alignment flags, the K slicing (written into g), grid and K-groups
 struct GemmPlan { dim3 grid; int kgroups, S, epi; };
 
-static GemmPlan prepare_gemm(GemmArgs& g, float* ws) {
+static GemmPlan prepare_gemm(GemmArgs& g, float* ws, int ta = 0, int tb = 0) {
     auto al = [](const void* p, int64_t ld) { return p && ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
-    g.vec_a = al(g.A, g.lda) && (!g.A2 || al(g.A2, g.lda2));
-    g.vec_b = al(g.B, g.ldb);
+    // (a float4 must be all in range or all out: the run it lies in is a multiple of 4 long -- gemm_body ld4)
+    g.vec_a = al(g.A, g.lda) && (!g.A2 || al(g.A2, g.lda2)) && (ta ? g.M : g.K) % 4 == 0;
+    g.vec_b = al(g.B, g.ldb) && (tb ? g.K : g.N) % 4 == 0;
     int S = ws ? split_factor(g.M, g.N, g.K) : 1;
     g.kchunk = ((g.K + S - 1) / S + kTK - 1) / kTK * kTK;
     S = g.K > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
@@ -628,7 +643,7 @@ static void launch_prepared(const GemmArgs& g, const GemmPlan& p, int ta, int tb
 
 static int launch_gemm(GemmArgs g, int ta, int tb, float* ws, hipStream_t st, ReduceJob* defer = nullptr) {
     if (defer) defer->pending = 0;
-    const GemmPlan p = prepare_gemm(g, ws);
+    const GemmPlan p = prepare_gemm(g, ws, ta, tb);
     const int S = p.S, epi = p.epi;
     launch_prepared(g, p, ta, tb, st);
     if (S > 1 && epi != 0) {
@@ -995,7 +1010,7 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
         DwJob& J = dg.jobs[dg.n++];
         g_dw_recorded = dg.n;
         J.q = q;
-        J.p = prepare_gemm(J.q, s.ws_dw);
+        J.p = prepare_gemm(J.q, s.ws_dw, 1, 0);
         J.rj = ReduceJob{J.q.ws, J.p.S, J.q.M, J.q.N, J.q.C, J.q.ldc, J.q.accumulate, J.p.S > 1 ? 1 : 0};
         J.ws_ln = s.ws_ln; J.nblk = nblk; J.N = a.N; J.doffset = a.doffset; J.dscale = a.dscale;
     } else {
