@@ -51,8 +51,11 @@ SHAPES = [   # name, rows, rows of the second (stacked) operand, K, N, LayerNorm
     ("dense3 512 x 128 -> 41 (no LayerNorm)", 512, 0, 128, 41, False),
 ]
 
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 feat = rnd(232965, 1204)
 for name, n, n2, K, N, norm in SHAPES:
+    if only and not name.startswith(only):
+        continue
     W = rnd(K, N) * 0.05
     off, sc = (rnd(1, N) * 0.1, 1 + rnd(1, N) * 0.1) if norm else (None, None)
     if K == 1204:
@@ -62,7 +65,7 @@ for name, n, n2, K, N, norm in SHAPES:
     else:
         x = rnd(n, K)
         x2 = rnd(n2, K) if n2 else None
-    for knob in (3, 5, 100):
+    for knob in ((3,) if only else (3, 5, 100)):
         _ffi.tune("gemm_min_steps", knob)
         us = timed(lambda: ops.dense_fwd(x, W, off, sc, norm, x2=x2))
         print(json.dumps({"shape": name, "gemm_min_steps": knob, "us_per_call": round(us, 2),
