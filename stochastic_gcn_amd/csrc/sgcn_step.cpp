@@ -84,6 +84,52 @@ struct Args {
     }
 };
 
+
+// The argument records of the ops that sgcn_step_run also LOOKS AHEAD at (the same reader serves the op's own case and the
+// peek of the op in front of it).  `drop()` is the layer's dropout site or nullptr.
+struct DenseFwdOp {
+    int32_t M, N, K, split, relu; float eps;
+    const float *X, *X2, *W, *off, *sc; int64_t ldx, ldx2, ldw, ldy, ws_cap;
+    float *Y, *xhat, *rstd, *ws; const int32_t *g1, *g2;
+    sgcn_dropout_t dr; bool has_drop;
+    void read(Args& a) {
+        M = a.i(); N = a.i(); K = a.i();
+        X = a.p<const float>(); ldx = a.next(); X2 = a.p<const float>(); ldx2 = a.next(); split = a.i();
+        W = a.p<const float>(); ldw = a.next(); off = a.p<const float>(); sc = a.p<const float>();
+        eps = a.f(); relu = a.i();
+        Y = a.p<float>(); ldy = a.next(); xhat = a.p<float>(); rstd = a.p<float>();
+        has_drop = a.drop(&dr) != nullptr;
+        ws = a.p<float>(); ws_cap = a.next(); g1 = a.p<const int32_t>(); g2 = a.p<const int32_t>();
+    }
+    const sgcn_dropout_t* drop() const { return has_drop ? &dr : nullptr; }
+    bool plain() const { return !off && !sc && !relu; }                    // no LayerNorm, no ReLU: an output layer
+};
+struct DenseBwdOp {
+    int32_t n, N, K, relu;
+    const float *dy, *y, *xhat, *rstd, *sc, *x, *W; int64_t lddy, ldy, ldx, ldw, lddw, lddx, ws_cap;
+    float *dW, *doff, *dsc, *dx, *gtmp, *ws; const int32_t* gidx;
+    sgcn_dropout_t dr; bool has_drop;
+    void read(Args& a) {
+        n = a.i(); N = a.i(); K = a.i();
+        dy = a.p<const float>(); lddy = a.next(); y = a.p<const float>(); ldy = a.next();
+        xhat = a.p<const float>(); rstd = a.p<const float>(); sc = a.p<const float>(); relu = a.i();
+        x = a.p<const float>(); ldx = a.next(); W = a.p<const float>(); ldw = a.next();
+        dW = a.p<float>(); lddw = a.next(); doff = a.p<float>(); dsc = a.p<float>();
+        dx = a.p<float>(); lddx = a.next();
+        has_drop = a.drop(&dr) != nullptr;
+        gtmp = a.p<float>(); ws = a.p<float>(); ws_cap = a.next(); gidx = a.p<const int32_t>();
+    }
+    const sgcn_dropout_t* drop() const { return has_drop ? &dr : nullptr; }
+};
+struct CeOp {
+    const float *z, *lab; int64_t ldz, ldl, lddz, ldp; int32_t n, c; float *dz, *pred, *stats, *rowstat;
+    void read(Args& a) {
+        z = a.p<const float>(); ldz = a.next(); lab = a.p<const float>(); ldl = a.next(); n = a.i(); c = a.i();
+        dz = a.p<float>(); lddz = a.next(); pred = a.p<float>(); ldp = a.next(); stats = a.p<float>(); rowstat = a.p<float>();
+    }
+};
+inline bool is_ce(int32_t op) { return op == SGCN_OP_SOFTMAX_CE || op == SGCN_OP_SIGMOID_CE; }
+
 }  // namespace
 
 extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int64_t* slots, int32_t nslots,
@@ -122,8 +168,10 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         return true;
     };
     int32_t skip_until = 0, dx_done_at = -1;
-    struct Head { bool on = false, has_drop = false; int32_t at = -1, K = 0, kg = 1; const float* x = nullptr; int64_t ldx = 0;
-                  const float* W = nullptr; int64_t ldw = 0; sgcn_dropout_t drop{}; } head;
+    struct Head { bool on = false; int32_t at = -1, kg = 1; DenseFwdOp f; } head;     // an output layer waiting for its loss op
+    auto peek = [&](int32_t j, Args& b) {          // the arguments of op j, if there is one and they are well-formed
+        return j < nops && ops[j].nargs >= 0 && ops[j].nargs <= SGCN_STEP_MAX_ARGS && eval_args(ops[j], b);
+    };
     for (int32_t k = 0; k < nops; k++) {
         const sgcn_step_op_t& op = ops[k];
         if (op.nargs < 0 || op.nargs > SGCN_STEP_MAX_ARGS)
@@ -149,102 +197,59 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         }
         switch (op.op) {
         case SGCN_OP_DENSE_FWD: {
-            const int32_t M = a.i(), N = a.i(), K = a.i();
-            const float* X = a.p<const float>(); const int64_t ldx = a.next();
-            const float* X2 = a.p<const float>(); const int64_t ldx2 = a.next();
-            const int32_t split = a.i();
-            const float* W = a.p<const float>(); const int64_t ldw = a.next();
-            const float* off = a.p<const float>(); const float* sc = a.p<const float>();
-            const float eps = a.f(); const int32_t relu = a.i();
-            float* Y = a.p<float>(); const int64_t ldy = a.next();
-            float* xhat = a.p<float>(); float* rstd = a.p<float>();
-            const sgcn_dropout_t* d = a.drop(&dr);
-            float* ws = a.p<float>(); const int64_t ws_cap = a.next();
-            const int32_t* g1 = a.p<const int32_t>(); const int32_t* g2 = a.p<const int32_t>();
+            DenseFwdOp f;
+            f.read(a);
             // The output layer (no LayerNorm, no ReLU, <= 64 classes, <= 128 inputs) directly in front of the loss: its
             // 5-MFLOP product becomes the head of the loss kernel's row pass (sgcn_dense.hip ce_head) instead of a launch
             head.on = false;
-            if ((fuse & 1) && !off && !sc && !relu && !X2 && !g1 && N <= 64 && K <= 128 && (int64_t)K * N * 4 <= 48 * 1024 && k + 1 < nops &&
-                (ops[k + 1].op == SGCN_OP_SOFTMAX_CE || ops[k + 1].op == SGCN_OP_SIGMOID_CE) && ops[k + 1].nargs >= 0 &&
-                ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
-                Args b;
+            Args b;
+            if ((fuse & 1) && f.plain() && !f.X2 && !f.g1 && f.N <= 64 && f.K <= 128 && (int64_t)f.K * f.N * 4 <= 48 * 1024 &&
+                peek(k + 1, b) && is_ce(ops[k + 1].op)) {
+                CeOp ce;
+                ce.read(b);
                 int S = 0, kgq = 0;
-                sgcn::gemm_fwd_shape(M, N, K, &S, &kgq);
-                if (S == 1 && kgq <= 2 && eval_args(ops[k + 1], b)) {
-                    const float* bz = b.p<const float>(); const int64_t bldz = b.next();
-                    (void)b.p<const float>(); (void)b.next();
-                    const int32_t bn = b.i(), bc = b.i();
-                    if (bz == Y && bldz == ldy && bn == M && bc == N) {
-                        head.on = true; head.at = k + 1; head.x = X; head.ldx = ldx; head.W = W; head.ldw = ldw; head.K = K;
-                        head.kg = kgq; head.has_drop = d != nullptr;
-                        if (d) head.drop = *d;
-                        break;                       // nothing launched: the loss op computes the logits
-                    }
+                sgcn::gemm_fwd_shape(f.M, f.N, f.K, &S, &kgq);
+                if (S == 1 && kgq <= 2 && ce.z == f.Y && ce.ldz == f.ldy && ce.n == f.M && ce.c == f.N) {
+                    head.on = true; head.at = k + 1; head.kg = kgq; head.f = f;
+                    break;                           // nothing launched: the loss op computes the logits
                 }
             }
             // the eager wrapper (ops.dense_fwd): split-K scratch only where the library asks for it
-            const int64_t need = N <= 128 ? sgcn_gemm_ws_floats(M, N, K) : 0;
-            if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
+            const int64_t need = f.N <= 128 ? sgcn_gemm_ws_floats(f.M, f.N, f.K) : 0;
+            if (need > f.ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch %lld > %lld floats", (long long)need, (long long)f.ws_cap);
             // A layer that is cut over K (its epilogue is a row pass already) with a narrow dense layer on ALL of its output
             // rows right behind it: that layer rides in the row pass (sgcn_gemm.hip splitk_ln_dense_kernel)
-            if ((fuse & 4) && need > 0 && k + 1 < nops && ops[k + 1].op == SGCN_OP_DENSE_FWD && ops[k + 1].nargs >= 0 &&
-                ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
-                Args b;
-                if (eval_args(ops[k + 1], b)) {
-                    const int32_t M2 = b.i(), N2 = b.i(), K2 = b.i();
-                    const float* Xb = b.p<const float>(); const int64_t ldxb = b.next();
-                    const float* X2b = b.p<const float>(); const int64_t ldx2b = b.next();
-                    const int32_t split2 = b.i();
-                    const float* W2 = b.p<const float>(); const int64_t ldw2 = b.next();
-                    const float* off2 = b.p<const float>(); const float* sc2 = b.p<const float>();
-                    const float eps2 = b.f(); const int32_t relu2 = b.i();
-                    float* Y2 = b.p<float>(); const int64_t ldy2 = b.next();
-                    float* xhat2 = b.p<float>(); float* rstd2 = b.p<float>();
-                    sgcn_dropout_t dr2;
-                    const sgcn_dropout_t* d2 = b.drop(&dr2);
-                    (void)b.p<float>(); const int64_t ws_cap2 = b.next();
-                    const int32_t* g1b = b.p<const int32_t>(); const int32_t* g2b = b.p<const int32_t>();
-                    // (an output layer in front of the loss is better off as the loss kernel's head: one pass fewer)
-                    const bool is_head = (fuse & 1) && !off2 && !sc2 && !relu2 && !X2b && N2 <= 64 && k + 2 < nops &&
-                                         (ops[k + 2].op == SGCN_OP_SOFTMAX_CE || ops[k + 2].op == SGCN_OP_SIGMOID_CE);
-                    const bool whole = !is_head && Xb == Y && ldxb == ldy && !g1b && !g2b && M2 == M && K2 == N &&
-                                       (X2b ? (X2b == Y + (int64_t)split2 * ldy && ldx2b == ldy) : true) &&
-                                       (!d2 || d2->rows == split2 || !X2b);
-                    if (whole && ws_cap2 >= 0) {
-                        int fusedq = 0;
-                        rc = sgcn::dense_fwd_pair(M, N, K, X, ldx, X2, ldx2, split, W, ldw, off, sc, eps, relu, Y, ldy, xhat, rstd, d,
-                                                  ws, g1, g2, N2, W2, ldw2, off2, sc2, eps2, relu2, Y2, ldy2, xhat2, rstd2, d2,
-                                                  stream, &fusedq);
-                        if (rc != SGCN_OK) break;
-                        if (fusedq) { skip_until = k + 2; break; }
-                    }
+            if ((fuse & 4) && need > 0 && peek(k + 1, b) && ops[k + 1].op == SGCN_OP_DENSE_FWD) {
+                DenseFwdOp q;
+                q.read(b);
+                // (an output layer in front of the loss is better off as the loss kernel's head: one pass fewer)
+                const bool is_head = (fuse & 1) && q.plain() && !q.X2 && q.N <= 64 && k + 2 < nops && is_ce(ops[k + 2].op);
+                const bool whole = !is_head && q.X == f.Y && q.ldx == f.ldy && !q.g1 && !q.g2 && q.M == f.M && q.K == f.N &&
+                                   (!q.X2 || (q.X2 == f.Y + (int64_t)q.split * f.ldy && q.ldx2 == f.ldy)) &&
+                                   (!q.has_drop || q.dr.rows == q.split || !q.X2);
+                if (whole) {
+                    int fusedq = 0;
+                    rc = sgcn::dense_fwd_pair(f.M, f.N, f.K, f.X, f.ldx, f.X2, f.ldx2, f.split, f.W, f.ldw, f.off, f.sc, f.eps, f.relu,
+                                              f.Y, f.ldy, f.xhat, f.rstd, f.drop(), f.ws, f.g1, f.g2, q.N, q.W, q.ldw, q.off, q.sc, q.eps,
+                                              q.relu, q.Y, q.ldy, q.xhat, q.rstd, q.drop(), stream, &fusedq);
+                    if (rc != SGCN_OK) break;
+                    if (fusedq) { skip_until = k + 2; break; }
                 }
             }
-            rc = sgcn_dense_fwd_f32(M, N, K, X, ldx, X2, ldx2, split, W, ldw, off, sc, eps, relu, Y, ldy, xhat, rstd, d,
-                                    need ? ws : nullptr, g1, g2, stream);
+            rc = sgcn_dense_fwd_f32(f.M, f.N, f.K, f.X, f.ldx, f.X2, f.ldx2, f.split, f.W, f.ldw, f.off, f.sc, f.eps, f.relu, f.Y, f.ldy,
+                                    f.xhat, f.rstd, f.drop(), need ? f.ws : nullptr, f.g1, f.g2, stream);
             break;
         }
         case SGCN_OP_DENSE_BWD: {
-            const int32_t n = a.i(), N = a.i(), K = a.i();
-            const float* dy = a.p<const float>(); const int64_t lddy = a.next();
-            const float* y = a.p<const float>(); const int64_t ldy = a.next();
-            const float* xhat = a.p<const float>(); const float* rstd = a.p<const float>();
-            const float* sc = a.p<const float>(); const int32_t relu = a.i();
-            const float* x = a.p<const float>(); const int64_t ldx = a.next();
-            const float* W = a.p<const float>(); const int64_t ldw = a.next();
-            float* dW = a.p<float>(); const int64_t lddw = a.next();
-            float* doff = a.p<float>(); float* dsc = a.p<float>();
-            float* dx = a.p<float>(); const int64_t lddx = a.next();
-            const sgcn_dropout_t* d = a.drop(&dr);
-            float* gtmp = a.p<float>();
-            float* ws = a.p<float>(); const int64_t ws_cap = a.next();
-            const int32_t* gidx = a.p<const int32_t>();
-            const bool norm = xhat != nullptr;
-            const int64_t need = (norm ? (sgcn_ln_act_bwd_ws_floats(n, N) + 3) / 4 * 4 : 0) +
-                                 std::max(sgcn_gemm_ws_floats(K, N, n), sgcn_gemm_ws_floats(n, K, N));
-            if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: backward scratch %lld > %lld floats", (long long)need, (long long)ws_cap);
-            rc = sgcn::dense_bwd_overlapped(n, N, K, dy, lddy, y, ldy, xhat, rstd, sc, relu, x, ldx, W, ldw, dW, lddw, doff,
-                                            dsc, k == dx_done_at ? nullptr : dx, lddx, d, gtmp, need ? ws : nullptr, gidx, stream);
+            DenseBwdOp w;
+            w.read(a);
+            const bool norm = w.xhat != nullptr;
+            const int64_t need = (norm ? (sgcn_ln_act_bwd_ws_floats(w.n, w.N) + 3) / 4 * 4 : 0) +
+                                 std::max(sgcn_gemm_ws_floats(w.K, w.N, w.n), sgcn_gemm_ws_floats(w.n, w.K, w.N));
+            if (need > w.ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: backward scratch %lld > %lld floats", (long long)need, (long long)w.ws_cap);
+            rc = sgcn::dense_bwd_overlapped(w.n, w.N, w.K, w.dy, w.lddy, w.y, w.ldy, w.xhat, w.rstd, w.sc, w.relu, w.x, w.ldx, w.W, w.ldw,
+                                            w.dW, w.lddw, w.doff, w.dsc, k == dx_done_at ? nullptr : w.dx, w.lddx, w.drop(), w.gtmp,
+                                            need ? w.ws : nullptr, w.gidx, stream);
             break;
         }
         case SGCN_OP_DW_FLUSH:
@@ -281,44 +286,28 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         }
         case SGCN_OP_SOFTMAX_CE:
         case SGCN_OP_SIGMOID_CE: {
-            const float* z = a.p<const float>(); const int64_t ldz = a.next();
-            const float* lab = a.p<const float>(); const int64_t ldl = a.next();
-            const int32_t n = a.i(), c = a.i();
-            float* dz = a.p<float>(); const int64_t lddz = a.next();
-            float* pred = a.p<float>(); const int64_t ldp = a.next();
-            float* stats = a.p<float>(); float* rowstat = a.p<float>();
+            CeOp ce;
+            ce.read(a);
+            const bool hd = head.on && head.at == k;
             // The backward of the LAST dense layer follows at once (it has neither LayerNorm nor ReLU): its input gradient
             // dx = dlogits . W^T is a tail of the loss kernel's row pass (sgcn_dense.hip ce_dx_tail), that op then only
             // records its weight-gradient GEMM
-            const float* tW = nullptr; int64_t tldw = 0, tlddx = 0; int32_t tK = 0; float* tdx = nullptr;
-            sgcn_dropout_t tdr; const sgcn_dropout_t* tdrop = nullptr;
-            if ((fuse & 2) && dz && c <= 64 && k + 1 < nops && ops[k + 1].op == SGCN_OP_DENSE_BWD && ops[k + 1].nargs >= 0 &&
-                ops[k + 1].nargs <= SGCN_STEP_MAX_ARGS) {
-                Args b;
-                if (eval_args(ops[k + 1], b)) {
-                    const int32_t bn = b.i(), bN = b.i(), bK = b.i();
-                    const float* bdy = b.p<const float>(); const int64_t blddy = b.next();
-                    (void)b.p<const float>(); (void)b.next();                                  // y, ldy
-                    const float* bxhat = b.p<const float>(); (void)b.p<const float>();          // xhat, rstd
-                    const float* bsc = b.p<const float>(); const int32_t brelu = b.i();
-                    (void)b.p<const float>(); (void)b.next();                                  // x, ldx
-                    const float* bW = b.p<const float>(); const int64_t bldw = b.next();
-                    (void)b.p<float>(); (void)b.next(); (void)b.p<float>(); (void)b.p<float>();  // dW, lddw, doff, dsc
-                    float* bdx = b.p<float>(); const int64_t blddx = b.next();
-                    const sgcn_dropout_t* bd = b.drop(&tdr);
-                    if (bn == n && bN == c && bdy == dz && blddy == lddz && !bxhat && !bsc && !brelu && bdx && bW && bK > 0 &&
-                        (int64_t)bK * c * 4 <= 48 * 1024) {
-                        tW = bW; tldw = bldw; tK = bK; tdx = bdx; tlddx = blddx; tdrop = bd;
-                        dx_done_at = k + 1;
-                    }
-                }
+            DenseBwdOp t{};
+            bool tail = false;
+            Args b;
+            if ((fuse & 2) && ce.dz && ce.c <= 64 && peek(k + 1, b) && ops[k + 1].op == SGCN_OP_DENSE_BWD) {
+                t.read(b);
+                tail = t.n == ce.n && t.N == ce.c && t.dy == ce.dz && t.lddy == ce.lddz && !t.xhat && !t.sc && !t.relu && t.dx && t.W &&
+                       t.K > 0 && (int64_t)t.K * ce.c * 4 <= 48 * 1024 &&
+                       (!hd || (t.W == head.f.W && t.K == head.f.K && t.ldw == head.f.ldw));      // the head's own layer
+                if (tail) dx_done_at = k + 1;
             }
-            // the loss / accuracy sums run beside the backward pass (joined before L2_PENALTY / ADAM)
-            const bool hd = head.on && head.at == k;
-            if (hd && tW && (tW != head.W || tK != head.K || tldw != head.ldw)) { tW = nullptr; tdx = nullptr; dx_done_at = -1; }   // not the same layer
-            rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, z, ldz, lab, ldl, n, c, dz, lddz, pred, ldp, stats, rowstat, stream, overlap,
-                               hd ? head.W : tW, hd ? head.ldw : tldw, hd ? head.K : tK, tdx, tlddx, tdrop,
-                               hd ? head.x : nullptr, hd ? head.ldx : 0, hd ? head.kg : 1, (hd && head.has_drop) ? &head.drop : nullptr);
+            const float* W = hd ? head.f.W : (tail ? t.W : nullptr);
+            // the loss / accuracy sums run beside the backward pass (joined before L2_PENALTY / ADAM) or ride in the optimizer's launch
+            rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, ce.z, ce.ldz, ce.lab, ce.ldl, ce.n, ce.c, ce.dz, ce.lddz, ce.pred, ce.ldp,
+                               ce.stats, ce.rowstat, stream, overlap, W, hd ? head.f.ldw : t.ldw, hd ? head.f.K : t.K,
+                               tail ? t.dx : nullptr, t.lddx, tail ? t.drop() : nullptr,
+                               hd ? head.f.X : nullptr, hd ? head.f.ldx : 0, hd ? head.kg : 1, hd ? head.f.drop() : nullptr);
             head.on = false;
             break;
         }
