@@ -46,6 +46,7 @@ def timed(fn, reps=100):
 
 SHAPES = [   # name, rows, rows of the second (stacked) operand, K, N, LayerNorm
     ("dense0 [dropout(x); x] 2 x 1018 x 1204 -> 128 (feature rows through an index)", 1018, 1018, 1204, 128, True),
+    ("dense0-half x 1018 x 1204 -> 128 (one stream only: what a dual-accumulator form would load)", 1018, 0, 1204, 128, True),
     ("dense1 [h; mu] 2 x 1018 x 128 -> 128", 1018, 1018, 128, 128, True),
     ("dense2 512 x 256 -> 128", 512, 0, 256, 128, True),
     ("dense3 512 x 128 -> 41 (no LayerNorm)", 512, 0, 128, 41, False),
@@ -61,7 +62,7 @@ for name, n, n2, K, N, norm in SHAPES:
     if K == 1204:
         idx = torch.randint(0, 232965, (n,), device=dev, dtype=torch.int32)
         x = ops.GatheredRows(feat, idx)
-        x2 = ops.GatheredRows(feat, idx)
+        x2 = ops.GatheredRows(feat, idx) if n2 else None
     else:
         x = rnd(n, K)
         x2 = rnd(n2, K) if n2 else None

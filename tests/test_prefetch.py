@@ -147,3 +147,27 @@ def test_native_prefetcher_stress_no_deadlock():
         if take == nb:
             assert pre.next() is None
         pre.close()
+
+
+def test_sampler_error_reaches_the_consumer_through_every_producer_shape():
+    """A batch the importance sampler cannot expand (only isolated vertices: 'Prob is empty', gcn/mult.cpp:17-18) is an error
+    of the call that asks for it -- also when the sampler's core and the packer run on different threads."""
+    import pytest
+    import scipy.sparse as sp
+    from stochastic_gcn_amd._ffi import SgcnError
+    from stochastic_gcn_amd.scheduler import NativePrefetcher
+    n = 64
+    rows = np.arange(0, 40)
+    a = sp.csr_matrix((np.ones(40, np.float32), (rows, (rows + 1) % 40)), shape=(n, n))      # vertices 40..63 are isolated
+    labels = np.eye(4, dtype=np.float32)[np.arange(n) % 4]
+    ph = {'adj': ['a0'], 'madj': ['m0'], 'fadj': ['f0'], 'fields': ['x0', 'x1'], 'ffields': ['ff0'], 'scales': ['s0'], 'labels': 'l'}
+    batches = [np.arange(0, 8, dtype=np.int32), np.arange(8, 16, dtype=np.int32), np.arange(48, 56, dtype=np.int32),
+               np.arange(16, 24, dtype=np.int32)]
+    for packers in (0, 1, 3):
+        sch = PyScheduler(a, labels, 1, np.array([2], dtype=np.int32), ph, 3, cv=False, importance=True)
+        pre = NativePrefetcher(sch, batches, 0, depth=2, pin=False, packers=packers)
+        assert pre.next() is not None and pre.next() is not None
+        with pytest.raises(SgcnError) as e:
+            pre.next()
+        assert "Prob is empty" in str(e.value)
+        pre.close()
