@@ -9,6 +9,7 @@
 // One wavefront per row; lanes stride the row (coalesced 256-byte pieces); wave reductions by
 // DPP shuffles (__shfl_xor over 64 lanes).
 #include "sgcn_dev.h"
+#include "sgcn_fuse.h"
 
 namespace sgcn {
 
@@ -205,35 +206,120 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int32_
 // the K x c weight matrix -- 2 x 41 fused multiply-adds per lane on a 512 x 41 batch -- instead of a 16-workgroup MFMA launch
 // of its own (7.8 us of the step's chain for 5 MFLOP).  k ascending from zero in one fmaf chain: the same bits as the GEMM
 // (sgcn_gemm.hip: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain), dropout mask of the layer's input included.
-struct CeDx { const float* W; int64_t ldw; int32_t K; float* dx; int64_t lddx; DropArgs drop;
+struct CeDx { const float* W; int64_t ldw; int32_t K, wflat; float* dx; int64_t lddx; DropArgs drop;
               // ... and the last layer's FORWARD as a head of the same pass: logits = dropout(x) . W for x = hx[row][0..K),
               // K <= 128, with the K-step / K-group order of additions of the launch it replaces (kg groups of alternating
               // 32-wide K-steps, partial sums added in group order: sgcn_gemm.hip gemm_body)
-              const float* hx; int64_t ldhx; int32_t kg; DropArgs hdrop; float* zout; int64_t ldzo; };
+              const float* hx; int64_t ldhx; int32_t kg; DropArgs hdrop; float* zout; int64_t ldzo;
+              // ... and the dense layer in front of it as a PRE-layer of the head (sgcn_fuse.h CeLastLayer): the head's
+              // input row is computed here -- dropout(px)[row][0..PK) . PW, LayerNorm, ReLU -- and stays in registers
+              const float* px; int64_t ldpx; int32_t PK, pS, pkchunk, pkg; const float* PW; DropArgs pdrop;
+              const float* poff; const float* psc; float peps; int32_t prelu, pepi;
+              float* pY; int64_t ldpy; float* pxhat; float* prstd; };
 
 // W is staged in LDS by the whole workgroup first (coalesced; lane j then reads its row W[j][0..c) with stride c floats --
 // odd for the class counts that occur, so conflict-free -- instead of 64 different cache lines per load instruction)
+// LDS layout of the loss kernel's weights: the output layer's [K][c] matrix in a region rounded up to whole 1 KB load
+// instructions, the pre-layer's [PK][K] matrix behind it
+__host__ __device__ inline int ce_w_region(int K, int c) { return (K * c + 255) / 256 * 256; }
+
 __device__ __forceinline__ void ce_dx_stage(const CeDx& t, int c, float* wl) {
-    // the matrix was written by the previous step's optimizer: every round of loads is a trip past the L2 (~2 us), so a
-    // thread requests ALL of its share (<= 48 values: 48 KB / 256 threads) before it stores any
-    constexpr int kMax = 48;
+    // The matrices were written by the previous step's optimizer: every round of loads is a trip past the L2 (~2 us), so
+    // ALL of them are requested before anything waits -- as direct global -> LDS loads (global_load_lds_dwordx4: 64 lanes x
+    // 16 bytes land contiguously at a wave-uniform LDS address), which costs no registers however large the matrix is.
+    // A lane past the end of a matrix re-reads its last 16 bytes into the region's padding.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto copy = [&](const float* src, int floats, float* dst) {
+        const int total4 = floats / 4;
+        for (int base4 = wave * kWave; base4 < total4; base4 += (kBlock / kWave) * kWave) {
+            const int i4 = min(base4 + lane, total4 - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)i4 * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + (int64_t)base4 * 4), 16, 0, 0);
+        }
+    };
     const int total = t.K * c;
-    if (t.ldw == c) {                       // the weights are contiguous in the flat parameter buffer: a flat copy
-        float v[kMax];
-#pragma unroll
-        for (int u = 0; u < kMax; u++) {
-            const int i = threadIdx.x + u * kBlock;
-            v[u] = i < total ? t.W[i] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < kMax; u++) {
-            const int i = threadIdx.x + u * kBlock;
-            if (i < total) wl[i] = v[u];
-        }
-    } else {                                // (a pitched matrix: one integer division per element -- not on the step's path)
+    if (t.wflat) copy(t.W, total, wl);          // (host: contiguous, 16-byte aligned, a multiple of four floats)
+    else                                    // (a pitched or unaligned matrix: element by element -- not on the step's path)
         for (int i = threadIdx.x; i < total; i += kBlock) wl[i] = t.W[(int64_t)(i / c) * t.ldw + (i % c)];
-    }
+    if (t.PW) copy(t.PW, t.PK * t.K, wl + ce_w_region(t.K, c));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+// The pre-layer for one row: returns the head's input (columns lane and lane + 64 of act(LN(dropout(px) . PW))) with the
+// additions in the order of the launch(es) it replaces -- per K slice z (split-K), K-groups of alternating 32-wide steps,
+// the groups' sums added in group order, the slices' sums added in z order starting from zero -- and stores y / xhat / rstd.
+__device__ __forceinline__ void ce_pre_layer(const CeDx& t, const float* pw, int64_t row, int lane, float xin[4], float out[2]) {
+    if (t.pdrop.on) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) xin[e] *= drop_factor(t.pdrop, (int)row, lane + e * kWave);
+    }
+    const int N = t.K;                      // the pre-layer's outputs = the output layer's inputs
+    const int c0 = lane < N ? lane : 0, c1 = lane + kWave < N ? lane + kWave : 0;
+    float v0 = 0.f, v1 = 0.f;
+    for (int z = 0; z < t.pS; z++) {
+        const int kbeg = z * t.pkchunk, kend = min(t.PK, kbeg + t.pkchunk);
+        float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+        for (int kb = kbeg, sl = 0; kb < kend; kb += 32, sl++) {
+            const int gi = t.pkg > 1 ? (sl & 1) : 0;
+            const int blk = kb >> 6, lb = kb & (kWave - 1);
+            const float xs = blk == 0 ? xin[0] : (blk == 1 ? xin[1] : (blk == 2 ? xin[2] : xin[3]));
+            const float* wk = pw + kb * N;
+            float p0 = a0[gi], p1 = a1[gi];
+            if (kb + 32 <= kend) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float w0[8], w1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { w0[u] = wk[(q * 8 + u) * N + c0]; w1[u] = wk[(q * 8 + u) * N + c1]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + q * 8 + u));
+                        p0 = fmaf(xv, w0[u], p0); p1 = fmaf(xv, w1[u], p1);
+                    }
+                }
+            } else {
+                for (int kk = 0; kb + kk < kend; kk++) {
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + kk));
+                    p0 = fmaf(xv, wk[kk * N + c0], p0); p1 = fmaf(xv, wk[kk * N + c1], p1);
+                }
+            }
+            a0[gi] = p0; a1[gi] = p1;
+        }
+        const float s0 = t.pkg > 1 ? a0[0] + a0[1] : a0[0], s1 = t.pkg > 1 ? a1[0] + a1[1] : a1[0];
+        if (t.pS > 1) { v0 += s0; v1 += s1; } else { v0 = s0; v1 = s1; }
+    }
+    const float v[2] = {v0, v1};
+    float* yr = t.pY + row * t.ldpy;
+    if (t.pepi == 2) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) if (lane + e * kWave < N) s += v[e];
+        const float mean = wave_sum(s) / (float)N;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) if (lane + e * kWave < N) { const float d = v[e] - mean; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) / (float)N + t.peps);
+        if (lane == 0) t.prstd[row] = rs;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            out[e] = 0.f;
+            if (c < N) {
+                const float h = (v[e] - mean) * rs;
+                t.pxhat[row * N + c] = h;
+                const float y = h * t.psc[c] + t.poff[c];
+                out[e] = t.prelu ? fmaxf(y, 0.f) : y;
+                yr[c] = out[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = lane + e * kWave;
+            out[e] = 0.f;
+            if (c < N) { out[e] = (t.pepi == 1 && t.prelu) ? fmaxf(v[e], 0.f) : v[e]; yr[c] = out[e]; }
+        }
+    }
 }
 // lane cc < c returns logit cc of `row`
 __device__ __forceinline__ float ce_head(const CeDx& t, const float* wl, int64_t row, int lane, int c, float x0, float x1) {
@@ -300,22 +386,32 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
     int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
     float* __restrict__ rowstat /* [2][n] */, CeDx tail) {
-    extern __shared__ float ce_lds[];
+    extern __shared__ __attribute__((aligned(1024))) float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-    const bool head = tail.hx != nullptr;            // c <= 64: logit k lives in lane k
+    const bool head = tail.hx != nullptr || tail.PW != nullptr;            // c <= 64: logit k lives in lane k
     // everything the row pass reads from memory is requested before the weight matrix is staged (one round trip, not four)
     const bool live = row < n;
     const float* lr = lab + (live ? row : 0) * ldl;
     const float lab0 = (live && lane < c) ? lr[lane] : 0.f;
-    float hx0 = 0.f, hx1 = 0.f;
-    if (head && live) {
+    float hx0 = 0.f, hx1 = 0.f, pin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (head && live && !tail.PW) {
         const float* xr = tail.hx + row * tail.ldhx;
         hx0 = lane < tail.K ? xr[lane] : 0.f; hx1 = lane + kWave < tail.K ? xr[lane + kWave] : 0.f;
+    }
+    if (tail.PW && live) {
+        const float* xr = tail.px + row * tail.ldpx;
+#pragma unroll
+        for (int e = 0; e < 4; e++) pin[e] = lane + e * kWave < tail.PK ? xr[lane + e * kWave] : 0.f;
     }
     if (tail.K > 0) ce_dx_stage(tail, c, ce_lds);
     if (!live) return;
     const float inv_n = 1.0f / (float)n;
+    if (tail.PW) {
+        float o[2];
+        ce_pre_layer(tail, ce_lds + ce_w_region(tail.K, c), row, lane, pin, o);
+        hx0 = o[0]; hx1 = o[1];
+    }
     const float myz = head ? ce_head(tail, ce_lds, row, lane, c, hx0, hx1) : 0.f;
     const float* zr = z + row * ldz;
     auto zv = [&](int k) { return head ? myz : zr[k]; };
@@ -377,20 +473,30 @@ __global__ __launch_bounds__(kBlock) void sigmoid_ce_kernel(
     const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
     int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
     float* __restrict__ rowstat /* [2][n] */, CeDx tail) {
-    extern __shared__ float ce_lds[];
+    extern __shared__ __attribute__((aligned(1024))) float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-    const bool head = tail.hx != nullptr;
+    const bool head = tail.hx != nullptr || tail.PW != nullptr;
     const bool live = row < n;
     const float lab0 = (live && lane < c) ? lab[row * ldl + lane] : 0.f;      // requested before the weights are staged
-    float hx0 = 0.f, hx1 = 0.f;
-    if (head && live) {
+    float hx0 = 0.f, hx1 = 0.f, pin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (head && live && !tail.PW) {
         const float* xr = tail.hx + row * tail.ldhx;
         hx0 = lane < tail.K ? xr[lane] : 0.f; hx1 = lane + kWave < tail.K ? xr[lane + kWave] : 0.f;
+    }
+    if (tail.PW && live) {
+        const float* xr = tail.px + row * tail.ldpx;
+#pragma unroll
+        for (int e = 0; e < 4; e++) pin[e] = lane + e * kWave < tail.PK ? xr[lane + e * kWave] : 0.f;
     }
     if (tail.K > 0) ce_dx_stage(tail, c, ce_lds);
     if (!live) return;
     const float inv = 1.0f / ((float)n * (float)c);
+    if (tail.PW) {
+        float o[2];
+        ce_pre_layer(tail, ce_lds + ce_w_region(tail.K, c), row, lane, pin, o);
+        hx0 = o[0]; hx1 = o[1];
+    }
     const float myz = head ? ce_head(tail, ce_lds, row, lane, c, hx0, hx1) : 0.f;
     float l = 0.f, hit = 0.f, mydz = 0.f;
     for (int k = lane; k < c; k += kWave) {
@@ -665,33 +771,52 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
 }
 // The loss kernels with the statistics reduction (loss / accuracy sums: nothing in the step depends on them
 // before the optimizer's join) on the auxiliary stream when `overlap`: one kernel less on the step's chain.
-// W != nullptr: the loss kernel works on the last dense layer's K x c weight matrix too --
-//   dx != nullptr:  it also writes dx[n x K] = dlogits . W^T (* the dropout mask of the layer's input);
-//   hx != nullptr:  it computes the logits itself, dropout(hx)[n x K] . W (kg = the K-groups of the launch it replaces),
-//                   writing them to `logits`.
-// The caller has checked c <= 64, K <= 128 for the head, and that a dlogits buffer is given for the tail.
+// `last` (sgcn_fuse.h): what of the network around the loss the kernel's row pass takes over -- nullptr / empty: nothing.
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream,
-            bool overlap, const float* W, int64_t ldw, int32_t K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop,
-            const float* hx, int64_t ldhx, int32_t kg, const sgcn_dropout_t* h_drop) {
+            bool overlap, const CeLastLayer* last) {
     CeDx tail{};
-    if (W && K > 0 && (dx || hx)) {
-        SGCN_REQUIRE(c <= kWave && ldw >= c && (int64_t)K * c * 4 <= 48 * 1024, "ce: bad fused last layer");
-        tail.W = W; tail.ldw = ldw; tail.K = K;
-        if (dx) {
-            SGCN_REQUIRE(lddx >= K, "ce: bad dx pitch");
-            tail.dx = dx; tail.lddx = lddx; tail.drop = drop_args(dx_drop);
-            SGCN_REQUIRE(!tail.drop.on || tail.drop.width == K, "ce: dropout width must be the layer's input width");
+    if (last && last->W && last->K > 0 && (last->dx || last->hx || last->pre)) {
+        const CeLastLayer& L = *last;
+        SGCN_REQUIRE(c <= kWave && L.ldw >= c && (int64_t)L.K * c * 4 <= 48 * 1024, "ce: bad fused last layer");
+        tail.W = L.W; tail.ldw = L.ldw; tail.K = L.K;
+        tail.wflat = (L.ldw == c && ((int64_t)L.K * c) % 4 == 0 && aligned16(L.W)) ? 1 : 0;
+        if (L.dx) {
+            SGCN_REQUIRE(L.lddx >= L.K, "ce: bad dx pitch");
+            tail.dx = L.dx; tail.lddx = L.lddx; tail.drop = drop_args(L.dx_drop);
+            SGCN_REQUIRE(!tail.drop.on || tail.drop.width == L.K, "ce: dropout width must be the layer's input width");
         }
-        if (hx) {
-            SGCN_REQUIRE(K <= 2 * kWave && ldhx >= K && kg >= 1 && kg <= 2, "ce: bad fused head");
-            tail.hx = hx; tail.ldhx = ldhx; tail.kg = kg; tail.hdrop = drop_args(h_drop);
+        if (L.hx || L.pre) {
+            SGCN_REQUIRE(L.K <= 2 * kWave && L.kg >= 1 && L.kg <= 2 && (L.pre || L.ldhx >= L.K), "ce: bad fused head");
+            tail.hx = L.hx; tail.ldhx = L.ldhx; tail.kg = L.kg; tail.hdrop = drop_args(L.h_drop);
             tail.zout = const_cast<float*>(logits); tail.ldzo = ldz;
-            SGCN_REQUIRE(!tail.hdrop.on || tail.hdrop.width == K, "ce: dropout width must be the layer's input width");
+            SGCN_REQUIRE(!tail.hdrop.on || tail.hdrop.width == L.K, "ce: dropout width must be the layer's input width");
+        }
+        if (L.pre) {
+            SGCN_REQUIRE(L.px && L.PW && L.pY && L.PK > 0 && L.PK <= 4 * kWave && L.ldpx >= L.PK && L.ldpy >= L.K && (L.PK * L.K) % 4 == 0 &&
+                         aligned16(L.PW) && L.pS >= 1 && L.pkg >= 1 && L.pkg <= 2 && L.pkchunk % 32 == 0 && L.pkchunk > 0 &&
+                         (int64_t)L.PK * L.K <= 32 * 4 * kBlock, "ce: bad fused pre-layer");
+            const int norm = (L.poff && L.psc) ? 1 : 0;
+            SGCN_REQUIRE(!norm || (L.pxhat && L.prstd), "ce: the pre-layer's LayerNorm needs xhat / rstd");
+            tail.px = L.px; tail.ldpx = L.ldpx; tail.PK = L.PK; tail.pS = L.pS; tail.pkchunk = L.pkchunk; tail.pkg = L.pkg;
+            tail.PW = L.PW; tail.pdrop = drop_args(L.p_drop); tail.poff = L.poff; tail.psc = L.psc; tail.peps = L.peps;
+            tail.prelu = L.prelu; tail.pepi = norm ? 2 : (L.prelu ? 1 : 0);
+            tail.pY = L.pY; tail.ldpy = L.ldpy; tail.pxhat = L.pxhat; tail.prstd = L.prstd;
+            SGCN_REQUIRE(!tail.pdrop.on || tail.pdrop.width == L.PK, "ce: dropout width must be the pre-layer's input width");
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = tail.K > 0 ? (size_t)tail.K * c * sizeof(float) : 0;
+    size_t lds = tail.K > 0 ? (size_t)ce_w_region(tail.K, c) * sizeof(float) : 0;
+    if (tail.PW) {
+        lds += ((size_t)tail.PK * tail.K + 255) / 256 * 256 * sizeof(float);
+        SGCN_REQUIRE(lds <= 160 * 1024, "ce: the two weight matrices do not fit the LDS");
+        static bool raised = false;        // > 64 KB of dynamic LDS needs the attribute, once per kernel
+        if (lds > 64 * 1024 && !raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&softmax_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sigmoid_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
     if (softmax)
         hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), lds, st, logits, ldz, labels, ldl,
                            n, c, dlogits, lddz, pred, ldp, rowstat, tail);
@@ -722,13 +847,13 @@ extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float
                                    int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
                                    float* pred, int64_t ldp, float* stats, float* rowstat,
                                    void* stream) {
-    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr);
+    return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr);
 }
 
 extern "C" int sgcn_sigmoid_ce_f32(const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n,
                                    int32_t c, float* dlogits, int64_t lddz, float* pred, int64_t ldp,
                                    float* stats, float* rowstat, void* stream) {
-    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr);
+    return sgcn::ce_impl(false, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr);
 }
 
 extern "C" int sgcn_l2_penalty_f32(const float* theta, int64_t lo, int64_t hi, float wd, float* grad,

@@ -625,12 +625,13 @@ static GemmPlan prepare_gemm(GemmArgs& g, float* ws, int ta = 0, int tb = 0) {
 // K slicing and K-groups a forward dense layer of this shape would get (sgcn_dense.hip's fused output head reproduces
 // the launch's order of additions, so it asks)
 namespace sgcn {
-void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups) {
+void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups, int* kchunk) {
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K;
     float dummy;
     const GemmPlan p = prepare_gemm(g, sgcn_gemm_ws_floats(M, N, K) > 0 ? &dummy : nullptr);
     *S = p.S; *kgroups = p.kgroups;
+    if (kchunk) *kchunk = g.kchunk;
 }
 }  // namespace sgcn
 
@@ -708,7 +709,7 @@ int dense_fwd_pair(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
     g.drop_a = drop_args(drop);
     const GemmPlan p = prepare_gemm(g, ws);
     int S2 = 0, kg2 = 0;
-    gemm_fwd_shape(M, N2, N, &S2, &kg2);
+    gemm_fwd_shape(M, N2, N, &S2, &kg2, nullptr);
     if (p.S <= 1 || S2 != 1 || kg2 > 2 || (size_t)N * N2 * sizeof(float) > 64 * 1024) return SGCN_OK;
     SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
     RowDense d{};
@@ -980,7 +981,7 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
             const sgcn_dropout_t* dr = a.drop;
             if (dr && dr->keep >= 1.0f) dr = nullptr;
             if (dr) { S = 1; GemmArgs q{}; q.M = a.n; q.N = a.K; q.K = a.N; kgq = prepare_gemm(q, nullptr).kgroups; }   // a masked output is never split
-            else gemm_fwd_shape(a.n, a.K, a.N, &S, &kgq);
+            else gemm_fwd_shape(a.n, a.K, a.N, &S, &kgq, nullptr);
             if (S == 1 && kgq <= 2) dx_in_row_pass = true, dx_kg = kgq;
         }
         const int rc = ln_act_bwd_launch(a.dy, a.lddy, a.y, a.ldy, a.xhat, a.rstd, a.scale, a.n, a.N, a.relu, a.g_tmp, a.N,

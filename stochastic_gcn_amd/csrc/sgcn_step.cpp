@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "sgcn_host.h"
+#include "sgcn_fuse.h"
 #include "sgcn_bwd.h"
 #include "../../include/sgcn.h"
 
@@ -39,9 +40,8 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
 bool scatter_park(float* H, int64_t ldh, const int32_t* idx, int32_t n, int32_t d, const float* src, int64_t lds);
 int ce_impl(bool softmax, const float* logits, int64_t ldz, const float* labels, int64_t ldl, int32_t n, int32_t c,
             float* dlogits, int64_t lddz, float* pred, int64_t ldp, float* stats, float* rowstat, void* stream, bool overlap,
-            const float* W, int64_t ldw, int32_t K, float* dx, int64_t lddx, const sgcn_dropout_t* dx_drop,
-            const float* hx, int64_t ldhx, int32_t kg, const sgcn_dropout_t* h_drop);
-void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups);       // sgcn_gemm.hip
+            const CeLastLayer* last);
+void gemm_fwd_shape(int M, int N, int K, int* S, int* kgroups, int* kchunk);       // sgcn_gemm.hip
 int dense_fwd_pair(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx, const float* X2, int64_t ldx2, int32_t split,
                    const float* W, int64_t ldw, const float* offset, const float* scale, float eps, int32_t relu, float* Y,
                    int64_t ldy, float* xhat, float* rstd, const sgcn_dropout_t* drop, float* ws, const int32_t* gidx,
@@ -168,7 +168,8 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         return true;
     };
     int32_t skip_until = 0, dx_done_at = -1;
-    struct Head { bool on = false; int32_t at = -1, kg = 1; DenseFwdOp f; } head;     // an output layer waiting for its loss op
+    // an output layer waiting for its loss op -- and, when it is folded too, the dense layer in front of it
+    struct Head { bool on = false, pre = false; int32_t at = -1, kg = 1, pS = 1, pkchunk = 0, pkg = 1; DenseFwdOp f, p; } head;
     auto peek = [&](int32_t j, Args& b) {          // the arguments of op j, if there is one and they are well-formed
         return j < nops && ops[j].nargs >= 0 && ops[j].nargs <= SGCN_STEP_MAX_ARGS && eval_args(ops[j], b);
     };
@@ -208,10 +209,36 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
                 CeOp ce;
                 ce.read(b);
                 int S = 0, kgq = 0;
-                sgcn::gemm_fwd_shape(f.M, f.N, f.K, &S, &kgq);
+                sgcn::gemm_fwd_shape(f.M, f.N, f.K, &S, &kgq, nullptr);
                 if (S == 1 && kgq <= 2 && ce.z == f.Y && ce.ldz == f.ldy && ce.n == f.M && ce.c == f.N) {
-                    head.on = true; head.at = k + 1; head.kg = kgq; head.f = f;
+                    head.on = true; head.pre = false; head.at = k + 1; head.kg = kgq; head.f = f;
                     break;                           // nothing launched: the loss op computes the logits
+                }
+            }
+            // ... and the dense layer in front of THAT (<= 256 inputs, <= 128 outputs = the output layer's inputs, all rows):
+            // its product, LayerNorm and ReLU become the pre-layer of the head -- three launches (MFMA tiles, split-K reduce,
+            // loss) and the logits' and the hidden row's round trips through memory become one row pass (fuse bit 4)
+            if ((fuse & 16) && (fuse & 1) && !f.X2 && !f.g1 && f.N <= 128 && f.K <= 256 && (f.K * f.N) % 4 == 0 &&
+                peek(k + 1, b) && ops[k + 1].op == SGCN_OP_DENSE_FWD && k + 2 < nops && is_ce(ops[k + 2].op)) {
+                DenseFwdOp q;
+                q.read(b);
+                Args c3;
+                CeOp ce;
+                int S = 0, kgq = 0, S0 = 0, kg0 = 0, kc0 = 0;
+                sgcn::gemm_fwd_shape(q.M, q.N, q.K, &S, &kgq, nullptr);
+                sgcn::gemm_fwd_shape(f.M, f.N, f.K, &S0, &kg0, &kc0);
+                const bool ok = q.plain() && !q.X2 && !q.g1 && q.N <= 64 && q.K == f.N && q.M == f.M && q.X == f.Y && q.ldx == f.ldy &&
+                                (int64_t)q.K * q.N * 4 <= 48 * 1024 && S == 1 && kgq <= 2 && S0 >= 1 && S0 <= 2 && kg0 <= 2 &&
+                                f.ldw == f.N && q.ldw == q.N && peek(k + 2, c3);
+                if (ok) {
+                    ce.read(c3);
+                    if (ce.z == q.Y && ce.ldz == q.ldy && ce.n == q.M && ce.c == q.N &&
+                        (((int64_t)q.K * q.N + 255) / 256 * 256 + ((int64_t)f.K * f.N + 255) / 256 * 256) * 4 <= 160 * 1024) {
+                        head.on = true; head.pre = true; head.at = k + 2; head.kg = kgq; head.f = q; head.p = f;
+                        head.pS = S0; head.pkchunk = kc0; head.pkg = kg0;
+                        skip_until = k + 2;          // neither layer is launched: the loss op computes both
+                        break;
+                    }
                 }
             }
             // the eager wrapper (ops.dense_fwd): split-K scratch only where the library asks for it
@@ -302,12 +329,23 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
                        (!hd || (t.W == head.f.W && t.K == head.f.K && t.ldw == head.f.ldw));      // the head's own layer
                 if (tail) dx_done_at = k + 1;
             }
-            const float* W = hd ? head.f.W : (tail ? t.W : nullptr);
+            sgcn::CeLastLayer L;
+            if (hd || tail) {
+                L.W = hd ? head.f.W : t.W; L.ldw = hd ? head.f.ldw : t.ldw; L.K = hd ? head.f.K : t.K;
+            }
+            if (tail) { L.dx = t.dx; L.lddx = t.lddx; L.dx_drop = t.drop(); }
+            if (hd) {
+                L.hx = head.pre ? nullptr : head.f.X; L.ldhx = head.f.ldx; L.kg = head.kg; L.h_drop = head.f.drop();
+                if (head.pre) {
+                    const DenseFwdOp& p = head.p;
+                    L.pre = true; L.px = p.X; L.ldpx = p.ldx; L.PK = p.K; L.PW = p.W; L.pS = head.pS; L.pkchunk = head.pkchunk;
+                    L.pkg = head.pkg; L.p_drop = p.drop(); L.poff = p.off; L.psc = p.sc; L.peps = p.eps; L.prelu = p.relu;
+                    L.pY = p.Y; L.ldpy = p.ldy; L.pxhat = p.xhat; L.prstd = p.rstd;
+                }
+            }
             // the loss / accuracy sums run beside the backward pass (joined before L2_PENALTY / ADAM) or ride in the optimizer's launch
             rc = sgcn::ce_impl(op.op == SGCN_OP_SOFTMAX_CE, ce.z, ce.ldz, ce.lab, ce.ldl, ce.n, ce.c, ce.dz, ce.lddz, ce.pred, ce.ldp,
-                               ce.stats, ce.rowstat, stream, overlap, W, hd ? head.f.ldw : t.ldw, hd ? head.f.K : t.K,
-                               tail ? t.dx : nullptr, t.lddx, tail ? t.drop() : nullptr,
-                               hd ? head.f.X : nullptr, hd ? head.f.ldx : 0, hd ? head.kg : 1, hd ? head.f.drop() : nullptr);
+                               ce.stats, ce.rowstat, stream, overlap, (hd || tail) ? &L : nullptr);
             head.on = false;
             break;
         }

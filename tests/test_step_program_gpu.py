@@ -186,11 +186,12 @@ def test_dense_scratch_is_sized_for_the_row_capacity():
                 assert lib.sgcn_gemm_ws_floats(M, N, K) <= GEMM_WS_BOUND and lib.sgcn_gemm_ws_floats(K, N, M) <= GEMM_WS_BOUND
 
 
-@pytest.mark.parametrize("fuse", [0, 1, 2, 3, 4, 8, 15])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3, 4, 8, 15, 17, 31])
 def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
     """sgcn_step_run folds the output layer into the loss kernel's row pass (its forward product as the head, its input
     gradient as the tail; a narrow dense layer in the reduce pass of the split-K layer in front of it; a layer's input
-    gradient in its LayerNorm backward pass: knob step_fuse, default 15 -- what every other test of this file runs); with the fusion partly or
+    gradient in its LayerNorm backward pass; the dense layer in front of the output layer as the pre-layer of the loss kernel's
+    head: knob step_fuse, default 31 -- what every other test of this file runs); with the fusion partly or
     wholly off the same program issues the separate launches, and every variant gives the eager path's bits."""
     from stochastic_gcn_amd import _ffi
     # (the mid-size Reddit recipe: its first layer, 192 inputs on ~1,000 rows, is cut over K like the full-size one -- the
@@ -201,12 +202,12 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
     try:
         a, la = _run(case, False, 4, False)
     finally:
-        _ffi.tune('step_fuse', 15)
+        _ffi.tune('step_fuse', 31)
     _ffi.tune('step_fuse', fuse)
     try:
         b, lb = _run(case, True, 4, False)
     finally:
-        _ffi.tune('step_fuse', 15)
+        _ffi.tune('step_fuse', 31)
     assert all(p is not None for p in b._programs.values())
     assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m)
     for ha, hb in zip(a.history, b.history):
