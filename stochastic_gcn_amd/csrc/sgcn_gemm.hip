@@ -429,18 +429,21 @@ struct RowDense {
 };
 
 __global__ __launch_bounds__(kBlock) void splitk_ln_dense_kernel(const float* __restrict__ ws, int32_t S, GemmArgs g, RowDense d) {
-    extern __shared__ float wl[];                 // layer 2's weights, [K2 = g.N][d.N]
+    extern __shared__ __attribute__((aligned(1024))) float wl[];                 // layer 2's weights, [K2 = g.N][d.N]
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     const bool live = row < g.M;
     const int K2 = g.N, total = K2 * d.N;
-    // everything the pass reads from memory is requested before anything is used
-    constexpr int kMax = 64;                      // 128 x 128 floats / 256 threads
-    float wv[kMax];
-#pragma unroll
-    for (int u = 0; u < kMax; u++) {
-        const int i = threadIdx.x + u * kBlock;
-        wv[u] = i < total ? d.W[i] : 0.f;
+    // everything the pass reads from memory is requested before anything is used; layer 2's weights go straight from global
+    // memory to the LDS (global_load_lds_dwordx4: no registers, all of them in flight at once; a lane past the end re-reads the
+    // last 16 bytes into the region's padding -- the host rounds the allocation up to whole 1 KB instructions)
+    {
+        const int total4 = total / 4, wave = threadIdx.x >> 6;
+        for (int base4 = wave * kWave; base4 < total4; base4 += (kBlock / kWave) * kWave) {
+            const int i4 = min(base4 + lane, total4 - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(d.W + (int64_t)i4 * 4),
+                                             (__attribute__((address_space(3))) void*)(wl + (int64_t)base4 * 4), 16, 0, 0);
+        }
     }
     float sc1[2] = {1.f, 1.f}, of1[2] = {0.f, 0.f}, sc2[2] = {1.f, 1.f}, of2[2] = {0.f, 0.f};
 #pragma unroll
@@ -461,11 +464,7 @@ __global__ __launch_bounds__(kBlock) void splitk_ln_dense_kernel(const float* __
             v[e] = s;
         }
     }
-#pragma unroll
-    for (int u = 0; u < kMax; u++) {
-        const int i = threadIdx.x + u * kBlock;
-        if (i < total) wl[i] = wv[u];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!live) return;
     // ---- layer 1's epilogue (splitk_ln_act_kernel)
@@ -710,7 +709,7 @@ int dense_fwd_pair(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
     const GemmPlan p = prepare_gemm(g, ws);
     int S2 = 0, kg2 = 0;
     gemm_fwd_shape(M, N2, N, &S2, &kg2, nullptr);
-    if (p.S <= 1 || S2 != 1 || kg2 > 2 || (size_t)N * N2 * sizeof(float) > 64 * 1024) return SGCN_OK;
+    if (p.S <= 1 || S2 != 1 || kg2 > 2 || (size_t)N * N2 * sizeof(float) > 64 * 1024 || (N * N2) % 4 || !aligned16(W2)) return SGCN_OK;
     SGCN_REQUIRE(!g.drop_a.on || g.drop_a.width == K, "dense_fwd: dropout width must be K");
     RowDense d{};
     d.W = W2; d.ldw = ldw2; d.N = N2; d.kg = kg2; d.offset = offset2; d.scale = scale2; d.eps = eps2; d.relu = relu2;
@@ -722,7 +721,7 @@ int dense_fwd_pair(int32_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
     launch_prepared(g, p, 0, 0, st);
     g.epi = p.epi;
     const unsigned rb = (unsigned)((g.M + (kBlock / kWave) - 1) / (kBlock / kWave));
-    hipLaunchKernelGGL(splitk_ln_dense_kernel, dim3(rb), dim3(kBlock), (size_t)N * N2 * sizeof(float), st, g.ws, p.S, g, d);
+    hipLaunchKernelGGL(splitk_ln_dense_kernel, dim3(rb), dim3(kBlock), ((size_t)N * N2 + 255) / 256 * 256 * sizeof(float), st, g.ws, p.S, g, d);
     SGCN_HIP_TRY(hipGetLastError());
     *fused = 1;
     return SGCN_OK;
