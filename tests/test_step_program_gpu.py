@@ -11,7 +11,7 @@ import model_cases as mc
 pytestmark = pytest.mark.gpu
 
 
-def _model(case, params, native, group=True):
+def _model(case, params, native, group=True, multitask=False):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.vrgcn import VRGCN
     from stochastic_gcn_amd.plaingcn import PlainGCN
@@ -21,16 +21,16 @@ def _model(case, params, native, group=True):
     cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
     fl = case['flags']
     m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
-            is_training=True, device=torch.device('cuda:0'))
+            is_training=True, device=torch.device('cuda:0'), multitask=multitask)
     m.set_params(params)
     return m
 
 
-def _run(case, native, steps, slot, group=True):
+def _run(case, native, steps, slot, group=True, multitask=False):
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.scheduler import StagingSlot
     params = mc.make_oracle_model(case, seed=3).params
-    m = _model(case, {k: v.copy() for k, v in params.items()}, native, group)
+    m = _model(case, {k: v.copy() for k, v in params.items()}, native, group, multitask)
     sch = mc.make_scheduler(case, 1)
     slots = [StagingSlot(pin=True) for _ in range(3)] if slot else None
     losses = []
@@ -214,3 +214,45 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
         assert torch.equal(ha[0], hb[0])
     for (l1, a1), (l2, a2) in zip(la, lb):
         assert torch.equal(l1, l2) and torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("fuse", [0, 31])
+def test_multitask_model_sigmoid_loss_program_equals_eager_and_oracle(fuse):
+    """The ppi form (gcn/models.py:77-79,86-90: multi-hot labels, sigmoid cross-entropy over all n x c elements): the loss
+    kernel's other flavour, with the layers around it folded into its row pass or not -- bit-identical to the eager path,
+    and the eager path's step against the oracle."""
+    from stochastic_gcn_amd import _ffi
+    from oracle import model_np as mnp, oracle_np as onp
+    case = mc.build_case(mc.REDDIT_MID)
+    rng = np.random.RandomState(5)
+    case['labels'] = (rng.rand(*case['labels'].shape) < 0.2).astype(np.float32)        # multi-hot
+    _ffi.tune('step_fuse', 0)
+    try:
+        a, la = _run(case, False, 3, False, multitask=True)
+    finally:
+        _ffi.tune('step_fuse', 31)
+    _ffi.tune('step_fuse', fuse)
+    try:
+        b, lb = _run(case, True, 3, False, multitask=True)
+    finally:
+        _ffi.tune('step_fuse', 31)
+    assert all(p is not None for p in b._programs.values())
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m)
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
+    if fuse:
+        return
+    # the oracle on the same batches and masks
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    om = mc.make_oracle_model(case, seed=3)
+    om.multitask = True
+    sch = mc.make_scheduler(case, 1)
+    for step in range(3):
+        feed = sch.minibatch(c['batch'])
+        masks = mnp.HashMasks(a.dropout_seed, step, 1.0 - fl['dropout'])
+        o_loss, o_acc, _, _, _ = om.run_one_step(feed, ph, fl['dropout'], masks)
+        assert abs(float(la[step][0]) - float(o_loss)) <= 1e-4 * max(1.0, abs(float(o_loss))), (step, float(la[step][0]), float(o_loss))
+        assert abs(float(la[step][1]) - float(o_acc)) <= 1e-5
+    dp = a.get_params()
+    for k, v in om.params.items():
+        assert onp.rel_err(dp[k], v) < 5e-4, k
