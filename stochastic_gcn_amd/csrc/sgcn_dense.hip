@@ -8,6 +8,8 @@
 //   adam         tf.train.AdamOptimizer update on the flat parameter buffer   gcn/models.py:50-51
 // One wavefront per row; lanes stride the row (coalesced 256-byte pieces); wave reductions by
 // DPP shuffles (__shfl_xor over 64 lanes).
+#include <algorithm>
+
 #include "sgcn_dev.h"
 #include "sgcn_fuse.h"
 
@@ -555,18 +557,8 @@ __global__ __launch_bounds__(kBlock) void l2_penalty_kernel(const float* __restr
     if (threadIdx.x == 0 && loss) loss[0] += 0.5f * wd * red[0];
 }
 
-__global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ theta,
-                                                      const float* __restrict__ grad,
-                                                      float* __restrict__ m, float* __restrict__ v,
-                                                      int64_t n, float lr_t, float b1, float b2,
-                                                      float eps) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const float g = grad[i];
-        const float mi = b1 * m[i] + (1.f - b1) * g;
-        const float vi = b2 * v[i] + (1.f - b2) * g * g;
-        m[i] = mi; v[i] = vi;
-        theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
-    }
+__global__ __launch_bounds__(kBlock) void adam_kernel(AdamArgs A) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * kBlock) adam_one(A, i, A.grad[i]);
 }
 
 // Adam with the step's loss / accuracy statistics riding along: workgroups [0, gridDim.x - 1) are adam_kernel, the LAST one
@@ -581,23 +573,32 @@ struct TailScatter {
 };
 constexpr int kTailRowsPerBlock = kBlock / 32;      // 32 lanes x float4 per 128 columns of a row
 
-__global__ __launch_bounds__(kBlock) void adam_stats_kernel(float* __restrict__ theta, const float* __restrict__ grad,
-                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                            float lr_t, float b1, float b2, float eps,
-                                                            const float* __restrict__ rowstat, int32_t rows, int32_t c,
-                                                            int32_t softmax, float* __restrict__ stats, int32_t nb, TailScatter sc) {
-    if ((int)blockIdx.x < nb) {
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)nb * kBlock) {
-            const float g = grad[i];
-            const float mi = b1 * m[i] + (1.f - b1) * g;
-            const float vi = b2 * v[i] + (1.f - b2) * g * g;
-            m[i] = mi; v[i] = vi;
-            theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+// ... and, when the step's grouped weight-gradient launch sits right in front of the optimizer, ITS reductions (split-K
+// partial tiles, LayerNorm parameter partials: reduce_multi_body) as the first workgroups of the launch, each applying the
+// update to the element it has just reduced; the Adam workgroups then walk only the GAPS the reductions do not cover.
+struct TailGaps { int64_t start[24]; int64_t len[24]; int32_t n; int64_t total; };   // total < 0: no reductions, everything is a gap
+
+__global__ __launch_bounds__(kBlock) void adam_stats_kernel(AdamArgs A, const float* __restrict__ rowstat, int32_t rows, int32_t c,
+                                                            int32_t softmax, float* __restrict__ stats, int32_t nb, TailScatter sc,
+                                                            ReduceMulti R, int32_t rblocks, TailGaps G) {
+    if ((int)blockIdx.x < rblocks) { reduce_multi_body(R, (int)blockIdx.x, &A); return; }
+    const int bx = (int)blockIdx.x - rblocks;
+    if (bx < nb) {
+        if (G.total < 0) {
+            for (int64_t i = (int64_t)bx * kBlock + threadIdx.x; i < A.n; i += (int64_t)nb * kBlock) adam_one(A, i, A.grad[i]);
+        } else {
+            for (int64_t t = (int64_t)bx * kBlock + threadIdx.x; t < G.total; t += (int64_t)nb * kBlock) {
+                int64_t r = t;
+                int q = 0;
+                while (q + 1 < G.n && r >= G.len[q]) { r -= G.len[q]; q++; }
+                const int64_t i = G.start[q] + r;
+                adam_one(A, i, A.grad[i]);
+            }
         }
         return;
     }
-    if ((int)blockIdx.x > nb) {                      // history rows: one 32-lane group per row, float4 per lane and 128 columns
-        const int b = (int)blockIdx.x - nb - 1;
+    if (bx > nb) {                                   // history rows: one 32-lane group per row, float4 per lane and 128 columns
+        const int b = bx - nb - 1;
         const int j = (sc.jobs > 1 && b >= sc.first[1]) ? 1 : 0;
         const int64_t i = (int64_t)(b - sc.first[j]) * kTailRowsPerBlock + threadIdx.x / 32;
         if (i >= sc.n[j]) return;
@@ -745,12 +746,67 @@ bool scatter_park(float* H, int64_t ldh, const int32_t* idx, int32_t n, int32_t 
     t.first[j + 1] = t.first[j] + (n + kTailRowsPerBlock - 1) / kTailRowsPerBlock;
     return true;
 }
+__global__ void reduce_multi_kernel(ReduceMulti R) { reduce_multi_body(R, (int)blockIdx.x, nullptr); }
+
+// reductions parked for the optimizer's launch (sgcn_gemm.hip dw_group_flush, when sgcn_step_run sees ADAM right behind it)
+namespace { struct PendingReduce { bool on = false; ReduceMulti R; int blocks = 0; }; PendingReduce& pending_reduce() { static PendingReduce p; return p; } }
+bool reduce_park(const ReduceMulti& R, int blocks) {
+    PendingReduce& p = pending_reduce();
+    if (p.on) return false;
+    p.on = true; p.R = R; p.blocks = blocks;
+    return true;
+}
+// the parked reductions as their own launch (no optimizer followed after all, or their outputs are not a clean cover)
+static int reduce_unpark(void* stream) {
+    PendingReduce& p = pending_reduce();
+    if (!p.on) return SGCN_OK;
+    p.on = false;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)p.blocks), dim3(256), 0, (hipStream_t)stream, p.R);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+int reduce_flush(void* stream) { return reduce_unpark(stream); }
+// the gaps of [0, n) that the parked reductions' outputs leave (false: they are not disjoint contiguous ranges inside it)
+static bool reduce_gaps(const ReduceMulti& R, const float* grad, int64_t n, TailGaps& G) {
+    struct Rg { int64_t lo, hi; } r[3 * kMaxGroup];
+    int nr = 0;
+    for (int k = 0; k < R.n; k++) {
+        if (R.j[k].pending) {
+            if (R.j[k].ldc != R.j[k].N) return false;
+            r[nr++] = Rg{R.j[k].C - grad, R.j[k].C - grad + (int64_t)R.j[k].M * R.j[k].N};
+        }
+        if (R.nblk[k] > 0) {
+            r[nr++] = Rg{R.doffset[k] - grad, R.doffset[k] - grad + R.d[k]};
+            r[nr++] = Rg{R.dscale[k] - grad, R.dscale[k] - grad + R.d[k]};
+        }
+    }
+    std::sort(r, r + nr, [](const Rg& a, const Rg& b) { return a.lo < b.lo; });
+    G.n = 0; G.total = 0;
+    int64_t at = 0;
+    for (int k = 0; k <= nr; k++) {
+        const int64_t lo = k < nr ? r[k].lo : n;
+        if (lo < at || (k < nr && r[k].hi > n)) return false;          // overlapping, or outside the buffer
+        if (lo > at) {
+            if (G.n >= 24) return false;
+            G.start[G.n] = at; G.len[G.n] = lo - at; G.total += lo - at; G.n++;
+        }
+        if (k < nr) at = r[k].hi;
+    }
+    if (G.n == 0) { G.start[0] = 0; G.len[0] = 0; G.n = 1; }
+    return true;
+}
 int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                     float eps, void* stream) {
     PendingStats& p = pending_stats();
     TailScatter sc = pending_scatter();
     pending_scatter().jobs = 0;
-    if ((!p.armed && sc.jobs == 0) || n <= 0) {
+    PendingReduce& pr = pending_reduce();
+    TailGaps G{};
+    G.total = -1;
+    bool red = false;
+    if (pr.on && n > 0 && theta && grad && m && v && reduce_gaps(pr.R, grad, n, G)) { red = true; pr.on = false; }
+    else { const int rc = reduce_unpark(stream); if (rc != SGCN_OK) return rc; G.total = -1; }
+    if ((!p.armed && sc.jobs == 0 && !red) || n <= 0) {
         const int rc = stats_flush(stream);
         if (rc != SGCN_OK) return rc;
         for (int j = 0; j < sc.jobs; j++) {
@@ -762,10 +818,13 @@ int adam_with_stats(float* theta, const float* grad, float* m, float* v, int64_t
     const bool st = p.armed != 0;
     p.armed = 0;
     SGCN_REQUIRE(theta && grad && m && v, "adam: null operand");
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
+    const int64_t walk = red ? G.total : n;
+    const unsigned blocks = (unsigned)std::min<int64_t>((walk + kBlock - 1) / kBlock, 2048);
     const unsigned extra = sc.jobs ? (unsigned)sc.first[sc.jobs] : 0u;
-    hipLaunchKernelGGL(adam_stats_kernel, dim3(blocks + 1 + extra), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m, v, n, lr_t,
-                       beta1, beta2, eps, st ? p.rowstat : nullptr, st ? p.n : 0, p.c, p.softmax, p.stats, (int32_t)blocks, sc);
+    const unsigned rblocks = red ? (unsigned)pr.blocks : 0u;
+    hipLaunchKernelGGL(adam_stats_kernel, dim3(rblocks + blocks + 1 + extra), dim3(kBlock), 0, (hipStream_t)stream,
+                       AdamArgs{theta, grad, m, v, n, lr_t, beta1, beta2, eps}, st ? p.rowstat : nullptr, st ? p.n : 0, p.c, p.softmax,
+                       p.stats, (int32_t)blocks, sc, red ? pr.R : ReduceMulti{}, (int32_t)rblocks, G);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }
@@ -872,8 +931,8 @@ extern "C" int sgcn_adam_f32(float* theta, const float* grad, float* m, float* v
     if (n == 0) return SGCN_OK;
     SGCN_REQUIRE(theta && grad && m && v, "adam: null operand");
     const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, theta, grad, m,
-                       v, n, lr_t, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                       AdamArgs{theta, grad, m, v, n, lr_t, beta1, beta2, eps});
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }

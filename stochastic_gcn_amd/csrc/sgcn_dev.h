@@ -131,9 +131,21 @@ __device__ __forceinline__ float drop_factor(const DropArgs& a, int row, int col
 // column walking all partials took 13-19 us once ln_act_bwd_kernel ran one row per wavefront.)  Shared by
 // the standalone reduce and the dense-layer backward's combined reduce (sgcn_gemm.hip).
 constexpr int kLnRedCols = 32;
+
+// One element of tf.train.AdamOptimizer's update (the ONE copy of this arithmetic: the stand-alone kernel, the optimizer
+// launch of the step program and the reductions that feed it all go through here, so that they agree bit for bit).
+struct AdamArgs { float* theta; const float* grad; float* m; float* v; int64_t n; float lr_t, b1, b2, eps; };
+__device__ __forceinline__ void adam_one(const AdamArgs& A, int64_t i, float g) {
+    const float mi = A.b1 * A.m[i] + (1.f - A.b1) * g;
+    const float vi = A.b2 * A.v[i] + (1.f - A.b2) * g * g;
+    A.m[i] = mi; A.v[i] = vi;
+    A.theta[i] -= A.lr_t * mi / (sqrtf(vi) + A.eps);
+}
+
+// `adam` != nullptr: the gradient element just reduced is consumed by the optimizer on the spot (it lives in A->grad)
 __device__ __forceinline__ void ln_param_reduce_cols32(const float* __restrict__ partial, int nblk, int d,
                                                        float* __restrict__ doffset, float* __restrict__ dscale,
-                                                       int cblock, bool accumulate = true) {
+                                                       int cblock, bool accumulate = true, const AdamArgs* adam = nullptr) {
     __shared__ float red[8][kLnRedCols];
     const int lane = threadIdx.x & (kLnRedCols - 1), part = threadIdx.x >> 5;      // 256 threads: 8 x 32
     const int c = cblock * kLnRedCols + lane;
@@ -154,8 +166,48 @@ __device__ __forceinline__ void ln_param_reduce_cols32(const float* __restrict__
         float s = red[0][lane];
 #pragma unroll
         for (int q = 1; q < 8; q++) s += red[q][lane];
-        if (c < d) doffset[c] = accumulate ? doffset[c] + s : s;
-        else dscale[c - d] = accumulate ? dscale[c - d] + s : s;
+        float* p = c < d ? doffset + c : dscale + (c - d);
+        const float g = accumulate ? *p + s : s;
+        *p = g;
+        if (adam) adam_one(*adam, p - adam->grad, g);
+    }
+}
+
+// The reductions behind the step's grouped weight-gradient launch (sgcn_gemm.hip): workgroups [gfirst[j], gfirst[j + 1]) add
+// job j's split-K partial tiles, workgroups [lfirst[j], lfirst[j + 1]) its LayerNorm parameter partials.
+constexpr int kMaxGroup = 6;
+struct ReduceJob {                // a split-K reduction the caller wants to launch itself
+    const float* ws; int32_t S, M, N; float* C; int64_t ldc; int32_t accumulate; int32_t pending;
+};
+struct ReduceMulti {
+    ReduceJob j[kMaxGroup];
+    const float* ln_partial[kMaxGroup];
+    float* doffset[kMaxGroup];
+    float* dscale[kMaxGroup];
+    int32_t nblk[kMaxGroup], d[kMaxGroup];
+    int32_t gfirst[kMaxGroup + 1], lfirst[kMaxGroup + 1];
+    int32_t n, ln_accumulate;
+};
+__device__ __forceinline__ void reduce_multi_body(const ReduceMulti& R, int b, const AdamArgs* adam) {
+    if (b < R.gfirst[R.n]) {
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < kMaxGroup; t++) q += (t < R.n && b >= R.gfirst[t]) ? 1 : 0;
+        const ReduceJob& j = R.j[q];
+        const int64_t i = (int64_t)(b - R.gfirst[q]) * blockDim.x + threadIdx.x;
+        const int64_t mn = (int64_t)j.M * j.N;
+        if (i >= mn) return;
+        float s = 0.f;
+        for (int z = 0; z < j.S; z++) s += j.ws[(int64_t)z * mn + i];
+        float* p = j.C + (i / j.N) * j.ldc + (i % j.N);
+        const float g = j.accumulate ? *p + s : s;
+        *p = g;
+        if (adam) adam_one(*adam, p - adam->grad, g);
+    } else {
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < kMaxGroup; t++) q += (t < R.n && b >= R.lfirst[t]) ? 1 : 0;
+        ln_param_reduce_cols32(R.ln_partial[q], R.nblk[q], R.d[q], R.doffset[q], R.dscale[q], b - R.lfirst[q], R.ln_accumulate != 0, adam);
     }
 }
 

@@ -270,7 +270,6 @@ __global__ __launch_bounds__(kBlock * KG) void gemm_kernel(GemmArgs g) {
 // Several independent plain GEMMs (epi == 0) of the same operand layout in ONE launch: workgroups [first[j], first[j + 1])
 // run job j exactly as its own launch would (same tiles, same K slices, same order of additions) -- the weight-gradient
 // GEMMs of a training step, which depend on nothing but their layer's g and are needed only by the optimizer.
-constexpr int kMaxGroup = 6;
 struct GemmGroup {
     GemmArgs g[kMaxGroup];
     int32_t first[kMaxGroup + 1];
@@ -301,10 +300,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int32_t S, in
     *p = accumulate ? *p + s : s;
 }
 
-struct ReduceJob {                // a split-K reduction the caller wants to launch itself
-    const float* ws; int32_t S, M, N; float* C; int64_t ldc; int32_t accumulate; int32_t pending;
-};
-
 // The two small reductions of a dense layer's backward in ONE launch: the split-K partial tiles of
 // dW (workgroups [0, gemm_blocks)) and the LayerNorm parameter-gradient partials (the rest).
 __global__ void dense_bwd_reduce_kernel(ReduceJob j, int32_t gemm_blocks, const float* __restrict__ ln_partial,
@@ -325,38 +320,9 @@ __global__ void dense_bwd_reduce_kernel(ReduceJob j, int32_t gemm_blocks, const 
 
 // The reductions of SEVERAL dense layers' backward in one launch (the step program's deferred weight-gradient group):
 // workgroups [gfirst[j], gfirst[j + 1]) add job j's split-K partial tiles, workgroups [lfirst[j], lfirst[j + 1]) its
-// LayerNorm parameter partials -- each exactly as that layer's own dense_bwd_reduce_kernel launch would.
-struct ReduceMulti {
-    ReduceJob j[kMaxGroup];
-    const float* ln_partial[kMaxGroup];
-    float* doffset[kMaxGroup];
-    float* dscale[kMaxGroup];
-    int32_t nblk[kMaxGroup], d[kMaxGroup];
-    int32_t gfirst[kMaxGroup + 1], lfirst[kMaxGroup + 1];
-    int32_t n, ln_accumulate;
-};
-
-__global__ void dense_bwd_reduce_multi_kernel(ReduceMulti R) {
-    const int b = (int)blockIdx.x;
-    if (b < R.gfirst[R.n]) {
-        int q = 0;
-#pragma unroll
-        for (int t = 1; t < kMaxGroup; t++) q += (t < R.n && b >= R.gfirst[t]) ? 1 : 0;
-        const ReduceJob& j = R.j[q];
-        const int64_t i = (int64_t)(b - R.gfirst[q]) * blockDim.x + threadIdx.x;
-        const int64_t mn = (int64_t)j.M * j.N;
-        if (i >= mn) return;
-        float s = 0.f;
-        for (int z = 0; z < j.S; z++) s += j.ws[(int64_t)z * mn + i];
-        float* p = j.C + (i / j.N) * j.ldc + (i % j.N);
-        *p = j.accumulate ? *p + s : s;
-    } else {
-        int q = 0;
-#pragma unroll
-        for (int t = 1; t < kMaxGroup; t++) q += (t < R.n && b >= R.lfirst[t]) ? 1 : 0;
-        ln_param_reduce_cols32(R.ln_partial[q], R.nblk[q], R.d[q], R.doffset[q], R.dscale[q], b - R.lfirst[q], R.ln_accumulate != 0);
-    }
-}
+// LayerNorm parameter partials -- each exactly as that layer's own dense_bwd_reduce_kernel launch would (sgcn_dev.h
+// reduce_multi_body; the optimizer's launch runs the same body with the update applied on the spot, sgcn_dense.hip).
+__global__ void dense_bwd_reduce_multi_kernel(ReduceMulti R) { reduce_multi_body(R, (int)blockIdx.x, nullptr); }
 
 // Split-K with the dense layer's epilogue: Y = act(LN(sum_z ws[z]) * scale + offset), one wavefront
 // per output row (the forward GEMM of the first layer is 2,042 x 128 x 1,204: 64 tiles whose
@@ -869,7 +835,8 @@ void dw_group_abort() {
     g_dw_recorded = 0;
 }
 
-int dw_group_flush(void* stream) {
+bool reduce_park(const ReduceMulti& R, int blocks);       // sgcn_dense.hip: the reductions ride in the optimizer's launch
+int dw_group_flush(void* stream, bool park_reduce) {
     DwGroupState& d = dw_state();
     d.active = false;
     const int n = d.n;
@@ -914,7 +881,8 @@ int dw_group_flush(void* stream) {
         if (d.jobs[k].nblk > 0) b += (2 * d.jobs[k].N + kLnRedCols - 1) / kLnRedCols;
     }
     for (int k = n; k <= kMaxGroup; k++) R.lfirst[k] = b;
-    if (b > 0) hipLaunchKernelGGL(dense_bwd_reduce_multi_kernel, dim3((unsigned)b), dim3(256), 0, st, R);
+    if (b > 0 && !(park_reduce && reduce_park(R, b)))
+        hipLaunchKernelGGL(dense_bwd_reduce_multi_kernel, dim3((unsigned)b), dim3(256), 0, st, R);
     SGCN_HIP_TRY(hipGetLastError());
     return SGCN_OK;
 }

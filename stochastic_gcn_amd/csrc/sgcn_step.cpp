@@ -30,7 +30,8 @@ int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64
 int aux_join(void* stream);
 int aux_fork(void* stream, void** aux_stream);
 int dw_group_begin();                    // sgcn_gemm.hip: record the weight-gradient GEMMs of the following DENSE_BWD ops ...
-int dw_group_flush(void* stream);        // ... and issue them as one grouped launch + one reduction launch
+int dw_group_flush(void* stream, bool park_reduce);   // ... and issue them as one grouped launch + one reduction launch
+int reduce_flush(void* stream);          // sgcn_dense.hip: reductions parked for an optimizer launch that did not come
 void dw_group_abort();
 void grad_store_mode(int on);            // sgcn_gemm.hip: parameter gradients are stored, not added to a zeroed buffer
 void stats_defer(int on);                // sgcn_dense.hip: the loss kernel's statistics reduction rides in the optimizer's launch
@@ -156,7 +157,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
     sgcn::stats_defer(park_stats ? 1 : 0);
     struct Guard {                       // an early return leaves no recorded job / mode behind
         bool on; void* st;
-        ~Guard() { if (on) sgcn::dw_group_abort(); sgcn::grad_store_mode(0); sgcn::stats_defer(0); sgcn::stats_flush(st); }
+        ~Guard() { if (on) sgcn::dw_group_abort(); sgcn::grad_store_mode(0); sgcn::stats_defer(0); sgcn::reduce_flush(st); sgcn::stats_flush(st); }
     } guard{grouped, stream};
     auto eval_args = [&](const sgcn_step_op_t& o, Args& a) {
         a.n = o.nargs; a.pos = 0;
@@ -280,7 +281,8 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             break;
         }
         case SGCN_OP_DW_FLUSH:
-            rc = sgcn::dw_group_flush(stream);
+            // the optimizer right behind the weight gradients: their reductions ride in its launch (fuse bit 5)
+            rc = sgcn::dw_group_flush(stream, (fuse & 32) && k + 1 < nops && ops[k + 1].op == SGCN_OP_ADAM);
             break;
         case SGCN_OP_GRAD_STORE:         // (mode of the whole run: set before the loop)
             break;
