@@ -167,12 +167,13 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  *   step_overlap (library default 1; the step program sets it from its flags, 0 unless --agg_overlap or a non-lean mode):
  *   in sgcn_step_run the AUX_* / VR_AGG_PRE ops (and, without --group_dw / --lean_sync, weight-gradient GEMMs and loss
  *   statistics) go to an auxiliary stream
- *   step_fuse (default 63): small dense products folded into the row pass next to them -- bit 0 the output layer's forward
+ *   step_fuse (default 127): small dense products folded into the row pass next to them -- bit 0 the output layer's forward
  *   product into the loss kernel (the op in front of the loss), bit 1 its input gradient (the op behind it), bit 2 a narrow
  *   dense layer into the split-K reduce pass of the layer in front of it (all three in sgcn_step_run), bit 3 a dense layer's
  *   input gradient into its LayerNorm / ReLU backward pass (sgcn_dense_bwd_f32), bit 4 (with bit 0) the dense layer in front
  *   of the output layer as the pre-layer of the loss kernel's head, bit 5 the grouped weight-gradient launch's reductions in
- *   the optimizer's launch (when ADAM directly follows DW_FLUSH); 0: one launch per piece, the same bits
+ *   the optimizer's launch (when ADAM directly follows DW_FLUSH), bit 6 (with bit 3) the LayerNorm backward pass of a layer
+ *   without an input gradient behind the row pass of the layer above it; 0: one launch per piece, the same bits
  *   gemm_min_steps: K-steps a split-K slice keeps at least (default 3) */
 int sgcn_tune(const char* key, int64_t value);
 int64_t sgcn_tune_get(const char* key);   /* current value, -1 for an unknown key */

@@ -65,14 +65,36 @@ __global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
 // MFMA launch it replaces (32-wide K-steps alternating between its K-groups, the groups' sums added in group order): the
 // same bits, one launch and one round trip of g through memory fewer (9.7 us of the step's chain, twice per step).
 struct LnBwdDx { const float* W; int32_t K, kg; DropArgs drop; float* dxo; int64_t lddxo; };
+// ... and, behind that tail, the LayerNorm / ReLU backward of the layer BELOW (its dy is the dx just produced, K <= 128 wide):
+// g = LN-backward(dx masked by y > 0) written to `g`, per-workgroup parameter partials to `partial` -- the row pass of the
+// next ln_act_bwd_kernel launch, without the launch.  y == nullptr: off.
+struct LnBwdNext { const float* y; int64_t ldy; const float* xhat; const float* rstd; const float* scale; int32_t norm, relu;
+                   float* g; float* partial; };
+
+// The LayerNorm backward's arithmetic, ONE expression tree for its two users (a layer's own row pass and the pass chained
+// behind the layer above): contraction is off and the fused multiply-adds are spelled out, so that the compiler cannot
+// fuse the two sites differently (it did: reusing g * scale in one and fusing it into the subtraction in the other --
+// one ulp, which the bit-identity of the chained and the unchained step would not survive).
+__device__ __forceinline__ void ln_bwd_stats(float g, float h, float sc, float& doff, float& dsc, float& s1, float& s2) {
+#pragma clang fp contract(off)
+    doff += g;                        // d(offset) column sum
+    dsc = fmaf(g, h, dsc);            // d(scale)
+    const float t2 = g * sc;
+    s1 += t2;
+    s2 = fmaf(t2, h, s2);
+}
+__device__ __forceinline__ float ln_bwd_out(float g, float h, float sc, float m1, float m2, float r) {
+#pragma clang fp contract(off)
+    return r * fmaf(-h, m2, fmaf(g, sc, -m1));
+}
 
 constexpr int kBwdRowsPerWave = 1;     // one row per wave: 4x the workgroups, a quarter of the dependent chain (the step is GPU-latency-bound)
 __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
     const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ scale,
     int32_t n, int32_t d, int32_t norm, int32_t relu, float* __restrict__ dx, int64_t lddx,
-    float* __restrict__ partial /* [gridDim.x][2][d] */, LnBwdDx t) {
-    extern __shared__ float lds[];      // [4 waves][2][d] (LayerNorm), then the tail's weights [d][K + 1]
+    float* __restrict__ partial /* [gridDim.x][2][d] */, LnBwdDx t, LnBwdNext nx) {
+    extern __shared__ float lds[];      // [4 waves][2][d] (LayerNorm), the tail's weights [d][K + 1], [4 waves][2][K] (the layer below)
     const int lane = threadIdx.x & 63, wave = threadIdx.x / kWave;
     const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kBwdRowsPerWave;
     float* my = lds + (size_t)wave * 2 * d;
@@ -122,17 +144,12 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
         float s1 = 0.f, s2 = 0.f;
         for (int c = lane; c < d; c += kWave) {
             const float g = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
-            const float h = hr[c];
-            my[c] += g;               // d(offset) column sum (lane-private columns: no race)
-            my[d + c] += g * h;       // d(scale)
-            const float t2 = g * scale[c];
-            s1 += t2;
-            s2 += t2 * h;
+            ln_bwd_stats(g, hr[c], scale[c], my[c], my[d + c], s1, s2);      // lane-private columns: no race
         }
         const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d, r = rstd[row];
         for (int c = lane; c < d; c += kWave) {
             const float g = (relu && !(yr[c] > 0.f)) ? 0.f : gr[c];
-            const float o = r * (g * scale[c] - m1 - hr[c] * m2);
+            const float o = ln_bwd_out(g, hr[c], scale[c], m1, m2, r);
             dr[c] = o;
             if (c < 2 * kWave) gk[c / kWave] = o;
         }
@@ -144,7 +161,12 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
         for (int c = threadIdx.x; c < 2 * d; c += kBlock)
             out[c] = (lds[c] + lds[2 * d + c]) + (lds[4 * d + c] + lds[6 * d + c]);
     }
-    if (!t.W || !have) return;
+    if (!t.W || (!have && !nx.y)) return;
+    const int d2 = t.K;                                  // (nx) the layer below is d2 wide
+    float* my2 = lds + (norm ? (size_t)8 * d : 0) + (size_t)d * kp + (size_t)wave * 2 * d2;
+    if (nx.y && nx.norm) for (int c = lane; c < 2 * d2; c += kWave) my2[c] = 0.f;
+    float dyl[2] = {0.f, 0.f};
+    if (have) {
     // ---- the tail: four output columns per lane
     float acc[4][2];
 #pragma unroll
@@ -193,8 +215,47 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
             float v = t.kg > 1 ? acc[e][0] + acc[e][1] : acc[e][0];
             if (t.drop.on) v *= drop_factor(t.drop, (int)myrow, j);
             t.dxo[myrow * t.lddxo + j] = v;
+            if (e < 2) dyl[e] = v;
         }
     }
+    }
+    if (!nx.y) return;
+    // ---- the layer below: ln_act_bwd_kernel's row pass on dy = dyl (two columns per lane, in its order of additions)
+    if (have) {
+        const float* yr = nx.y + myrow * nx.ldy;
+        float* gr = nx.g + myrow * (int64_t)d2;
+        if (!nx.norm) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = lane + e * kWave;
+                if (c < d2) gr[c] = (nx.relu && !(yr[c] > 0.f)) ? 0.f : dyl[e];
+            }
+        } else {
+            const float* hr = nx.xhat + myrow * (int64_t)d2;
+            float s1 = 0.f, s2 = 0.f, gg[2] = {0.f, 0.f}, hh[2] = {0.f, 0.f}, sc[2] = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = lane + e * kWave;
+                if (c < d2) {
+                    gg[e] = (nx.relu && !(yr[c] > 0.f)) ? 0.f : dyl[e];
+                    hh[e] = hr[c]; sc[e] = nx.scale[c];
+                    ln_bwd_stats(gg[e], hh[e], sc[e], my2[c], my2[d2 + c], s1, s2);
+                }
+            }
+            const float m1 = wave_sum(s1) / (float)d2, m2 = wave_sum(s2) / (float)d2, r = nx.rstd[myrow];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = lane + e * kWave;
+                if (c < d2) gr[c] = ln_bwd_out(gg[e], hh[e], sc[e], m1, m2, r);
+            }
+        }
+    }
+    if (!nx.norm) return;
+    __syncthreads();
+    const float* l2 = lds + (norm ? (size_t)8 * d : 0) + (size_t)d * kp;
+    float* out2 = nx.partial + (size_t)blockIdx.x * 2 * d2;
+    for (int c = threadIdx.x; c < 2 * d2; c += kBlock)
+        out2[c] = (l2[c] + l2[2 * d2 + c]) + (l2[4 * d2 + c] + l2[6 * d2 + c]);
 }
 
 // doffset[c] += sum_b partial[b][0][c]; dscale[c] += sum_b partial[b][1][c]   (fixed order)
@@ -666,7 +727,9 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
                             const float* rstd, const float* scale, int32_t n, int32_t d, int32_t relu,
                             float* dx, int64_t lddx, float* doffset, float* dscale, float* ws,
                             bool reduce_params, int32_t* nblk, hipStream_t st, const float* tail_W, int32_t tail_K,
-                            int32_t tail_kg, const sgcn_dropout_t* tail_drop, float* tail_dx, int64_t tail_lddx) {
+                            int32_t tail_kg, const sgcn_dropout_t* tail_drop, float* tail_dx, int64_t tail_lddx,
+                            const float* nx_y, int64_t nx_ldy, const float* nx_xhat, const float* nx_rstd, const float* nx_scale,
+                            int32_t nx_relu, float* nx_g, float* nx_partial) {
     SGCN_REQUIRE(n >= 0 && d >= 0, "ln_act_bwd: negative size");
     if (nblk) *nblk = 0;
     if (n == 0 || d == 0) return SGCN_OK;
@@ -675,6 +738,7 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
                  "ln_act_bwd: null operand");
     SGCN_REQUIRE(!norm || (size_t)d * 8 * sizeof(float) <= 64 * 1024, "ln_act_bwd: d too large for LDS");
     LnBwdDx t{};
+    LnBwdNext nx{};
     size_t lds = norm ? (size_t)d * 8 * sizeof(float) : 0;
     if (tail_W) {
         SGCN_REQUIRE(tail_dx && d <= 2 * kWave && d % 4 == 0 && aligned16(tail_W) && tail_K > 0 && tail_K <= 4 * kWave &&
@@ -682,6 +746,13 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
         t.W = tail_W; t.K = tail_K; t.kg = tail_kg; t.drop = drop_args(tail_drop); t.dxo = tail_dx; t.lddxo = tail_lddx;
         SGCN_REQUIRE(!t.drop.on || t.drop.width == tail_K, "ln_act_bwd: dropout width must be the layer's input width");
         lds += (size_t)d * (tail_K + 1) * sizeof(float);
+        if (nx_y) {
+            SGCN_REQUIRE(tail_K <= 2 * kWave && nx_g && nx_ldy >= tail_K && (!nx_scale || (nx_xhat && nx_rstd && nx_partial)),
+                         "ln_act_bwd: bad chained layer");
+            nx.y = nx_y; nx.ldy = nx_ldy; nx.xhat = nx_xhat; nx.rstd = nx_rstd; nx.scale = nx_scale; nx.norm = nx_scale ? 1 : 0;
+            nx.relu = nx_relu; nx.g = nx_g; nx.partial = nx_partial;
+            if (nx.norm) lds += (size_t)8 * tail_K * sizeof(float);
+        }
         SGCN_REQUIRE(lds <= 160 * 1024, "ln_act_bwd: weights too large for LDS");
         static size_t raised = 0;          // > 64 KB of dynamic LDS needs the attribute
         if (lds > 64 * 1024 && lds > raised) {
@@ -692,7 +763,7 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
     const int rows_per_block = 4 * kBwdRowsPerWave;
     const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(ln_act_bwd_kernel, dim3(blocks), dim3(kBlock), lds, st, dy, lddy, y, ldy, xhat, rstd, scale, n, d, norm,
-                       relu, dx, lddx, ws, t);
+                       relu, dx, lddx, ws, t, nx);
     if (nblk) *nblk = norm ? (int32_t)blocks : 0;
     if (norm && reduce_params)
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + kLnRedCols - 1) / kLnRedCols), dim3(256), 0, st, ws,

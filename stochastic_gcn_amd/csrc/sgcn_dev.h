@@ -217,6 +217,8 @@ int ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64_t ldy
                       const float* rstd, const float* scale, int32_t n, int32_t d, int32_t relu, float* dx,
                       int64_t lddx, float* doffset, float* dscale, float* ws, bool reduce_params, int32_t* nblk,
                       hipStream_t st, const float* tail_W = nullptr, int32_t tail_K = 0, int32_t tail_kg = 1,
-                      const sgcn_dropout_t* tail_drop = nullptr, float* tail_dx = nullptr, int64_t tail_lddx = 0);
+                      const sgcn_dropout_t* tail_drop = nullptr, float* tail_dx = nullptr, int64_t tail_lddx = 0,
+                      const float* nx_y = nullptr, int64_t nx_ldy = 0, const float* nx_xhat = nullptr, const float* nx_rstd = nullptr,
+                      const float* nx_scale = nullptr, int32_t nx_relu = 0, float* nx_g = nullptr, float* nx_partial = nullptr);
 
 }  // namespace sgcn

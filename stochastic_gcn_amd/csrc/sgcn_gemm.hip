@@ -927,7 +927,10 @@ static int bwd_scratch(const DenseBwdArgs& a, hipStream_t st, bool overlap, BwdS
 }
 
 // One dense layer's backward.
-static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* stream) {
+// `lower` / `slower`: the layer BELOW (its dy is this layer's dx), whose LayerNorm / ReLU backward pass rides behind this
+// layer's input-gradient tail when both fit the row pass (*lower_done = true: only its weight-gradient job is left to do)
+static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* stream, const DenseBwdArgs* lower = nullptr,
+                         const BwdScratch* slower = nullptr, bool* lower_done = nullptr, int32_t* lower_nblk = nullptr) {
     SGCN_REQUIRE(a.n >= 0 && a.N >= 0 && a.K >= 0, "dense_bwd: negative size");
     if (a.n == 0 || a.N == 0 || a.K == 0) return SGCN_OK;
     SGCN_REQUIRE(a.dy && a.x && a.W && a.dW, "dense_bwd: null operand");
@@ -937,7 +940,10 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
     int32_t nblk = 0;
     bool dx_in_row_pass = false;
     int dx_kg = 1;
-    if (a.scale || a.relu) {
+    if (lower_done && !lower && *lower_done) {            // this layer's row pass has run behind the layer above's: g is in g_tmp
+        nblk = lower_nblk ? *lower_nblk : 0;
+        g = a.g_tmp; ldg = a.N;
+    } else if (a.scale || a.relu) {
         SGCN_REQUIRE(a.g_tmp && a.y, "dense_bwd: LayerNorm / ReLU backward needs y and an n x N scratch");
         SGCN_REQUIRE(!a.scale || a.ws, "dense_bwd: LayerNorm backward needs the workspace");
         // the input gradient dx = g . W^T in the same row pass where the launch it replaces would have run as ONE chain per
@@ -951,10 +957,21 @@ static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* strea
             else gemm_fwd_shape(a.n, a.K, a.N, &S, &kgq, nullptr);
             if (S == 1 && kgq <= 2) dx_in_row_pass = true, dx_kg = kgq;
         }
+        const bool chain = dx_in_row_pass && lower && slower && lower_done && a.K <= 128 && lower->dy == a.dx && lower->lddy == a.lddx &&
+                           lower->n == a.n && lower->N == a.K && (lower->scale || lower->relu) && lower->g_tmp && lower->y &&
+                           (!lower->scale || (lower->xhat && lower->rstd && slower->ws_ln)) &&
+                           (size_t)(8 * a.N + a.N * (a.K + 1) + 8 * a.K) * sizeof(float) <= 160 * 1024;
         const int rc = ln_act_bwd_launch(a.dy, a.lddy, a.y, a.ldy, a.xhat, a.rstd, a.scale, a.n, a.N, a.relu, a.g_tmp, a.N,
                                          a.doffset, a.dscale, s.ws_ln, /*reduce_params=*/false, &nblk, st,
-                                         dx_in_row_pass ? a.W : nullptr, a.K, dx_kg, a.drop, a.dx, a.lddx);
+                                         dx_in_row_pass ? a.W : nullptr, a.K, dx_kg, a.drop, a.dx, a.lddx,
+                                         chain ? lower->y : nullptr, chain ? lower->ldy : 0, chain ? lower->xhat : nullptr,
+                                         chain ? lower->rstd : nullptr, chain ? lower->scale : nullptr, chain ? lower->relu : 0,
+                                         chain ? lower->g_tmp : nullptr, chain ? slower->ws_ln : nullptr);
         if (rc != SGCN_OK) return rc;
+        if (chain) {
+            *lower_done = true;
+            if (lower_nblk) *lower_nblk = (lower->scale && a.scale) ? nblk : (lower->scale ? (a.n + 3) / 4 : 0);
+        }
         g = a.g_tmp; ldg = a.N;
     }
     if (s.st_dw != st) {                  // fork: the aux stream sees everything the main stream did so far
@@ -1010,6 +1027,27 @@ static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int6
     const int rc = bwd_scratch(a, (hipStream_t)stream, overlap, s);
     if (rc != SGCN_OK) return rc;
     return dense_bwd_run(a, s, stream);
+}
+
+// Two consecutive layers' backward (upper, then the layer below it) with the lower one's LayerNorm / ReLU backward pass
+// behind the upper one's row pass when the shapes allow it (knob step_fuse bit 6); otherwise exactly the two calls.
+int dense_bwd_chain(const DenseBwdArgs& up, const DenseBwdArgs& lo, void* stream) {
+    const bool overlap = tune_get("step_overlap") != 0;
+    if (up.n == 0 || up.N == 0 || up.K == 0 || lo.n == 0 || lo.N == 0 || lo.K == 0)
+        return SGCN_OK;                       // (degenerate: nothing to do for either -- the caller checked sizes are >= 0)
+    BwdScratch su{}, sl{};
+    int rc = bwd_scratch(up, (hipStream_t)stream, overlap, su);
+    if (rc != SGCN_OK) return rc;
+    rc = bwd_scratch(lo, (hipStream_t)stream, overlap, sl);
+    if (rc != SGCN_OK) return rc;
+    bool lower_done = false;
+    int32_t lower_nblk = 0;
+    // (both layers' scratch must be their own regions of the ring: the shared per-call buffer of the undeferred form would
+    // hold two layers' LayerNorm partials at once)
+    const bool try_chain = (tune_get("step_fuse") & 64) && !lo.dx && su.deferred && sl.deferred;
+    rc = dense_bwd_run(up, su, stream, try_chain ? &lo : nullptr, try_chain ? &sl : nullptr, &lower_done, &lower_nblk);
+    if (rc != SGCN_OK) return rc;
+    return dense_bwd_run(lo, sl, stream, nullptr, nullptr, &lower_done, &lower_nblk);
 }
 
 int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64_t lddy, const float* y, int64_t ldy,

@@ -36,11 +36,11 @@ int g_tune_cs_pace = 0;
 int g_tune_cs_slack = 0;
 int g_tune_cs_noextra = 0;
 int g_tune_step_overlap = 1;
-int g_tune_step_fuse = 63;           // bit 0: the output layer's forward as the loss kernel's head, bit 1: its input gradient as the
+int g_tune_step_fuse = 127;           // bit 0: the output layer's forward as the loss kernel's head, bit 1: its input gradient as the
                                      // tail, bit 2: the dense layer behind a split-K layer in that layer's reduce pass, bit 3: a layer's
                                      // input gradient in its LayerNorm / ReLU backward pass, bit 4: the dense layer in front of the output
                                      // layer as the pre-layer of the loss kernel's head, bit 5: the weight gradients' reductions in the
-                                     // optimizer's launch
+                                     // optimizer's launch, bit 6: the first layer's LayerNorm backward behind the second layer's row pass
 int g_tune_cs_g2_wide = 0;
 int g_tune_cs_last_pct = 90;
 int g_tune_gemm_min_steps = 0;
@@ -285,7 +285,7 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "cs_slack")) { SGCN_REQUIRE(value >= 0, "cs_slack >= 0"); g_tune_cs_slack = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_noextra")) { g_tune_cs_noextra = value != 0; return SGCN_OK; }
     if (!strcmp(key, "step_overlap")) { g_tune_step_overlap = value != 0; return SGCN_OK; }
-    if (!strcmp(key, "step_fuse")) { SGCN_REQUIRE(value >= 0 && value <= 63, "step_fuse in 0..63"); g_tune_step_fuse = (int)value; return SGCN_OK; }
+    if (!strcmp(key, "step_fuse")) { SGCN_REQUIRE(value >= 0 && value <= 127, "step_fuse in 0..127"); g_tune_step_fuse = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
     if (!strcmp(key, "gemm_min_steps")) { g_tune_gemm_min_steps = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_last_pct")) { SGCN_REQUIRE(value >= 0 && value <= 100, "cs_last_pct in [0, 100]"); g_tune_cs_last_pct = (int)value; return SGCN_OK; }

@@ -28,6 +28,7 @@ int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64
                          float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop, float* g_tmp, float* ws,
                          const int32_t* gidx, void* stream);
 int aux_join(void* stream);
+int dense_bwd_chain(const DenseBwdArgs& up, const DenseBwdArgs& lo, void* stream);   // sgcn_gemm.hip
 int aux_fork(void* stream, void** aux_stream);
 int dw_group_begin();                    // sgcn_gemm.hip: record the weight-gradient GEMMs of the following DENSE_BWD ops ...
 int dw_group_flush(void* stream, bool park_reduce);   // ... and issue them as one grouped launch + one reduction launch
@@ -275,6 +276,25 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             const int64_t need = (norm ? (sgcn_ln_act_bwd_ws_floats(w.n, w.N) + 3) / 4 * 4 : 0) +
                                  std::max(sgcn_gemm_ws_floats(w.K, w.N, w.n), sgcn_gemm_ws_floats(w.n, w.K, w.N));
             if (need > w.ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: backward scratch %lld > %lld floats", (long long)need, (long long)w.ws_cap);
+            // The layer below follows at once and consumes nothing but this layer's dx (it is the first layer: no dx of its
+            // own): its LayerNorm / ReLU backward pass rides behind this layer's row pass (sgcn_gemm.hip dense_bwd_chain)
+            Args b;
+            if ((fuse & 64) && w.dx && k != dx_done_at && peek(k + 1, b) && ops[k + 1].op == SGCN_OP_DENSE_BWD) {
+                DenseBwdOp q;
+                q.read(b);
+                const bool qnorm = q.xhat != nullptr;
+                const int64_t need2 = (qnorm ? (sgcn_ln_act_bwd_ws_floats(q.n, q.N) + 3) / 4 * 4 : 0) +
+                                      std::max(sgcn_gemm_ws_floats(q.K, q.N, q.n), sgcn_gemm_ws_floats(q.n, q.K, q.N));
+                if (q.dy == w.dx && q.lddy == w.lddx && q.n == w.n && q.N == w.K && !q.dx && need2 <= q.ws_cap) {
+                    const sgcn::DenseBwdArgs up{w.n, w.N, w.K, w.dy, w.lddy, w.y, w.ldy, w.xhat, w.rstd, w.sc, w.relu, w.x, w.ldx, w.W, w.ldw,
+                                                w.dW, w.lddw, w.doff, w.dsc, w.dx, w.lddx, w.drop(), w.gtmp, need ? w.ws : nullptr, w.gidx};
+                    const sgcn::DenseBwdArgs lo{q.n, q.N, q.K, q.dy, q.lddy, q.y, q.ldy, q.xhat, q.rstd, q.sc, q.relu, q.x, q.ldx, q.W, q.ldw,
+                                                q.dW, q.lddw, q.doff, q.dsc, nullptr, q.lddx, q.drop(), q.gtmp, need2 ? q.ws : nullptr, q.gidx};
+                    rc = sgcn::dense_bwd_chain(up, lo, stream);
+                    skip_until = k + 2;
+                    break;
+                }
+            }
             rc = sgcn::dense_bwd_overlapped(w.n, w.N, w.K, w.dy, w.lddy, w.y, w.ldy, w.xhat, w.rstd, w.sc, w.relu, w.x, w.ldx, w.W, w.ldw,
                                             w.dW, w.lddw, w.doff, w.dsc, k == dx_done_at ? nullptr : w.dx, w.lddx, w.drop(), w.gtmp,
                                             need ? w.ws : nullptr, w.gidx, stream);

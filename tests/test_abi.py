@@ -28,7 +28,7 @@ def test_status_codes_and_error_message_without_gpu():
     rc = _ffi.lib.sgcn_tune(b"no_such_knob", 1)
     assert rc == -1
     assert b"unknown key" in _ffi.lib.sgcn_last_error()
-    assert _ffi.lib.sgcn_tune_get(b"step_fuse") == 63 and _ffi.lib.sgcn_tune(b"step_fuse", 64) == -1
+    assert _ffi.lib.sgcn_tune_get(b"step_fuse") == 127 and _ffi.lib.sgcn_tune(b"step_fuse", 128) == -1
     # argument validation happens before any HIP call, so it is testable on CPU
     rc = _ffi.lib.sgcn_spmm_csr_f32(None, None, None, 4, 4, 8, None, 8, None, None, None, None, 8,
                                     0.0, None, None)

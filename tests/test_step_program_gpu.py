@@ -186,13 +186,13 @@ def test_dense_scratch_is_sized_for_the_row_capacity():
                 assert lib.sgcn_gemm_ws_floats(M, N, K) <= GEMM_WS_BOUND and lib.sgcn_gemm_ws_floats(K, N, M) <= GEMM_WS_BOUND
 
 
-@pytest.mark.parametrize("fuse", [0, 1, 2, 3, 4, 8, 15, 17, 31, 32, 63])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3, 4, 8, 15, 17, 31, 32, 63, 72, 127])
 def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
     """sgcn_step_run folds the output layer into the loss kernel's row pass (its forward product as the head, its input
     gradient as the tail; a narrow dense layer in the reduce pass of the split-K layer in front of it; a layer's input
     gradient in its LayerNorm backward pass; the dense layer in front of the output layer as the pre-layer of the loss kernel's
-    head; the weight gradients' reductions in the optimizer's launch: knob step_fuse, default 63 -- what every other test of
-    this file runs); with the fusion partly or
+    head; the weight gradients' reductions in the optimizer's launch; the first layer's LayerNorm backward behind the second
+    layer's row pass: knob step_fuse, default 127 -- what every other test of this file runs); with the fusion partly or
     wholly off the same program issues the separate launches, and every variant gives the eager path's bits."""
     from stochastic_gcn_amd import _ffi
     # (the mid-size Reddit recipe: its first layer, 192 inputs on ~1,000 rows, is cut over K like the full-size one -- the
@@ -203,12 +203,12 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
     try:
         a, la = _run(case, False, 4, False)
     finally:
-        _ffi.tune('step_fuse', 63)
+        _ffi.tune('step_fuse', 127)
     _ffi.tune('step_fuse', fuse)
     try:
         b, lb = _run(case, True, 4, False)
     finally:
-        _ffi.tune('step_fuse', 63)
+        _ffi.tune('step_fuse', 127)
     assert all(p is not None for p in b._programs.values())
     assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m)
     for ha, hb in zip(a.history, b.history):
@@ -217,7 +217,7 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
         assert torch.equal(l1, l2) and torch.equal(a1, a2)
 
 
-@pytest.mark.parametrize("fuse", [0, 63])
+@pytest.mark.parametrize("fuse", [0, 127])
 def test_multitask_model_sigmoid_loss_program_equals_eager_and_oracle(fuse):
     """The ppi form (gcn/models.py:77-79,86-90: multi-hot labels, sigmoid cross-entropy over all n x c elements): the loss
     kernel's other flavour, with the layers around it folded into its row pass or not -- bit-identical to the eager path,
@@ -231,12 +231,12 @@ def test_multitask_model_sigmoid_loss_program_equals_eager_and_oracle(fuse):
     try:
         a, la = _run(case, False, 3, False, multitask=True)
     finally:
-        _ffi.tune('step_fuse', 63)
+        _ffi.tune('step_fuse', 127)
     _ffi.tune('step_fuse', fuse)
     try:
         b, lb = _run(case, True, 3, False, multitask=True)
     finally:
-        _ffi.tune('step_fuse', 63)
+        _ffi.tune('step_fuse', 127)
     assert all(p is not None for p in b._programs.values())
     assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m)
     for (l1, a1), (l2, a2) in zip(la, lb):
