@@ -217,6 +217,55 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
         assert torch.equal(l1, l2) and torch.equal(a1, a2)
 
 
+SHAPES = {   # changes to the mid-size Reddit recipe (hidden1 64, f 96 -> 192 inputs, 41 classes, two pre-processing layers)
+    'hidden128': dict(hidden1=128),                     # the widest layer the row passes fold
+    'hidden256': dict(hidden1=256),                     # ... and one they must leave to the MFMA launches
+    'hidden100': dict(hidden1=100),                     # 100 % 32 != 0: a partial K-step in every folded product
+    'hidden30': dict(hidden1=30),                       # 30 % 4 != 0: no vector staging of the weights
+    'one_fc': dict(num_fc_layers=1),                    # nothing to chain behind the upper layer's backward pass
+    'three_fc': dict(num_fc_layers=3),                  # three parameter layers above one another
+    'no_layer_norm': dict(layer_norm=False),            # ReLU only: no parameter partials, no split-K reduce pass to ride in
+    'no_dropout': dict(dropout=0.0),
+    'two_classes': dict(classes=2),
+    'classes64': dict(classes=64),                      # the widest output layer the loss kernel takes as its head
+    'classes70': dict(classes=70),                      # ... and one it does not
+    'features50': dict(f=50),                           # 100 inputs: the first layer is not cut over K
+    'batch7': dict(batch=7),                            # fewer rows than one workgroup's waves in the last layers
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_folded_products_on_other_shapes(shape):
+    """Every folding decision of sgcn_step_run is a guard on widths (hidden size <= 128, classes <= 64, multiples of 4 for
+    the vector staging, a layer cut over K or not, LayerNorm or not): the recipe on shapes on both sides of each guard, the
+    step program with everything folded against the eager path with nothing folded -- the same bits."""
+    from stochastic_gcn_amd import _ffi
+    import copy
+    cfg = copy.deepcopy(mc.REDDIT_MID)
+    cfg.update(n=6000)
+    for k, v in SHAPES[shape].items():
+        if k in cfg:
+            cfg[k] = v
+        else:
+            cfg['flags'][k] = v
+    case = mc.build_case(cfg)
+    _ffi.tune('step_fuse', 0)
+    try:
+        a, la = _run(case, False, 4, False)
+    finally:
+        _ffi.tune('step_fuse', 127)
+    b, lb = _run(case, True, 4, False)
+    if shape == 'hidden256':     # wider than the LayerNorm epilogue's 128 columns: no program, the per-layer path (whose
+        assert 'wide' in b._program_note and not any(b._programs.values())     # backward pass still folds what fits)
+    else:
+        assert all(p is not None for p in b._programs.values())
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    for ha, hb in zip(a.history, b.history):
+        assert torch.equal(ha[0], hb[0])
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
+
+
 @pytest.mark.parametrize("fuse", [0, 127])
 def test_multitask_model_sigmoid_loss_program_equals_eager_and_oracle(fuse):
     """The ppi form (gcn/models.py:77-79,86-90: multi-hot labels, sigmoid cross-entropy over all n x c elements): the loss
