@@ -48,7 +48,7 @@ def summarize(src, steps):
         print("%-92s %8d %10.2f %12.1f %10.2f %6.2f" % (r[0][:92], r[1], r[1] / steps, r[2] / 1e3, r[3], r[4]))
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("--gaps", "--timeline")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("--gaps", "--timeline", "--stepgaps")):
     if len(sys.argv) > 1 and sys.argv[1] == "--summarize":
         summarize(sys.argv[2], int(sys.argv[3]))
     else:
@@ -122,3 +122,29 @@ def timeline(src, n=70):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--timeline":
     timeline(sys.argv[2])
+
+
+def stepgaps(src):
+    """Where in the step the queue idles: over the steady-state training steps with the usual kernel count, the median idle
+    time in FRONT of each kernel of the step and the kernel's median duration."""
+    import numpy as np
+    f = glob.glob(os.path.join(src, "**", "*results.db"), recursive=True)
+    t = sqlite3.connect(f[0])
+    rows = list(t.execute("select name, start, end from kernels order by start"))
+    adam = [i for i, r in enumerate(rows) if "adam_" in r[0]]
+    adam = adam[len(adam) // 3:]
+    lens = np.diff(adam)
+    usual = int(np.bincount(lens).argmax())
+    steps = [a for a, n in zip(adam[:-1], lens) if n == usual]
+    gap = np.array([[rows[a + j + 1][1] - rows[a + j][2] for j in range(usual)] for a in steps]) / 1e3
+    dur = np.array([[rows[a + j + 1][2] - rows[a + j + 1][1] for j in range(usual)] for a in steps]) / 1e3
+    print("%d steady-state steps of %d kernels: idle in front of each kernel / its duration (median us; p90 of the idle)"
+          % (len(steps), usual))
+    for j in range(usual):
+        print("  idle %6.2f (p90 %6.2f)  run %6.2f  %s" % (np.median(gap[:, j]), np.percentile(gap[:, j], 90),
+                                                            np.median(dur[:, j]), rows[steps[0] + j + 1][0][:60]))
+    print("  per step: idle %.1f us + kernels %.1f us" % (np.median(gap.sum(1)), np.median(dur.sum(1))))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--stepgaps":
+    stepgaps(sys.argv[2])

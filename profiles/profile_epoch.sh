@@ -13,5 +13,6 @@ f=gpurun_out/${tag}_train_epoch_kernels.txt
 python profiles/epoch_profile.py --summarize "$out" 894 > $f 2>&1
 python profiles/epoch_profile.py --gaps "$out" >> $f 2>&1
 python profiles/epoch_profile.py --timeline "$out" >> $f 2>&1
+python profiles/epoch_profile.py --stepgaps "$out" >> $f 2>&1
 tail -3 "$out/run.log" >> $f
 rm -rf "$out"

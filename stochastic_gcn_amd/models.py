@@ -637,34 +637,82 @@ class GCN(Model):
         current step computes instead of queueing behind it (the copy is ~1 MB: 20-25 us of an otherwise idle compute stream
         per step).  run_one_step calls it itself; a loop that knows its next batch calls it one batch EARLY (train.py), so
         that the copy is complete, and known to be, when the step that reads it is queued."""
-        if pb.slot is None or getattr(pb, '_staged', None) is not None:
-            return getattr(pb, '_staged', None)
+        if pb.slot is None:
+            return None
+        if getattr(pb, '_staged', None) is not None and getattr(pb, '_ring_owner', None) is self:
+            return pb._staged
         dev = self.device
         n_i = max(pb.n_i, 1)
         cs = self.__dict__.get('_copy_stream')
         if cs is None:
             cs = self._copy_stream = torch.cuda.Stream(device=dev)
+        nw = n_i + max(pb.n_f, 1)
+        words = self._ring_buffer(pb, nw, cs)
         with torch.cuda.stream(cs):
-            words = pb.slot.buf[:n_i + max(pb.n_f, 1)].to(dev, non_blocking=True)
+            words.copy_(pb.slot.buf[:nw], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(cs)
         pb.slot.event = ev                # the producer waits on it before reusing the slot
         pb._staged = (words, ev)
         return pb._staged
 
+    # The staged batches' device buffers are a RING this model owns, not allocations: a tensor that is allocated on the
+    # copy stream and read on the step's stream makes the caching allocator record an event on the step's stream when it is
+    # freed -- a marker packet between two steps' kernels, 1.5-3 us of every step (0.0408 -> 0.0402 s per Reddit epoch, A/B in one box).  The
+    # ring needs the step's stream to say "done" only once per _RING_GROUP steps: the buffers of a group are written again
+    # _RING_GROUPS groups later, and the copy stream (never the step's) waits for the event recorded behind the group's last
+    # step.
+    _RING_GROUP, _RING_GROUPS = 16, 3
+
+    def _ring_buffer(self, pb, nw, cs):
+        G, NG = self._RING_GROUP, self._RING_GROUPS
+        ring = self.__dict__.get('_ring')
+        if ring is None:
+            ring = self._ring = dict(bufs=[None] * (G * NG), n=0, done={})
+        i = ring['n']
+        ring['n'] = i + 1
+        main = torch.cuda.current_stream()
+        if i % G == 0 and i >= G * NG:
+            g = i // G - NG                       # the group whose buffers this one takes over
+            ev = ring['done'].pop(g, None)
+            for stale in [k for k in ring['done'] if k < g]:
+                del ring['done'][stale]
+            if ev is not None:
+                cs.wait_event(ev)
+            else:                                 # a batch of that group was staged but never run: everything queued so far
+                cs.wait_stream(main)
+        buf = ring['bufs'][i % (G * NG)]
+        if buf is None or buf.numel() < nw:
+            if buf is not None:                   # steps in flight may still read the smaller one
+                buf.record_stream(cs)
+            buf = ring['bufs'][i % (G * NG)] = torch.empty(nw + nw // 4, dtype=pb.slot.buf.dtype, device=self.device)
+            cs.wait_stream(main)                  # (allocated on the step's stream: ordered behind whatever used the block)
+        pb._ring_i, pb._ring_owner = i, self
+        return buf[:nw]
+
+    def _ring_step_queued(self, pb):
+        """behind the step that read batch `pb`'s ring buffer: the last step of a group marks the group reusable"""
+        i = getattr(pb, '_ring_i', None)
+        if i is not None and i % self._RING_GROUP == self._RING_GROUP - 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._ring['done'][i // self._RING_GROUP] = ev
+
     def _run_program(self, prog, pb, sync):
         t = time()
         dev = self.device
         n_i = max(pb.n_i, 1)
         if pb.slot is not None:
-            staged = getattr(pb, '_staged', None) or self.stage(pb)
-            words, ev = staged
+            words, ev = self.stage(pb)
+            if self._ring['n'] - pb._ring_i > self._RING_GROUP * (self._RING_GROUPS - 1):
+                raise RuntimeError("this minibatch was staged %d batches ago: its device buffer has been handed on "
+                                   "(Model.stage keeps %d batches)" % (self._ring['n'] - pb._ring_i,
+                                                                       self._RING_GROUP * (self._RING_GROUPS - 1)))
             main = torch.cuda.current_stream()
             # a copy the caller staged one batch ahead (stage()) has completed by the time its step is queued: the step's
             # queue then needs no barrier on the copy engine's signal (3-10 us per step, and most of the step-to-step jitter)
             if not ev.query():
                 main.wait_event(ev)
-            words.record_stream(main)
             ip = words.data_ptr()
             fp = ip + 4 * n_i
             self._live_batch = words
@@ -694,7 +742,11 @@ class GCN(Model):
             nL, c = m[5 + 2 * self.L], int(prog.pred.cols)
             pred = prog.tensor_of(prog.pred, nL).clone()
             off, r_, c_ = m[pb.o_labels], m[pb.o_labels + 1], m[pb.o_labels + 2]
-            src = words[n_i + off:n_i + off + r_ * c_] if pb.slot is not None else fb[off:off + r_ * c_].view(torch.int32)
+            if pb.slot is not None:           # (a copy: the ring buffer is written again a few dozen batches on)
+                src = words[n_i + off:n_i + off + r_ * c_].clone()
+                self._ring_step_queued(pb)
+            else:
+                src = fb[off:off + r_ * c_].view(torch.int32)
             self.cur = _EvalCur(src.view(torch.float32).view(r_, c_))
             self.dropout_step += 1
             loss, acc = prog.loss_t, prog.acc_t
@@ -716,6 +768,8 @@ class GCN(Model):
                     n = m[5 + 2 * l]
                     idx = words[m[4 + 2 * l]:m[4 + 2 * l] + n] if pb.slot is not None else ib[m[4 + 2 * l]:m[4 + 2 * l] + n]
                     self.history_hook(self.history[l][0], idx, prog.tensor_of(nh, n), ops.scatter_rows)
+        if pb.slot is not None:
+            self._ring_step_queued(pb)
         self.dropout_step += 1
         loss, acc = prog.loss_t, prog.acc_t
         if sync:

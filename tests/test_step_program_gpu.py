@@ -217,6 +217,45 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
         assert torch.equal(l1, l2) and torch.equal(a1, a2)
 
 
+def test_staged_batches_cycle_through_the_models_ring_of_device_buffers():
+    """Model.stage copies a pinned minibatch into a ring of device buffers one batch ahead of its step; a buffer is written
+    again three groups of sixteen batches later, behind an event of the step's stream recorded once per group.  110 steps
+    (the ring more than twice around) with the copy a batch ahead, against the eager path fed from pageable memory; a
+    minibatch that is run after its buffer has been handed on is refused."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.scheduler import StagingSlot
+    case = mc.build_case('reddit_cvd_pp')
+    a, la = _run(case, False, 110, False)
+    params = mc.make_oracle_model(case, seed=3).params
+    b = _model(case, {k: v.copy() for k, v in params.items()}, True)
+    sch = mc.make_scheduler(case, 1)
+    slots = [StagingSlot(pin=True) for _ in range(4)]
+
+    def fetch(i):
+        if sch.start >= sch.data.shape[0]:
+            sch.start = 0
+        pb = sch.minibatch_packed(case['cfg']['batch'], FLAGS.plan_t, slots[i % 4])
+        pb.dropout = case['flags']['dropout']
+        return pb
+    lb, first = [], None
+    nxt = fetch(0)
+    for step in range(110):
+        pb, nxt = nxt, fetch(step + 1)
+        b.stage(nxt)
+        first = first or pb
+        out = b.run_one_step(None, pb, sync=False)
+        lb.append((out[1].clone(), out[2].clone()))
+    torch.cuda.synchronize()
+    assert b._ring['n'] == 111 and len(b._ring['bufs']) == 48 and all(t is not None for t in b._ring['bufs'])
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m)
+    for ha, hb in zip(a.history, b.history):
+        assert torch.equal(ha[0], hb[0])
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
+    with pytest.raises(RuntimeError, match="handed on"):
+        b.run_one_step(None, first, sync=False)
+
+
 SHAPES = {   # changes to the mid-size Reddit recipe (hidden1 64, f 96 -> 192 inputs, 41 classes, two pre-processing layers)
     'hidden128': dict(hidden1=128),                     # the widest layer the row passes fold
     'hidden256': dict(hidden1=256),                     # ... and one they must leave to the MFMA launches
