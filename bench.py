@@ -193,7 +193,7 @@ def train_epoch_leg(data, dev, epochs=6):
         val = {"error": repr(e)}
     # each aggregation edge is used by the forward aggregate; sampled edges again by the backward
     return {"epoch_time_s": best, "epoch_times_s": walls, "steps": le['steps'], "batch_size": 512,
-            "ms_per_step": best / le['steps'] * 1e3, "sch_wait_s": le['sch_wait_s'],
+            "ms_per_step": best / le['steps'] * 1e3, "sch_wait_s": le["sch_wait_s"], "host_loop_s": le.get("host_loop_s"),
             "producer_busy_s": le.get('producer_s'),
             "gpu_chain_us": chain.get("gpu_chain_us"), "host_launch_us": chain.get("host_launch_us"), "chain_probe": chain,
             "validation": val,

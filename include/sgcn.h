@@ -554,6 +554,29 @@ typedef struct {
 int sgcn_step_run(const sgcn_step_op_t* host_ops, int32_t nops, const int64_t* host_slots, int32_t nslots,
                   void* stream);
 
+/* The slot table of one minibatch, filled in C (ABI v8: as NumPy expressions on the launching thread this was ~25 us of a
+ * 135 us step, on a thread that has ~115 us of work per step):
+ *   host_slots[i] = host_meta[idx[i]] * mul[i] + (base[i] == 1 ? ip : base[i] == 2 ? fp : 0)           i < n
+ * (host_meta: the descriptor table of sgcn_sched_batch_packed; ip / fp: device addresses of the minibatch's int32 / fp32
+ * sections), behind the program's capacity checks -- host_meta[cap_idx[j]] <= cap_max[j] for j < n_cap (row counts against
+ * the arena the program was built for), host_meta[ws_idx[j]] * ws_ld[j] <= ws_floats for j < n_ws (plan workspaces) -- then the
+ * step's dropout keys host_slots[key_slot[j]] = fmix32(fmix32(seed * 0x9E3779B1 + key_layer[j] * 0x85EBCA77 + 0x27D4EB2F)
+ * + step * 0xC2B2AE3D) (sgcn_dropout_t.key of site key_layer[j] at this step) and host_slots[lr_slot] = the bits of `lr`
+ * (the Adam step size of this step).  Returns SGCN_OK; 1 when the minibatch does not fit the program (host_slots
+ * untouched: the caller runs this minibatch op by op); SGCN_ERR_INVALID on an index outside host_meta / host_slots. */
+typedef struct {
+    int64_t n;      const int64_t* idx;      const int64_t* mul;       const int64_t* base;
+    int64_t n_cap;  const int64_t* cap_idx;  const int64_t* cap_max;
+    int64_t n_ws;   const int64_t* ws_idx;   const int64_t* ws_ld;     int64_t ws_floats;
+    int64_t n_keys; const int64_t* key_slot; const int64_t* key_layer; int64_t lr_slot;
+} sgcn_step_fill_t;
+int sgcn_step_fill(const sgcn_step_fill_t* fill, const int64_t* host_meta, int64_t meta_len, int64_t ip, int64_t fp,
+                   int64_t seed, int64_t step, float lr, int64_t* host_slots, int64_t nslots);
+
+/* hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, stream): the staging copy of a packed minibatch
+ * (stochastic_gcn_amd/models.py Model.stage) as one foreign call instead of a stream context + tensor copy. */
+int sgcn_copy_h2d_async(void* dev_dst, const void* host_src, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 7          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 8          # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -47,6 +47,14 @@ class StepOp(C.Structure):
     """include/sgcn.h sgcn_step_op_t"""
     _fields_ = [("op", C.c_int32), ("nargs", C.c_int32), ("mul", C.c_int64 * STEP_MAX_ARGS),
                 ("slot", C.c_int32 * STEP_MAX_ARGS), ("add", C.c_int64 * STEP_MAX_ARGS)]
+
+
+class StepFill(C.Structure):
+    """include/sgcn.h sgcn_step_fill_t"""
+    _fields_ = [("n", C.c_int64), ("idx", C.c_void_p), ("mul", C.c_void_p), ("base", C.c_void_p),
+                ("n_cap", C.c_int64), ("cap_idx", C.c_void_p), ("cap_max", C.c_void_p),
+                ("n_ws", C.c_int64), ("ws_idx", C.c_void_p), ("ws_ld", C.c_void_p), ("ws_floats", C.c_int64),
+                ("n_keys", C.c_int64), ("key_slot", C.c_void_p), ("key_layer", C.c_void_p), ("lr_slot", C.c_int64)]
 
 
 class Dropout(C.Structure):
@@ -134,6 +142,9 @@ SIGNATURES = {
     "sgcn_csr_transpose_index": (C.c_int, [C.c_int32, C.c_int64, P, P, P, P, P, P, P]),
     "sgcn_gather_f32": (C.c_int, [P, P, C.c_int64, P, P]),
     "sgcn_step_run": (C.c_int, [C.POINTER(StepOp), C.c_int32, P, C.c_int32, P]),
+    "sgcn_step_fill": (C.c_int, [C.POINTER(StepFill), P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float,
+                                 P, C.c_int64]),
+    "sgcn_copy_h2d_async": (C.c_int, [P, P, C.c_int64, P]),
     "sgcn_adam_f32": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "sgcn_sched_create": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.POINTER(C.c_void_p)]),

@@ -134,6 +134,45 @@ inline bool is_ce(int32_t op) { return op == SGCN_OP_SOFTMAX_CE || op == SGCN_OP
 
 }  // namespace
 
+extern "C" int sgcn_step_fill(const sgcn_step_fill_t* f, const int64_t* meta, int64_t meta_len, int64_t ip, int64_t fp,
+                              int64_t seed, int64_t step, float lr, int64_t* slots, int64_t nslots) {
+    if (!f || !meta || !slots || meta_len < 0 || nslots < 0 || f->n < 0 || f->n_cap < 0 || f->n_ws < 0 || f->n_keys < 0 ||
+        f->n > nslots || f->lr_slot < 0 || f->lr_slot >= nslots)
+        return sgcn::fail(SGCN_ERR_INVALID, "step_fill: bad argument");
+    auto in_meta = [&](int64_t i) { return i >= 0 && i < meta_len; };
+    for (int64_t j = 0; j < f->n_cap; j++) {
+        if (!in_meta(f->cap_idx[j])) return sgcn::fail(SGCN_ERR_INVALID, "step_fill: capacity check outside the descriptor table");
+        if (meta[f->cap_idx[j]] > f->cap_max[j]) return 1;
+    }
+    for (int64_t j = 0; j < f->n_ws; j++) {
+        if (!in_meta(f->ws_idx[j])) return sgcn::fail(SGCN_ERR_INVALID, "step_fill: workspace check outside the descriptor table");
+        if (meta[f->ws_idx[j]] * f->ws_ld[j] > f->ws_floats) return 1;
+    }
+    for (int64_t i = 0; i < f->n; i++)
+        if (!in_meta(f->idx[i])) return sgcn::fail(SGCN_ERR_INVALID, "step_fill: slot %lld reads outside the descriptor table", (long long)i);
+    for (int64_t j = 0; j < f->n_keys; j++)
+        if (f->key_slot[j] < 0 || f->key_slot[j] >= nslots) return sgcn::fail(SGCN_ERR_INVALID, "step_fill: key slot out of range");
+    for (int64_t i = 0; i < f->n; i++)
+        slots[i] = meta[f->idx[i]] * f->mul[i] + (f->base[i] == 1 ? ip : f->base[i] == 2 ? fp : 0);
+    auto fmix32 = [](uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; };
+    for (int64_t j = 0; j < f->n_keys; j++) {
+        const uint32_t site = fmix32((uint32_t)seed * 0x9E3779B1u + (uint32_t)f->key_layer[j] * 0x85EBCA77u + 0x27D4EB2Fu);
+        slots[f->key_slot[j]] = (int64_t)fmix32(site + (uint32_t)step * 0xC2B2AE3Du);
+    }
+    uint32_t bits;
+    memcpy(&bits, &lr, sizeof(bits));
+    slots[f->lr_slot] = (int64_t)bits;
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_copy_h2d_async(void* dst, const void* src, int64_t bytes, void* stream) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return sgcn::fail(SGCN_ERR_INVALID, "copy_h2d_async: bad argument");
+    if (bytes == 0) return SGCN_OK;
+    const hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return sgcn::fail(SGCN_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    return SGCN_OK;
+}
+
 extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int64_t* slots, int32_t nslots,
                              void* stream) {
     if (nops < 0 || (nops > 0 && !ops) || nslots < 0 || (nslots > 0 && !slots))

@@ -18,6 +18,7 @@ history_vars`` (gcn/models.py:339-347) -- but executes eagerly on one MI355X:
   * history rows are scattered after the optimizer step, as the reference orders it
     (gcn/models.py:186-194).
 """
+import math
 import os
 from time import time
 
@@ -26,6 +27,7 @@ import scipy.sparse as sp
 import torch
 
 from . import ops
+from ._ffi import check, lib as _lib
 from .flags import FLAGS
 from .layers import (AugmentedDropoutDense, Dense, DetDropoutFC, Dropout, SparseInput)
 from .scheduler import PackedBatch, build_plan
@@ -490,7 +492,32 @@ class GCN(Model):
                 for name, _ in self.named_vars()}
 
     # ---- one step -----------------------------------------------------------------------
+    # The epoch counters (gcn/vrgcn.py:50-69) are linear in the minibatches' sizes: the step-program path adds the
+    # minibatch's descriptor table to a pending sum (one vector add per step) and the counters take it in when they are read.
+    def _counter(name):
+        def get(self):
+            if self.__dict__.get('_pend_n'):
+                self._flush_counts()
+            return self.__dict__['_c_' + name]
+
+        def put(self, v):
+            if self.__dict__.get('_pend_n'):
+                self._flush_counts()
+            self.__dict__['_c_' + name] = v
+        return property(get, put)
+    g_ops, nn_ops, amt_data = _counter('g_ops'), _counter('nn_ops'), _counter('amt_data')
+    field_sizes, adj_sizes, fadj_sizes = _counter('field_sizes'), _counter('adj_sizes'), _counter('fadj_sizes')
+    del _counter
+
+    def _flush_counts(self):
+        m, base, ND = self._pend.tolist(), self._pend_o_csr, _CSR_DESC
+        self._pend_n, self._pend = 0, None
+        self._count_sizes(dict(adj=[m[base + 3 * l * ND + 2] for l in range(self.L)],
+                               fadj=[m[base + (3 * l + 2) * ND + 2] for l in range(self.L)],
+                               fields=[m[5 + 2 * l] for l in range(self.L + 1)]))
+
     def init_counts(self):
+        self._pend_n, self._pend = 0, None
         self.run_t = 0
         self.g_t = 0
         self.g_ops = 0
@@ -560,8 +587,13 @@ class GCN(Model):
         """tf.train.AdamOptimizer(lr, beta1, beta2, eps=1e-8) on the flat buffers."""
         self.adam_t += 1
         b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
-        lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
-        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, b1, b2, 1e-8)
+        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self._adam_lr(self.adam_t), b1, b2, 1e-8)
+
+    @staticmethod
+    def _adam_lr(t):
+        """the bias-corrected step size of Adam's step t (both step paths: the same double, rounded to fp32 by the kernel)"""
+        b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
+        return float(FLAGS.learning_rate) * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
 
     def update_history(self, cur):
         """tf.scatter_update(history, fields[l], new_history) (gcn/models.py:160-166)."""
@@ -628,8 +660,7 @@ class GCN(Model):
             except Unsupported as e:
                 progs[key] = None
                 self._program_note = str(e)
-        prog = progs[key]
-        return prog if (prog is not None and prog.fits(feed_dict)) else None
+        return progs[key]          # (whether THIS minibatch fits its buffers: StepProgram.fill, in _run_program)
 
     def stage(self, pb):
         """Start the H2D copy of a packed minibatch that lives in a pinned staging slot -- ONE copy [int32 section | fp32
@@ -646,12 +677,13 @@ class GCN(Model):
         cs = self.__dict__.get('_copy_stream')
         if cs is None:
             cs = self._copy_stream = torch.cuda.Stream(device=dev)
+            self._copy_stream_h = cs.cuda_stream
         nw = n_i + max(pb.n_f, 1)
         words = self._ring_buffer(pb, nw, cs)
-        with torch.cuda.stream(cs):
-            words.copy_(pb.slot.buf[:nw], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(cs)
+        pb._words_ptr = words.data_ptr()
+        check(_lib.sgcn_copy_h2d_async(pb._words_ptr, pb.slot.ptr, 4 * nw, self._copy_stream_h))
+        ev = torch.cuda.Event()
+        ev.record(cs)
         pb.slot.event = ev                # the producer waits on it before reusing the slot
         pb._staged = (words, ev)
         return pb._staged
@@ -671,8 +703,8 @@ class GCN(Model):
             ring = self._ring = dict(bufs=[None] * (G * NG), n=0, done={})
         i = ring['n']
         ring['n'] = i + 1
-        main = torch.cuda.current_stream()
         if i % G == 0 and i >= G * NG:
+            main = torch.cuda.current_stream()
             g = i // G - NG                       # the group whose buffers this one takes over
             ev = ring['done'].pop(g, None)
             for stale in [k for k in ring['done'] if k < g]:
@@ -686,9 +718,9 @@ class GCN(Model):
             if buf is not None:                   # steps in flight may still read the smaller one
                 buf.record_stream(cs)
             buf = ring['bufs'][i % (G * NG)] = torch.empty(nw + nw // 4, dtype=pb.slot.buf.dtype, device=self.device)
-            cs.wait_stream(main)                  # (allocated on the step's stream: ordered behind whatever used the block)
+            cs.wait_stream(torch.cuda.current_stream())                  # (allocated on the step's stream: ordered behind whatever used the block)
         pb._ring_i, pb._ring_owner = i, self
-        return buf[:nw]
+        return buf              # (the whole buffer: the minibatch is its first nw words)
 
     def _ring_step_queued(self, pb):
         """behind the step that read batch `pb`'s ring buffer: the last step of a group marks the group reusable"""
@@ -699,46 +731,54 @@ class GCN(Model):
             self._ring['done'][i // self._RING_GROUP] = ev
 
     def _run_program(self, prog, pb, sync):
+        """One step as a program; None when the minibatch does not fit it (the caller then runs it layer by layer)."""
         t = time()
         dev = self.device
         n_i = max(pb.n_i, 1)
+        main = torch.cuda.current_stream()
         if pb.slot is not None:
             words, ev = self.stage(pb)
             if self._ring['n'] - pb._ring_i > self._RING_GROUP * (self._RING_GROUPS - 1):
                 raise RuntimeError("this minibatch was staged %d batches ago: its device buffer has been handed on "
                                    "(Model.stage keeps %d batches)" % (self._ring['n'] - pb._ring_i,
                                                                        self._RING_GROUP * (self._RING_GROUPS - 1)))
-            main = torch.cuda.current_stream()
             # a copy the caller staged one batch ahead (stage()) has completed by the time its step is queued: the step's
-            # queue then needs no barrier on the copy engine's signal (3-10 us per step, and most of the step-to-step jitter)
+            # queue then needs no barrier on the copy engine's signal (3-10 us per step, and most of the step-to-step jitter).
+            # When it has not -- a launching thread two ring groups ahead of the GPU, its copies held back by the ring's
+            # events -- it is the HOST that waits: that is the back-pressure of the loop, and the queue (dozens of steps
+            # deep at that point) still gets no barrier
             if not ev.query():
-                main.wait_event(ev)
-            ip = words.data_ptr()
+                ev.synchronize()
+            ip = pb._words_ptr
             fp = ip + 4 * n_i
-            self._live_batch = words
+            live = words
         else:
             ib = torch.from_numpy(pb.ibuf[:n_i]).to(dev, non_blocking=True)
             fb = torch.from_numpy(pb.fbuf[:max(pb.n_f, 1)]).to(dev, non_blocking=True)
             ip, fp = ib.data_ptr(), fb.data_ptr()
-            self._live_batch = (ib, fb)
-        m, base, ND = pb.m, pb.o_csr, _CSR_DESC
-        self._count_sizes(dict(adj=[m[base + 3 * l * ND + 2] for l in range(self.L)],
-                               fadj=[m[base + (3 * l + 2) * ND + 2] for l in range(self.L)],
-                               fields=[m[5 + 2 * l] for l in range(self.L + 1)]))
-        self.g_t += time() - t
-        t = time()
-        lr_t = 0.0
+            live = (ib, fb)
+        # sizes, addresses, dropout keys and the step size into the program's slot table (one foreign call, which also
+        # checks the minibatch against the program's buffers)
+        lr_t = self._adam_lr(self.adam_t + 1) if self.is_training else 0.0
+        if not prog.fill(pb, ip, fp, self.dropout_step, lr_t):
+            return None
+        self._live_batch = live
         if self.is_training:
             self.adam_t += 1
-            b1, b2 = float(FLAGS.beta1), float(FLAGS.beta2)
-            lr_t = float(FLAGS.learning_rate) * np.sqrt(1 - b2 ** self.adam_t) / (1 - b1 ** self.adam_t)
-        prog.fill(pb, ip, fp, self.dropout_step, lr_t)
-        stream = torch.cuda.current_stream().cuda_stream
+        if self.__dict__.get('_pend') is None:
+            self._pend, self._pend_o_csr = pb.meta.copy(), pb.o_csr
+        else:
+            self._pend += pb.meta
+        self._pend_n = self.__dict__.get('_pend_n', 0) + 1
+        self.g_t += time() - t
+        t = time()
+        stream = main.cuda_stream
         if not self.is_training:
             # evaluation (gcn/train.py:133-160): forward + loss + prediction + the test model's history scatter as ONE
             # foreign call.  pred is copied out of the program's arena (the next batch overwrites it); the labels stay a
             # view of this batch's own staging copy
             prog.run('all', stream)
+            m = pb.m
             nL, c = m[5 + 2 * self.L], int(prog.pred.cols)
             pred = prog.tensor_of(prog.pred, nL).clone()
             off, r_, c_ = m[pb.o_labels], m[pb.o_labels + 1], m[pb.o_labels + 2]
@@ -764,6 +804,7 @@ class GCN(Model):
             if self.history_hook is None:
                 prog.run('hist', stream)
             else:
+                m = pb.m
                 for l, nh in prog.new_history.items():
                     n = m[5 + 2 * l]
                     idx = words[m[4 + 2 * l]:m[4 + 2 * l] + n] if pb.slot is not None else ib[m[4 + 2 * l]:m[4 + 2 * l] + n]
@@ -789,7 +830,9 @@ class GCN(Model):
             prog = self._program(feed_dict, drop)
             if prog is not None:
                 self.dropout = prog.dropout
-                return self._run_program(prog, feed_dict, sync)
+                out = self._run_program(prog, feed_dict, sync)
+                if out is not None:
+                    return out
         t = time()
         if not self.is_training:
             self.dropout = 0.0

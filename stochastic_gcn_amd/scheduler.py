@@ -264,7 +264,7 @@ class PackedBatch(object):
         self.L, self.cv, self.meta = L, cv, meta
         self._ibuf, self._fbuf, self.n_i, self.n_f = ibuf, fbuf, n_i, n_f
         self.slot = slot
-        self.m = meta.tolist()
+        self._m = self._meta_ptr = None
         o = 4 + 2 * (L + 1)
         self.o_scales = o; o += 2 * L
         self.o_ffields = o; o += 2 * L
@@ -273,6 +273,18 @@ class PackedBatch(object):
         self.o_csr = o
 
     # lazily built host views --------------------------------------------------------------------
+    @property
+    def m(self):
+        if self._m is None:
+            self._m = self.meta.tolist()
+        return self._m
+
+    @property
+    def meta_ptr(self):
+        if self._meta_ptr is None:
+            self._meta_ptr = self.meta.ctypes.data
+        return self._meta_ptr
+
     @property
     def ibuf(self):
         if self._ibuf is None:
@@ -447,6 +459,10 @@ class NativePrefetcher(object):
         self._keep = schs
         self.pending = []
         self.max_words = 0
+        # next() runs on the launching thread, once per step: its out-parameters are made once
+        self._out = (C.c_int32(), C.c_int64(), C.c_int64(), C.c_void_p())
+        self._out_ref = tuple(C.byref(o) for o in self._out)
+        self._meta_len, self._cv = int(sch._meta_len), sch.c_sch.cv
 
     def next(self):
         if self._h is None:
@@ -455,14 +471,15 @@ class NativePrefetcher(object):
             idx = self.pending.pop(0)
             self.slots[idx].wait()
             check(lib.sgcn_prefetch_release(self._h, idx))
-        meta = np.zeros(self.sch._meta_len, dtype=np.int64)
-        slot, n_i, n_f, spill = C.c_int32(), C.c_int64(), C.c_int64(), C.c_void_p()
-        rc = lib.sgcn_prefetch_next(self._h, C.byref(slot), meta.ctypes.data, C.byref(n_i), C.byref(n_f),
-                                    C.byref(spill))
+        meta = np.empty(self._meta_len, dtype=np.int64)          # (sgcn_prefetch_next writes all of it)
+        meta_ptr = meta.ctypes.data
+        slot, n_i, n_f, spill = self._out
+        rc = lib.sgcn_prefetch_next(self._h, self._out_ref[0], meta_ptr, self._out_ref[1], self._out_ref[2], self._out_ref[3])
         if rc == 1:
             self.close()
             return None
-        check(rc)
+        if rc:
+            check(rc)
         n_i, n_f, idx = n_i.value, n_f.value, slot.value
         self.max_words = max(self.max_words, max(n_i, 1) + max(n_f, 1))
         if spill.value:      # outgrew the slot: copy out of the producer's heap buffer, free the slot at once
@@ -471,7 +488,9 @@ class NativePrefetcher(object):
             check(lib.sgcn_prefetch_release(self._h, idx))
             return PackedBatch(self.L, self.sch.c_sch.cv, meta, raw[:ni], raw[ni:].view(np.float32), n_i, n_f, None)
         self.pending.append(idx)
-        return PackedBatch(self.L, self.sch.c_sch.cv, meta, None, None, n_i, n_f, self.slots[idx])
+        pb = PackedBatch(self.L, self._cv, meta, None, None, n_i, n_f, self.slots[idx])
+        pb._meta_ptr = meta_ptr
+        return pb
 
     def close(self):
         if self._h is not None:

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._ffi import StepOp, check, lib
+from ._ffi import StepFill, StepOp, check, lib
 from .flags import FLAGS
 from .layers import AugmentedDropoutDense, Dense, Dropout, PlainAggregator, VRAggregator
 from .scheduler import CSR_DESC, PackedBatch
@@ -567,6 +567,19 @@ class StepProgram(object):
         so = self.stats_off
         self.loss_t, self.acc_t = self.arena[so + 2], self.arena[so + 3]
         self._keys = sorted(self._key_slots.items())
+        # the same tables for sgcn_step_fill (the arrays above stay the owners: the struct holds their addresses)
+        self._f_base = f[:, 2].copy()
+        self._key_slot = np.array([sl for _, sl in self._keys], dtype=np.int64)
+        self._key_layer = np.array([li for li, _ in self._keys], dtype=np.int64)
+        self._c_fill = StepFill(
+            n=self._f_idx.shape[0], idx=self._f_idx.ctypes.data, mul=self._f_mul.ctypes.data, base=self._f_base.ctypes.data,
+            n_cap=self._cap_idx.shape[0], cap_idx=self._cap_idx.ctypes.data, cap_max=self._cap_max.ctypes.data,
+            n_ws=self._ns_idx.shape[0], ws_idx=self._ns_idx.ctypes.data, ws_ld=self._ns_ldw.ctypes.data,
+            ws_floats=int(self.plan_ws_floats), n_keys=len(self._keys), key_slot=self._key_slot.ctypes.data,
+            key_layer=self._key_layer.ctypes.data, lr_slot=self.lr_slot)
+        self._c_fill_ref = C.byref(self._c_fill)
+        self._runs = {'all': (self.c_all, self.n_all), 'fb': (self.c_fb, self.n_fb), 'opt': (self.c_opt, self.n_opt),
+                      'hist': (self.c_hist, self.n_hist)}
 
     # ---- per step ---------------------------------------------------------------------------------
     def fits(self, pb):
@@ -578,18 +591,16 @@ class StepProgram(object):
         return True
 
     def fill(self, pb, ip, fp, step, lr_t):
-        s = self.slots
-        n = self._f_idx.shape[0]
-        np.multiply(pb.meta[self._f_idx], self._f_mul, out=s[:n])
-        s[:n] += self._f_ip * ip + self._f_fp * fp
-        m = self.model
-        for li, slot in self._keys:
-            s[slot] = ops.dropout_key(m.dropout_seed, li, step)
-        s[self.lr_slot] = _fbits(lr_t)
+        """The minibatch's slot table (sgcn_step_fill: capacity checks, sizes and addresses, the step's dropout keys, the
+        Adam step size); False when the minibatch does not fit the program."""
+        rc = lib.sgcn_step_fill(self._c_fill_ref, pb.meta_ptr, pb.meta.shape[0], ip, fp, self.model.dropout_seed, step, lr_t,
+                                self._slots_ptr, self.nslots)
+        if rc < 0:
+            check(rc)
+        return rc == 0
 
     def run(self, which, stream):
-        arr, n = {'all': (self.c_all, self.n_all), 'fb': (self.c_fb, self.n_fb), 'opt': (self.c_opt, self.n_opt),
-                  'hist': (self.c_hist, self.n_hist)}[which]
+        arr, n = self._runs[which]
         if n:
             check(lib.sgcn_step_run(arr, n, self._slots_ptr, self.nslots, stream))
 

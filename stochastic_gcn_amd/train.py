@@ -402,6 +402,7 @@ class Trainer(object):
             if hasattr(pre, 'close'):
                 pre.close()
                 self.producer_s = getattr(pre, 'stats', None)
+        host_loop_s = time() - t        # everything queued: below the epoch time = the host runs ahead of the GPU
         ev1.record()
         torch.cuda.synchronize()
         # 'TF time' of the epoch line (gcn/train.py:227-229; scripts/analyze-time.py reads it) is the time spent
@@ -412,7 +413,7 @@ class Trainer(object):
         if outs is not None:      # Averager(1) of the reference = the last step's values
             self.avg_loss.add(float(outs[1]))
             self.avg_acc.add(float(outs[2]))
-        self.last_epoch = dict(train_wall_s=time() - t, steps=n_steps, sch_wait_s=tsch,
+        self.last_epoch = dict(train_wall_s=time() - t, steps=n_steps, sch_wait_s=tsch, host_loop_s=host_loop_s,
                                producer_s=getattr(self, 'producer_s', None),
                                sampled_edges=float(train_model.adj_sizes.sum()),
                                full_edges=float(train_model.fadj_sizes.sum()),
