@@ -144,6 +144,16 @@ def stepgaps(src):
         print("  idle %6.2f (p90 %6.2f)  run %6.2f  %s" % (np.median(gap[:, j]), np.percentile(gap[:, j], 90),
                                                             np.median(dur[:, j]), rows[steps[0] + j + 1][0][:60]))
     print("  per step: idle %.1f us + kernels %.1f us" % (np.median(gap.sum(1)), np.median(dur.sum(1))))
+    # ... and over ALL steady-state steps (whatever their kernel count): the epoch pays the mean, not the median
+    st = np.array([rows[a][1] for a in adam], dtype=np.int64)
+    per = np.diff(st) / 1e3
+    per = per[per < 2000]                       # (an epoch boundary is not a step)
+    busy = np.array([sum(rows[i][2] - rows[i][1] for i in range(a + 1, b + 1)) for a, b in zip(adam[:-1], adam[1:])]) / 1e3
+    busy = busy[:len(np.diff(st))][np.diff(st) / 1e3 < 2000]
+    slow = [(int(i), round(float(p), 1)) for i, p in enumerate(np.diff(st) / 1e3) if 160 < p < 2000]
+    print("  periods over 160 us (step index in the window, us):", slow[:40])
+    print("  all %d steps: period mean %.1f / median %.1f / p90 %.1f / max %.1f us; kernel time mean %.1f / p90 %.1f us"
+          % (len(per), per.mean(), np.median(per), np.percentile(per, 90), per.max(), busy.mean(), np.percentile(busy, 90)))
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--stepgaps":
