@@ -64,7 +64,12 @@ __global__ __launch_bounds__(kBlock) void ln_act_fwd_kernel(
 // the staging writes and the per-lane reads are conflict-free, and lane j accumulates in exactly the order of the 32 x 128
 // MFMA launch it replaces (32-wide K-steps alternating between its K-groups, the groups' sums added in group order): the
 // same bits, one launch and one round trip of g through memory fewer (9.7 us of the step's chain, twice per step).
-struct LnBwdDx { const float* W; int32_t K, kg; DropArgs drop; float* dxo; int64_t lddxo; };
+struct LnBwdDx { const float* W; int32_t K, kg; DropArgs drop; float* dxo; int64_t lddxo;
+                 // dma (d = 32 | 64 | 128): the K x d matrix goes from global memory straight into the LDS
+                 // (global_load_lds_dwordx4: no staging registers, no transposing stores), row-major as it lies, its 16-byte
+                 // chunks XOR-swizzled within a row by the row index so that the lanes' 128-bit reads of a column block --
+                 // lane j owns output row j -- fall into different banks
+                 int32_t dma; };
 // ... and, behind that tail, the LayerNorm / ReLU backward of the layer BELOW (its dy is the dx just produced, K <= 128 wide):
 // g = LN-backward(dx masked by y > 0) written to `g`, per-workgroup parameter partials to `partial` -- the row pass of the
 // next ln_act_bwd_kernel launch, without the launch.  y == nullptr: off.
@@ -100,7 +105,17 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     float* my = lds + (size_t)wave * 2 * d;
     float* wt = lds + (norm ? (size_t)8 * d : 0);
     const int kp = t.K + 1;
-    if (t.W) {                          // stage W^T: element i = j * d + k of the contiguous K x d matrix -> wt[k][j]
+    const int wregion = t.dma ? (t.K * d + 255) / 256 * 256 : d * kp;      // floats
+    if (t.W && t.dma) {
+        // LDS slot s (16 bytes) = row j = s / P, chunk s % P of the row  <-  chunk (s % P) ^ (j % P) of W's row j   (P = d / 4)
+        const int P = d >> 2, sh = __ffs(P) - 1, total4 = t.K * P;
+        for (int base4 = wave * kWave; base4 < total4; base4 += kBlock) {
+            const int sl = min(base4 + lane, total4 - 1);                // (past the end: into the region's padding)
+            const int j = sl >> sh, src4 = (j << sh) + ((sl & (P - 1)) ^ (j & (P - 1)));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.W + (int64_t)src4 * 4),
+                                             (__attribute__((address_space(3))) void*)(wt + (int64_t)base4 * 4), 16, 0, 0);
+        }
+    } else if (t.W) {                   // stage W^T: element i = j * d + k of the contiguous K x d matrix -> wt[k][j]
         // every round of loads is a trip past the L2 (~2 us), so a thread requests its whole share -- up to 32 float4 for
         // the 256 x 128 matrix -- before it stores any (d % 4 == 0 and a 16-byte aligned matrix: checked by the host)
         const int total4 = t.K * d / 4;
@@ -155,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
         }
     }
     if (!norm && !t.W) return;
+    if (t.dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (norm) {
         float* out = partial + (size_t)blockIdx.x * 2 * d;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     }
     if (!t.W || (!have && !nx.y)) return;
     const int d2 = t.K;                                  // (nx) the layer below is d2 wide
-    float* my2 = lds + (norm ? (size_t)8 * d : 0) + (size_t)d * kp + (size_t)wave * 2 * d2;
+    float* my2 = lds + (norm ? (size_t)8 * d : 0) + (size_t)wregion + (size_t)wave * 2 * d2;
     if (nx.y && nx.norm) for (int c = lane; c < 2 * d2; c += kWave) my2[c] = 0.f;
     float dyl[2] = {0.f, 0.f};
     if (have) {
@@ -174,6 +190,10 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     int jj[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) jj[e] = lane + e * kWave < t.K ? lane + e * kWave : 0;
+    int rowf[4], sw[4];                 // (dma) the lane's four rows: first float of the row, its swizzle
+    const int Pm = (d >> 2) - 1;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { rowf[e] = jj[e] * d; sw[e] = jj[e] & Pm; }
     for (int s0 = 0; s0 * 32 < d; s0++) {
         const int gi = t.kg > 1 ? (s0 & 1) : 0;
         const float xs = s0 < 2 ? gk[0] : gk[1];
@@ -183,7 +203,22 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
         float p[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) p[e] = acc[e][gi];
-        if (kn == 32) {
+        if (t.dma) {                    // d % 32 == 0: whole K-steps, eight 16-byte chunks each, k ascending as below
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int c = (kb >> 2) + q;
+                float4 w[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[e] = *reinterpret_cast<const float4*>(wt + rowf[e] + ((c ^ sw[e]) << 2));
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), lb + q * 4 + u));
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        p[e] = fmaf(xv, u == 0 ? w[e].x : u == 1 ? w[e].y : u == 2 ? w[e].z : w[e].w, p[e]);
+                }
+            }
+        } else if (kn == 32) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float w[8][4];
@@ -252,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void ln_act_bwd_kernel(
     }
     if (!nx.norm) return;
     __syncthreads();
-    const float* l2 = lds + (norm ? (size_t)8 * d : 0) + (size_t)d * kp;
+    const float* l2 = lds + (norm ? (size_t)8 * d : 0) + (size_t)wregion;
     float* out2 = nx.partial + (size_t)blockIdx.x * 2 * d2;
     for (int c = threadIdx.x; c < 2 * d2; c += kBlock)
         out2[c] = (l2[c] + l2[2 * d2 + c]) + (l2[4 * d2 + c] + l2[6 * d2 + c]);
@@ -745,7 +780,8 @@ int sgcn::ln_act_bwd_launch(const float* dy, int64_t lddy, const float* y, int64
                      tail_lddx >= tail_K && tail_kg >= 1 && tail_kg <= 2, "ln_act_bwd: bad input-gradient tail");
         t.W = tail_W; t.K = tail_K; t.kg = tail_kg; t.drop = drop_args(tail_drop); t.dxo = tail_dx; t.lddxo = tail_lddx;
         SGCN_REQUIRE(!t.drop.on || t.drop.width == tail_K, "ln_act_bwd: dropout width must be the layer's input width");
-        lds += (size_t)d * (tail_K + 1) * sizeof(float);
+        t.dma = (d == 32 || d == 64 || d == 128) ? 1 : 0;
+        lds += (t.dma ? ((size_t)tail_K * d + 255) / 256 * 256 : (size_t)d * (tail_K + 1)) * sizeof(float);
         if (nx_y) {
             SGCN_REQUIRE(tail_K <= 2 * kWave && nx_g && nx_ldy >= tail_K && (!nx_scale || (nx_xhat && nx_rstd && nx_partial)),
                          "ln_act_bwd: bad chained layer");
