@@ -260,6 +260,7 @@ SHAPES = {   # changes to the mid-size Reddit recipe (hidden1 64, f 96 -> 192 in
     'hidden128': dict(hidden1=128),                     # the widest layer the row passes fold
     'hidden256': dict(hidden1=256),                     # ... and one they must leave to the MFMA launches
     'hidden100': dict(hidden1=100),                     # 100 % 32 != 0: a partial K-step in every folded product
+    'hidden32': dict(hidden1=32),                       # the narrowest layer whose backward weights go by swizzled direct loads
     'hidden30': dict(hidden1=30),                       # 30 % 4 != 0: no vector staging of the weights
     'one_fc': dict(num_fc_layers=1),                    # nothing to chain behind the upper layer's backward pass
     'three_fc': dict(num_fc_layers=3),                  # three parameter layers above one another
