@@ -137,7 +137,9 @@ inline bool is_ce(int32_t op) { return op == SGCN_OP_SOFTMAX_CE || op == SGCN_OP
 extern "C" int sgcn_step_fill(const sgcn_step_fill_t* f, const int64_t* meta, int64_t meta_len, int64_t ip, int64_t fp,
                               int64_t seed, int64_t step, float lr, int64_t* slots, int64_t nslots) {
     if (!f || !meta || !slots || meta_len < 0 || nslots < 0 || f->n < 0 || f->n_cap < 0 || f->n_ws < 0 || f->n_keys < 0 ||
-        f->n > nslots || f->lr_slot < 0 || f->lr_slot >= nslots)
+        f->n > nslots || f->lr_slot < 0 || f->lr_slot >= nslots || (f->n > 0 && (!f->idx || !f->mul || !f->base)) ||
+        (f->n_cap > 0 && (!f->cap_idx || !f->cap_max)) || (f->n_ws > 0 && (!f->ws_idx || !f->ws_ld)) ||
+        (f->n_keys > 0 && (!f->key_slot || !f->key_layer)))
         return sgcn::fail(SGCN_ERR_INVALID, "step_fill: bad argument");
     auto in_meta = [&](int64_t i) { return i >= 0 && i < meta_len; };
     for (int64_t j = 0; j < f->n_cap; j++) {
