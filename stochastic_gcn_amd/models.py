@@ -692,9 +692,11 @@ class GCN(Model):
     # copy stream and read on the step's stream makes the caching allocator record an event on the step's stream when it is
     # freed -- a marker packet between two steps' kernels, 1.5-3 us of every step (0.0408 -> 0.0402 s per Reddit epoch, A/B in one box).  The
     # ring needs the step's stream to say "done" only once per _RING_GROUP steps: the buffers of a group are written again
-    # _RING_GROUPS groups later, and the copy stream (never the step's) waits for the event recorded behind the group's last
+    # _RING_GROUPS groups later (128 batches, ~100 MB for Reddit: a launching thread that far ahead of the GPU is held back
+    # by its copies; with 48 the hold set in every 16 steps and the epoch was 1-2 % slower, A/B in one box), and the copy
+    # stream (never the step's) waits for the event recorded behind the group's last
     # step.
-    _RING_GROUP, _RING_GROUPS = 16, 3
+    _RING_GROUP, _RING_GROUPS = 16, 8
 
     def _ring_buffer(self, pb, nw, cs):
         G, NG = self._RING_GROUP, self._RING_GROUPS

@@ -219,7 +219,7 @@ def test_output_layer_in_the_loss_kernel_or_as_its_own_launches(fuse):
 
 def test_staged_batches_cycle_through_the_models_ring_of_device_buffers():
     """Model.stage copies a pinned minibatch into a ring of device buffers one batch ahead of its step; a buffer is written
-    again three groups of sixteen batches later, behind an event of the step's stream recorded once per group.  110 steps
+    again a few groups of sixteen batches later (eight by default, three here), behind an event of the step's stream recorded once per group.  110 steps
     (the ring more than twice around) with the copy a batch ahead, against the eager path fed from pageable memory; a
     minibatch that is run after its buffer has been handed on is refused."""
     from stochastic_gcn_amd.flags import FLAGS
@@ -228,6 +228,7 @@ def test_staged_batches_cycle_through_the_models_ring_of_device_buffers():
     a, la = _run(case, False, 110, False)
     params = mc.make_oracle_model(case, seed=3).params
     b = _model(case, {k: v.copy() for k, v in params.items()}, True)
+    b._RING_GROUPS = 3                        # (default 8: 128 buffers; 48 here, so that 110 steps go round more than twice)
     sch = mc.make_scheduler(case, 1)
     slots = [StagingSlot(pin=True) for _ in range(4)]
 
