@@ -257,6 +257,36 @@ def test_staged_batches_cycle_through_the_models_ring_of_device_buffers():
         b.run_one_step(None, first, sync=False)
 
 
+def test_full_size_reddit_program_equals_the_unfolded_eager_path():
+    """BASELINE config 3 at FULL size (S-Reddit: 232,965 vertices, 602 features, hidden 128, batch 512: the shapes the
+    bench's epoch runs -- first layer cut over K into the split-K reduce pass, 256 x 128 and 128 x 128 weights by swizzled
+    direct loads, the chained LayerNorm backward, 41 classes in the loss kernel): three steps as the step program with every
+    fold on, against the eager per-layer path with none -- the path tests/test_model_gpu.py holds against the NumPy oracle
+    at this size -- bit for bit."""
+    from stochastic_gcn_amd import _ffi, synthetic
+    from oracle import model_np as mnp
+    n, train_adj, full_adj, _, _, _, labels, tr, va, te = synthetic.reddit_like(with_features=False)
+    rng = np.random.RandomState(0)
+    feats = rng.standard_normal((n, 602)).astype(np.float32)
+    nbr = train_adj.dot(feats).astype(np.float32)
+    fl = mnp.make_flags(normalization='graphsage', weight_decay=0.0, dropout=0.2, layer_norm=True, hidden1=128,
+                        num_fc_layers=2, cv=True, cvd=True, degree=1, preprocess=True)
+    case = dict(cfg=dict(model='vr', n=n, classes=41, batch=512), flags=fl, adj=train_adj, feats=feats, nbr=nbr,
+                labels=labels, train=tr.astype(np.int32)[:4096], L_sched=1, ph=mc.placeholders(1, 41))
+    _ffi.tune('step_fuse', 0)
+    try:
+        a, la = _run(case, False, 3, True)
+    finally:
+        _ffi.tune('step_fuse', 127)
+    b, lb = _run(case, True, 3, True)
+    assert all(p is not None for p in b._programs.values())
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    for ha, hb in zip(a.history, b.history):
+        assert torch.equal(ha[0], hb[0])
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
+
+
 SHAPES = {   # changes to the mid-size Reddit recipe (hidden1 64, f 96 -> 192 inputs, 41 classes, two pre-processing layers)
     'hidden128': dict(hidden1=128),                     # the widest layer the row passes fold
     'hidden256': dict(hidden1=256),                     # ... and one they must leave to the MFMA launches
