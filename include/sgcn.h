@@ -328,12 +328,15 @@ int sgcn_dense_bwd_f32(int32_t n, int32_t N, int32_t K, const float* dev_dy, int
 /* Softmax cross-entropy over n rows: stats[4] = {sum_i CE_i, #rows whose arg-max matches the label
  * arg-max, mean CE (the loss), accuracy}; dlogits (nullable) = (softmax * sum(labels) - labels) / n;
  * pred (nullable) = softmax; rowstat: 2*n floats of scratch (per-row CE and hit flag, summed
- * in a fixed order).                                           gcn/models.py:68-94,198-202 */
+ * in a fixed order) -- 3*n when pred is given (ABI v9): rowstat[2n + i] = argmax(pred[i]) + 4096 * argmax(labels[i]),
+ * the two class indices gcn/utils.py:521-529 takes per row for the F1 scores (first maximum, as np.argmax; exact in
+ * fp32 for c <= 4096), so that an evaluation sweep brings 4 bytes per row to the host instead of 2 c floats.
+ *                                                              gcn/models.py:68-94,198-202 */
 int sgcn_softmax_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,
                         int32_t n, int32_t c, float* dev_dlogits, int64_t lddz, float* dev_pred,
                         int64_t ldp, float* dev_stats, float* dev_rowstat, void* stream);
 /* Multitask (ppi) loss: mean sigmoid cross-entropy with logits over all n*c elements, element
- * accuracy, pred = sigmoid(z), dlogits = (pred - y)/(n*c).  stats/rowstat as sgcn_softmax_ce_f32.
+ * accuracy, pred = sigmoid(z), dlogits = (pred - y)/(n*c).  stats as sgcn_softmax_ce_f32, rowstat: 2*n floats.
  * Replaces tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean   gcn/models.py:77-79,86-90,198-200 */
 int sgcn_sigmoid_ce_f32(const float* dev_logits, int64_t ldz, const float* dev_labels, int64_t ldl,
                         int32_t n, int32_t c, float* dev_dlogits, int64_t lddz, float* dev_pred, int64_t ldp,

@@ -483,7 +483,7 @@ __device__ __forceinline__ void ce_dx_tail(const CeDx& t, const float* wl, int64
 __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     const float* __restrict__ z, int64_t ldz, const float* __restrict__ lab, int64_t ldl, int32_t n,
     int32_t c, float* __restrict__ dz, int64_t lddz, float* __restrict__ pred, int64_t ldp,
-    float* __restrict__ rowstat /* [2][n] */, CeDx tail) {
+    float* __restrict__ rowstat /* [2][n], [3][n] with pred */, CeDx tail) {
     extern __shared__ __attribute__((aligned(1024))) float ce_lds[];
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
@@ -532,16 +532,27 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_kernel(
     for (int k = lane; k < c; k += kWave) { se += __expf(zv(k) - m); sl += lv(k); }
     se = wave_sum(se); sl = wave_sum(sl);
     const float lse = m + __logf(se);
-    float l = 0.f, mydz = 0.f;
+    float l = 0.f, mydz = 0.f, pm = -1.f;
+    int apm = 0;
     for (int k = lane; k < c; k += kWave) {
         const float logp = zv(k) - lse, p = __expf(logp);
         l -= lv(k) * logp;
         mydz = (p * sl - lv(k)) * inv_n;
         if (dz) dz[row * lddz + k] = mydz;
-        if (pred) pred[row * ldp + k] = p;
+        if (pred) { pred[row * ldp + k] = p; if (p > pm) { pm = p; apm = k; } }
     }
     l = wave_sum(l);
     if (lane == 0) { rowstat[row] = l; rowstat[n + row] = (am == alm) ? 1.f : 0.f; }
+    if (pred) {
+        // evaluation: the row's classes for the F1 scores (gcn/utils.py:521-529 takes np.argmax of the PREDICTION, i.e. of
+        // the rounded probabilities, and of the labels): third plane of rowstat, prediction + 4096 * label (exact in fp32)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float op = __shfl_xor(pm, o, 64); const int oa = __shfl_xor(apm, o, 64);
+            if (op > pm || (op == pm && oa < apm)) { pm = op; apm = oa; }
+        }
+        if (lane == 0) rowstat[2 * (int64_t)n + row] = (float)(apm + 4096 * alm);
+    }
     if (tail.dx) ce_dx_tail(tail, ce_lds, row, lane, c, mydz);
 }
 

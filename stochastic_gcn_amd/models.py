@@ -570,6 +570,11 @@ class GCN(Model):
         want_pred = not self.is_training or self._want_grad
         ce = ops.sigmoid_ce if self.multitask else ops.softmax_ce
         stats, dlogits, pred = ce(z, labels, want_grad=want_grad, want_pred=want_pred)
+        # the rows' classes for the F1 scores (sgcn_softmax_ce_f32: argmax(pred) + 4096 * argmax(labels)), single-label only
+        n = int(z.shape[0])
+        self.eval_classes = stats[4 + 2 * n:4 + 3 * n] if (want_pred and not self.multitask) else None
+        if self.__dict__.get('eval_light') and self.eval_classes is not None:
+            self.eval_vec, self.eval_rows = stats, n          # (Trainer.evaluate: the same vector the step program hands out)
         if FLAGS.weight_decay and self._wd_range[1] > self._wd_range[0]:
             ops.l2_penalty(self.theta, self._wd_range[0], self._wd_range[1], FLAGS.weight_decay, loss=stats[2:3])
         return stats[2], stats[3], pred, dlogits
@@ -782,6 +787,17 @@ class GCN(Model):
             prog.run('all', stream)
             m = pb.m
             nL, c = m[5 + 2 * self.L], int(prog.pred.cols)
+            if self.__dict__.get('eval_light') and not self.multitask:
+                # Trainer.evaluate's form: ONE copy out of the arena per batch -- [stats(4) | CE per row | hit per row |
+                # class indices per row] -- instead of prediction, labels and statistics as three tensors
+                so = prog.stats_off
+                self.eval_vec, self.eval_rows = prog.arena[so:so + 4 + 3 * nL].clone(), nL
+                if pb.slot is not None:
+                    self._ring_step_queued(pb)
+                self.cur = self.eval_classes = None
+                self.dropout_step += 1
+                self.run_t += time() - t
+                return [None, None, None]
             pred = prog.tensor_of(prog.pred, nL).clone()
             off, r_, c_ = m[pb.o_labels], m[pb.o_labels + 1], m[pb.o_labels + 2]
             if pb.slot is not None:           # (a copy: the ring buffer is written again a few dozen batches on)
@@ -790,6 +806,8 @@ class GCN(Model):
             else:
                 src = fb[off:off + r_ * c_].view(torch.int32)
             self.cur = _EvalCur(src.view(torch.float32).view(r_, c_))
+            so = prog.stats_off + 4 + 2 * nL
+            self.eval_classes = None if self.multitask else prog.arena[so:so + nL].clone()
             self.dropout_step += 1
             loss, acc = prog.loss_t, prog.acc_t
             if sync:

@@ -347,7 +347,8 @@ def softmax_ce(logits, labels, want_grad=True, want_pred=False):
     zp, ldz = _rows2d(logits, "logits")
     lp, ldl = _rows2d(labels, "labels")
     n, c = int(logits.shape[0]), int(logits.shape[1])
-    stats = torch.empty(4 + 2 * n, dtype=torch.float32, device=logits.device)   # [stats | per-row scratch]
+    # [stats | per-row scratch | with pred: the rows' classes, argmax(pred) + 4096 * argmax(labels)]
+    stats = torch.empty(4 + (3 if want_pred else 2) * n, dtype=torch.float32, device=logits.device)
     dz = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
     pred = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_pred else None
     check(lib.sgcn_softmax_ce_f32(zp, ldz, lp, ldl, n, c, _ptr(dz), c, _ptr(pred), c, stats.data_ptr(),

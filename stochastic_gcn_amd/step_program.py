@@ -484,8 +484,8 @@ class StepProgram(object):
         nL = self.rows[self.L]
         c = logits.cols
         lab_b = self._pb.o_labels
-        stats, self.stats_off = self._alloc_vec(4 + 2 * nL.cap)
         train = m.is_training
+        stats, self.stats_off = self._alloc_vec(4 + (2 if train else 3) * nL.cap)     # (evaluation: + the rows' classes)
         dz = self._alloc(nL, c) if train else None
         self.pred = self._alloc(nL, c) if not train else None
         rowstat = K(stats[2] + 16)

@@ -28,7 +28,7 @@ from .models import make_template
 from .parallel import DataParallel
 from .plaingcn import PlainGCN
 from .scheduler import NativePrefetcher, PyScheduler
-from .utils import Averager, RunningStat, calc_f1, load_data
+from .utils import Averager, RunningStat, calc_f1, f1_from_classes, load_data
 from .vrgcn import VRGCN
 
 
@@ -319,7 +319,7 @@ class Trainer(object):
 
     # ---- evaluation (gcn/train.py:133-160) ------------------------------------------------------
     def evaluate(self, data):
-        total_pred, total_labs, stats = [], [], []
+        total_pred, total_labs, total_cls, stats = [], [], [], []
         t_test = time()
         N = len(data)
         chunks = [data[st:min(st + FLAGS.test_batch_size, N)] for st in range(0, N, FLAGS.test_batch_size)]
@@ -334,23 +334,52 @@ class Trainer(object):
             return pre.next() if pre else \
                 self.eval_sch.batch_packed(chunks[i], FLAGS.plan_t, self.eval_slots[i % len(self.eval_slots)])
         nxt = fetch(0) if chunks else None
+        vecs, rows = [], []
+        self.test_model.eval_light = not self.multitask
         for k in range(len(chunks)):
             batch = nxt
             nxt = fetch(k + 1) if k + 1 < len(chunks) else None
             if nxt is not None and pre is not None:      # its H2D copy starts one batch early (train_epoch)
                 self.test_model.stage(nxt)
             los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
+            vec = self.test_model.__dict__.pop('eval_vec', None)
+            if vec is not None:                 # single-label: ONE vector per batch [stats | CE | hit | classes per row]
+                vecs.append(vec)
+                rows.append(self.test_model.eval_rows)
+                continue
             stats.append(torch.stack([los, acc]) * prd.shape[0])
-            total_pred.append(prd)
-            total_labs.append(self.test_model.cur.labels)
+            cls = getattr(self.test_model, 'eval_classes', None)
+            if cls is not None:                 # single-label: the loss kernel's class indices, 4 bytes per row
+                total_cls.append(cls)
+            else:
+                total_pred.append(prd)
+                total_labs.append(self.test_model.cur.labels)
         if pre is not None and hasattr(pre, 'close'):
             pre.close()
+        self.test_model.eval_light = False
+        assert not (vecs and stats), "evaluation batches took both result forms"
+        if vecs:
+            # the same fp32 arithmetic as below, on the device: (loss, accuracy) x rows per batch, summed over the batches
+            w = torch.tensor(rows, dtype=torch.float32, device=vecs[0].device)
+            tot = (torch.stack([v[2:4] for v in vecs]) * w[:, None]).sum(dim=0).cpu().numpy() / max(N, 1)
+            allv = torch.cat(vecs).cpu().numpy()
+            v, pos = [], 0
+            for r in rows:
+                v.append(allv[pos + 4 + 2 * r:pos + 4 + 3 * r])
+                pos += 4 + 3 * r
+            v = np.concatenate(v).astype(np.int64)
+            micro, macro = f1_from_classes(v // 4096, v % 4096)
+            return float(tot[0]), float(tot[1]), micro, macro, (time() - t_test)
         if not stats:
             return 0.0, 0.0, 0.0, 0.0, time() - t_test
         tot = torch.stack(stats).sum(dim=0).cpu().numpy() / max(N, 1)      # the only host sync
-        total_pred = torch.cat(total_pred).cpu().numpy()
-        total_labs = torch.cat(total_labs).cpu().numpy()
-        micro, macro = calc_f1(total_pred, total_labs, self.multitask)
+        if total_cls and not total_pred:
+            v = torch.cat(total_cls).cpu().numpy().astype(np.int64)        # argmax(pred) + 4096 * argmax(labels) per row
+            micro, macro = f1_from_classes(v // 4096, v % 4096)
+        else:
+            total_pred = torch.cat(total_pred).cpu().numpy()
+            total_labs = torch.cat(total_labs).cpu().numpy()
+            micro, macro = calc_f1(total_pred, total_labs, self.multitask)
         return float(tot[0]), float(tot[1]), micro, macro, (time() - t_test)
 
     # ---- one training epoch (gcn/train.py:182-209) ----------------------------------------------

@@ -176,6 +176,42 @@ def test_evaluation_through_the_step_program_equals_the_eager_path():
     assert res[True][0][0] != res[True][0][1]         # the second sweep read the history the first one wrote
 
 
+def test_f1_scores_from_the_loss_kernels_class_indices_are_sklearns():
+    """An evaluation sweep brings argmax(pred) + 4096 * argmax(labels) per row to the host (third plane of the loss
+    kernel's row scratch) instead of the prediction and label matrices: the indices against np.argmax of what
+    run_one_step returns, and Trainer.evaluate's F1 pair against gcn/utils.py:521-529's sklearn call on the matrices --
+    on both step paths."""
+    import numpy as np
+    import torch
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+    from stochastic_gcn_amd.utils import calc_f1
+    for native in (False, True):
+        FLAGS.reset()
+        FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+                     hidden1=64, num_fc_layers=2, batch_size=256, test_batch_size=512, learning_rate=0.01, seed=1,
+                     prefetch=2, cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, native_step=native)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Trainer(data=_data(), verbose=False)
+            tr.train_epoch()
+            preds, labs, clss = [], [], []
+            orig = tr.test_model.run_one_step
+
+            def spy(sess, batch, sync=True):
+                tr.test_model.eval_light = False          # (the full outputs: evaluate then takes the class indices per batch)
+                out = orig(sess, batch, sync=sync)
+                preds.append(out[2].clone()); labs.append(tr.test_model.cur.labels.clone())
+                clss.append(tr.test_model.eval_classes.clone())
+                return out
+            tr.test_model.run_one_step = spy
+            _, _, micro, macro, _ = tr.evaluate(tr.val_d)
+        pred, lab = torch.cat(preds).cpu().numpy(), torch.cat(labs).cpu().numpy()
+        v = torch.cat(clss).cpu().numpy().astype(np.int64)
+        assert np.array_equal(v % 4096, pred.argmax(1)) and np.array_equal(v // 4096, lab.argmax(1))
+        want = calc_f1(pred, lab, False)
+        assert abs(micro - want[0]) < 1e-12 and abs(macro - want[1]) < 1e-12 and 0 < micro < 1
+
+
 def test_no_library_gemm_on_the_product_path(monkeypatch):
     """the size-keyed rocBLAS path (torch.mm above 512 M multiply-adds: Exact mode, large
     evaluation batches) is gone.  With every torch matmul entry point booby-trapped, the Reddit recipe (CVD+PP,
