@@ -71,7 +71,7 @@ class _Sampler(object):
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:          # (interpreter shutdown clears module globals before the last objects die)
             lib.sgcn_sched_destroy(h)
             self._h = None
 
