@@ -335,13 +335,16 @@ class Trainer(object):
                 self.eval_sch.batch_packed(chunks[i], FLAGS.plan_t, self.eval_slots[i % len(self.eval_slots)])
         nxt = fetch(0) if chunks else None
         vecs, rows = [], []
-        self.test_model.eval_light = not self.multitask
         for k in range(len(chunks)):
             batch = nxt
             nxt = fetch(k + 1) if k + 1 < len(chunks) else None
             if nxt is not None and pre is not None:      # its H2D copy starts one batch early (train_epoch)
                 self.test_model.stage(nxt)
-            los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
+            self.test_model.eval_light = not self.multitask       # (for this call only: models.py _run_program / loss)
+            try:
+                los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
+            finally:
+                self.test_model.eval_light = False
             vec = self.test_model.__dict__.pop('eval_vec', None)
             if vec is not None:                 # single-label: ONE vector per batch [stats | CE | hit | classes per row]
                 vecs.append(vec)
@@ -356,7 +359,6 @@ class Trainer(object):
                 total_labs.append(self.test_model.cur.labels)
         if pre is not None and hasattr(pre, 'close'):
             pre.close()
-        self.test_model.eval_light = False
         assert not (vecs and stats), "evaluation batches took both result forms"
         if vecs:
             # the same fp32 arithmetic as below, on the device: (loss, accuracy) x rows per batch, summed over the batches
