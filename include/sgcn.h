@@ -33,7 +33,11 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 9.
+ *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
+ *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
+ *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
+ *   v9  sgcn_softmax_ce_f32: with a prediction output, rowstat has a third plane (the rows' class indices) */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
