@@ -33,11 +33,12 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 9.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 10.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
- *   v9  sgcn_softmax_ce_f32: with a prediction output, rowstat has a third plane (the rows' class indices) */
+ *   v9  sgcn_softmax_ce_f32: with a prediction output, rowstat has a third plane (the rows' class indices)
+ *   v10 sgcn_ldsplan_* / sgcn_spmm_lds_f32: the LDS-staged column sweep for graphs with locality */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -161,6 +162,58 @@ int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K, int32_t d,
 /* The kernel variant and launch geometry sgcn_spmm_cs_f32 dispatches for (plan, d) under the
  * current knobs, as text (bench.py reports it as roofline.kernel). */
 int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_t buflen);
+
+/* ---- LDS-staged column sweep: static graphs WITH locality (sgcn_spmm_lds.hip) ----------------
+ * The column sweep above moves one B row from an L2 to the registers per nonzero; on a graph
+ * whose rows share columns inside a compute unit's tile (communities) that traffic can live in
+ * the LDS instead.  A TILE is NW x RW virtual rows of ONE workgroup (wave w keeps the
+ * accumulators of its RW rows in registers); the tile's nonzeros are sorted by sweep position
+ * of their column and cut into CHUNKS of at most S distinct columns; a chunk's pieces of B are
+ * staged once into an LDS ring and every nonzero of the chunk reads its piece from there.
+ * Nonzeros whose column the tile references fewer than `min_reuse` times are left out of the
+ * plan and returned as a residual CSR (same M x K), to be added by sgcn_spmm_cs_f32 / _csr_f32.
+ *   entries[2 i] = value bits, entries[2 i + 1] = word:
+ *       word = LDS byte address of the piece ((chunk parity) * S * P + slot * P, P = 256 * VW bytes;
+ *              the zero piece at 2 * S * P for pads)  |  register offset of the row (local row * VW)
+ *   entries are ordered (tile, wave, chunk); a wave's share of a chunk is padded to a multiple of
+ *   U entries (pads: value 0 on the zero piece); two groups of U pad entries end the array (the
+ *   kernel reads its entry stream two groups ahead).
+ *   ent_ptr[(first chunk of the tile) * NW + w * (chunks of the tile) + k] = first entry of wave w in
+ *   the tile's k-th chunk (one more element ends the array).
+ * New -- the reference has no such kernel; the op is gcn/layers.py:31-37 (dot(x, y, sparse=True)). */
+typedef struct {
+    int32_t VW, NW, RW, S, U;       /* floats per lane (2: 128-column slabs), waves per tile (8), rows per wave
+                                       (192 / VW = 96), ring slots per half (128), entries per group (8)  */
+    int64_t ntiles, nchunks, nent;
+    const int32_t* dev_tile_chunk_ptr; /* [ntiles + 1]                                            */
+    const int32_t* dev_chunk_cols;  /* [nchunks * S] column of every slot (padded with a valid one) */
+    const int64_t* dev_ent_ptr;     /* [nchunks * NW + 1]                                          */
+    const uint32_t* dev_entries;    /* [2 * (nent + 2 U)]                                          */
+    const int32_t* dev_tile_rows;   /* [ntiles * NW * RW] output row of each virtual row, -1 = pad  */
+    const int32_t* dev_tile_slots;  /* [ntiles * NW * RW] workspace slot, -1 = store to C directly  */
+    const sgcn_fix_t* dev_fix; int64_t nfix; int64_t nslots;
+    float* dev_ws; int64_t ws_elems;
+} sgcn_ldsplan_t;
+/* Host-side builder (a handle: the sizes are known only once the plan exists).
+ *   col_pos   nullable [K]: sweep position of every column (a permutation; community by community);
+ *   row_group nullable [M]: tiles are formed inside groups, groups in label order;
+ *   T         rows longer than T become strided virtual rows (<= 0: 2048);
+ *   min_reuse a column is staged for a tile only if the tile references it at least this often (>= 1).
+ * sizes[8] = {ntiles, nchunks, nent, nfix, nslots, residual nnz, staged pieces (sum over chunks of distinct
+ * columns), 0}. */
+typedef struct sgcn_ldsplan_host sgcn_ldsplan_host_t;
+int sgcn_ldsplan_create(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val,
+                        int32_t M, int32_t K, const int32_t* host_col_pos, const int32_t* host_row_group,
+                        int32_t VW, int32_t T, int32_t min_reuse, sgcn_ldsplan_host_t** out);
+int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* sizes8);
+int sgcn_ldsplan_export(const sgcn_ldsplan_host_t* h, int32_t* tile_chunk_ptr, int32_t* chunk_cols,
+                        int64_t* ent_ptr, uint32_t* entries, int32_t* tile_rows, int32_t* tile_slots,
+                        sgcn_fix_t* fix, int32_t* res_rowptr, int32_t* res_col, float* res_val);
+void sgcn_ldsplan_destroy(sgcn_ldsplan_host_t* h);
+/* C[M x d] = rscale (.) (A_local * B[g]) + beta * C   (A_local = the planned nonzeros; the residual is the caller's) */
+int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t K, int32_t d,
+                      const float* dev_B, int64_t ldb, const int32_t* dev_gidx, const float* dev_rscale,
+                      float* dev_C, int64_t ldc, float beta, void* stream);
 
 /* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)

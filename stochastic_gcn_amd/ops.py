@@ -750,6 +750,165 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
     return out
 
 
+# ---- LDS-staged column sweep for graphs with locality (sgcn_spmm_lds.hip) --------------------------
+class LdsPlanHost(object):
+    """The host arrays of an LDS-sweep plan (include/sgcn.h sgcn_ldsplan_*): what ``LdsSweepCSR`` uploads, and what
+    the CPU tests decode (``decode`` rebuilds the planned matrix from the kernel's own operands)."""
+
+    def __init__(self, a, labels=None, VW=2, T=0, min_reuse=2):
+        a = a.tocsr()
+        rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(a.indices, dtype=np.int32)
+        val = np.ascontiguousarray(a.data, dtype=np.float32)
+        M, K = int(a.shape[0]), int(a.shape[1])
+        col_pos = row_group = None
+        if labels is not None:
+            row_labels, col_labels = labels if isinstance(labels, tuple) else (labels, labels)
+            if col_labels is not None:
+                col_labels = np.ascontiguousarray(col_labels, dtype=np.int32)
+                if col_labels.shape[0] != K:
+                    raise ValueError("one label per column")
+                pos2col = np.argsort(col_labels, kind='stable').astype(np.int32)        # sweep position -> column
+                col_pos = np.empty_like(pos2col)
+                col_pos[pos2col] = np.arange(K, dtype=np.int32)
+            if row_labels is not None:
+                row_group = np.ascontiguousarray(row_labels, dtype=np.int32)
+                if row_group.shape[0] != M:
+                    raise ValueError("one label per row")
+        h = C.c_void_p()
+        check(lib.sgcn_ldsplan_create(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, K,
+                                      col_pos.ctypes.data if col_pos is not None else None,
+                                      row_group.ctypes.data if row_group is not None else None,
+                                      int(VW), int(T), int(min_reuse), C.byref(h)))
+        try:
+            sizes = np.zeros(8, dtype=np.int64)
+            check(lib.sgcn_ldsplan_sizes(h, sizes.ctypes.data))
+            nt, nch, nent, nfix, nslots, rnnz, staged = (int(x) for x in sizes[:7])
+            self.VW, self.NW, self.RW, self.S, self.U = int(VW), 8, 192 // int(VW), 128, 8
+            R = self.NW * self.RW
+            self.tile_chunk_ptr = np.empty(nt + 1, dtype=np.int32)
+            self.chunk_cols = np.empty(nch * self.S, dtype=np.int32)
+            self.ent_ptr = np.empty(nch * self.NW + 1, dtype=np.int64)
+            self.entries = np.empty(2 * (nent + 2 * self.U), dtype=np.uint32)
+            self.tile_rows = np.empty(nt * R, dtype=np.int32)
+            self.tile_slots = np.empty(nt * R, dtype=np.int32)
+            self.fix = np.empty((nfix, 3), dtype=np.int32)
+            res_rowptr = np.empty(M + 1, dtype=np.int32)
+            res_col = np.empty(rnnz, dtype=np.int32)
+            res_val = np.empty(rnnz, dtype=np.float32)
+            check(lib.sgcn_ldsplan_export(h, self.tile_chunk_ptr.ctypes.data, self.chunk_cols.ctypes.data,
+                                          self.ent_ptr.ctypes.data, self.entries.ctypes.data, self.tile_rows.ctypes.data,
+                                          self.tile_slots.ctypes.data, self.fix.ctypes.data if nfix else None,
+                                          res_rowptr.ctypes.data, res_col.ctypes.data if rnnz else None,
+                                          res_val.ctypes.data if rnnz else None))
+        finally:
+            lib.sgcn_ldsplan_destroy(h)
+        import scipy.sparse as sp
+        self.shape = (M, K)
+        self.ntiles, self.nchunks, self.nent, self.nfix, self.nslots, self.staged = nt, nch, nent, nfix, nslots, staged
+        self.nnz = int(a.nnz)
+        self.residual = sp.csr_matrix((res_val, res_col, res_rowptr), shape=(M, K))
+        self.local_nnz = self.nnz - rnnz
+
+    def decode(self):
+        """(row, column, value, workspace slot) of every non-pad entry, read back from the kernel's operands: the ring
+        slot of an entry's LDS address -> ``chunk_cols``, its register offset -> ``tile_rows``."""
+        piece = 256 * self.VW
+        half = self.S * piece
+        ent = self.entries.reshape(-1, 2)
+        rows, cols, vals, slots = [], [], [], []
+        for t in range(self.ntiles):
+            cb, ce = int(self.tile_chunk_ptr[t]), int(self.tile_chunk_ptr[t + 1])
+            nc = ce - cb
+            for w in range(self.NW):
+                base = cb * self.NW + w * nc
+                for k in range(nc):
+                    e0, e1 = int(self.ent_ptr[base + k]), int(self.ent_ptr[base + k + 1])
+                    if e1 == e0:
+                        continue
+                    assert (e1 - e0) % self.U == 0
+                    word = ent[e0:e1, 1]
+                    addr = word & np.uint32(~np.uint32(piece - 1))
+                    real = addr != 2 * half                       # pads sit on the zero piece
+                    assert np.all(ent[e0:e1, 0][~real] == 0)
+                    assert np.all(addr[real] // half == (k & 1)), "entry in the wrong ring half"
+                    slot = (addr[real] % half) // piece
+                    lr = (word[real] & np.uint32(0xff)) // self.VW
+                    place = (t * self.NW + w) * self.RW + lr.astype(np.int64)
+                    rows.append(self.tile_rows[place])
+                    slots.append(self.tile_slots[place])
+                    cols.append(self.chunk_cols[(cb + k) * self.S + slot.astype(np.int64)])
+                    vals.append(ent[e0:e1, 0][real].view(np.float32))
+        cat = lambda x, dt: np.concatenate(x) if x else np.zeros(0, dtype=dt)          # noqa: E731
+        return cat(rows, np.int32), cat(cols, np.int32), cat(vals, np.float32), cat(slots, np.int32)
+
+
+class LdsSweepCSR(object):
+    """A static CSR re-laid for the LDS-staged column sweep (sgcn_spmm_lds.hip): for graphs whose rows share columns
+    inside a tile of 768 rows (communities; ``labels`` = community per vertex, e.g. from ``reorder_labels``).  The
+    nonzeros whose column a tile references fewer than ``min_reuse`` times are multiplied by the ordinary column sweep
+    (``self.residual``: a ColumnSweepCSR) into the same output."""
+
+    def __init__(self, a, device, labels=None, VW=2, T=0, min_reuse=2, residual_G=2, host=None):
+        h = host if host is not None else LdsPlanHost(a, labels=labels, VW=VW, T=T, min_reuse=min_reuse)
+        self.host_stats = dict(ntiles=h.ntiles, nchunks=h.nchunks, nent=h.nent, staged=h.staged, nnz=h.nnz,
+                               local_nnz=h.local_nnz, pad_fraction=1.0 - h.local_nnz / max(h.nent, 1),
+                               reuse=h.local_nnz / max(h.staged, 1))
+        self.shape, self.nnz, self.device = h.shape, h.nnz, device
+        self.VW, self.NW, self.RW, self.S, self.U = h.VW, h.NW, h.RW, h.S, h.U
+        self.ntiles, self.nchunks, self.nent, self.nfix, self.nslots = h.ntiles, h.nchunks, h.nent, h.nfix, h.nslots
+        to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)          # noqa: E731
+        self.tile_chunk_ptr, self.chunk_cols = to(h.tile_chunk_ptr), to(h.chunk_cols)
+        self.ent_ptr, self.entries = to(h.ent_ptr), to(h.entries.view(np.int32))
+        self.tile_rows, self.tile_slots = to(h.tile_rows), to(h.tile_slots)
+        self.fix = to(h.fix) if h.nfix else None
+        self.ws = None
+        self.residual = None
+        if h.residual.nnz:
+            self.residual = ColumnSweepCSR(h.residual, device, G=residual_G) if residual_G else \
+                DeviceCSR.from_scipy(h.residual, device)
+
+    def struct(self, d):
+        ldw = (d + 3) // 4 * 4
+        need = self.nslots * ldw
+        if need and (self.ws is None or self.ws.numel() < need):
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        return _ffi.LdsPlan(self.VW, self.NW, self.RW, self.S, self.U, self.ntiles, self.nchunks, self.nent,
+                            self.tile_chunk_ptr.data_ptr(), self.chunk_cols.data_ptr(), self.ent_ptr.data_ptr(),
+                            self.entries.data_ptr(), self.tile_rows.data_ptr(), self.tile_slots.data_ptr(),
+                            _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
+                            0 if self.ws is None else self.ws.numel())
+
+    def autotune(self, B, d=None):
+        """The residual's sweep clock (the LDS kernel itself is not clock-paced)."""
+        if isinstance(self.residual, ColumnSweepCSR):
+            return self.residual.autotune(B, d=d)
+        return None
+
+
+def spmm_lds(A, B, out=None, gidx=None, rscale=None, beta=0.0, d=None, local_only=False):
+    """C = rscale (.) (A B[g]) + beta C for an LdsSweepCSR: the planned nonzeros through the LDS ring
+    (sgcn_spmm_lds_f32), then the residual on top (column sweep with beta = 1)."""
+    M, K = A.shape
+    bptr, ldb = _rows2d(B, "B")
+    d = int(B.shape[1] if d is None else d)
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an existing `out`")
+        pitch = (d + 3) // 4 * 4
+        out = torch.empty((M, pitch), dtype=torch.float32, device=B.device)[:, :d]
+    cptr, ldc = _rows2d(out, "out")
+    plan = A.struct(d)
+    check(lib.sgcn_spmm_lds_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(gidx, torch.int32, "gidx")),
+                                _ptr(_dev(rscale, torch.float32, "rscale")), cptr, ldc, float(beta), _stream()))
+    if A.residual is not None and not local_only:
+        if isinstance(A.residual, ColumnSweepCSR):
+            spmm_cs(A.residual, B, out=out, gidx=gidx, rscale=rscale, beta=1.0, d=d)
+        else:
+            spmm(A.residual, B, out=out, gidx=gidx, rscale=rscale, beta=1.0, d=d)
+    return out
+
+
 # ---- fp32 MFMA GEMM / fused dense layer (sgcn_gemm.hip) ------------------------------------------
 # Every dense product of the model runs on this library's own kernel, whatever its size (round 3: the size-keyed
 # rocBLAS path above 512 M multiply-adds -- Exact-mode and large evaluation batches -- is gone: one code path; the

@@ -786,3 +786,67 @@ def test_column_sweep_plan_cache_round_trip_both_group_counts(dev, tmp_path):
             f.truncate(1000)                                                    # cache miss, not a crash at startup
         assert not ops.ColumnSweepCSR.cached(a, dev, path, G=G)[1]
     assert [ops.ColumnSweepCSR.choose_g(d) for d in (32, 128, 256, 320, 602, 640)] == [2, 2, 2, 1, 2, 2]
+
+
+# ---- LDS-staged column sweep (sgcn_spmm_lds.hip) ---------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6), (500, 500, 256, 0),
+                                         (64, 64, 130, 2), (90, 70, 30, 2), (5000, 3000, 602, 6), (2000, 1500, 129, 3)])
+@pytest.mark.parametrize("min_reuse", [1, 2])
+def test_lds_sweep_vs_oracle(dev, M, K, d, pad, min_reuse):
+    """The LDS-staged sweep (+ its residual through the ordinary sweep) against the oracle: plain product, split rows,
+    labels, row scale / gather index / beta, bit-identical reruns, pitch padding untouched."""
+    from stochastic_gcn_amd import ops
+    a = rand_csr(M, K, 0.08 if M < 1000 else 0.01, M + d, long_rows=[(0, min(K, 300)), (M // 2, min(K, 150))])
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((K, d + pad)).astype(np.float32)
+    Bd = T(B, dev)[:, :d]
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    lab = (rng.randint(0, 3, M).astype(np.int32), rng.randint(0, 3, K).astype(np.int32))
+    for labels, T_ in ((None, 0), (lab, 32)):
+        A = ops.LdsSweepCSR(a, dev, labels=labels, T=T_, min_reuse=min_reuse)
+        if T_:
+            assert A.nfix >= 1
+        if min_reuse == 1:
+            assert A.residual is None
+        out_full = torch.full((M, d + pad), 7.0, device=dev)
+        out = ops.spmm_lds(A, Bd, out=out_full[:, :d])
+        assert onp.rel_err(out.cpu().numpy(), ref) <= TOL
+        if pad:
+            assert torch.all(out_full[:, d:] == 7.0)
+        assert torch.equal(ops.spmm_lds(A, Bd), out)                   # deterministic
+    H = rng.standard_normal((4000, d + pad)).astype(np.float32)
+    g = rng.choice(4000, K, replace=False).astype(np.int32)
+    rs = rng.rand(M).astype(np.float32)
+    c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
+    o2 = T(c0, dev)
+    ops.spmm_lds(A, T(H, dev)[:, :d], out=o2[:, :d], gidx=T(g, dev), rscale=T(rs, dev), beta=0.5)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, H[:, :d], gidx=g, rscale=rs, C_in=c0[:, :d], beta=0.5)
+    assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
+    if pad:
+        np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
+
+
+def test_lds_sweep_on_communities_vs_oracle_and_column_sweep(dev):
+    """A graph WITH communities at a size where tiles, chunks and the XCD placement all matter (a few hundred chunks
+    per tile): the LDS sweep == the oracle == the plain column sweep up to summation order."""
+    from stochastic_gcn_amd import ops, synthetic
+    data = synthetic.reddit_sbm(n=30000, m=1500000, classes=7, splits=(20000, 4000, 6000), p_in=0.8, seed=2)
+    a = data[2]
+    comm = data[6].argmax(1).astype(np.int32)
+    d = 602
+    rng = np.random.RandomState(0)
+    B = np.zeros((a.shape[1], 608), np.float32)
+    B[:, :d] = rng.standard_normal((a.shape[1], d))
+    Bd = T(B, dev)[:, :d]
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    A = ops.LdsSweepCSR(a, dev, labels=comm, min_reuse=2)
+    assert A.host_stats["reuse"] > 3 and A.residual is not None
+    c1 = ops.spmm_lds(A, Bd)
+    assert onp.rel_err(c1.cpu().numpy(), ref) <= TOL
+    c0 = ops.spmm_cs(ops.ColumnSweepCSR(a, dev, G=2), Bd)
+    assert float((c0 - c1).abs().max() / c0.abs().max()) <= 1e-5
+    assert torch.equal(ops.spmm_lds(A, Bd), c1)
+    # the planned part alone + the residual alone = the whole (linearity over the split)
+    loc = ops.spmm_lds(A, Bd, local_only=True)
+    res = ops.spmm_cs(A.residual, Bd)
+    assert float((loc + res - c1).abs().max() / c1.abs().max()) <= 1e-5

@@ -1,0 +1,80 @@
+"""The LDS-sweep plan (sgcn_ldsplan_*, host arithmetic) without a GPU: the kernel's own operands, decoded the way the
+kernel reads them (ring slot of an entry's LDS address -> chunk_cols, register offset -> tile_rows), plus the residual
+CSR, are exactly the matrix the plan was built from."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+
+def _matrix(m, k, dens, seed, long_rows=()):
+    rng = np.random.RandomState(seed)
+    a = sp.random(m, k, density=dens, format='lil', random_state=rng, dtype=np.float32)
+    for r, n in long_rows:
+        cols = rng.choice(k, min(n, k), replace=False)
+        a[r, cols] = rng.rand(len(cols)).astype(np.float32) + 0.1
+    a = a.tocsr()
+    a.data[:] = rng.standard_normal(a.nnz).astype(np.float32)
+    a.sort_indices()
+    return a
+
+
+def _check(a, labels, min_reuse, T=0):
+    from stochastic_gcn_amd import ops
+    h = ops.LdsPlanHost(a, labels=labels, min_reuse=min_reuse, T=T)
+    r, c, v, s = h.decode()
+    assert r.shape[0] + h.residual.nnz == a.nnz                       # nothing lost, nothing doubled
+    assert np.all(r >= 0)
+    loc = sp.coo_matrix((v.astype(np.float64), (r, c)), shape=a.shape).tocsr()
+    diff = abs((loc + h.residual.astype(np.float64)) - a.astype(np.float64))
+    assert diff.nnz == 0 or diff.max() == 0.0
+    # a split row's pieces land in consecutive workspace slots of ITS fix record
+    fix = {int(f[0]): (int(f[1]), int(f[2])) for f in h.fix}
+    for row, slot in zip(r[s >= 0], s[s >= 0]):
+        f0, n = fix[int(row)]
+        assert f0 <= slot < f0 + n
+    assert not np.any(np.isin(r[s < 0], list(fix.keys())))
+    return h
+
+
+@pytest.mark.parametrize("m,k,dens", [(5, 7, 0.5), (100, 300, 0.1), (1000, 1000, 0.02), (3000, 2000, 0.01)])
+def test_plan_is_the_matrix(m, k, dens):
+    a = _matrix(m, k, dens, m + k, long_rows=[(0, 200)])
+    rng = np.random.RandomState(1)
+    h1 = _check(a, None, 1)
+    assert h1.residual.nnz == 0 and h1.local_nnz == a.nnz
+    _check(a, None, 2)
+    lab = (rng.randint(0, 3, m).astype(np.int32), rng.randint(0, 3, k).astype(np.int32))
+    h = _check(a, lab, 2, T=16)
+    assert h.nfix >= 1 and h.ntiles >= 3 or m < 10
+
+
+def test_plan_edge_cases():
+    _check(sp.csr_matrix((10, 10), dtype=np.float32), None, 1)        # no nonzeros at all
+    _check(sp.csr_matrix((0, 5), dtype=np.float32), None, 1)          # no rows
+    a = _matrix(50, 40, 0.3, 3)
+    a[7] = 0                                                          # an empty row in the middle
+    a = a.tocsr()
+    a.eliminate_zeros()
+    _check(a, None, 3)
+
+
+def test_plan_rejects_bad_input():
+    from stochastic_gcn_amd import ops, _ffi
+    a = _matrix(20, 20, 0.3, 5)
+    with pytest.raises(_ffi.SgcnError):
+        ops.LdsPlanHost(a, labels=(None, np.zeros(20, np.int32) - 1), min_reuse=1) if False else \
+            ops.LdsPlanHost(a, labels=(np.full(20, -1, np.int32), None), min_reuse=1)
+    with pytest.raises(ValueError):
+        ops.LdsPlanHost(a, labels=(None, np.zeros(19, np.int32)))
+
+
+def test_plan_on_a_graph_with_communities_stages_shared_columns():
+    from stochastic_gcn_amd import synthetic
+    data = synthetic.reddit_sbm(n=20000, m=800000, classes=5, splits=(15000, 2000, 3000), p_in=0.8, seed=2)
+    a = data[2]
+    comm = data[6].argmax(1).astype(np.int32)
+    h = _check(a, comm, 2)
+    assert h.local_nnz / a.nnz > 0.75                # the in-community nonzeros ride the ring ...
+    assert h.local_nnz / h.staged > 4.0              # ... with real reuse per staged piece
+    flat = _check(a, None, 2)                        # without labels the same matrix shares far less
+    assert flat.local_nnz / max(flat.staged, 1) < h.local_nnz / h.staged
