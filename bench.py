@@ -517,15 +517,19 @@ def main(argv=None):
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # SGCN_FORCE_PG=1: a one-rank job takes the collective paths too (a real RCCL process group of one rank), so that
+    # `bench.py --gpus 1` shows RCCL loading and prints grad_allreduce_ms
+    pg = world > 1 or os.environ.get("SGCN_FORCE_PG", "0") not in ("", "0")
+    if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if local_rank == 0:
         g.build(quiet=True)          # no-op when the in-tree .so files travelled with the snapshot
-    if world > 1:
+    if pg:
         dist.barrier()
     from stochastic_gcn_amd import ops, _ffi
     for kv in args.tune:
@@ -602,7 +606,7 @@ def main(argv=None):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     ev_ar = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-             for _ in range(args.steps)] if (world > 1 and not args.shard) else []
+             for _ in range(args.steps)] if (pg and not args.shard) else []
 
     def step_sharded(i=None):
         gather = args.shard == "allgather"
@@ -625,7 +629,7 @@ def main(argv=None):
             ev[i][1].record()
         if not args.no_backward:
             mm(A.transpose, dC, out=dX)
-        if world > 1:
+        if pg:
             if i is not None:
                 ev_ar[i][0].record()
             dist.all_reduce(grad)
@@ -634,17 +638,17 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if pg:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if pg:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -668,7 +672,7 @@ def main(argv=None):
         "config": {"workload": wname + ", fwd A.X%s, d=%d (pitch %d)%s" % (
             "" if args.no_backward else " + bwd A^T.dC", d, pitch,
             (", + all-gather of the dense operand per product" if args.shard == "allgather" else "") if sh is not None
-            else (", + RCCL all-reduce of %d grad floats" % gfl if world > 1 else "")),
+            else (", + RCCL all-reduce of %d grad floats" % gfl if pg else "")),
             "N": n, "nnz": nnz, "d": d,
             "per_gpu": ("nnz-balanced row block of ONE graph, dense operand %s; rank 0 rows [%d, %d), %d nnz"
                         % (args.shard, sh.lo, sh.hi, sh.local_nnz)) if sh is not None
@@ -789,7 +793,7 @@ def main(argv=None):
             out["train_epoch"] = {"error": repr(e)}
         dog.cancel()
     emit()
-    if world > 1:
+    if pg:
         dist.destroy_process_group()
     return out
 

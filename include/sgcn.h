@@ -168,27 +168,38 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  * whose rows share columns inside a compute unit's tile (communities) that traffic can live in
  * the LDS instead.  A TILE is NW x RW virtual rows of ONE workgroup (wave w keeps the
  * accumulators of its RW rows in registers); the tile's nonzeros are sorted by sweep position
- * of their column and cut into CHUNKS of at most S distinct columns; a chunk's pieces of B are
- * staged once into an LDS ring and every nonzero of the chunk reads its piece from there.
- * Nonzeros whose column the tile references fewer than `min_reuse` times are left out of the
- * plan and returned as a residual CSR (same M x K), to be added by sgcn_spmm_cs_f32 / _csr_f32.
- *   entries[2 i] = value bits, entries[2 i + 1] = word:
- *       word = LDS byte address of the piece ((chunk parity) * S * P + slot * P, P = 256 * VW bytes;
- *              the zero piece at 2 * S * P for pads)  |  register offset of the row (local row * VW)
+ * of their column and cut into CHUNKS of at most S distinct columns (and at most 256 -- general
+ * plans 128 -- entries per wave); a chunk's pieces of B are staged once into an LDS ring and every nonzero of the chunk
+ * reads its piece from there.  Nonzeros whose column the tile references fewer than `min_reuse`
+ * times are left out of the plan and returned as a residual CSR (same M x K), to be added by
+ * sgcn_spmm_cs_f32 / _csr_f32.
+ *   words[i] = LDS byte address of the piece ((chunk index mod 3) * S * P + slot * P, P = 256 * VW bytes;
+ *              the zero piece at 3 * S * P for pads)  |  register offset of the row (local row * VW)
+ *   vals[i]  = the nonzero's value (general plans).  UNIT plans: every nonzero of a row has the same
+ *              value (row-normalised adjacency); it is kept once per row in row_fold[M] (1 for empty
+ *              rows) and applied with the row scale -- no vals.
  *   entries are ordered (tile, wave, chunk); a wave's share of a chunk is padded to a multiple of
- *   U entries (pads: value 0 on the zero piece); two groups of U pad entries end the array (the
- *   kernel reads its entry stream two groups ahead).
+ *   U entries (pads: value 0 on the zero piece); 256 pad entries end the arrays (the kernel loads
+ *   256 slots from the start of a wave's share, whatever its length).
  *   ent_ptr[(first chunk of the tile) * NW + w * (chunks of the tile) + k] = first entry of wave w in
  *   the tile's k-th chunk (one more element ends the array).
+ *   chunk_hdr[(chunk * NW + w) * 16 ..]: what wave w needs to REQUEST the chunk, in one 64-byte read: the
+ *   S / NW column ids of its ring slots, then its entry count in groups of U, then the 64-bit index of
+ *   its first entry (low, high word).  (chunk_cols / ent_ptr hold the same facts chunk-wise.)
  * New -- the reference has no such kernel; the op is gcn/layers.py:31-37 (dot(x, y, sparse=True)). */
 typedef struct {
     int32_t VW, NW, RW, S, U;       /* floats per lane (2: 128-column slabs), waves per tile (8), rows per wave
-                                       (192 / VW = 96), ring slots per half (128), entries per group (8)  */
+                                       (192 / VW = 96), slots per ring part (80; three parts), entries per group (8) */
+    int32_t unit;                   /* != 0: values folded into dev_row_fold, dev_vals unused             */
+    int32_t xcd_tile_ptr[9];        /* tiles [p[x], p[x + 1]) run on XCD x: contiguous ranges of equal estimated time    */
     int64_t ntiles, nchunks, nent;
     const int32_t* dev_tile_chunk_ptr; /* [ntiles + 1]                                            */
     const int32_t* dev_chunk_cols;  /* [nchunks * S] column of every slot (padded with a valid one) */
+    const int32_t* dev_chunk_hdr;   /* [nchunks * NW * 16]                                         */
     const int64_t* dev_ent_ptr;     /* [nchunks * NW + 1]                                          */
-    const uint32_t* dev_entries;    /* [2 * (nent + 2 U)]                                          */
+    const uint32_t* dev_words;      /* [nent + 256]                                                */
+    const float* dev_vals;          /* [nent + 256] (general plans)                                */
+    const float* dev_row_fold;      /* [M] (unit plans)                                            */
     const int32_t* dev_tile_rows;   /* [ntiles * NW * RW] output row of each virtual row, -1 = pad  */
     const int32_t* dev_tile_slots;  /* [ntiles * NW * RW] workspace slot, -1 = store to C directly  */
     const sgcn_fix_t* dev_fix; int64_t nfix; int64_t nslots;
@@ -198,22 +209,28 @@ typedef struct {
  *   col_pos   nullable [K]: sweep position of every column (a permutation; community by community);
  *   row_group nullable [M]: tiles are formed inside groups, groups in label order;
  *   T         rows longer than T become strided virtual rows (<= 0: 2048);
- *   min_reuse a column is staged for a tile only if the tile references it at least this often (>= 1).
- * sizes[8] = {ntiles, nchunks, nent, nfix, nslots, residual nnz, staged pieces (sum over chunks of distinct
- * columns), 0}. */
+ *   min_reuse a column is staged for a tile only if the tile references it at least this often (>= 1);
+ *   mode      0: a unit plan when the values allow it, 1: always a general plan.
+ * sizes[17] = {ntiles, nchunks, nent, nfix, nslots, residual nnz, staged pieces (sum over chunks of distinct
+ * columns), unit, xcd_tile_ptr[0..8]}. */
 typedef struct sgcn_ldsplan_host sgcn_ldsplan_host_t;
 int sgcn_ldsplan_create(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val,
                         int32_t M, int32_t K, const int32_t* host_col_pos, const int32_t* host_row_group,
-                        int32_t VW, int32_t T, int32_t min_reuse, sgcn_ldsplan_host_t** out);
-int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* sizes8);
+                        int32_t VW, int32_t T, int32_t min_reuse, int32_t mode, sgcn_ldsplan_host_t** out);
+int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* sizes17);
 int sgcn_ldsplan_export(const sgcn_ldsplan_host_t* h, int32_t* tile_chunk_ptr, int32_t* chunk_cols,
-                        int64_t* ent_ptr, uint32_t* entries, int32_t* tile_rows, int32_t* tile_slots,
-                        sgcn_fix_t* fix, int32_t* res_rowptr, int32_t* res_col, float* res_val);
+                        int32_t* chunk_hdr, int64_t* ent_ptr, uint32_t* words, float* vals, float* row_fold,
+                        int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix, int32_t* res_rowptr,
+                        int32_t* res_col, float* res_val);
 void sgcn_ldsplan_destroy(sgcn_ldsplan_host_t* h);
-/* C[M x d] = rscale (.) (A_local * B[g]) + beta * C   (A_local = the planned nonzeros; the residual is the caller's) */
+/* C[M x d] = rscale (.) (A_local * B) + beta * C   (A_local = the planned nonzeros; the residual is the caller's) */
 int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t K, int32_t d,
-                      const float* dev_B, int64_t ldb, const int32_t* dev_gidx, const float* dev_rscale,
+                      const float* dev_B, int64_t ldb, const float* dev_rscale,
                       float* dev_C, int64_t ldc, float beta, void* stream);
+
+/* Experiments: per-wave cycle counts by phase of the next sgcn_spmm_lds_f32 launches into dev_buf (8 x 8 uint64 per
+ * workgroup; NULL switches it off).  profiles/lds_phase_probe.py reads it. */
+int sgcn_lds_profile_buffer(void* dev_buf);
 
 /* Runtime tuning knobs for experiments (bench.py --tune key=value); unknown key -> error.
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)

@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from stochastic_gcn_amd import ops, synthetic  # noqa: E402
 
 
@@ -53,9 +53,9 @@ def main():
                 t0 = time.time()
                 lab, ncomm = ops.reorder_labels(a)
                 lp_s = time.time() - t0
-            for mr in (1, 2, 3):
+            for mr, general in ((1, False), (2, False), (2, True), (3, False)):
                 t0 = time.time()
-                A = ops.LdsSweepCSR(a, dev, labels=lab, min_reuse=mr)
+                A = ops.LdsSweepCSR(a, dev, labels=lab, min_reuse=mr, general=general)
                 build_s = time.time() - t0
                 if A.residual is not None:
                     A.autotune(Bd)

@@ -868,6 +868,7 @@ __global__ void reduce_multi_kernel(ReduceMulti R) { reduce_multi_body(R, (int)b
 
 // reductions parked for the optimizer's launch (sgcn_gemm.hip dw_group_flush, when sgcn_step_run sees ADAM right behind it)
 namespace { struct PendingReduce { bool on = false; ReduceMulti R; int blocks = 0; }; PendingReduce& pending_reduce() { static PendingReduce p; return p; } }
+bool reduce_parked() { return pending_reduce().on; }       // (its operands point into the aux ring: sgcn_gemm.hip aux_join)
 bool reduce_park(const ReduceMulti& R, int blocks) {
     PendingReduce& p = pending_reduce();
     if (p.on) return false;
@@ -1024,6 +1025,8 @@ extern "C" int sgcn_softmax_ce_f32(const float* logits, int64_t ldz, const float
                                    int64_t ldl, int32_t n, int32_t c, float* dlogits, int64_t lddz,
                                    float* pred, int64_t ldp, float* stats, float* rowstat,
                                    void* stream) {
+    // the class plane of rowstat packs prediction + 4096 * label into one exact fp32
+    SGCN_REQUIRE(!(pred && rowstat) || c <= 4096, "softmax_ce: the class plane of rowstat holds at most 4096 classes (c = %d)", c);
     return sgcn::ce_impl(true, logits, ldz, labels, ldl, n, c, dlogits, lddz, pred, ldp, stats, rowstat, stream, false, nullptr);
 }
 

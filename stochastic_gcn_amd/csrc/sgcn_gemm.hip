@@ -768,6 +768,7 @@ int aux_fork(void* stream, void** aux_stream) {
     return SGCN_OK;
 }
 
+bool reduce_parked();           // sgcn_dense.hip: a reduction parked for the optimizer's launch still reads the ring
 int aux_join(void* stream) {
     AuxCtx& c = aux_ctx();
     if (c.pending) {
@@ -775,7 +776,10 @@ int aux_join(void* stream) {
         SGCN_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c.join, 0));
         c.pending = false;
     }
-    if (g_dw_recorded > 0) return SGCN_OK;          // recorded jobs still own their regions of the ring
+    // recorded jobs still own their regions of the ring, and so does a reduction parked for the optimizer (its split-K
+    // partials and LayerNorm partials live there until adam_with_stats launches it): no reset, and above all no
+    // free-and-regrow, until both are gone -- the join at the end of sgcn_step_run does it
+    if (g_dw_recorded > 0 || reduce_parked()) return SGCN_OK;
     c.off = 0;
     if (c.want > c.cap) {                 // a call did not fit: grow for the next step (nothing is in flight on
         SGCN_HIP_TRY(hipStreamSynchronize(c.st));          // the aux stream once it is idle)

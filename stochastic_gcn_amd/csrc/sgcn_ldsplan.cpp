@@ -16,9 +16,12 @@
 
 struct sgcn_ldsplan_host {
     int32_t VW, NW, RW, S, U, M, K;
-    std::vector<int32_t> tile_chunk_ptr, chunk_cols, tile_rows, tile_slots;
+    std::vector<int32_t> tile_chunk_ptr, chunk_cols, chunk_hdr, tile_rows, tile_slots;
     std::vector<int64_t> ent_ptr;
-    std::vector<uint32_t> entries;          // 2 per entry: value bits, word
+    std::vector<uint32_t> words;
+    std::vector<float> vals, row_fold;
+    int32_t unit = 0;
+    int32_t xcd_tile_ptr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<sgcn_fix_t> fix;
     int64_t nslots = 0, nent = 0, staged = 0;
     std::vector<int32_t> res_rowptr, res_col;
@@ -51,7 +54,8 @@ struct Edge { int32_t pos, col, w, lr; float val; int32_t row; };
 
 struct TileOut {
     std::vector<int32_t> chunk_cols;                // nchunks * S
-    std::vector<std::vector<uint32_t>> wave_ent;    // per wave: entries (2 words each), chunk after chunk
+    std::vector<std::vector<uint32_t>> wave_word;   // per wave: entry words, chunk after chunk
+    std::vector<std::vector<float>> wave_val;       // ... and values
     std::vector<std::vector<int64_t>> wave_cnt;     // per wave: entries per chunk (padded)
     std::vector<Edge> residual;
     int64_t staged = 0;
@@ -63,16 +67,16 @@ extern "C" {
 
 int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t K,
                         const int32_t* col_pos, const int32_t* row_group, int32_t VW, int32_t T, int32_t min_reuse,
-                        sgcn_ldsplan_host_t** out) {
+                        int32_t mode, sgcn_ldsplan_host_t** out) {
     if (!out || M < 0 || K < 0 || (M > 0 && (!rowptr || !col || !val)))
         return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: bad argument");
     if (VW != 2) return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: VW must be 2 (128-column slabs)");
     if (min_reuse < 1) min_reuse = 1;
     if (T <= 0) T = 2048;
-    const int32_t NW = 8, RW = 192 / VW, S = 128, GE = 8;
+    const int32_t NW = 8, RW = 192 / VW, S = 80, GE = 8, NPART = 3;
     const int32_t R = NW * RW;
     const uint32_t piece = 256u * (uint32_t)VW;
-    const uint32_t zero_addr = 2u * S * piece;
+    const uint32_t zero_addr = (uint32_t)NPART * S * piece;
     for (int32_t r = 0; r < M; r++)
         if (rowptr[r + 1] < rowptr[r]) return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: rowptr not monotone at %d", r);
     if (row_group)
@@ -92,6 +96,19 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
     }
     auto* h = new sgcn_ldsplan_host();
     h->VW = VW; h->NW = NW; h->RW = RW; h->S = S; h->U = GE; h->M = M; h->K = K;
+
+    // unit plan: every nonzero of a row carries the same value (bit for bit) -> kept once per row, beside the row scale
+    h->row_fold.assign((size_t)M, 1.0f);
+    h->unit = mode == 0 ? 1 : 0;
+    for (int32_t r = 0; r < M && h->unit; r++) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (e > b) h->row_fold[(size_t)r] = val[b];
+        for (int32_t p = b + 1; p < e; p++)
+            if (std::memcmp(&val[p], &val[b], 4) != 0) { h->unit = 0; break; }
+    }
+    if (!h->unit) std::fill(h->row_fold.begin(), h->row_fold.end(), 1.0f);
+    // entries per wave and chunk the kernel's entry ring holds: 4 registers of 64 words (unit), 2 of words + 2 of values
+    const int32_t CAP = h->unit ? 256 : 128;
 
     // split rows -> workspace slots, consecutive per row, in row order (the fix-up adds them in this order)
     std::vector<int32_t> first_slot((size_t)M, -1);
@@ -173,6 +190,7 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
 
     // per tile (independent: a few host threads): sort by sweep position, count references per column, chunk
     std::vector<TileOut> outs((size_t)ntiles);
+    std::atomic<int> overflow{0};
     auto build_tile = [&](int64_t t) {
         const TileRows& tr = tiles[(size_t)t];
         TileOut& o = outs[(size_t)t];
@@ -187,9 +205,10 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         }
         // by sweep position; ties (the same column): by wave, then in row-stream order (stable) -- deterministic
         std::stable_sort(e.begin(), e.end(), [](const Edge& x, const Edge& y) { return x.pos < y.pos; });
-        o.wave_ent.assign((size_t)NW, {});
+        o.wave_word.assign((size_t)NW, {});
+        o.wave_val.assign((size_t)NW, {});
         o.wave_cnt.assign((size_t)NW, {});
-        std::vector<int64_t> cnt((size_t)NW, 0);
+        std::vector<int64_t> cnt((size_t)NW, 0), add((size_t)NW, 0);
         int32_t nslot = 0;                   // slots used in the open chunk
         int64_t nchunks = 0;
         auto close_chunk = [&]() {
@@ -198,8 +217,8 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             for (int32_t s = nslot; s < S; s++) o.chunk_cols.push_back(last);      // unused slots fetch a valid column
             for (int32_t wv = 0; wv < NW; wv++) {
                 while (cnt[(size_t)wv] % GE) {                                     // pads: value 0 on the zero piece
-                    o.wave_ent[(size_t)wv].push_back(0u);
-                    o.wave_ent[(size_t)wv].push_back(zero_addr);
+                    o.wave_word[(size_t)wv].push_back(zero_addr);
+                    o.wave_val[(size_t)wv].push_back(0.f);
                     cnt[(size_t)wv]++;
                 }
                 o.wave_cnt[(size_t)wv].push_back(cnt[(size_t)wv]);
@@ -215,16 +234,22 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             if ((int64_t)(j - i) < min_reuse) {
                 for (size_t q = i; q < j; q++) o.residual.push_back(e[q]);
             } else {
-                if (nslot == S) close_chunk();
-                const uint32_t addr = (uint32_t)(nchunks & 1) * S * piece + (uint32_t)nslot * piece;
+                // a chunk holds at most S columns and at most CAP entries per wave (what the kernel loads per chunk)
+                std::fill(add.begin(), add.end(), 0);
+                for (size_t q = i; q < j; q++) add[(size_t)e[q].w]++;
+                bool over = nslot == S;
+                for (int32_t wv = 0; wv < NW; wv++) {
+                    over = over || cnt[(size_t)wv] + add[(size_t)wv] > CAP;
+                    if (add[(size_t)wv] > CAP) overflow = 1;          // (one column, more entries of one wave than the ring holds: duplicates)
+                }
+                if (over) close_chunk();
+                const uint32_t addr = (uint32_t)(nchunks % NPART) * S * piece + (uint32_t)nslot * piece;
                 o.chunk_cols.push_back(e[i].col);
                 nslot++;
                 o.staged++;
                 for (size_t q = i; q < j; q++) {
-                    uint32_t bits;
-                    std::memcpy(&bits, &e[q].val, 4);
-                    o.wave_ent[(size_t)e[q].w].push_back(bits);
-                    o.wave_ent[(size_t)e[q].w].push_back(addr | (uint32_t)(e[q].lr * VW));
+                    o.wave_word[(size_t)e[q].w].push_back(addr | (uint32_t)(e[q].lr * VW));
+                    o.wave_val[(size_t)e[q].w].push_back(e[q].val);
                     cnt[(size_t)e[q].w]++;
                 }
             }
@@ -242,23 +267,28 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         for (auto& th : pool) th.join();
     }
 
+    if (overflow) {
+        delete h;
+        return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: a column holds more entries of one wave than a chunk may (duplicate nonzeros?)");
+    }
     // assemble: chunks tile after tile; entries in (tile, wave, chunk) order
     h->tile_chunk_ptr.assign((size_t)ntiles + 1, 0);
     int64_t nchunks = 0, nent = 0;
     for (int64_t t = 0; t < ntiles; t++) {
         nchunks += (int64_t)outs[(size_t)t].chunk_cols.size() / S;
         h->tile_chunk_ptr[(size_t)t + 1] = (int32_t)nchunks;
-        for (int32_t wv = 0; wv < NW; wv++) nent += (int64_t)outs[(size_t)t].wave_ent[(size_t)wv].size() / 2;
+        for (int32_t wv = 0; wv < NW; wv++) nent += (int64_t)outs[(size_t)t].wave_word[(size_t)wv].size();
         h->staged += outs[(size_t)t].staged;
     }
-    if (nchunks >= (1ll << 31) / S || (nent + 2 * GE) * 8 >= (1ll << 32)) {
+    if (nchunks >= (1ll << 31) / S) {
         delete h;
-        return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: plan too large (entry offsets must stay below 4 GiB)");
+        return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: plan too large");
     }
     h->nent = nent;
     h->chunk_cols.reserve((size_t)nchunks * S);
     h->ent_ptr.assign((size_t)nchunks * NW + 1, 0);
-    h->entries.reserve((size_t)(nent + 2 * GE) * 2);
+    h->words.reserve((size_t)(nent + 256));
+    h->vals.reserve((size_t)(nent + 256));
     int64_t e0 = 0;
     for (int64_t t = 0; t < ntiles; t++) {
         const TileOut& o = outs[(size_t)t];
@@ -269,11 +299,51 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
                 h->ent_ptr[(size_t)(cb * NW + wv * nc + k)] = e0;
                 e0 += o.wave_cnt[(size_t)wv][(size_t)k];
             }
-            h->entries.insert(h->entries.end(), o.wave_ent[(size_t)wv].begin(), o.wave_ent[(size_t)wv].end());
+            h->words.insert(h->words.end(), o.wave_word[(size_t)wv].begin(), o.wave_word[(size_t)wv].end());
+            h->vals.insert(h->vals.end(), o.wave_val[(size_t)wv].begin(), o.wave_val[(size_t)wv].end());
         }
     }
     h->ent_ptr[(size_t)nchunks * NW] = e0;
-    for (int32_t q = 0; q < 2 * GE; q++) { h->entries.push_back(0u); h->entries.push_back(zero_addr); }   // read-ahead
+    // contiguous tile ranges for the 8 XCDs, balanced by estimated TIME, not by count: a tile costs its entries (per wave)
+    // plus a fixed amount per chunk (measured: ~39 cycles per entry of a wave, ~1800 per chunk for barrier, fill issue and
+    // pipeline start), and tiles of large sparse communities have four times the chunks of small dense ones
+    {
+        std::vector<double> w((size_t)ntiles);
+        double tot = 0;
+        for (int64_t t = 0; t < ntiles; t++) {
+            int64_t ne = 0;
+            for (int32_t wv = 0; wv < NW; wv++) ne += (int64_t)outs[(size_t)t].wave_word[(size_t)wv].size();
+            w[(size_t)t] = 39.0 * (double)ne / NW + 1800.0 * (double)(h->tile_chunk_ptr[(size_t)t + 1] - h->tile_chunk_ptr[(size_t)t]) + 20000.0;
+            tot += w[(size_t)t];
+        }
+        double acc = 0;
+        int64_t t = 0;
+        for (int x = 1; x < 8; x++) {
+            while (t < ntiles && acc + 0.5 * w[(size_t)t] < tot * x / 8.0) acc += w[(size_t)t++];
+            h->xcd_tile_ptr[x] = (int32_t)t;
+        }
+        h->xcd_tile_ptr[0] = 0;
+        h->xcd_tile_ptr[8] = (int32_t)ntiles;
+    }
+    // per (chunk, wave) header, 16 ints: what a wave needs to request a chunk, in ONE 64-byte load -- the column ids of
+    // its 2 * FPW ring slots, its entry count (in groups) and the position of its entries
+    {
+        const int32_t per = S / NW;                          // slots a wave fetches per chunk
+        h->chunk_hdr.assign((size_t)nchunks * NW * 16, 0);
+        for (int64_t t = 0; t < ntiles; t++) {
+            const int64_t cb = h->tile_chunk_ptr[(size_t)t], nc = h->tile_chunk_ptr[(size_t)t + 1] - cb;
+            for (int64_t k = 0; k < nc; k++)
+                for (int32_t wv = 0; wv < NW; wv++) {
+                    int32_t* hd = &h->chunk_hdr[(size_t)((cb + k) * NW + wv) * 16];
+                    for (int32_t q = 0; q < per; q++) hd[q] = h->chunk_cols[(size_t)(cb + k) * S + (size_t)wv * per + q];
+                    const int64_t a = h->ent_ptr[(size_t)(cb * NW + wv * nc + k)], b = h->ent_ptr[(size_t)(cb * NW + wv * nc + k) + 1];
+                    hd[per] = (int32_t)((b - a) / GE);
+                    hd[per + 1] = (int32_t)(uint32_t)(a & 0xffffffffll);
+                    hd[per + 2] = (int32_t)(a >> 32);
+                }
+        }
+    }
+    for (int32_t q = 0; q < 256; q++) { h->words.push_back(zero_addr); h->vals.push_back(0.f); }   // the kernel's over-read
 
     // residual CSR: rows in order, a row's nonzeros by column
     h->res_rowptr.assign((size_t)M + 1, 0);
@@ -316,19 +386,23 @@ int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* s) {
     s[4] = h->nslots;
     s[5] = (int64_t)h->res_col.size();
     s[6] = h->staged;
-    s[7] = 0;
+    s[7] = h->unit;
+    for (int x = 0; x < 9; x++) s[8 + x] = h->xcd_tile_ptr[x];
     return SGCN_OK;
 }
 
-int sgcn_ldsplan_export(const sgcn_ldsplan_host_t* h, int32_t* tile_chunk_ptr, int32_t* chunk_cols, int64_t* ent_ptr,
-                        uint32_t* entries, int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix,
-                        int32_t* res_rowptr, int32_t* res_col, float* res_val) {
+int sgcn_ldsplan_export(const sgcn_ldsplan_host_t* h, int32_t* tile_chunk_ptr, int32_t* chunk_cols, int32_t* chunk_hdr,
+                        int64_t* ent_ptr, uint32_t* words, float* vals, float* row_fold, int32_t* tile_rows,
+                        int32_t* tile_slots, sgcn_fix_t* fix, int32_t* res_rowptr, int32_t* res_col, float* res_val) {
     if (!h) return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_export: null plan");
     auto cp = [](void* dst, const void* src, size_t bytes) { if (dst && bytes) std::memcpy(dst, src, bytes); };
     cp(tile_chunk_ptr, h->tile_chunk_ptr.data(), h->tile_chunk_ptr.size() * 4);
     cp(chunk_cols, h->chunk_cols.data(), h->chunk_cols.size() * 4);
+    cp(chunk_hdr, h->chunk_hdr.data(), h->chunk_hdr.size() * 4);
     cp(ent_ptr, h->ent_ptr.data(), h->ent_ptr.size() * 8);
-    cp(entries, h->entries.data(), h->entries.size() * 4);
+    cp(words, h->words.data(), h->words.size() * 4);
+    cp(vals, h->vals.data(), h->vals.size() * 4);
+    cp(row_fold, h->row_fold.data(), h->row_fold.size() * 4);
     cp(tile_rows, h->tile_rows.data(), h->tile_rows.size() * 4);
     cp(tile_slots, h->tile_slots.data(), h->tile_slots.size() * 4);
     cp(fix, h->fix.data(), h->fix.size() * sizeof(sgcn_fix_t));

@@ -44,6 +44,7 @@ int g_tune_step_fuse = 127;           // bit 0: the output layer's forward as th
 int g_tune_cs_g2_wide = 0;
 int g_tune_cs_last_pct = 90;
 int g_tune_gemm_min_steps = 0;
+int g_tune_lds_dbg = 0;             // experiments on the LDS sweep: bit 0 no ring fills after the first, bit 1 no arithmetic
 }  // namespace
 
 int tune_get(const char* key) {
@@ -60,6 +61,7 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_g2_wide")) return g_tune_cs_g2_wide;
     if (!strcmp(key, "cs_last_pct")) return g_tune_cs_last_pct;
     if (!strcmp(key, "gemm_min_steps")) return g_tune_gemm_min_steps;
+    if (!strcmp(key, "lds_dbg")) return g_tune_lds_dbg;
     return -1;
 }
 
@@ -288,6 +290,7 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "step_fuse")) { SGCN_REQUIRE(value >= 0 && value <= 127, "step_fuse in 0..127"); g_tune_step_fuse = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
     if (!strcmp(key, "gemm_min_steps")) { g_tune_gemm_min_steps = (int)value; return SGCN_OK; }
+    if (!strcmp(key, "lds_dbg")) { g_tune_lds_dbg = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_last_pct")) { SGCN_REQUIRE(value >= 0 && value <= 100, "cs_last_pct in [0, 100]"); g_tune_cs_last_pct = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_unroll")) {

@@ -5,166 +5,187 @@
 // rate).  The only level below the L2 that can absorb that traffic is the LDS, and it can only if the rows that live on
 // ONE compute unit share columns.  On a graph with communities they do: a tile of 768 rows of one community references
 // every column of that community ~7 times.  So here
-//   * one workgroup (8 wavefronts, 2 per SIMD at 256 VGPRs) owns a TILE of 8 x RW virtual rows; a wave keeps the
-//     RW x (64 lanes x VW floats) accumulators of its rows in 192 pinned VGPRs (v[64:255]);
-//   * the tile's nonzeros are sorted by (community-ordered) column and cut into CHUNKS of at most S distinct columns;
-//     a chunk's S pieces of B (one 64*VW-float slab of a B row each) are staged ONCE into one half of an LDS ring by
+//   * one workgroup (8 wavefronts, 2 per SIMD at 256 VGPRs) owns a TILE of 8 x 96 virtual rows; a wave keeps the
+//     96 x (64 lanes x float2) accumulators of its rows in 192 pinned VGPRs (v[64:255]);
+//   * the tile's nonzeros are sorted by (community-ordered) column and cut into CHUNKS of at most 128 distinct columns;
+//     a chunk's pieces of B (the 128-column slab of a B row: 512 bytes) are staged ONCE into one half of an LDS ring by
 //     global_load_lds_dwordx4 (no staging registers) while the previous chunk is consumed from the other half;
-//   * a nonzero is then: ds_read (a whole-wave, conflict-free read of the staged piece), s_set_gpr_idx_idx (selects the
-//     row's accumulators: the gfx9 VGPR-indexing mode, as in sgcn_spmm_cs.hip) and VW/2 v_pk_fma_f32.  Its plan entry
-//     {value, LDS address of the piece | register offset of the row} arrives through the SCALAR cache (s_load), so the
-//     vector memory path carries nothing but the ring fills and the LDS path nothing but pieces.
+//   * a nonzero is then: ds_read_b64 (a whole-wave, conflict-free read of the staged piece), s_set_gpr_idx_idx (selects
+//     the row's accumulators: the gfx9 VGPR-indexing mode, as in sgcn_spmm_cs.hip) and ONE packed add / FMA;
+//   * its plan entry -- a 32-bit word = LDS address of the piece | register offset of the row -- was loaded a chunk
+//     ahead with the wave's other entries (64 per VGPR) and comes down by v_readlane.
+// Values: when every planned nonzero of a row has the same value (any row-normalised adjacency: the reference's
+// D^-1 A, gcn/utils.py:299-309) the plan FOLDS it into the row scale ("unit" plans): an entry is 4 bytes and a nonzero
+// is a packed ADD.  Otherwise the values travel beside the words and a nonzero is a packed FMA.
 // Columns a tile references fewer than `min_reuse` times are not worth a ring slot; the plan leaves those nonzeros to
 // a residual CSR that the ordinary column sweep adds afterwards (ops.LdsSweepCSR).
 //
-// Determinism: an accumulator receives its nonzeros in plan order; split rows meet in the ordered fix-up
-// (cs_fix-style); no atomics.  Same contract as sgcn_spmm_cs_f32 minus cscale.
+// Determinism: an accumulator receives its nonzeros in plan order; split rows meet in the ordered fix-up; no atomics.
+// Contract of sgcn_spmm_cs_f32 minus cscale and gidx.
 #include "sgcn_dev.h"
 
 namespace sgcn {
 
 struct LdsArgs {
     const int32_t* tile_chunk_ptr;      // [ntiles + 1]
-    const int32_t* chunk_cols;          // [nchunks * S] column (B row) of every ring slot, padded with a valid column
-    const int64_t* ent_ptr;             // [nchunks * NW + 1], entries in (tile, wave, chunk) order
-    const uint64_t* entries;            // {value bits, word}: word = LDS byte address of the piece | register offset
+    const int32_t* chunk_hdr;           // [nchunks * NW * 16] per (chunk, wave): its S / NW column ids, entry groups, entry index
+    const uint32_t* words;              // LDS byte address of the piece | register offset of the row
+    const float* vals;                  // parallel to words; unused by unit plans
+    const float* row_fold;              // unit plans: the value of the row's planned nonzeros (else null)
     const int32_t* tile_rows;           // [ntiles * NW * RW]
     const int32_t* tile_slots;
     const float* B; int64_t ldb;
-    const int32_t* gidx; const float* rscale;
+    const float* rscale;
     float* C; int64_t ldc; float beta;
     int32_t d, nslab, ntiles;
+    int32_t xcd_ptr[9];                 // tiles [xcd_ptr[x], xcd_ptr[x + 1]) run on XCD x
     float* ws; int64_t ldw;
+    int32_t wide;                       // B spans 4 GiB or more: 64-bit row offsets in the fills
+    unsigned long long* prof;           // experiments (sgcn_lds_profile_buffer): per workgroup and wave, cycles spent in
+                                        // {prologue, fill issue, chunk statements, fill wait, barrier, epilogue, all} + chunk count
+    int32_t dbg;                        // experiments (lds_dbg knob): bit 0 no piece fills, bit 1 no arithmetic, bit 2 no stores
 };
 
-typedef uint32_t ent16_t __attribute__((ext_vector_type(16)));     // 8 plan entries {value, word} in 16 SGPRs
 typedef float acc32_t __attribute__((ext_vector_type(32)));
 
 // ---- the inner loop: ONE asm statement per (wave, chunk) ---------------------------------------------------------------
-// Registers (fixed: the statement is the only code that runs while loads are in flight, so nothing the compiler does --
-// spills, copies -- can observe a register a load has not written yet):
-//   E0 E1 E2  s[36:51] s[52:67] s[68:83]   three groups of 8 plan entries, rotating: applied / read for / being loaded.
-//                                           Operands ("+s"): they carry the read-ahead from one chunk to the next.
-//   V0 V1     v[32:47] v[48:63]            pieces of the group being applied / of the next group (clobbers)
-//   v[28:31]                               LDS addresses (clobbers)
-//   a0 .. a5  v[64:255]                    the accumulators: row r of the wave at v[64 + 2 r : 65 + 2 r] ("+v")
-// A GROUP (8 nonzeros) of the steady state, phase P = group index mod 6 (the entry buffers rotate with period 3, the
-// piece buffers with period 2):
-//     s_waitcnt lgkmcnt(0)        this group's pieces and the next group's entries have landed -- both were requested
-//                                 before the previous group's eight FMAs
-//     8 x (v_and_or_b32, ds_read_b64)   next group's pieces: address = (word & ~511) | lane * 8
-//     s_load_dwordx16             the entries of the group after next, into the buffer whose FMAs were issued a group ago
-//     8 x (s_set_gpr_idx_idx, v_pk_fma_f32)   the row's accumulators are selected by the word's low byte (the gfx9
-//                                 VGPR-indexing mode); the value is the low word of the entry's scalar pair (op_sel_hi)
-// i.e. per nonzero 2 VALU + ~2 scalar instructions and one LDS read; no vector-memory instruction at all.
-// The statement ends with everything landed (s_waitcnt lgkmcnt(0)); the read-ahead of the chunk's last group ran into the
-// next chunk's ring half, so the next statement starts by reading its first group's pieces again (after the barrier).
-#define SGCN_LDS_READ8(EN, VN)                                                 \
-    "v_and_or_b32 v28, s[" #EN "+1], %[mask], %[lane]\n\t"                      \
-    "v_and_or_b32 v29, s[" #EN "+3], %[mask], %[lane]\n\t"                      \
-    "v_and_or_b32 v30, s[" #EN "+5], %[mask], %[lane]\n\t"                      \
-    "v_and_or_b32 v31, s[" #EN "+7], %[mask], %[lane]\n\t"                      \
-    "ds_read_b64 v[" #VN "+0:" #VN "+1], v28\n\t"                               \
-    "ds_read_b64 v[" #VN "+2:" #VN "+3], v29\n\t"                               \
-    "ds_read_b64 v[" #VN "+4:" #VN "+5], v30\n\t"                               \
-    "ds_read_b64 v[" #VN "+6:" #VN "+7], v31\n\t"                               \
-    "v_and_or_b32 v28, s[" #EN "+9], %[mask], %[lane]\n\t"                      \
-    "v_and_or_b32 v29, s[" #EN "+11], %[mask], %[lane]\n\t"                     \
-    "v_and_or_b32 v30, s[" #EN "+13], %[mask], %[lane]\n\t"                     \
-    "v_and_or_b32 v31, s[" #EN "+15], %[mask], %[lane]\n\t"                     \
-    "ds_read_b64 v[" #VN "+8:" #VN "+9], v28\n\t"                               \
-    "ds_read_b64 v[" #VN "+10:" #VN "+11], v29\n\t"                             \
-    "ds_read_b64 v[" #VN "+12:" #VN "+13], v30\n\t"                             \
-    "ds_read_b64 v[" #VN "+14:" #VN "+15], v31\n\t"
-#define SGCN_LDS_FMA1(EC, VC, K, OP)                                           \
-    #OP " s[" #EC "+2*" #K "+1]" SGCN_LDS_IDXMODE_##OP "\n\t"                    \
-    "v_pk_fma_f32 v[64:65], s[" #EC "+2*" #K ":" #EC "+2*" #K "+1], v[" #VC "+2*" #K ":" #VC "+2*" #K "+1], v[64:65] op_sel_hi:[0,1,1]\n\t"
-#define SGCN_LDS_IDXMODE_s_set_gpr_idx_on ", 0xc"
-#define SGCN_LDS_IDXMODE_s_set_gpr_idx_idx ""
-#define SGCN_LDS_GROUP(P, EC, EN, EL, VC, VN, PNEXT)                           \
-    "Lg" #P "_%=:\n\t"                                                          \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                  \
-    SGCN_LDS_READ8(EN, VN)                                                      \
-    "s_load_dwordx16 s[" #EL ":" #EL "+15], %[base], %[off]\n\t"                \
-    SGCN_LDS_FMA1(EC, VC, 0, s_set_gpr_idx_on)                                  \
-    SGCN_LDS_FMA1(EC, VC, 1, s_set_gpr_idx_idx)                                 \
-    SGCN_LDS_FMA1(EC, VC, 2, s_set_gpr_idx_idx)                                 \
-    SGCN_LDS_FMA1(EC, VC, 3, s_set_gpr_idx_idx)                                 \
-    SGCN_LDS_FMA1(EC, VC, 4, s_set_gpr_idx_idx)                                 \
-    SGCN_LDS_FMA1(EC, VC, 5, s_set_gpr_idx_idx)                                 \
-    SGCN_LDS_FMA1(EC, VC, 6, s_set_gpr_idx_idx)                                 \
-    SGCN_LDS_FMA1(EC, VC, 7, s_set_gpr_idx_idx)                                 \
-    "s_set_gpr_idx_off\n\t"                                                     \
-    "s_add_u32 %[off], %[off], 64\n\t"                                          \
-    "s_sub_u32 %[n], %[n], 1\n\t"                                               \
-    "s_cmp_eq_u32 %[n], 0\n\t"                                                  \
-    "s_cbranch_scc0 Lg" #PNEXT "_%=\n\t"                                        \
-    "s_mov_b32 %[ph], " #PNEXT "\n\t"                                           \
-    "s_branch Lx_%=\n\t"
-#define SGCN_LDS_ENTRY(P, EC, VC)                                              \
-    "Le" #P "_%=:\n\t"                                                          \
-    SGCN_LDS_READ8(EC, VC)                                                      \
-    "s_branch Lg" #P "_%=\n\t"
+// Everything that is in flight lives and dies inside the statement, on fixed registers (the compiler never sees -- and
+// never copies -- a register a load has not written yet):
+//   v[64:255]   the accumulators ("+v" operands): row r of the wave at v[64 + 2 r : 65 + 2 r]
+//   v[32:47] / v[48:63]   the pieces of the even / odd group of 8 nonzeros
+//   v[28:31]    LDS addresses
+//   v[24:27]    the wave's plan entries of the current / next BLOCK of 64, one per lane: unit plans words in v26 (even
+//               blocks) / v27 (odd); general plans {word, value} in v[24:25] / v[26:27]
+//   s[36:43] / s[44:51]   the even / odd group's words; s[52:67] / s[68:83] their values, one per even-aligned pair
+// The entries themselves were staged into the LDS (the wave's 1 KB of the entry ring) by the same global_load_lds
+// burst that fetches a chunk's pieces, two chunks ahead; a block's 64 entries come out with one ds_read a block ahead and
+// down to scalars by v_readlane with immediate lanes -- so the statement is the blocks unrolled, left at the first group
+// boundary where the count runs out.  A GROUP of 8 nonzeros:
+//     8 x (v_readlane [x 2], v_and_or_b32, ds_read_b64)   the NEXT group: address = (word & ~511) | lane * 8
+//     s_waitcnt lgkmcnt(8)                                this group's pieces have landed (LDS returns in order)
+//     s_set_gpr_idx_on, 8 x (s_set_gpr_idx_idx, v_pk_add_f32 | v_pk_fma_f32), s_set_gpr_idx_off
+// i.e. per nonzero 3 (unit) or 4 VALU instructions, ~1.5 scalar, one LDS read, no vector memory.
+#define SGCN_LDS_RD1_U(Q, K, EW, EX, LANE)                                                                    \
+    "v_readlane_b32 s[36+8*" #Q "+" #K "], " #EW ", " #LANE "\n\t"
+#define SGCN_LDS_RD1_V(Q, K, EW, EX, LANE)                                                                    \
+    "v_readlane_b32 s[36+8*" #Q "+" #K "], " #EW ", " #LANE "\n\t"                                            \
+    "v_readlane_b32 s[52+16*" #Q "+2*" #K "], " #EX ", " #LANE "\n\t"
+#define SGCN_LDS_AD1(Q, K, T)                                                                                 \
+    "v_and_or_b32 v[28+" #T "], s[36+8*" #Q "+" #K "], %[mask], %[lane]\n\t"
+#define SGCN_LDS_DS1(Q, K, T)                                                                                 \
+    "ds_read_b64 v[32+16*" #Q "+2*" #K ":32+16*" #Q "+2*" #K "+1], v[28+" #T "]\n\t"
+// the reads of one group: entries at lanes L0 .. L0 + 7 of entry register EW (values: EX) -> parity Q
+#define SGCN_LDS_READ8(M, Q, EW, EX, L0, L1, L2, L3, L4, L5, L6, L7)                                           \
+    SGCN_LDS_RD1_##M(Q, 0, EW, EX, L0) SGCN_LDS_RD1_##M(Q, 1, EW, EX, L1)                                     \
+    SGCN_LDS_RD1_##M(Q, 2, EW, EX, L2) SGCN_LDS_RD1_##M(Q, 3, EW, EX, L3)                                     \
+    SGCN_LDS_AD1(Q, 0, 0) SGCN_LDS_AD1(Q, 1, 1) SGCN_LDS_AD1(Q, 2, 2) SGCN_LDS_AD1(Q, 3, 3)                   \
+    SGCN_LDS_DS1(Q, 0, 0) SGCN_LDS_DS1(Q, 1, 1) SGCN_LDS_DS1(Q, 2, 2) SGCN_LDS_DS1(Q, 3, 3)                   \
+    SGCN_LDS_RD1_##M(Q, 4, EW, EX, L4) SGCN_LDS_RD1_##M(Q, 5, EW, EX, L5)                                     \
+    SGCN_LDS_RD1_##M(Q, 6, EW, EX, L6) SGCN_LDS_RD1_##M(Q, 7, EW, EX, L7)                                     \
+    SGCN_LDS_AD1(Q, 4, 0) SGCN_LDS_AD1(Q, 5, 1) SGCN_LDS_AD1(Q, 6, 2) SGCN_LDS_AD1(Q, 7, 3)                   \
+    SGCN_LDS_DS1(Q, 4, 0) SGCN_LDS_DS1(Q, 5, 1) SGCN_LDS_DS1(Q, 6, 2) SGCN_LDS_DS1(Q, 7, 3)
+// unit plans: acc += piece (source 0 and destination indexed: mode 0x9); general: acc += value * piece (source 2 and
+// destination indexed: mode 0xc; the value is the low word of an even-aligned scalar pair: op_sel_hi [0, 1, 1])
+#define SGCN_LDS_MODE_U "0x9"
+#define SGCN_LDS_MODE_V "0xc"
+#define SGCN_LDS_OP1_U(Q, K)                                                                                  \
+    "v_pk_add_f32 v[64:65], v[64:65], v[32+16*" #Q "+2*" #K ":32+16*" #Q "+2*" #K "+1]\n\t"
+#define SGCN_LDS_OP1_V(Q, K)                                                                                  \
+    "v_pk_fma_f32 v[64:65], s[52+16*" #Q "+2*" #K ":52+16*" #Q "+2*" #K "+1], v[32+16*" #Q "+2*" #K ":32+16*" #Q "+2*" #K "+1], v[64:65] op_sel_hi:[0,1,1]\n\t"
+#define SGCN_LDS_APPLY8(M, Q, WAIT)                                                                           \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                                        \
+    "s_set_gpr_idx_on s[36+8*" #Q "+0], " SGCN_LDS_MODE_##M "\n\t" SGCN_LDS_OP1_##M(Q, 0)                      \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" SGCN_LDS_OP1_##M(Q, 1)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" SGCN_LDS_OP1_##M(Q, 2)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" SGCN_LDS_OP1_##M(Q, 3)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" SGCN_LDS_OP1_##M(Q, 4)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" SGCN_LDS_OP1_##M(Q, 5)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_OP1_##M(Q, 6)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_OP1_##M(Q, 7)                                            \
+    "s_set_gpr_idx_off\n\t"                                                                                   \
+    "s_sub_u32 %[n], %[n], 1\n\t"                                                                             \
+    "s_cmp_eq_u32 %[n], 0\n\t"                                                                                \
+    "s_cbranch_scc1 Lx_%=\n\t"
+// a block = 64 entries in EW (/ EX); ENEXT fetches the next block's entries into NW (/ NX) first -- it is the OLDEST LDS
+// operation in flight when the first group waits (lgkmcnt(8) then covers it: LDS returns in order), so the block's last
+// group can read ahead from NW's first lanes
+#define SGCN_LDS_BLOCK(M, EW, EX, NW, NX, ENEXT)                                                              \
+    ENEXT                                                                                                     \
+    SGCN_LDS_READ8(M, 1, EW, EX, 8, 9, 10, 11, 12, 13, 14, 15)         SGCN_LDS_APPLY8(M, 0, 8)                \
+    SGCN_LDS_READ8(M, 0, EW, EX, 16, 17, 18, 19, 20, 21, 22, 23)       SGCN_LDS_APPLY8(M, 1, 8)                \
+    SGCN_LDS_READ8(M, 1, EW, EX, 24, 25, 26, 27, 28, 29, 30, 31)       SGCN_LDS_APPLY8(M, 0, 8)                \
+    SGCN_LDS_READ8(M, 0, EW, EX, 32, 33, 34, 35, 36, 37, 38, 39)       SGCN_LDS_APPLY8(M, 1, 8)                \
+    SGCN_LDS_READ8(M, 1, EW, EX, 40, 41, 42, 43, 44, 45, 46, 47)       SGCN_LDS_APPLY8(M, 0, 8)                \
+    SGCN_LDS_READ8(M, 0, EW, EX, 48, 49, 50, 51, 52, 53, 54, 55)       SGCN_LDS_APPLY8(M, 1, 8)                \
+    SGCN_LDS_READ8(M, 1, EW, EX, 56, 57, 58, 59, 60, 61, 62, 63)       SGCN_LDS_APPLY8(M, 0, 8)                \
+    SGCN_LDS_READ8(M, 0, NW, NX, 0, 1, 2, 3, 4, 5, 6, 7)               SGCN_LDS_APPLY8(M, 1, 8)
+#define SGCN_LDS_CLOBBER_V "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",   \
+        "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", \
+        "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define SGCN_LDS_CLOBBER_SW "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",  \
+        "s50", "s51"
+#define SGCN_LDS_CLOBBER_SV "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
+        "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", \
+        "s83"
+#define SGCN_LDS_ACC "+{v[64:95]}"(a0), "+{v[96:127]}"(a1), "+{v[128:159]}"(a2), "+{v[160:191]}"(a3),          \
+                     "+{v[192:223]}"(a4), "+{v[224:255]}"(a5)
 
-// n groups (> 0) of this wave's entry stream, starting in phase `ph` (both updated); `off` = byte offset (from `base`) of
-// the entries two groups ahead of the first one (what the next s_load fetches; updated).
-__device__ __forceinline__ void lds_chunk(ent16_t& E0, ent16_t& E1, ent16_t& E2, acc32_t& a0, acc32_t& a1, acc32_t& a2,
-                                          acc32_t& a3, acc32_t& a4, acc32_t& a5, const uint64_t* base, uint32_t& off,
-                                          uint32_t& n, uint32_t& ph, uint32_t mask, uint32_t lane_off) {
-    asm volatile("s_cmp_eq_u32 %[ph], 0\n\t"
-                 "s_cbranch_scc1 Le0_%=\n\t"
-                 "s_cmp_eq_u32 %[ph], 1\n\t"
-                 "s_cbranch_scc1 Le1_%=\n\t"
-                 "s_cmp_eq_u32 %[ph], 2\n\t"
-                 "s_cbranch_scc1 Le2_%=\n\t"
-                 "s_cmp_eq_u32 %[ph], 3\n\t"
-                 "s_cbranch_scc1 Le3_%=\n\t"
-                 "s_cmp_eq_u32 %[ph], 4\n\t"
-                 "s_cbranch_scc1 Le4_%=\n\t"
-                 "s_branch Le5_%=\n\t"
-                 SGCN_LDS_ENTRY(0, 36, 32)
-                 SGCN_LDS_ENTRY(1, 52, 48)
-                 SGCN_LDS_ENTRY(2, 68, 32)
-                 SGCN_LDS_ENTRY(3, 36, 48)
-                 SGCN_LDS_ENTRY(4, 52, 32)
-                 SGCN_LDS_ENTRY(5, 68, 48)
-                 //             P  EC  EN  EL  VC  VN  next
-                 SGCN_LDS_GROUP(0, 36, 52, 68, 32, 48, 1)
-                 SGCN_LDS_GROUP(1, 52, 68, 36, 48, 32, 2)
-                 SGCN_LDS_GROUP(2, 68, 36, 52, 32, 48, 3)
-                 SGCN_LDS_GROUP(3, 36, 52, 68, 48, 32, 4)
-                 SGCN_LDS_GROUP(4, 52, 68, 36, 32, 48, 5)
-                 SGCN_LDS_GROUP(5, 68, 36, 52, 48, 32, 0)
-                 "Lx_%=:\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "+{s[36:51]}"(E0), "+{s[52:67]}"(E1), "+{s[68:83]}"(E2),
-                   "+{v[64:95]}"(a0), "+{v[96:127]}"(a1), "+{v[128:159]}"(a2), "+{v[160:191]}"(a3),
-                   "+{v[192:223]}"(a4), "+{v[224:255]}"(a5), [off] "+s"(off), [n] "+s"(n), [ph] "+s"(ph)
-                 : [base] "s"(base), [mask] "v"(mask), [lane] "v"(lane_off)
-                 : "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
-                   "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57",
-                   "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory");
+// n (> 0) groups of 8 entries; `ea`: this lane's LDS address of its entry of the wave's first block (the wave's 1 KB of
+// the entry ring: unit plans 4 blocks of 64 words; general plans 2 blocks of words, then their values at + 512)
+template <bool UNIT>
+__device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2, acc32_t& a3, acc32_t& a4, acc32_t& a5,
+                                          uint32_t n, uint32_t ea, uint32_t mask, uint32_t lane_off) {
+    if constexpr (UNIT) {
+        asm volatile("ds_read_b32 v26, %[ea]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     SGCN_LDS_READ8(U, 0, v26, v26, 0, 1, 2, 3, 4, 5, 6, 7)
+                     SGCN_LDS_BLOCK(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:256\n\t")
+                     SGCN_LDS_BLOCK(U, v27, v27, v26, v26, "ds_read_b32 v26, %[ea] offset:512\n\t")
+                     SGCN_LDS_BLOCK(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:768\n\t")
+                     SGCN_LDS_BLOCK(U, v27, v27, v27, v27, "ds_read_b32 v26, %[ea]\n\t")
+                     "Lx_%=:\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : SGCN_LDS_ACC, [n] "+s"(n)
+                     : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off)
+                     : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "memory");
+    } else {
+        asm volatile("ds_read2_b32 v[24:25], %[ea] offset1:128\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     SGCN_LDS_READ8(V, 0, v24, v25, 0, 1, 2, 3, 4, 5, 6, 7)
+                     SGCN_LDS_BLOCK(V, v24, v25, v26, v27, "ds_read2_b32 v[26:27], %[ea] offset0:64 offset1:192\n\t")
+                     SGCN_LDS_BLOCK(V, v26, v27, v26, v27, "ds_read2_b32 v[24:25], %[ea] offset1:128\n\t")
+                     "Lx_%=:\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : SGCN_LDS_ACC, [n] "+s"(n)
+                     : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off)
+                     : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, SGCN_LDS_CLOBBER_SV, "scc", "memory");
+    }
 }
 
-// 128-column slabs: a lane holds a float2 of every row of its wave; S ring slots (512-byte pieces) per half.
-template <int S>
+// 128-column slabs: a lane holds a float2 of every row of its wave.  The piece ring has THREE parts of S slots (512-byte
+// pieces): chunk k is consumed from part k % 3 while chunks k + 1 and k + 2 are in flight into the other two -- a fill has
+// two chunk times to land (measured with two halves: the waves spent half their cycles waiting for a fill issued one
+// chunk earlier).  The waves' entries travel the same way, 1 KB per wave and chunk, into the entry ring behind it.
+template <int S, bool UNIT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lds_spmm_kernel(LdsArgs a) {
-    constexpr int VW = 2, NW = 8, GE = 8;               // floats per lane, waves per tile, entries per group
+    constexpr int VW = 2, NW = 8;                       // floats per lane, waves per tile
     constexpr int RW = 192 / VW;                        // rows per wave: 192 accumulator registers
     constexpr int PIECE = 64 * VW * 4;                  // bytes of one staged piece
-    constexpr int HALF = S * PIECE;
-    constexpr int LPP = PIECE / 16;                     // lanes that fetch one piece (dwordx4 each)
-    constexpr int PPI = 64 / LPP;                       // pieces per fill instruction
+    constexpr int PART = S * PIECE;
+    constexpr int LPP = PIECE / 16;                     // lanes that fetch one piece (dwordx4 each): 32
+    constexpr int PPI = 64 / LPP;                       // pieces per fill instruction: 2
     constexpr int FPW = S / PPI / NW;                   // fill instructions per wave and chunk
-    static_assert(S % (PPI * NW) == 0, "ring slots must divide evenly over the waves' fill instructions");
+    static_assert(PPI == 2 && S % (PPI * NW) == 0, "ring slots must divide evenly over the waves' fill instructions");
+    constexpr int ERING = 3 * PART + PIECE;             // the entry ring: 3 x NW x 1 KB behind the pieces and the zero piece
+    constexpr int HRING = ERING + 3 * NW * 1024;        // the header ring: 3 x NW x 64 bytes
     typedef float VT __attribute__((ext_vector_type(2)));
-    extern __shared__ __attribute__((aligned(1024))) char ring[];       // two halves + one zero piece (the pads' operand)
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
 
-    // workgroup b runs on XCD b % 8 (round-robin dispatch): every XCD gets a contiguous eighth of the tiles, ordered
-    // (slab, tile) -- the 32 workgroups an XCD runs at a time are neighbouring tiles of one slab, i.e. rows of the same
-    // few communities fetching the same pieces through one L2.  Pure placement.
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int lo = (int)((int64_t)a.ntiles * x / 8), hi = (int)((int64_t)a.ntiles * (x + 1) / 8);
+    // workgroup b runs on XCD b % 8 (round-robin dispatch): every XCD gets a contiguous range of the tiles (the plan cuts
+    // the ranges to equal estimated time), ordered (slab, tile) -- the 32 workgroups an XCD runs at a time are neighbouring
+    // tiles of one slab, i.e. rows of the same few communities fetching the same pieces through one L2.  Pure placement.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int lo = a.xcd_ptr[xcd], hi = a.xcd_ptr[xcd + 1];
     const int ntx = hi - lo;
     if (q >= ntx * a.nslab) return;
     const int slab = q / ntx, tile = lo + q % ntx;
@@ -177,78 +198,166 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint32_t lane_off = (uint32_t)lane * (VW * 4);
     const uint32_t mask = ~(uint32_t)(PIECE - 1);
 
-    ent16_t E0 = {}, E1 = {}, E2 = {};
     acc32_t a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {};
 
-    // the pads' operand: PIECE bytes of zeros behind the ring
-    if (threadIdx.x < PIECE / 4) reinterpret_cast<float*>(ring + 2 * HALF)[threadIdx.x] = 0.f;
+    // the pads' operand: PIECE bytes of zeros behind the piece ring
+    if (threadIdx.x < PIECE / 4) reinterpret_cast<float*>(ring + 3 * PART)[threadIdx.x] = 0.f;
 
     const int c0 = __builtin_amdgcn_readfirstlane(a.tile_chunk_ptr[tile]);
     const int c1 = __builtin_amdgcn_readfirstlane(a.tile_chunk_ptr[tile + 1]);
     const char* Bb = reinterpret_cast<const char*>(a.B);
     const int64_t ldb_bytes = a.ldb * 4;
-    // my share of a fill instruction: piece `lane / LPP` of the instruction, 16 bytes at `(lane % LPP) * 16`; a lane
+    // my share of a fill instruction: lanes 0-31 fetch its first piece, lanes 32-63 its second, 16 bytes each; a lane
     // past the row's pitch (last slab) re-reads the slab's first bytes instead of running off the row
-    const int lp = lane / LPP;
-    int64_t boff = (int64_t)fbase * 4 + (lane % LPP) * 16;
-    if (boff + 16 > ldb_bytes) boff = (int64_t)fbase * 4;
+    const bool second = lane >= LPP;
+    uint32_t boff = (uint32_t)fbase * 4 + (lane % LPP) * 16;
+    if ((int64_t)boff + 16 > ldb_bytes) boff = (uint32_t)fbase * 4;
 
-    int32_t cols[FPW];
-    auto load_cols = [&](int c) {
-#pragma unroll
-        for (int g = 0; g < FPW; g++) {
-            int32_t col = a.chunk_cols[(int64_t)c * S + (wave * FPW + g) * PPI + lp];
-            if (a.gidx) col = a.gidx[col];
-            cols[g] = col;
-        }
+    // A (chunk, wave) header -- the wave's 2 FPW column ids, its entry count, the index of its first entry: 64 bytes --
+    // travels like everything else: global_load_lds into the wave's slot of the header ring a chunk before it is needed,
+    // then ONE asm statement reads it (ds_read + wait + v_readlane) into scalars.  No scalar memory instruction in the
+    // loop (the chunk statement opens with s_waitcnt lgkmcnt(0), which would wait for an outstanding s_load too:
+    // measured with the ids on the scalar path, 0.7 us of exposed latency per chunk) and no compiler-visible load either
+    // (the compiler's own s_waitcnt for one would be vmcnt(0): it would wait for the fills just issued).
+    static_assert(FPW == 5, "the header statement below reads 10 column ids");
+    struct Hdr { int32_t col[2 * FPW]; uint32_t n; int64_t e; };
+    auto hdr_fetch = [&](int c, int slot) {                 // chunk c's header -> my slot of the header ring
+        if (lane < 16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.chunk_hdr + ((int64_t)c * NW + wave) * 16 + lane),
+                                             (__attribute__((address_space(3))) void*)(ring + HRING + (slot * NW + wave) * 64), 4, 0, 0);
     };
-    auto fill = [&](int half) {
+    auto hdr_get = [&](int slot) -> Hdr {                   // (after the s_waitcnt vmcnt that covers its fetch)
+        Hdr h;
+        uint32_t elo, ehi;
+        const uint32_t addr = (uint32_t)(HRING + (slot * NW + wave) * 64) + (lane & 15) * 4;
+        asm volatile("ds_read_b32 v28, %[addr]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readlane_b32 %[c0], v28, 0\n\t"
+                     "v_readlane_b32 %[c1], v28, 1\n\t"
+                     "v_readlane_b32 %[c2], v28, 2\n\t"
+                     "v_readlane_b32 %[c3], v28, 3\n\t"
+                     "v_readlane_b32 %[c4], v28, 4\n\t"
+                     "v_readlane_b32 %[c5], v28, 5\n\t"
+                     "v_readlane_b32 %[c6], v28, 6\n\t"
+                     "v_readlane_b32 %[c7], v28, 7\n\t"
+                     "v_readlane_b32 %[c8], v28, 8\n\t"
+                     "v_readlane_b32 %[c9], v28, 9\n\t"
+                     "v_readlane_b32 %[n], v28, 10\n\t"
+                     "v_readlane_b32 %[elo], v28, 11\n\t"
+                     "v_readlane_b32 %[ehi], v28, 12"
+                     : [c0] "=s"(h.col[0]), [c1] "=s"(h.col[1]), [c2] "=s"(h.col[2]), [c3] "=s"(h.col[3]), [c4] "=s"(h.col[4]),
+                       [c5] "=s"(h.col[5]), [c6] "=s"(h.col[6]), [c7] "=s"(h.col[7]), [c8] "=s"(h.col[8]), [c9] "=s"(h.col[9]),
+                       [n] "=s"(h.n), [elo] "=s"(elo), [ehi] "=s"(ehi)
+                     : [addr] "v"(addr)
+                     : "v28", "memory");
+        h.e = (int64_t)(((uint64_t)ehi << 32) | elo);
+        return h;
+    };
+    // chunk -> ring part p: its pieces (FPW instructions) and my entries of it (one instruction: 1 KB from the wave's
+    // stream position -- unit plans 256 words; general plans 128 words by lanes 0-31 and their 128 values by lanes 32-63;
+    // what lies behind the wave's count is fetched and never applied)
+    auto fill = [&](int p, const Hdr& h) {
 #pragma unroll
         for (int g = 0; g < FPW; g++) {
-            const char* src = Bb + (int64_t)cols[g] * ldb_bytes + boff;
-            char* dst = ring + half * HALF + (wave * FPW + g) * 1024;
+            if (a.dbg & 1) break;                           // (experiment: entries and headers only)
+            // (row offsets as scalars, picked per half-wave: a select between the two column ids themselves is turned into
+            // a per-lane vector index by the compiler -- a dozen compares per fill)
+            const char* src;
+            if (a.wide) {
+                const int64_t r0 = (int64_t)h.col[2 * g] * ldb_bytes, r1 = (int64_t)h.col[2 * g + 1] * ldb_bytes;
+                src = Bb + (second ? r1 : r0) + boff;
+            } else {                                        // scalar base + 32-bit lane offset: 3 VALU per fill instead of 8
+                const uint32_t r0 = (uint32_t)h.col[2 * g] * (uint32_t)ldb_bytes, r1 = (uint32_t)h.col[2 * g + 1] * (uint32_t)ldb_bytes;
+                src = Bb + (size_t)((second ? r1 : r0) + boff);
+            }
+            char* dst = ring + p * PART + (wave * FPW + g) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
+        const char* esrc;
+        if (UNIT) esrc = reinterpret_cast<const char*>(a.words + h.e) + lane * 16;
+        else esrc = (second ? reinterpret_cast<const char*>(a.vals + h.e) : reinterpret_cast<const char*>(a.words + h.e)) + (lane % LPP) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)esrc,
+                                         (__attribute__((address_space(3))) void*)(ring + ERING + (p * NW + wave) * 1024), 16, 0, 0);
     };
+    constexpr int kPerChunk = FPW + 1;                      // the wave's requests of one chunk: pieces + entries
 
-    // this wave's entries: contiguous over the tile's chunks ((tile, wave, chunk) order); ent_ptr through the scalar cache
     const int nc = c1 - c0;
-    const __attribute__((address_space(4))) int64_t* eptr =
-        (const __attribute__((address_space(4))) int64_t*)(a.ent_ptr) + ((int64_t)c0 * NW + (int64_t)wave * nc);
+    // (experiments: the wave's cycle counts by phase; a.prof is null in production and the stamps fold away)
+    unsigned long long t_fill = 0, t_comp = 0, t_wait = 0, t_bar = 0, t_all0 = 0, t_pro = 0, t_mark = 0;
+    auto stamp = [&]() -> unsigned long long { return a.prof ? __builtin_readcyclecounter() : 0ull; };
+    t_all0 = stamp();
     if (nc > 0) {
-        int64_t ecur = eptr[0];
-        const uint64_t* ep = a.entries + ecur;             // (entry offsets from a.entries stay below 4 GiB: checked on the host)
-        load_cols(c0);
-        fill(0);
-        if (nc > 1) load_cols(c0 + 1);
-        // groups 0 and 1 of the wave's stream -> E0, E1 (the array ends in two pad groups: reading ahead is safe)
-        asm volatile("s_load_dwordx16 s[36:51], %[ptr], 0x0\n\t"
-                     "s_load_dwordx16 s[52:67], %[ptr], 0x40\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "+{s[36:51]}"(E0), "+{s[52:67]}"(E1) : [ptr] "s"(ep) : "memory");
-        uint32_t eoff = (uint32_t)((ecur + 2 * GE) * 8);    // byte offset of the group the next s_load fetches
-        uint32_t ph = 0;
+        uint32_t n0, n1 = 0, n2 = 0;
+        hdr_fetch(c0, 0);
+        if (nc > 1) hdr_fetch(c0 + 1, 1);
+        if (nc > 2) hdr_fetch(c0 + 2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const Hdr h = hdr_get(0);
+            fill(0, h);
+            n0 = h.n;
+        }
+        if (nc > 1) {
+            const Hdr h = hdr_get(1);
+            fill(1, h);
+            n1 = h.n;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t_pro = stamp() - t_all0;
+        int part = 0;                                       // k % 3: the ring part of chunk k
         for (int k = 0; k < nc; k++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                // chunk k's pieces have landed; everybody is past chunk k - 1
-            if (k + 1 < nc) {
-                fill((k + 1) & 1);                          // the next chunk's pieces go in flight ...
-                if (k + 2 < nc) load_cols(c0 + k + 2);      // ... and the column ids of the one after
+            // chunk k has landed for everybody (each wave waited for its own fills below); everybody is past chunk k - 1.
+            // A bare s_barrier: __syncthreads() would add a fence, i.e. wait for the fills just issued as well.
+            const bool more = k + 2 < nc;
+            const int p2 = part >= 1 ? part - 1 : 2;        // (k + 2) % 3: the part chunk k - 1 left
+            Hdr h;
+            if (more) h = hdr_get(p2);                      // chunk k + 2's header came in during the last iteration (it is
+            t_mark = stamp();                               // mine alone: read ahead of the barrier, its latency in the barrier's)
+            asm volatile("s_barrier" ::: "memory");
+            { const unsigned long long t = stamp(); t_bar += t - t_mark; t_mark = t; }
+            if (more) {
+                n2 = h.n;
+                if (k + 3 < nc) hdr_fetch(c0 + k + 3, part);    // the next one's goes first (older than the fills: see the wait)
+                fill(p2, h);                                // chunk k + 2 goes in flight
             }
-            const int64_t e1 = eptr[k + 1];
-            uint32_t n = (uint32_t)((e1 - ecur) / GE);
-            ecur = e1;
-            if (n) lds_chunk(E0, E1, E2, a0, a1, a2, a3, a4, a5, a.entries, eoff, n, ph, mask, lane_off);
+            { const unsigned long long t = stamp(); t_fill += t - t_mark; t_mark = t; }
+            if (n0 && !(a.dbg & 2))
+                lds_chunk<UNIT>(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off);
+            { const unsigned long long t = stamp(); t_comp += t - t_mark; t_mark = t; }
+            n0 = n1; n1 = n2;
+            part = part == 2 ? 0 : part + 1;
+            // chunk k + 1 was requested an iteration ago: everything older than this iteration's fills has to be here
+            // before the barrier (the header fetch was issued ahead of them: it is covered too)
+            if (more && !(a.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerChunk) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            { const unsigned long long t = stamp(); t_wait += t - t_mark; }
         }
     }
+    const unsigned long long t_epi0 = stamp();
 
-    // epilogue: row r of this wave sits at register offset r * VW
+    // epilogue: row r of this wave sits at register offset r * VW.  The wave's row ids / workspace slots come in with two
+    // vector loads (lane r: row r) and down by v_readlane -- a scalar load per row would expose its latency 96 times.
     const int32_t* rows = a.tile_rows + ((int64_t)tile * NW + wave) * RW;
     const int32_t* slots = a.tile_slots + ((int64_t)tile * NW + wave) * RW;
+    const int rows_lo = rows[lane], rows_hi = lane < RW - 64 ? rows[64 + lane] : -1;
+    const int slots_lo = slots[lane], slots_hi = lane < RW - 64 ? slots[64 + lane] : -1;
+    // the rows' factors the same way (unit plans: the folded value; the caller's row scale): lane r holds row r's
+    float fold_lo = 1.0f, fold_hi = 1.0f, rs_lo = 1.0f, rs_hi = 1.0f;
+    if (UNIT) {
+        if (rows_lo >= 0) fold_lo = a.row_fold[rows_lo];
+        if (rows_hi >= 0) fold_hi = a.row_fold[rows_hi];
+    }
+    if (a.rscale) {
+        if (rows_lo >= 0) rs_lo = a.rscale[rows_lo];
+        if (rows_hi >= 0) rs_hi = a.rscale[rows_hi];
+    }
+    auto lane_f = [](float lo, float hi, int r) -> float {
+        return __int_as_float(r < 64 ? __builtin_amdgcn_readlane(__float_as_int(lo), r) : __builtin_amdgcn_readlane(__float_as_int(hi), r - 64));
+    };
     const int left_cols = a.d - f;
     for (int r = 0; r < RW; r++) {
-        const int row = rows[r];
+        const int row = r < 64 ? __builtin_amdgcn_readlane(rows_lo, r) : __builtin_amdgcn_readlane(rows_hi, r - 64);
         float x0, x1;
         asm volatile("s_set_gpr_idx_on %[i], 0x1\n\t"
                      "v_mov_b32 %[x0], v64\n\t"
@@ -258,21 +367,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                      : [i] "s"(r * VW), "{v[64:95]}"(a0), "{v[96:127]}"(a1), "{v[128:159]}"(a2),
                        "{v[160:191]}"(a3), "{v[192:223]}"(a4), "{v[224:255]}"(a5));
         const VT accv = {x0, x1};
-        if (row < 0 || !act) continue;
-        const int slot = slots[r];
-        if (slot >= 0) {
-            float* w = a.ws + (int64_t)slot * a.ldw + f;
-            if (left_cols >= VW) vstore<VW>(w, accv); else vstore_head<VW>(w, accv, left_cols);
+        if (row < 0 || !act || (a.dbg & 4)) continue;
+        const int slot = r < 64 ? __builtin_amdgcn_readlane(slots_lo, r) : __builtin_amdgcn_readlane(slots_hi, r - 64);
+        if (slot >= 0) {                                    // a split row's piece: raw sum, scaled by the fix-up
+            float* wsp = a.ws + (int64_t)slot * a.ldw + f;
+            if (left_cols >= VW) vstore<VW>(wsp, accv); else vstore_head<VW>(wsp, accv, left_cols);
         } else {
             float* out = a.C + (int64_t)row * a.ldc + f;
-            const float rs = a.rscale ? a.rscale[row] : 1.0f;
-            VT res = accv * rs;
+            VT res = accv;
+            if (UNIT) res = res * lane_f(fold_lo, fold_hi, r);
+            if (a.rscale) res = res * lane_f(rs_lo, rs_hi, r);
             if (a.beta != 0.f) {
                 if (left_cols >= VW) res += a.beta * vload<VW>(out);
                 else for (int e = 0; e < left_cols; e++) res[e] += a.beta * out[e];
             }
             if (left_cols >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left_cols);
         }
+    }
+    if (a.prof && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        unsigned long long* o = a.prof + ((size_t)blockIdx.x * NW + wave) * 8;
+        o[0] = t_pro; o[1] = t_fill; o[2] = t_comp; o[3] = t_wait; o[4] = t_bar; o[5] = t_end - t_epi0; o[6] = t_end - t_all0;
+        o[7] = (unsigned long long)nc;
     }
 }
 
@@ -290,7 +406,9 @@ __global__ __launch_bounds__(kBlock) void lds_fix_kernel(LdsArgs a, const sgcn_f
     VT acc = vzero<4>();
     for (int q = 0; q < fx.nslots; q++) acc += vload<4>(w + (int64_t)q * a.ldw);
     float* out = a.C + (int64_t)fx.row * a.ldc + (int64_t)vi * 4;
-    VT res = acc * (a.rscale ? a.rscale[fx.row] : 1.0f);
+    VT res = acc;
+    if (a.row_fold) res = res * a.row_fold[fx.row];
+    if (a.rscale) res = res * a.rscale[fx.row];
     const int left = a.d - vi * 4;
     if (a.beta != 0.f) {
         if (left >= 4) res += a.beta * vload<4>(out);
@@ -303,41 +421,60 @@ __global__ __launch_bounds__(kBlock) void lds_fix_kernel(LdsArgs a, const sgcn_f
 
 using namespace sgcn;
 
+namespace { unsigned long long* g_lds_prof = nullptr; }
+// experiments: a device buffer of 8 x 8 uint64 per workgroup of the next launches (NULL: off) -- profiles/lds_phase_probe.py
+extern "C" int sgcn_lds_profile_buffer(void* dev_buf) { g_lds_prof = (unsigned long long*)dev_buf; return SGCN_OK; }
+
 extern "C" int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t K, int32_t d,
-                                 const float* B, int64_t ldb, const int32_t* gidx, const float* rscale,
+                                 const float* B, int64_t ldb, const float* rscale,
                                  float* C, int64_t ldc, float beta, void* stream) {
     SGCN_REQUIRE(plan && M >= 0 && K >= 0 && d >= 0, "spmm_lds: bad argument");
     if (M == 0 || d == 0) return SGCN_OK;
-    SGCN_REQUIRE(plan->NW == 8 && plan->VW == 2 && plan->RW == 96 && plan->U == 8 && plan->S == 128,
-                 "spmm_lds: the plan must be built for 8 waves x 96 rows x float2, groups of 8 entries, 128 ring slots");
-    SGCN_REQUIRE(plan->dev_tile_chunk_ptr && plan->dev_chunk_cols && plan->dev_ent_ptr && plan->dev_entries &&
+    SGCN_REQUIRE(plan->NW == 8 && plan->VW == 2 && plan->RW == 96 && plan->U == 8 && plan->S == 80,
+                 "spmm_lds: the plan must be built for 8 waves x 96 rows x float2, groups of 8 entries, 3 x 80 ring slots");
+    SGCN_REQUIRE(plan->dev_tile_chunk_ptr && plan->dev_chunk_hdr && plan->dev_words &&
                  plan->dev_tile_rows && plan->dev_tile_slots && B && C, "spmm_lds: null operand");
+    SGCN_REQUIRE(plan->unit ? plan->dev_row_fold != nullptr : plan->dev_vals != nullptr,
+                 "spmm_lds: a unit plan needs its row values, a general plan its entry values");
     SGCN_REQUIRE(pick_vw(d, {B, C, plan->dev_ws}, {ldb, ldc}) >= 4,
                  "spmm_lds: rows must be 16-byte aligned (pitch a multiple of 4 floats covering d)");
     hipStream_t st = (hipStream_t)stream;
     LdsArgs a{};
-    a.tile_chunk_ptr = plan->dev_tile_chunk_ptr; a.chunk_cols = plan->dev_chunk_cols;
-    a.ent_ptr = plan->dev_ent_ptr; a.entries = reinterpret_cast<const uint64_t*>(plan->dev_entries);
+    a.tile_chunk_ptr = plan->dev_tile_chunk_ptr; a.chunk_hdr = plan->dev_chunk_hdr;
+    a.words = plan->dev_words; a.vals = plan->dev_vals;
+    a.row_fold = plan->unit ? plan->dev_row_fold : nullptr;
     a.tile_rows = plan->dev_tile_rows; a.tile_slots = plan->dev_tile_slots;
-    a.B = B; a.ldb = ldb; a.gidx = gidx; a.rscale = rscale; a.C = C; a.ldc = ldc; a.beta = beta;
+    a.B = B; a.ldb = ldb; a.rscale = rscale; a.C = C; a.ldc = ldc; a.beta = beta;
     a.d = d; a.ntiles = (int32_t)plan->ntiles;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
     if (plan->nfix > 0)
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
                      "spmm_lds: workspace missing or too small");
-    const int slabw = 64 * plan->VW;
-    a.nslab = (d + slabw - 1) / slabw;
-    const int64_t per_xcd = (plan->ntiles + 7) / 8;
+    a.nslab = (d + 127) / 128;
+    a.wide = ((int64_t)K * ldb * 4 + 4096 >= (1ll << 32)) ? 1 : 0;
+    a.dbg = tune_get("lds_dbg");
+    a.prof = g_lds_prof;
+    int64_t per_xcd = 0;
+    SGCN_REQUIRE(plan->xcd_tile_ptr[0] == 0 && plan->xcd_tile_ptr[8] == plan->ntiles, "spmm_lds: malformed XCD tile ranges");
+    for (int x = 0; x < 8; x++) {
+        SGCN_REQUIRE(plan->xcd_tile_ptr[x + 1] >= plan->xcd_tile_ptr[x], "spmm_lds: malformed XCD tile ranges");
+        per_xcd = std::max<int64_t>(per_xcd, plan->xcd_tile_ptr[x + 1] - plan->xcd_tile_ptr[x]);
+        a.xcd_ptr[x] = plan->xcd_tile_ptr[x];
+    }
+    a.xcd_ptr[8] = plan->xcd_tile_ptr[8];
     const int64_t blocks = 8 * per_xcd * a.nslab;
     SGCN_REQUIRE(blocks < (1ll << 31), "spmm_lds: too many work items");
-    constexpr int lds = 2 * 128 * 512 + 512;
+    constexpr int lds = 3 * 80 * 512 + 512 + 3 * 8 * 1024 + 3 * 8 * 64;
     static bool once = false;                   // (an attribute of the function, not of a launch)
     if (!once) {
-        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<128>),
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once = true;
     }
-    hipLaunchKernelGGL((lds_spmm_kernel<128>), dim3((unsigned)blocks), dim3(512), lds, st, a);
+    if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<80, true>), dim3((unsigned)blocks), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((lds_spmm_kernel<80, false>), dim3((unsigned)blocks), dim3(512), lds, st, a);
     SGCN_HIP_TRY(hipGetLastError());
     if (plan->nfix > 0) {
         const int nvec = (d + 3) / 4;

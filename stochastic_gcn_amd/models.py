@@ -242,10 +242,17 @@ class Model(object):
         self._want_grad = False
         self.grad_hook = None      # parallel.py installs the RCCL all-reduce here
         self.history_hook = None   # parallel.py: all-gather + apply every rank's history rows
+        self.history_join = None   # parallel.py: the exchange is asynchronous; every reader of the history joins it first
 
     # -- reference API --------------------------------------------------------------------
+    def join_history(self):
+        """Data parallel: the history rows the ranks exchanged behind the last step land now (a no-op otherwise)."""
+        if self.history_join is not None:
+            self.history_join()
+
     def save(self, sess=None, path=None):
         """Weights + history (gcn/models.py:204-209 saves self.vars + self.history_vars)."""
+        self.join_history()
         path = path or "tmp/%s.ckpt.npz" % self.name
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         blob = {"var/" + n: v.detach().cpu().numpy() for n, v in self.named_vars()}
@@ -261,6 +268,7 @@ class Model(object):
         for n, v in self.named_vars():
             v.copy_(torch.from_numpy(z["var/" + n]).to(self.device))
         if load_history:
+            self.join_history()
             for i, h in enumerate(self.history_vars):
                 h.copy_(torch.from_numpy(z["history/%d" % i]).to(self.device))
         print("Model restored from file: %s" % path)
@@ -677,6 +685,11 @@ class GCN(Model):
             return None
         if getattr(pb, '_staged', None) is not None and getattr(pb, '_ring_owner', None) is self:
             return pb._staged
+        # only the step-program path reads the staged copy: a model that steps eagerly (sparse input features, det-dropout,
+        # native_step off) would copy every batch twice and keep a ring of dead device buffers
+        drop = float(getattr(pb, 'dropout', 0.0) or 0.0) if self.is_training else 0.0
+        if self._program(pb, drop) is None:
+            return None
         dev = self.device
         n_i = max(pb.n_i, 1)
         cs = self.__dict__.get('_copy_stream')
@@ -845,6 +858,7 @@ class GCN(Model):
         program's statistics slot, which the next step overwrites: read (or ``.clone()``) them before the
         next ``run_one_step`` -- the Trainer reads the last step's only (tests/test_step_program_gpu.py
         asserts the aliasing).  The eager path returns fresh tensors."""
+        self.join_history()                   # (the previous step's exchange: its first reader is this step's aggregator)
         if isinstance(feed_dict, PackedBatch):
             drop = float(getattr(feed_dict, 'dropout', 0.0) or 0.0) if self.is_training else 0.0
             prog = self._program(feed_dict, drop)
@@ -888,6 +902,7 @@ class GCN(Model):
     def get_pred_and_grad(self, sess, feed_dict):
         """Prediction and the gradient of the loss wrt the first variable (gcn/models.py:196),
         without touching weights or history."""
+        self.join_history()
         self.dropout = float(feed_dict.get(self.placeholders['dropout'], 0.0))
         cur = self.get_data(feed_dict)
         self.forward(cur)

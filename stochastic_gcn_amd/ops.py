@@ -755,7 +755,7 @@ class LdsPlanHost(object):
     """The host arrays of an LDS-sweep plan (include/sgcn.h sgcn_ldsplan_*): what ``LdsSweepCSR`` uploads, and what
     the CPU tests decode (``decode`` rebuilds the planned matrix from the kernel's own operands)."""
 
-    def __init__(self, a, labels=None, VW=2, T=0, min_reuse=2):
+    def __init__(self, a, labels=None, VW=2, T=0, min_reuse=2, general=False):
         a = a.tocsr()
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
@@ -779,17 +779,21 @@ class LdsPlanHost(object):
         check(lib.sgcn_ldsplan_create(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, K,
                                       col_pos.ctypes.data if col_pos is not None else None,
                                       row_group.ctypes.data if row_group is not None else None,
-                                      int(VW), int(T), int(min_reuse), C.byref(h)))
+                                      int(VW), int(T), int(min_reuse), 1 if general else 0, C.byref(h)))
         try:
-            sizes = np.zeros(8, dtype=np.int64)
+            sizes = np.zeros(17, dtype=np.int64)
             check(lib.sgcn_ldsplan_sizes(h, sizes.ctypes.data))
-            nt, nch, nent, nfix, nslots, rnnz, staged = (int(x) for x in sizes[:7])
-            self.VW, self.NW, self.RW, self.S, self.U = int(VW), 8, 192 // int(VW), 128, 8
+            nt, nch, nent, nfix, nslots, rnnz, staged, unit = (int(x) for x in sizes[:8])
+            self.xcd_tile_ptr = [int(x) for x in sizes[8:17]]
+            self.VW, self.NW, self.RW, self.S, self.U, self.unit = int(VW), 8, 192 // int(VW), 80, 8, unit
             R = self.NW * self.RW
             self.tile_chunk_ptr = np.empty(nt + 1, dtype=np.int32)
             self.chunk_cols = np.empty(nch * self.S, dtype=np.int32)
+            self.chunk_hdr = np.empty(nch * self.NW * 16, dtype=np.int32)
             self.ent_ptr = np.empty(nch * self.NW + 1, dtype=np.int64)
-            self.entries = np.empty(2 * (nent + 2 * self.U), dtype=np.uint32)
+            self.words = np.empty(nent + 256, dtype=np.uint32)
+            self.vals = np.empty(nent + 256, dtype=np.float32)
+            self.row_fold = np.empty(M, dtype=np.float32)
             self.tile_rows = np.empty(nt * R, dtype=np.int32)
             self.tile_slots = np.empty(nt * R, dtype=np.int32)
             self.fix = np.empty((nfix, 3), dtype=np.int32)
@@ -797,7 +801,8 @@ class LdsPlanHost(object):
             res_col = np.empty(rnnz, dtype=np.int32)
             res_val = np.empty(rnnz, dtype=np.float32)
             check(lib.sgcn_ldsplan_export(h, self.tile_chunk_ptr.ctypes.data, self.chunk_cols.ctypes.data,
-                                          self.ent_ptr.ctypes.data, self.entries.ctypes.data, self.tile_rows.ctypes.data,
+                                          self.chunk_hdr.ctypes.data, self.ent_ptr.ctypes.data, self.words.ctypes.data, self.vals.ctypes.data,
+                                          self.row_fold.ctypes.data if M else None, self.tile_rows.ctypes.data,
                                           self.tile_slots.ctypes.data, self.fix.ctypes.data if nfix else None,
                                           res_rowptr.ctypes.data, res_col.ctypes.data if rnnz else None,
                                           res_val.ctypes.data if rnnz else None))
@@ -814,8 +819,7 @@ class LdsPlanHost(object):
         """(row, column, value, workspace slot) of every non-pad entry, read back from the kernel's operands: the ring
         slot of an entry's LDS address -> ``chunk_cols``, its register offset -> ``tile_rows``."""
         piece = 256 * self.VW
-        half = self.S * piece
-        ent = self.entries.reshape(-1, 2)
+        part = self.S * piece
         rows, cols, vals, slots = [], [], [], []
         for t in range(self.ntiles):
             cb, ce = int(self.tile_chunk_ptr[t]), int(self.tile_chunk_ptr[t + 1])
@@ -824,21 +828,25 @@ class LdsPlanHost(object):
                 base = cb * self.NW + w * nc
                 for k in range(nc):
                     e0, e1 = int(self.ent_ptr[base + k]), int(self.ent_ptr[base + k + 1])
+                    hd = self.chunk_hdr[((cb + k) * self.NW + w) * 16:((cb + k) * self.NW + w + 1) * 16]
+                    per = self.S // self.NW
+                    assert np.array_equal(hd[:per], self.chunk_cols[(cb + k) * self.S + w * per:(cb + k) * self.S + (w + 1) * per])
+                    assert hd[per] * self.U == e1 - e0 and (int(hd[per + 1]) & 0xffffffff) | (int(hd[per + 2]) << 32) == e0
                     if e1 == e0:
                         continue
-                    assert (e1 - e0) % self.U == 0
-                    word = ent[e0:e1, 1]
+                    assert (e1 - e0) % self.U == 0 and e1 - e0 <= (256 if self.unit else 128)
+                    word = self.words[e0:e1]
                     addr = word & np.uint32(~np.uint32(piece - 1))
-                    real = addr != 2 * half                       # pads sit on the zero piece
-                    assert np.all(ent[e0:e1, 0][~real] == 0)
-                    assert np.all(addr[real] // half == (k & 1)), "entry in the wrong ring half"
-                    slot = (addr[real] % half) // piece
+                    real = addr != 3 * part                       # pads sit on the zero piece
+                    assert np.all(self.vals[e0:e1][~real] == 0)
+                    assert np.all(addr[real] // part == k % 3), "entry in the wrong part of the ring"
+                    slot = (addr[real] % part) // piece
                     lr = (word[real] & np.uint32(0xff)) // self.VW
                     place = (t * self.NW + w) * self.RW + lr.astype(np.int64)
                     rows.append(self.tile_rows[place])
                     slots.append(self.tile_slots[place])
                     cols.append(self.chunk_cols[(cb + k) * self.S + slot.astype(np.int64)])
-                    vals.append(ent[e0:e1, 0][real].view(np.float32))
+                    vals.append(self.vals[e0:e1][real])
         cat = lambda x, dt: np.concatenate(x) if x else np.zeros(0, dtype=dt)          # noqa: E731
         return cat(rows, np.int32), cat(cols, np.int32), cat(vals, np.float32), cat(slots, np.int32)
 
@@ -849,17 +857,20 @@ class LdsSweepCSR(object):
     nonzeros whose column a tile references fewer than ``min_reuse`` times are multiplied by the ordinary column sweep
     (``self.residual``: a ColumnSweepCSR) into the same output."""
 
-    def __init__(self, a, device, labels=None, VW=2, T=0, min_reuse=2, residual_G=2, host=None):
-        h = host if host is not None else LdsPlanHost(a, labels=labels, VW=VW, T=T, min_reuse=min_reuse)
+    def __init__(self, a, device, labels=None, VW=2, T=0, min_reuse=2, residual_G=2, host=None, general=False):
+        h = host if host is not None else LdsPlanHost(a, labels=labels, VW=VW, T=T, min_reuse=min_reuse, general=general)
         self.host_stats = dict(ntiles=h.ntiles, nchunks=h.nchunks, nent=h.nent, staged=h.staged, nnz=h.nnz,
-                               local_nnz=h.local_nnz, pad_fraction=1.0 - h.local_nnz / max(h.nent, 1),
+                               local_nnz=h.local_nnz, pad_fraction=1.0 - h.local_nnz / max(h.nent, 1), unit=h.unit,
                                reuse=h.local_nnz / max(h.staged, 1))
         self.shape, self.nnz, self.device = h.shape, h.nnz, device
-        self.VW, self.NW, self.RW, self.S, self.U = h.VW, h.NW, h.RW, h.S, h.U
+        self.VW, self.NW, self.RW, self.S, self.U, self.unit = h.VW, h.NW, h.RW, h.S, h.U, h.unit
+        self.xcd_tile_ptr = list(h.xcd_tile_ptr)
         self.ntiles, self.nchunks, self.nent, self.nfix, self.nslots = h.ntiles, h.nchunks, h.nent, h.nfix, h.nslots
         to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)          # noqa: E731
-        self.tile_chunk_ptr, self.chunk_cols = to(h.tile_chunk_ptr), to(h.chunk_cols)
-        self.ent_ptr, self.entries = to(h.ent_ptr), to(h.entries.view(np.int32))
+        self.tile_chunk_ptr, self.chunk_cols, self.chunk_hdr = to(h.tile_chunk_ptr), to(h.chunk_cols), to(h.chunk_hdr)
+        self.ent_ptr, self.words = to(h.ent_ptr), to(h.words.view(np.int32))
+        self.vals = None if h.unit else to(h.vals)
+        self.row_fold = to(h.row_fold) if h.unit else None
         self.tile_rows, self.tile_slots = to(h.tile_rows), to(h.tile_slots)
         self.fix = to(h.fix) if h.nfix else None
         self.ws = None
@@ -873,9 +884,11 @@ class LdsSweepCSR(object):
         need = self.nslots * ldw
         if need and (self.ws is None or self.ws.numel() < need):
             self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-        return _ffi.LdsPlan(self.VW, self.NW, self.RW, self.S, self.U, self.ntiles, self.nchunks, self.nent,
-                            self.tile_chunk_ptr.data_ptr(), self.chunk_cols.data_ptr(), self.ent_ptr.data_ptr(),
-                            self.entries.data_ptr(), self.tile_rows.data_ptr(), self.tile_slots.data_ptr(),
+        return _ffi.LdsPlan(self.VW, self.NW, self.RW, self.S, self.U, self.unit, (C.c_int32 * 9)(*self.xcd_tile_ptr),
+                            self.ntiles, self.nchunks, self.nent,
+                            self.tile_chunk_ptr.data_ptr(), self.chunk_cols.data_ptr(), self.chunk_hdr.data_ptr(),
+                            self.ent_ptr.data_ptr(), self.words.data_ptr(), _ptr(self.vals), _ptr(self.row_fold),
+                            self.tile_rows.data_ptr(), self.tile_slots.data_ptr(),
                             _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
                             0 if self.ws is None else self.ws.numel())
 
@@ -886,8 +899,8 @@ class LdsSweepCSR(object):
         return None
 
 
-def spmm_lds(A, B, out=None, gidx=None, rscale=None, beta=0.0, d=None, local_only=False):
-    """C = rscale (.) (A B[g]) + beta C for an LdsSweepCSR: the planned nonzeros through the LDS ring
+def spmm_lds(A, B, out=None, rscale=None, beta=0.0, d=None, local_only=False):
+    """C = rscale (.) (A B) + beta C for an LdsSweepCSR: the planned nonzeros through the LDS ring
     (sgcn_spmm_lds_f32), then the residual on top (column sweep with beta = 1)."""
     M, K = A.shape
     bptr, ldb = _rows2d(B, "B")
@@ -899,13 +912,13 @@ def spmm_lds(A, B, out=None, gidx=None, rscale=None, beta=0.0, d=None, local_onl
         out = torch.empty((M, pitch), dtype=torch.float32, device=B.device)[:, :d]
     cptr, ldc = _rows2d(out, "out")
     plan = A.struct(d)
-    check(lib.sgcn_spmm_lds_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(gidx, torch.int32, "gidx")),
-                                _ptr(_dev(rscale, torch.float32, "rscale")), cptr, ldc, float(beta), _stream()))
+    check(lib.sgcn_spmm_lds_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(rscale, torch.float32, "rscale")),
+                                cptr, ldc, float(beta), _stream()))
     if A.residual is not None and not local_only:
         if isinstance(A.residual, ColumnSweepCSR):
-            spmm_cs(A.residual, B, out=out, gidx=gidx, rscale=rscale, beta=1.0, d=d)
+            spmm_cs(A.residual, B, out=out, rscale=rscale, beta=1.0, d=d)
         else:
-            spmm(A.residual, B, out=out, gidx=gidx, rscale=rscale, beta=1.0, d=d)
+            spmm(A.residual, B, out=out, rscale=rscale, beta=1.0, d=d)
     return out
 
 

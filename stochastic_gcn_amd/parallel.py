@@ -16,6 +16,12 @@ The reference is single-process (one tf.Session, gcn/train.py:130); this module 
   * history consistency (policy H-a): after the optimizer step the ranks all-gather their
     ``(fields[l], new_history rows)`` and every replica applies all W updates in rank order
     (deterministic; a vertex updated by two ranks in one step keeps the higher rank's row).
+    The all-gather is ASYNCHRONOUS: it is issued behind the optimizer and joined in front of the
+    history's next reader -- the next step's aggregator (``join_history``) -- so it rides beside the
+    host's work on the next batch instead of on the step's dependent chain.
+
+``SGCN_FORCE_PG=1`` makes a one-rank job take the collective paths as well (a real process group
+of one rank): the RCCL smoke test, and ``bench.py --gpus 1`` printing its all-reduce time.
 """
 import os
 
@@ -34,7 +40,10 @@ class DataParallel(object):
         self.device = device
         self.history_cap = None          # upper bound of |fields[l]| per step (rows), or None
         self._hist_bufs = {}
-        if self.world > 1 and init and not dist.is_initialized():
+        self._pending = []               # history all-gathers in flight: (work, recv, history, cap, d, scatter_fn)
+        self.force = os.environ.get("SGCN_FORCE_PG", "0") not in ("", "0")
+        self.backend = None
+        if (self.world > 1 or self.force) and init and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             backend = backend or os.environ.get("SGCN_DIST_BACKEND") or \
@@ -43,10 +52,12 @@ class DataParallel(object):
             if backend == "nccl":
                 kw["device_id"] = device
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+        if dist.is_initialized():
+            self.backend = dist.get_backend()
 
     @property
     def active(self):
-        return self.world > 1
+        return self.world > 1 or (self.force and dist.is_initialized())
 
     # ---- sharding ---------------------------------------------------------------------------
     def vertex_range(self, n):
@@ -65,9 +76,14 @@ class DataParallel(object):
 
     # ---- collectives ------------------------------------------------------------------------
     def allreduce_mean_(self, flat):
+        """Mean over the ranks, in place.  RCCL averages inside the collective (ReduceOp.AVG: no extra kernel on the
+        step's dependent chain); gloo has no AVG: sum, then one division."""
         if self.active:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(self.world)
+            if self.backend == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(self.world)
         return flat
 
     def broadcast_(self, flat, src=0):
@@ -105,18 +121,20 @@ class DataParallel(object):
         """Install the gradient all-reduce into a model's step and align the replicas' weights."""
         model.grad_hook = self.allreduce_mean_
         model.history_hook = self.sync_history
+        model.history_join = self.join_history
         model.dropout_seed = int(getattr(model, "dropout_seed", 0)) + 7919 * self.rank   # independent masks per rank
         self.broadcast_(model.theta)
 
     def sync_history(self, history, idx, rows, scatter_fn):
         """All-gather this step's (idx[n], rows[n x d]) and apply every rank's update to the local
-        replica ``history`` in rank order.
+        replica ``history`` in rank order -- the apply happens in ``join_history``, which every reader
+        of the history calls first (Model.run_one_step, save, the trainer's copy into the test model).
 
         Fixed-capacity path (``history_cap`` rows, set by the trainer from batch size and
-        degrees): ONE all-gather of a preallocated int32 buffer ``[cap ids | cap x d row bits]``
-        per rank, ids padded with -1 (the scatter kernel skips them) -- no size exchange, no
-        host synchronisation, so the step stays asynchronous.  Without a bound: a size exchange
-        (one host sync) followed by a padded all-gather."""
+        degrees): ONE asynchronous all-gather of a preallocated int32 buffer ``[cap ids | cap x d
+        row bits]`` per rank, ids padded with -1 (the scatter kernel skips them) -- no size exchange,
+        no host synchronisation.  Without a bound: a size exchange (one host sync) followed by a
+        padded all-gather."""
         if not self.active:
             scatter_fn(history, idx, rows)
             return
@@ -126,29 +144,43 @@ class DataParallel(object):
         if cap is not None and n > cap:      # a rank-local branch here would desynchronise the ranks
             raise RuntimeError("history exchange: %d rows exceed history_cap=%d" % (n, cap))
         if cap is None or cap * (d + 1) * 4 > self.HISTORY_FIXED_LIMIT_BYTES:
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-            dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
-            cap = max(int(s.item()) for s in sizes)
+            sizes = torch.zeros(self.world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
+            cap = int(sizes.max().item())
             bufs = None
         else:
-            bufs = self._hist_bufs.get((cap, d, dev))
+            # one send / receive pair per history tensor in flight (a model with two aggregator layers has two
+            # exchanges pending between a step's optimizer and the next step's first aggregator)
+            key = (cap, d, dev, len(self._pending))
+            bufs = self._hist_bufs.get(key)
         if bufs is None:
             send = torch.empty(cap * (d + 1), dtype=torch.int32, device=dev)
             recv = torch.empty(self.world * cap * (d + 1), dtype=torch.int32, device=dev)
             bufs = (send, recv)
             if self.history_cap is not None and cap == self.history_cap:
-                self._hist_bufs[(cap, d, dev)] = bufs
+                self._hist_bufs[(cap, d, dev, len(self._pending))] = bufs
         send, recv = bufs
         send[:n] = idx.tensor() if hasattr(idx, "tensor") and not torch.is_tensor(idx) else idx
         send[n:cap] = -1
         send[cap:].view(torch.float32).view(cap, d)[:n] = rows
-        per = cap * (d + 1)
-        dist.all_gather([recv[r * per:(r + 1) * per] for r in range(self.world)], send)
-        for r in range(self.world):
-            blk = recv[r * per:(r + 1) * per]
-            scatter_fn(history, blk[:cap], blk[cap:].view(torch.float32).view(cap, d))
+        work = dist.all_gather_into_tensor(recv, send, async_op=True)
+        self._pending.append((work, recv, history, cap, d, scatter_fn))
+
+    def join_history(self):
+        """Wait for the history exchanges in flight and apply them (rank order, issue order).  On RCCL the wait is a
+        stream dependency, not a host block."""
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        for work, recv, history, cap, d, scatter_fn in pend:
+            work.wait()
+            per = cap * (d + 1)
+            for r in range(self.world):
+                blk = recv[r * per:(r + 1) * per]
+                scatter_fn(history, blk[:cap], blk[cap:].view(torch.float32).view(cap, d))
 
     def shutdown(self):
+        self.join_history()
         if self.active and dist.is_initialized():
             dist.destroy_process_group()
 
@@ -249,7 +281,7 @@ class ShardedSpMM(object):
         send = torch.zeros((cap, pitch), dtype=torch.float32, device=X_local.device)
         send[:X_local.shape[0], :d] = X_local
         recv = torch.empty((par.world, cap, pitch), dtype=torch.float32, device=X_local.device)
-        dist.all_gather([recv[r] for r in range(par.world)], send)
+        dist.all_gather_into_tensor(recv.view(par.world * cap, pitch), send)
         if all(c == cap for c in self.row_counts):
             return recv.view(par.world * cap, pitch)[:, :d]
         full = torch.empty((self.shape[0], pitch), dtype=torch.float32, device=X_local.device)

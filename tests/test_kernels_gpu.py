@@ -792,11 +792,17 @@ def test_column_sweep_plan_cache_round_trip_both_group_counts(dev, tmp_path):
 @pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6), (500, 500, 256, 0),
                                          (64, 64, 130, 2), (90, 70, 30, 2), (5000, 3000, 602, 6), (2000, 1500, 129, 3)])
 @pytest.mark.parametrize("min_reuse", [1, 2])
-def test_lds_sweep_vs_oracle(dev, M, K, d, pad, min_reuse):
+@pytest.mark.parametrize("unit", [False, True])
+def test_lds_sweep_vs_oracle(dev, M, K, d, pad, min_reuse, unit):
     """The LDS-staged sweep (+ its residual through the ordinary sweep) against the oracle: plain product, split rows,
-    labels, row scale / gather index / beta, bit-identical reruns, pitch padding untouched."""
+    labels, row scale / beta, bit-identical reruns, pitch padding untouched -- for general values (packed FMA per nonzero)
+    and for a row-normalised matrix (unit plan: the value folded into the row scale, packed ADD per nonzero)."""
     from stochastic_gcn_amd import ops
     a = rand_csr(M, K, 0.08 if M < 1000 else 0.01, M + d, long_rows=[(0, min(K, 300)), (M // 2, min(K, 150))])
+    if unit:                                               # D^-1 A: one value per row (gcn/utils.py:299-309)
+        a.data[:] = 1.0
+        a = sp.diags((1.0 / np.maximum(np.diff(a.indptr), 1)).astype(np.float32)).dot(a).tocsr().astype(np.float32)
+        a.sort_indices()
     rng = np.random.RandomState(d)
     B = rng.standard_normal((K, d + pad)).astype(np.float32)
     Bd = T(B, dev)[:, :d]
@@ -804,6 +810,7 @@ def test_lds_sweep_vs_oracle(dev, M, K, d, pad, min_reuse):
     lab = (rng.randint(0, 3, M).astype(np.int32), rng.randint(0, 3, K).astype(np.int32))
     for labels, T_ in ((None, 0), (lab, 32)):
         A = ops.LdsSweepCSR(a, dev, labels=labels, T=T_, min_reuse=min_reuse)
+        assert bool(A.unit) == unit
         if T_:
             assert A.nfix >= 1
         if min_reuse == 1:
@@ -814,13 +821,11 @@ def test_lds_sweep_vs_oracle(dev, M, K, d, pad, min_reuse):
         if pad:
             assert torch.all(out_full[:, d:] == 7.0)
         assert torch.equal(ops.spmm_lds(A, Bd), out)                   # deterministic
-    H = rng.standard_normal((4000, d + pad)).astype(np.float32)
-    g = rng.choice(4000, K, replace=False).astype(np.int32)
     rs = rng.rand(M).astype(np.float32)
     c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
     o2 = T(c0, dev)
-    ops.spmm_lds(A, T(H, dev)[:, :d], out=o2[:, :d], gidx=T(g, dev), rscale=T(rs, dev), beta=0.5)
-    ref2 = onp.spmm(a.indptr, a.indices, a.data, H[:, :d], gidx=g, rscale=rs, C_in=c0[:, :d], beta=0.5)
+    ops.spmm_lds(A, Bd, out=o2[:, :d], rscale=T(rs, dev), beta=0.5)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, B[:, :d], rscale=rs, C_in=c0[:, :d], beta=0.5)
     assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
     if pad:
         np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
@@ -840,9 +845,13 @@ def test_lds_sweep_on_communities_vs_oracle_and_column_sweep(dev):
     Bd = T(B, dev)[:, :d]
     ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
     A = ops.LdsSweepCSR(a, dev, labels=comm, min_reuse=2)
-    assert A.host_stats["reuse"] > 3 and A.residual is not None
+    assert A.host_stats["reuse"] > 3 and A.residual is not None and A.unit
     c1 = ops.spmm_lds(A, Bd)
     assert onp.rel_err(c1.cpu().numpy(), ref) <= TOL
+    Ag = ops.LdsSweepCSR(a, dev, labels=comm, min_reuse=2, general=True)       # the same plan with the values kept per nonzero
+    assert not Ag.unit
+    cg = ops.spmm_lds(Ag, Bd)
+    assert float((cg - c1).abs().max() / c1.abs().max()) <= 1e-5
     c0 = ops.spmm_cs(ops.ColumnSweepCSR(a, dev, G=2), Bd)
     assert float((c0 - c1).abs().max() / c0.abs().max()) <= 1e-5
     assert torch.equal(ops.spmm_lds(A, Bd), c1)

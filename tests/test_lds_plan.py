@@ -18,10 +18,13 @@ def _matrix(m, k, dens, seed, long_rows=()):
     return a
 
 
-def _check(a, labels, min_reuse, T=0):
+def _check(a, labels, min_reuse, T=0, general=True):
     from stochastic_gcn_amd import ops
-    h = ops.LdsPlanHost(a, labels=labels, min_reuse=min_reuse, T=T)
+    h = ops.LdsPlanHost(a, labels=labels, min_reuse=min_reuse, T=T, general=general)
+    assert not (general and h.unit)
     r, c, v, s = h.decode()
+    if h.unit:                                   # the values live once per row
+        assert np.all(v == h.row_fold[r])
     assert r.shape[0] + h.residual.nnz == a.nnz                       # nothing lost, nothing doubled
     assert np.all(r >= 0)
     loc = sp.coo_matrix((v.astype(np.float64), (r, c)), shape=a.shape).tocsr()
@@ -68,12 +71,29 @@ def test_plan_rejects_bad_input():
         ops.LdsPlanHost(a, labels=(None, np.zeros(19, np.int32)))
 
 
+def test_unit_plans_fold_row_constant_values():
+    """A row-normalised adjacency (the reference's D^-1 A, gcn/utils.py:299-309) gives a unit plan: one value per row;
+    a matrix whose rows mix values does not, and `general=True` never folds."""
+    rng = np.random.RandomState(3)
+    a = _matrix(400, 300, 0.1, 9)
+    a.data[:] = 1.0
+    deg = np.maximum(np.diff(a.indptr), 1)
+    a = sp.diags((1.0 / deg).astype(np.float32)).dot(a).tocsr().astype(np.float32)
+    h = _check(a, None, 2, general=False)
+    assert h.unit == 1
+    assert _check(a, None, 2, general=True).unit == 0
+    b = _matrix(400, 300, 0.1, 9)
+    assert _check(b, None, 2, general=False).unit == 0
+    assert np.all(_check(b, None, 2, general=False).row_fold == 1.0)
+
+
 def test_plan_on_a_graph_with_communities_stages_shared_columns():
     from stochastic_gcn_amd import synthetic
     data = synthetic.reddit_sbm(n=20000, m=800000, classes=5, splits=(15000, 2000, 3000), p_in=0.8, seed=2)
     a = data[2]
     comm = data[6].argmax(1).astype(np.int32)
-    h = _check(a, comm, 2)
+    h = _check(a, comm, 2, general=False)
+    assert h.unit == 1                               # row-normalised: values fold into the row scale
     assert h.local_nnz / a.nnz > 0.75                # the in-community nonzeros ride the ring ...
     assert h.local_nnz / h.staged > 4.0              # ... with real reuse per staged piece
     flat = _check(a, None, 2)                        # without labels the same matrix shares far less

@@ -68,10 +68,16 @@ def w_history(par):
     def scatter(h, i, r):
         onp.scatter_rows(h.numpy(), i.numpy(), r.numpy())
     par.sync_history(H, torch.from_numpy(idx), torch.from_numpy(rows), scatter)    # size-exchange path
+    assert not H.any()                                     # asynchronous: nothing lands before the join
+    par.join_history()
     H2 = torch.zeros((N, d))
     par.history_cap = 12                                   # fixed-capacity path (-1 padded ids)
     par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows), scatter)
-    par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows), scatter)   # reuses its buffers
+    par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows), scatter)   # two exchanges in flight: own buffers each
+    par.join_history()
+    par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows), scatter)   # reuses the first pair
+    par.join_history()
+    par.join_history()                                     # nothing pending: a no-op
     par.history_cap = None
     return dict(H=H.numpy(), H2=H2.numpy(), idx=idx, rows=rows)
 
@@ -104,6 +110,7 @@ def w_train_step(par):
         hist = torch.from_numpy(om.history[0])
         par.sync_history(hist, torch.from_numpy(feed[ph['fields'][0]]), torch.from_numpy(om._new_hist[0]),
                          lambda h, i, r: onp.scatter_rows(h.numpy(), i.numpy(), r.numpy()))
+        par.join_history()                                 # (the product joins in front of the next step's aggregator)
         out["avg_grad%d" % step] = flat.numpy().copy()
     out["theta"] = np.concatenate([om.params[k].ravel() for k in names])
     out["hist"] = om.history[0]

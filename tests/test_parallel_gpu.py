@@ -204,8 +204,9 @@ def _train_worker(rank, world, port, native, out_dir):
         trn = Trainer(data=data, verbose=False)
         for _ in range(2):
             trn.train_epoch()
-    torch.cuda.synchronize()
     m = trn.train_model
+    m.join_history()                              # the last step's exchange (asynchronous: joined by the history's next reader)
+    torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "t%d_%d.npz" % (int(native), rank)), theta=m.theta.cpu().numpy(),
              hist=m.history[0][0].cpu().numpy(), used_program=np.array([bool(getattr(m, '_programs', {}))]))
     trn.par.shutdown()
@@ -265,6 +266,7 @@ def _oracle_pair_worker(rank, world, port, steps, out_dir):
             masks = tm._masks(dm, 1.0 - fl['dropout'])
             # device: forward, backward, all-reduce(mean) of the flat gradient, Adam, history all-gather + scatter
             outs = dm.run_one_step(None, feed)
+            dm.join_history()                             # (otherwise joined in front of the next step's aggregator)
             d_acts, dg = [tm._np(a) for a in dm.activations[1:]], dm.get_grads()
             # oracle: the same step, its own collectives on CPU tensors
             logits, o_acts = om.forward(feed, ph, fl['dropout'], masks)
@@ -281,6 +283,7 @@ def _oracle_pair_worker(rank, world, port, steps, out_dir):
             hist = torch.from_numpy(om.history[0])
             par.sync_history(hist, torch.from_numpy(feed[ph['fields'][0]]), torch.from_numpy(om._new_hist[0]),
                              lambda h, i, r: onp.scatter_rows(h.numpy(), i.numpy(), r.numpy()))
+            par.join_history()
             worst = 0.0
             for da, oa in zip(d_acts, o_acts):
                 for dd, oo in (zip(da, oa) if isinstance(oa, tuple) else [(da, oa)]):
@@ -332,3 +335,70 @@ def test_two_rank_cvd_pp_training_steps_match_the_two_rank_oracle(tmp_path):
     print("2-rank CVD+PP vs 2-rank oracle, 3 steps: activations %.1e  mean gradient %.1e  weights %.1e  history %.1e"
           % (max(x["err_act"].max() for x in r), max(x["err_grad"].max() for x in r),
              max(x["err_param"].max() for x in r), max(x["err_hist"].max() for x in r)))
+
+
+# ---- RCCL itself: one rank (SGCN_FORCE_PG=1) ---------------------------------------------------------------------------
+def _rccl_worker(rank, world, port, force, out_dir):
+    """Three program-path training steps + an all-gathered sharded product, with a REAL one-rank RCCL process group
+    (force) or without any process group (not force): the same numbers, bit for bit."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SGCN_FORCE_PG="1" if force else "0")
+    os.environ.pop("SGCN_DIST_BACKEND", None)
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from stochastic_gcn_amd import synthetic
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.parallel import ShardedSpMM
+    from stochastic_gcn_amd.train import Trainer
+    torch.cuda.set_device(0)
+    data = synthetic.reddit_like(n=6000, m=60000, f=32, classes=6, splits=(3600, 800, 1600), seed=5,
+                                 with_features=True, planted=True)
+    FLAGS.reset()
+    FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+                 hidden1=64, num_fc_layers=2, batch_size=256, test_batch_size=512, cv=True, cvd=True, test_cv=True,
+                 degree=1, test_degree=1, seed=1, native_step=True, max_steps=3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        trn = Trainer(data=data, verbose=False)
+        trn.train_epoch()
+    m, par = trn.train_model, trn.par
+    assert par.active == force and dist.is_initialized() == force
+    if force:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1 and par.backend == "nccl"
+        assert m.grad_hook is not None and m.history_hook is not None and len(par._pending) == 1
+    m.join_history()
+    # the collectives on their own: mean all-reduce (identity on one rank), padded row all-gather
+    g = torch.Generator(device=trn.device); g.manual_seed(3)
+    flat = torch.randn(1000, device=trn.device, generator=g)
+    ref = flat.clone()
+    par.allreduce_mean_(flat)
+    sh = ShardedSpMM(par, data[2], trn.device, kernel="cs", d=30)
+    X = torch.randn((data[0], 30), device=trn.device, generator=g)
+    full = sh.allgather_rows(X[sh.lo:sh.hi].contiguous())
+    c = sh.forward_allgather(X[sh.lo:sh.hi].contiguous())
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl%d.npz" % int(force)), theta=m.theta.cpu().numpy(), hist=m.history[0][0].cpu().numpy(),
+             used_program=np.array([bool(getattr(m, '_programs', {}))]), steps=np.array([m.adam_t]),
+             allreduce_ok=np.array([bool(torch.equal(flat, ref))]), gathered_ok=np.array([bool(torch.equal(full, X))]),
+             c=c.cpu().numpy())
+    par.shutdown()
+
+
+def test_rccl_one_rank_training_steps_and_allgather_equal_the_single_process_path(tmp_path):
+    """First contact with RCCL: init_process_group("nccl", world_size=1, device_id=...),
+    DataParallel.attach, three program-path training steps -- prog.run('fb') -> all-reduce (ReduceOp.AVG) ->
+    prog.run('opt') -> asynchronous history all-gather, joined in front of the next step's aggregator -- and
+    ShardedSpMM.allgather_rows, against the same run without a process group: bit-identical weights, history and
+    products (gloo stages through the host and synchronises; only RCCL can show a stream-ordering bug)."""
+    import torch.multiprocessing as mp
+    res = {}
+    for force in (True, False):
+        mp.spawn(_rccl_worker, args=(1, tg._free_port(), force, str(tmp_path)), nprocs=1, join=True)
+        res[force] = np.load(os.path.join(str(tmp_path), "rccl%d.npz" % int(force)))
+    for force in (True, False):
+        assert res[force]["used_program"][0] and res[force]["steps"][0] == 3
+        assert res[force]["allreduce_ok"][0] and res[force]["gathered_ok"][0]
+    np.testing.assert_array_equal(res[True]["theta"], res[False]["theta"])
+    np.testing.assert_array_equal(res[True]["hist"], res[False]["hist"])
+    np.testing.assert_array_equal(res[True]["c"], res[False]["c"])
+    assert np.abs(res[True]["hist"]).sum() > 0
