@@ -37,6 +37,12 @@ L2_PEAK = 34.5e12          # aggregate L2 bandwidth, MI355X_MICROARCH.md "L2 (pe
 HBM_COPY = 6.29e12         # measured float4-copy ceiling (ibid.)
 
 
+def _finish_args(args):
+    if args.kernel is None:
+        args.kernel = "lds" if args.workload == "reddit-sbm" else "cs"
+    return args
+
+
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -56,8 +62,12 @@ def parse(argv=None):
     p.add_argument("--no-strong", action="store_true", help="--gpus N > 1: skip the strong-scaling leg (ONE graph row-block sharded)")
     p.add_argument("--epoch-timeout", type=int, default=240, help="watchdog of the train-epoch leg, s")
     p.add_argument("--no-backward", action="store_true")
-    p.add_argument("--kernel", default="cs", choices=["rows", "cs"],
-                   help="rows = row-gather SpMM (sgcn_spmm.hip); cs = column-sweep (sgcn_spmm_cs.hip)")
+    p.add_argument("--kernel", default=None, choices=["rows", "cs", "lds"],
+                   help="rows = row-gather SpMM (sgcn_spmm.hip); cs = column-sweep (sgcn_spmm_cs.hip); lds = LDS-staged "
+                        "sweep for graphs with communities (sgcn_spmm_lds.hip) + the column sweep on its residual; "
+                        "default: lds for reddit-sbm, cs otherwise")
+    p.add_argument("--lds-min-reuse", type=int, default=3,
+                   help="--kernel lds: a column is staged for a tile only if the tile references it this often")
     p.add_argument("--cs-t", type=int, default=0)
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
@@ -76,7 +86,7 @@ def parse(argv=None):
                    help="[test hook] no GPU work: only the launch / rendezvous / collective skeleton of "
                         "the run (what the CPU test of `--gpus N` exercises under SGCN_DIST_BACKEND=gloo); "
                         "the JSON line carries \"dry_run\": true and no throughput")
-    return p.parse_args(argv)
+    return _finish_args(p.parse_args(argv))
 
 
 def _free_port():
@@ -393,7 +403,7 @@ def strong_leg(args, dev, world, rank, full_adj0, d, pitch, steps):
     from stochastic_gcn_amd.parallel import DataParallel, ShardedSpMM
     par = DataParallel(device=dev, init=False)
     n = full_adj0.shape[0]
-    sh = ShardedSpMM(par, full_adj0, dev, kernel=args.kernel, d=d)
+    sh = ShardedSpMM(par, full_adj0, dev, kernel="cs" if args.kernel == "lds" else args.kernel, d=d)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)                              # the same operand on every rank
     Xp = torch.zeros((n, pitch), device=dev)
@@ -401,7 +411,7 @@ def strong_leg(args, dev, world, rank, full_adj0, d, pitch, steps):
     dCp = torch.zeros((n, pitch), device=dev)
     dCp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
     X, dC = Xp[:, :d], dCp[:, :d]
-    if args.kernel == "cs":
+    if args.kernel in ("cs", "lds"):
         sh.autotune(X, dC)
     C = torch.zeros((n, pitch), device=dev)[sh.lo:sh.hi, :d]
     dX = torch.zeros((n, pitch), device=dev)[sh.lo:sh.hi, :d]
@@ -557,11 +567,13 @@ def main(argv=None):
             import types
             r_, w_ = (int(x) for x in args.emulate_shard.split("/"))
             par = types.SimpleNamespace(rank=r_, world=w_, active=False)    # no peers: no collectives
-        sh = ShardedSpMM(par, full_adj, dev, kernel=args.kernel, with_transpose=not args.no_backward,
+        sh = ShardedSpMM(par, full_adj, dev, kernel="cs" if args.kernel == "lds" else args.kernel, with_transpose=not args.no_backward,
                          d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d))
         A = sh.A
-    elif args.kernel == "cs":
+    elif args.kernel in ("cs", "lds"):
         comm = None
+        if args.kernel == "lds" and reorder == "none":
+            raise SystemExit("bench.py: --kernel lds needs communities (--reorder lp | labels)")
         if reorder == "lp":
             t_lp = time.time()
             comm, ncomm = ops.reorder_labels(full_adj)
@@ -570,11 +582,20 @@ def main(argv=None):
         elif reorder == "labels":
             comm = np.ascontiguousarray(data10[6].argmax(1), dtype=np.int32)
             reorder_info = {"method": "dataset labels", "communities": int(comm.max()) + 1}
-        cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1)) if comm is None else 1)
-        gk = dict(G=cs_g, align=args.cs_align) if (cs_g != 1 and comm is None) else dict(col_labels=comm, row_labels=comm)
-        A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
-        A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
-        mm = ops.spmm_cs
+        if args.kernel == "lds":
+            # planned nonzeros through the LDS ring, the rest (columns a tile references < min_reuse times) through the
+            # two-lane-group column sweep into the same output
+            A = ops.LdsSweepCSR(full_adj, dev, labels=comm, min_reuse=args.lds_min_reuse)
+            A.transpose = None if args.no_backward else ops.LdsSweepCSR(full_adj.T.tocsr(), dev, labels=comm,
+                                                                        min_reuse=args.lds_min_reuse)
+            mm = ops.spmm_lds
+            reorder_info["lds_plan"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in A.host_stats.items()}
+        else:
+            cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1)) if comm is None else 1)
+            gk = dict(G=cs_g, align=args.cs_align) if (cs_g != 1 and comm is None) else dict(col_labels=comm, row_labels=comm)
+            A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
+            A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
+            mm = ops.spmm_cs
     else:
         A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)
         mm = ops.spmm
@@ -592,12 +613,12 @@ def main(argv=None):
         gen.manual_seed(1234)                      # one B / dC for the whole job
         Xp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
         dCp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
-        if args.kernel == "cs" and not any(kv.startswith("cs_pace") for kv in args.tune):
+        if args.kernel in ("cs", "lds") and not any(kv.startswith("cs_pace") for kv in args.tune):
             sh.autotune(X, None if args.no_backward else dC)
         C, dX = C[sh.lo:sh.hi], dX[sh.lo:sh.hi]
         Xl, dCl = X[sh.lo:sh.hi].contiguous(), dC[sh.lo:sh.hi].contiguous()
-    elif args.kernel == "cs" and not any(kv.startswith("cs_pace") for kv in args.tune):
-        tuned = {"fwd": A.autotune(X)}                  # untimed setup, once per plan and width
+    elif args.kernel in ("cs", "lds") and not any(kv.startswith("cs_pace") for kv in args.tune):
+        tuned = {"fwd": A.autotune(X)}                  # untimed setup, once per plan and width (lds: its residual's clock)
         if not args.no_backward:
             tuned["bwd"] = A.transpose.autotune(dC)
     gfl = args.grad_floats or reddit_grad_floats()
@@ -663,6 +684,20 @@ def main(argv=None):
         nnz_l, m_l = sh.local_nnz, sh.hi - sh.lo
         bytes_alg = nnz_l * 8 + (m_l + 1) * 4 + sh.distinct_cols * d * 4 + m_l * d * 4
     achieved = bytes_alg / (fwd_ms * 1e-3)
+    lds_parts = None
+    if args.kernel == "lds" and sh is None:     # the forward product's two kernels on their own (untimed region)
+        def _t(fn, reps=5):
+            fn()
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(reps):
+                fn()
+            b_.record()
+            b_.synchronize()
+            return a_.elapsed_time(b_) / reps
+        lds_parts = {"planned_part": round(_t(lambda: ops.spmm_lds(A, X, out=C, local_only=True)), 4),
+                     "residual_part": round(_t(lambda: ops.spmm_cs(A.residual, X, out=C, beta=1.0)), 4)
+                     if A.residual is not None else 0.0}
     out = {
         "metric": "training edges/s (SpMM)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -681,8 +716,10 @@ def main(argv=None):
             # column sweep: passes over the feature dimension x rounds of resident tiles, as the library reports it
             "kernel_launches_per_spmm": int(re.search(r" x (\d+) launches", A.variant(d)).group(1))
             if args.kernel == "cs" else 1,
+            "lds_parts_ms": lds_parts,
             "cs_autotune_ms_pace": tuned},
         "roofline": {"bound": "hbm", "kernel": ((A.variant(d) + " + cs_fix_kernel: one SpMM") if args.kernel == "cs"
+                                else A.variant(d) if args.kernel == "lds"
                                 else "sgcn::spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,

@@ -495,6 +495,7 @@ class ColumnSweepCSR(object):
         self._tile_nnz = np.diff(tile_ptr).astype(np.int64)
         self._hint, self._hint_round = None, None
         self.pace = {}          # d -> ns per nonzero of the heaviest tile (autotuned), -1 = unpaced
+        self.tuned_ms, self._guard, self._tuning = {}, {}, False
         to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731
         self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
         self.tile_rows, self.tile_slots = to(tile_rows), to(tile_slots)
@@ -530,6 +531,7 @@ class ColumnSweepCSR(object):
         self._tile_nnz = (np.diff(tile_ptr) // G).astype(np.int64)       # steps per tile (what the pace counts)
         self._hint, self._hint_round = None, None
         self.pace = {}
+        self.tuned_ms, self._guard, self._tuning = {}, {}, False
         to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731
         self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
         self.tile_rows, self.tile_slots = to(tile_rows), to(tile_slots)
@@ -618,6 +620,7 @@ class ColumnSweepCSR(object):
         self._tile_nnz = (np.diff(tile_ptr) // G).astype(np.int64)         # steps per tile (what the pace counts)
         self._hint, self._hint_round = None, None
         self.pace = {int(d): int(p) for d, p in z["pace"]}
+        self.tuned_ms, self._guard, self._tuning = {}, {}, False
         to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)          # noqa: E731
         self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(z["colrow"]), to(z["val"])
         self.tile_rows, self.tile_slots = to(z["tile_rows"]), to(z["tile_slots"])
@@ -681,6 +684,13 @@ class ColumnSweepCSR(object):
         sustainable pace depends on the graph, d and the chip's clocks; too fast loses the
         lock-step and with it the L2 hits, too slow leaves the memory system idle)."""
         d = int(B.shape[1] if d is None else d)
+        self._tuning = True
+        try:
+            return self._autotune(B, d, candidates, reps, refine)
+        finally:
+            self._tuning = False
+
+    def _autotune(self, B, d, candidates, reps, refine):
         if candidates is None:           # ns per step of the heaviest tile (a G = 2 step is one load for two nonzeros)
             candidates = (-1, 200, 220, 240, 260, 280, 320, 380) if getattr(self, 'G', 1) == 1 else \
                 (-1, 130, 160, 190, 210, 230, 250, 280, 320)
@@ -724,7 +734,45 @@ class ColumnSweepCSR(object):
                     break
                 best = (t, int(best[1] * 1.04 + 0.5))
         self.pace[d] = best[1]
+        self.tuned_ms[d] = float(best[0])
+        self._guard.pop(d, None)
         return best
+
+    # ---- lost-lock guard ----------------------------------------------------------------------------
+    # The clock-paced sweep is tuned once per plan and width; a pace that has become too fast (another box, a clock or
+    # thermal change) loses the lock-step for good and the product costs ~2x, silently.  Every GUARD_EVERY-th product
+    # of a tuned plan is timed with a pair of events that are read back -- without waiting -- by a later call; two
+    # samples in a row above GUARD_FACTOR x the tuned time re-run the autotune on that call's operand.
+    GUARD_EVERY = 8
+    GUARD_FACTOR = 1.3
+
+    def _guard_before(self, d):
+        """Called by spmm_cs ahead of the launches: returns the event pair to record around them, or None."""
+        if self.grouped or self.pace.get(d, 0) <= 0 or d not in self.tuned_ms:
+            return None
+        g = self._guard.setdefault(d, {"calls": 0, "pending": None, "strikes": 0, "retunes": 0, "last_ms": None})
+        g["calls"] += 1
+        if g["pending"] is not None or g["calls"] % self.GUARD_EVERY:
+            return None
+        g["pending"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        return g["pending"]
+
+    def _guard_after(self, d, B):
+        """Called by spmm_cs behind the launches: reads a finished sample, re-tunes after two slow ones in a row."""
+        g = self._guard.get(d)
+        if g is None or g["pending"] is None or not g["pending"][1].query():
+            return
+        e0, e1 = g["pending"]
+        g["pending"] = None
+        g["last_ms"] = e0.elapsed_time(e1)
+        if g["last_ms"] > self.GUARD_FACTOR * self.tuned_ms[d]:
+            g["strikes"] += 1
+        else:
+            g["strikes"] = 0
+        if g["strikes"] >= 2:
+            n = g["retunes"] + 1
+            self.autotune(B, d=d)                      # (resets the guard's state for d)
+            self._guard[d] = {"calls": 0, "pending": None, "strikes": 0, "retunes": n, "last_ms": None}
 
 
 def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=None):
@@ -743,10 +791,17 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
         if cscale is not None:
             raise ValueError("a grouped column-sweep plan does not take cscale (scale B instead)")
         gidx = A.pos2col if gidx is None else _dev(gidx, torch.int32, "gidx")[A.pos2col.long()]
+    ev = A._guard_before(d) if not A._tuning else None
+    if ev is not None:
+        ev[0].record()
     check(lib.sgcn_spmm_cs_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(gidx, torch.int32, "gidx")),
                                _ptr(_dev(rscale, torch.float32, "rscale")),
                                _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),
                                _stream()))
+    if ev is not None:
+        ev[1].record()
+    if not A._tuning and A._guard:
+        A._guard_after(d, B)
     return out
 
 
@@ -892,8 +947,20 @@ class LdsSweepCSR(object):
                             _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
                             0 if self.ws is None else self.ws.numel())
 
+    def variant(self, d):
+        """What spmm_lds dispatches for this plan and width, as text (bench.py: roofline.kernel)."""
+        nslab = (int(d) + 127) // 128
+        txt = ("sgcn::lds_spmm_kernel<80, %s> x 1 launch (%d tiles of 768 rows x %d passes of 128 columns = %d workgroups; "
+               "%d chunks, %.1f nonzeros per staged piece, %.1f %% of the nonzeros)"
+               % ("true" if self.unit else "false", self.ntiles, nslab, self.ntiles * nslab, self.nchunks,
+                  self.host_stats["reuse"], 100.0 * self.host_stats["local_nnz"] / max(self.nnz, 1)))
+        if isinstance(self.residual, ColumnSweepCSR):
+            txt += " + residual: " + self.residual.variant(d)
+        return txt
+
     def autotune(self, B, d=None):
-        """The residual's sweep clock (the LDS kernel itself is not clock-paced)."""
+        """The residual's sweep clock (the LDS kernel itself is not clock-paced).  (Running the two kernels side by side
+        on split compute units -- CU-masked streams -- was measured and lost: profiles/r24_lds_side_by_side_probe.jsonl.)"""
         if isinstance(self.residual, ColumnSweepCSR):
             return self.residual.autotune(B, d=d)
         return None

@@ -859,3 +859,40 @@ def test_lds_sweep_on_communities_vs_oracle_and_column_sweep(dev):
     loc = ops.spmm_lds(A, Bd, local_only=True)
     res = ops.spmm_cs(A.residual, Bd)
     assert float((loc + res - c1).abs().max() / c1.abs().max()) <= 1e-5
+
+
+def test_column_sweep_lost_lock_guard_retunes(dev):
+    """The clock-paced sweep watches itself: with a pace that is deliberately too fast (the lock-step is lost, the
+    product costs ~2x) two timed samples in a row exceed 1.3 x the tuned time and the plan re-tunes on the spot; a
+    healthy plan is never re-tuned and the guard leaves its results alone."""
+    from stochastic_gcn_amd import ops, synthetic
+    n, _, full_adj, *_ = synthetic.reddit_like(with_features=False)
+    d = 602
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    B = torch.zeros((n, 608), device=dev)
+    B[:, :d] = torch.randn((n, d), device=dev, generator=g)
+    Bd = B[:, :d]
+    A = ops.ColumnSweepCSR(full_adj, dev, G=2)
+    t_tuned, pace = A.autotune(Bd)
+    assert pace > 0 and A.tuned_ms[d] == t_tuned
+    ref = ops.spmm_cs(A, Bd).clone()
+
+    def run(k):
+        for _ in range(k):
+            out = ops.spmm_cs(A, Bd)
+            torch.cuda.synchronize()            # (the guard never waits: let its samples complete between calls)
+        return out
+    run(4 * A.GUARD_EVERY)
+    assert A._guard[d]["retunes"] == 0 and A._guard[d]["last_ms"] is not None       # healthy: sampled, left alone
+    assert A._guard[d]["last_ms"] <= 1.25 * t_tuned
+    A.pace[d] = max(60, pace // 2)                  # far too fast: every wave runs ahead of the window
+    slow = run(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.spmm_cs(A, Bd); e1.record(); e1.synchronize()
+    assert e0.elapsed_time(e1) > 1.3 * t_tuned, "the test needs a pace that actually loses the lock-step"
+    assert torch.equal(slow, ref)                   # (the pace never changes the result)
+    run(3 * A.GUARD_EVERY)
+    assert A._guard[d]["retunes"] == 1              # two slow samples in a row -> one re-tune
+    assert abs(A.pace[d] - pace) <= 0.25 * pace
+    e0.record(); out = ops.spmm_cs(A, Bd); e1.record(); e1.synchronize()
+    assert e0.elapsed_time(e1) <= 1.2 * t_tuned and torch.equal(out, ref)
