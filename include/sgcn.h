@@ -173,8 +173,8 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  * reads its piece from there.  Nonzeros whose column the tile references fewer than `min_reuse`
  * times are left out of the plan and returned as a residual CSR (same M x K), to be added by
  * sgcn_spmm_cs_f32 / _csr_f32.
- *   words[i] = LDS byte address of the piece ((chunk index mod 3) * S * P + slot * P, P = 256 * VW bytes;
- *              the zero piece at 3 * S * P for pads)  |  register offset of the row (local row * VW)
+ *   words[i] = LDS byte address of the piece ((chunk index mod nparts) * S * P + slot * P, P = 256 * VW
+ *              bytes; the zero piece at nparts * S * P for pads)  |  register offset of the row (local row * VW)
  *   vals[i]  = the nonzero's value (general plans).  UNIT plans: every nonzero of a row has the same
  *              value (row-normalised adjacency); it is kept once per row in row_fold[M] (1 for empty
  *              rows) and applied with the row scale -- no vals.
@@ -183,19 +183,20 @@ int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_
  *   256 slots from the start of a wave's share, whatever its length).
  *   ent_ptr[(first chunk of the tile) * NW + w * (chunks of the tile) + k] = first entry of wave w in
  *   the tile's k-th chunk (one more element ends the array).
- *   chunk_hdr[(chunk * NW + w) * 16 ..]: what wave w needs to REQUEST the chunk, in one 64-byte read: the
- *   S / NW column ids of its ring slots, then its entry count in groups of U, then the 64-bit index of
- *   its first entry (low, high word).  (chunk_cols / ent_ptr hold the same facts chunk-wise.)
+ *   chunk_hdr[(chunk * NW + w) * 32 ..]: what wave w needs to REQUEST the chunk, in one 128-byte read: the
+ *   S / NW column ids of its ring slots (words 0-15), its entry count in groups of U (16), the 64-bit index
+ *   of its first entry (17 low, 18 high).  (chunk_cols / ent_ptr hold the same facts chunk-wise.)
  * New -- the reference has no such kernel; the op is gcn/layers.py:31-37 (dot(x, y, sparse=True)). */
 typedef struct {
     int32_t VW, NW, RW, S, U;       /* floats per lane (2: 128-column slabs), waves per tile (8), rows per wave
-                                       (192 / VW = 96), slots per ring part (80; three parts), entries per group (8) */
+                                       (192 / VW = 96), slots per ring part (80 | 128), entries per group (8)    */
+    int32_t nparts;                 /* ring parts: 3 (S = 80) or 2 (S = 128)                              */
     int32_t unit;                   /* != 0: values folded into dev_row_fold, dev_vals unused             */
     int32_t xcd_tile_ptr[9];        /* tiles [p[x], p[x + 1]) run on XCD x: contiguous ranges of equal estimated time    */
     int64_t ntiles, nchunks, nent;
     const int32_t* dev_tile_chunk_ptr; /* [ntiles + 1]                                            */
     const int32_t* dev_chunk_cols;  /* [nchunks * S] column of every slot (padded with a valid one) */
-    const int32_t* dev_chunk_hdr;   /* [nchunks * NW * 16]                                         */
+    const int32_t* dev_chunk_hdr;   /* [nchunks * NW * 32]                                         */
     const int64_t* dev_ent_ptr;     /* [nchunks * NW + 1]                                          */
     const uint32_t* dev_words;      /* [nent + 256]                                                */
     const float* dev_vals;          /* [nent + 256] (general plans)                                */
@@ -210,14 +211,16 @@ typedef struct {
  *   row_group nullable [M]: tiles are formed inside groups, groups in label order;
  *   T         rows longer than T become strided virtual rows (<= 0: 2048);
  *   min_reuse a column is staged for a tile only if the tile references it at least this often (>= 1);
- *   mode      0: a unit plan when the values allow it, 1: always a general plan.
- * sizes[17] = {ntiles, nchunks, nent, nfix, nslots, residual nnz, staged pieces (sum over chunks of distinct
- * columns), unit, xcd_tile_ptr[0..8]}. */
+ *   mode      0: a unit plan when the values allow it, 1: always a general plan;
+ *   ring_slots 128 (two ring parts; <= 0 selects it) or 80 (three parts: a fill has two chunk times to land).
+ * sizes[19] = {ntiles, nchunks, nent, nfix, nslots, residual nnz, staged pieces (sum over chunks of distinct
+ * columns), unit, xcd_tile_ptr[0..8], S, nparts}. */
 typedef struct sgcn_ldsplan_host sgcn_ldsplan_host_t;
 int sgcn_ldsplan_create(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val,
                         int32_t M, int32_t K, const int32_t* host_col_pos, const int32_t* host_row_group,
-                        int32_t VW, int32_t T, int32_t min_reuse, int32_t mode, sgcn_ldsplan_host_t** out);
-int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* sizes17);
+                        int32_t VW, int32_t T, int32_t min_reuse, int32_t mode, int32_t ring_slots,
+                        sgcn_ldsplan_host_t** out);
+int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* sizes19);
 int sgcn_ldsplan_export(const sgcn_ldsplan_host_t* h, int32_t* tile_chunk_ptr, int32_t* chunk_cols,
                         int32_t* chunk_hdr, int64_t* ent_ptr, uint32_t* words, float* vals, float* row_fold,
                         int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix, int32_t* res_rowptr,

@@ -43,7 +43,7 @@ class CsPlan(C.Structure):
 class LdsPlan(C.Structure):
     """include/sgcn.h sgcn_ldsplan_t"""
     _fields_ = [("VW", C.c_int32), ("NW", C.c_int32), ("RW", C.c_int32), ("S", C.c_int32), ("U", C.c_int32),
-                ("unit", C.c_int32), ("xcd_tile_ptr", C.c_int32 * 9), ("ntiles", C.c_int64), ("nchunks", C.c_int64), ("nent", C.c_int64),
+                ("nparts", C.c_int32), ("unit", C.c_int32), ("xcd_tile_ptr", C.c_int32 * 9), ("ntiles", C.c_int64), ("nchunks", C.c_int64), ("nent", C.c_int64),
                 ("dev_tile_chunk_ptr", C.c_void_p), ("dev_chunk_cols", C.c_void_p), ("dev_chunk_hdr", C.c_void_p),
                 ("dev_ent_ptr", C.c_void_p), ("dev_words", C.c_void_p), ("dev_vals", C.c_void_p), ("dev_row_fold", C.c_void_p),
                 ("dev_tile_rows", C.c_void_p), ("dev_tile_slots", C.c_void_p),
@@ -106,7 +106,7 @@ SIGNATURES = {
     "sgcn_spmm_cs_f32": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,
                                    P, P, P, C.c_int64, C.c_float, P]),
     "sgcn_ldsplan_create": (C.c_int, [P, P, P, C.c_int32, C.c_int32, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                      C.POINTER(C.c_void_p)]),
+                                      C.c_int32, C.POINTER(C.c_void_p)]),
     "sgcn_ldsplan_sizes": (C.c_int, [C.c_void_p, P]),
     "sgcn_ldsplan_export": (C.c_int, [C.c_void_p, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "sgcn_ldsplan_destroy": (None, [C.c_void_p]),

@@ -15,7 +15,7 @@
 #include <vector>
 
 struct sgcn_ldsplan_host {
-    int32_t VW, NW, RW, S, U, M, K;
+    int32_t VW, NW, RW, S, U, M, K, nparts;
     std::vector<int32_t> tile_chunk_ptr, chunk_cols, chunk_hdr, tile_rows, tile_slots;
     std::vector<int64_t> ent_ptr;
     std::vector<uint32_t> words;
@@ -67,13 +67,16 @@ extern "C" {
 
 int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t K,
                         const int32_t* col_pos, const int32_t* row_group, int32_t VW, int32_t T, int32_t min_reuse,
-                        int32_t mode, sgcn_ldsplan_host_t** out) {
+                        int32_t mode, int32_t ring_slots, sgcn_ldsplan_host_t** out) {
     if (!out || M < 0 || K < 0 || (M > 0 && (!rowptr || !col || !val)))
         return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: bad argument");
     if (VW != 2) return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: VW must be 2 (128-column slabs)");
     if (min_reuse < 1) min_reuse = 1;
     if (T <= 0) T = 2048;
-    const int32_t NW = 8, RW = 192 / VW, S = 80, GE = 8, NPART = 3;
+    if (ring_slots <= 0) ring_slots = 128;
+    if (ring_slots != 80 && ring_slots != 128)
+        return sgcn::fail(SGCN_ERR_INVALID, "ldsplan_create: ring_slots is 80 (three ring parts) or 128 (two)");
+    const int32_t NW = 8, RW = 192 / VW, S = ring_slots, GE = 8, NPART = ring_slots == 80 ? 3 : 2;
     const int32_t R = NW * RW;
     const uint32_t piece = 256u * (uint32_t)VW;
     const uint32_t zero_addr = (uint32_t)NPART * S * piece;
@@ -95,7 +98,7 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         }
     }
     auto* h = new sgcn_ldsplan_host();
-    h->VW = VW; h->NW = NW; h->RW = RW; h->S = S; h->U = GE; h->M = M; h->K = K;
+    h->VW = VW; h->NW = NW; h->RW = RW; h->S = S; h->U = GE; h->M = M; h->K = K; h->nparts = NPART;
 
     // unit plan: every nonzero of a row carries the same value (bit for bit) -> kept once per row, beside the row scale
     h->row_fold.assign((size_t)M, 1.0f);
@@ -325,21 +328,21 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         h->xcd_tile_ptr[0] = 0;
         h->xcd_tile_ptr[8] = (int32_t)ntiles;
     }
-    // per (chunk, wave) header, 16 ints: what a wave needs to request a chunk, in ONE 64-byte load -- the column ids of
-    // its 2 * FPW ring slots, its entry count (in groups) and the position of its entries
+    // per (chunk, wave) header, 32 ints: what a wave needs to request a chunk, in ONE 128-byte load -- the column ids of
+    // its S / NW ring slots (words 0-15), its entry count in groups (16) and the position of its entries (17, 18)
     {
         const int32_t per = S / NW;                          // slots a wave fetches per chunk
-        h->chunk_hdr.assign((size_t)nchunks * NW * 16, 0);
+        h->chunk_hdr.assign((size_t)nchunks * NW * 32, 0);
         for (int64_t t = 0; t < ntiles; t++) {
             const int64_t cb = h->tile_chunk_ptr[(size_t)t], nc = h->tile_chunk_ptr[(size_t)t + 1] - cb;
             for (int64_t k = 0; k < nc; k++)
                 for (int32_t wv = 0; wv < NW; wv++) {
-                    int32_t* hd = &h->chunk_hdr[(size_t)((cb + k) * NW + wv) * 16];
+                    int32_t* hd = &h->chunk_hdr[(size_t)((cb + k) * NW + wv) * 32];
                     for (int32_t q = 0; q < per; q++) hd[q] = h->chunk_cols[(size_t)(cb + k) * S + (size_t)wv * per + q];
                     const int64_t a = h->ent_ptr[(size_t)(cb * NW + wv * nc + k)], b = h->ent_ptr[(size_t)(cb * NW + wv * nc + k) + 1];
-                    hd[per] = (int32_t)((b - a) / GE);
-                    hd[per + 1] = (int32_t)(uint32_t)(a & 0xffffffffll);
-                    hd[per + 2] = (int32_t)(a >> 32);
+                    hd[16] = (int32_t)((b - a) / GE);
+                    hd[17] = (int32_t)(uint32_t)(a & 0xffffffffll);
+                    hd[18] = (int32_t)(a >> 32);
                 }
         }
     }
@@ -388,6 +391,8 @@ int sgcn_ldsplan_sizes(const sgcn_ldsplan_host_t* h, int64_t* s) {
     s[6] = h->staged;
     s[7] = h->unit;
     for (int x = 0; x < 9; x++) s[8 + x] = h->xcd_tile_ptr[x];
+    s[17] = h->S;
+    s[18] = h->nparts;
     return SGCN_OK;
 }
 

@@ -162,11 +162,13 @@ __device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2,
     }
 }
 
-// 128-column slabs: a lane holds a float2 of every row of its wave.  The piece ring has THREE parts of S slots (512-byte
-// pieces): chunk k is consumed from part k % 3 while chunks k + 1 and k + 2 are in flight into the other two -- a fill has
-// two chunk times to land (measured with two halves: the waves spent half their cycles waiting for a fill issued one
-// chunk earlier).  The waves' entries travel the same way, 1 KB per wave and chunk, into the entry ring behind it.
-template <int S, bool UNIT>
+// 128-column slabs: a lane holds a float2 of every row of its wave.  The piece ring has NPART parts of S slots
+// (512-byte pieces): chunk k is consumed from part k % NPART while the next NPART - 1 chunks are in flight into the
+// others.  Three parts of 80 slots give a fill two chunk times to land; two parts of 128 slots give it one, but
+// a third fewer chunks -- and a chunk costs ~1800 cycles of barrier, request issue and pipeline start whatever its size.
+// The waves' entries travel the same way, 1 KB per wave and chunk, into the entry ring behind the pieces; their
+// headers (128 bytes) into the header ring behind that.
+template <int S, int NPART, bool UNIT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lds_spmm_kernel(LdsArgs a) {
     constexpr int VW = 2, NW = 8;                       // floats per lane, waves per tile
     constexpr int RW = 192 / VW;                        // rows per wave: 192 accumulator registers
@@ -175,9 +177,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int LPP = PIECE / 16;                     // lanes that fetch one piece (dwordx4 each): 32
     constexpr int PPI = 64 / LPP;                       // pieces per fill instruction: 2
     constexpr int FPW = S / PPI / NW;                   // fill instructions per wave and chunk
-    static_assert(PPI == 2 && S % (PPI * NW) == 0, "ring slots must divide evenly over the waves' fill instructions");
-    constexpr int ERING = 3 * PART + PIECE;             // the entry ring: 3 x NW x 1 KB behind the pieces and the zero piece
-    constexpr int HRING = ERING + 3 * NW * 1024;        // the header ring: 3 x NW x 64 bytes
+    static_assert(PPI == 2 && S % (PPI * NW) == 0 && 2 * FPW <= 16, "ring slots: a multiple of 16, at most 128");
+    static_assert(NPART == 2 || NPART == 3, "two or three ring parts");
+    constexpr int LA = NPART - 1;                       // chunks requested ahead
+    constexpr int ERING = NPART * PART + PIECE;         // the entry ring: NPART x NW x 1 KB behind the pieces and the zero piece
+    constexpr int HRING = ERING + NPART * NW * 1024;    // the header ring: NPART x NW x 128 bytes
     typedef float VT __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(1024))) char ring[];
 
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     acc32_t a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {};
 
     // the pads' operand: PIECE bytes of zeros behind the piece ring
-    if (threadIdx.x < PIECE / 4) reinterpret_cast<float*>(ring + 3 * PART)[threadIdx.x] = 0.f;
+    if (threadIdx.x < PIECE / 4) reinterpret_cast<float*>(ring + NPART * PART)[threadIdx.x] = 0.f;
 
     const int c0 = __builtin_amdgcn_readfirstlane(a.tile_chunk_ptr[tile]);
     const int c1 = __builtin_amdgcn_readfirstlane(a.tile_chunk_ptr[tile + 1]);
@@ -213,23 +217,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t boff = (uint32_t)fbase * 4 + (lane % LPP) * 16;
     if ((int64_t)boff + 16 > ldb_bytes) boff = (uint32_t)fbase * 4;
 
-    // A (chunk, wave) header -- the wave's 2 FPW column ids, its entry count, the index of its first entry: 64 bytes --
-    // travels like everything else: global_load_lds into the wave's slot of the header ring a chunk before it is needed,
-    // then ONE asm statement reads it (ds_read + wait + v_readlane) into scalars.  No scalar memory instruction in the
-    // loop (the chunk statement opens with s_waitcnt lgkmcnt(0), which would wait for an outstanding s_load too:
-    // measured with the ids on the scalar path, 0.7 us of exposed latency per chunk) and no compiler-visible load either
-    // (the compiler's own s_waitcnt for one would be vmcnt(0): it would wait for the fills just issued).
-    static_assert(FPW == 5, "the header statement below reads 10 column ids");
-    struct Hdr { int32_t col[2 * FPW]; uint32_t n; int64_t e; };
+    // A (chunk, wave) header -- the column ids of the wave's ring slots (16 words), its entry count in groups, the index
+    // of its first entry: 32 words -- travels like everything else: global_load_lds into the wave's slot of the header
+    // ring a chunk before it is needed, then ONE asm statement reads it (ds_read + wait + v_readlane) into scalars.  No
+    // scalar memory instruction in the loop (the chunk statement opens with s_waitcnt lgkmcnt(0), which would wait for an
+    // outstanding s_load too: measured with the ids on the scalar path, 0.7 us of exposed latency per chunk) and no
+    // compiler-visible load either (the compiler's own s_waitcnt for one would be vmcnt(0): the fills just issued).
+    struct Hdr { int32_t col[16]; uint32_t n; int64_t e; };
     auto hdr_fetch = [&](int c, int slot) {                 // chunk c's header -> my slot of the header ring
-        if (lane < 16)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.chunk_hdr + ((int64_t)c * NW + wave) * 16 + lane),
-                                             (__attribute__((address_space(3))) void*)(ring + HRING + (slot * NW + wave) * 64), 4, 0, 0);
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.chunk_hdr + ((int64_t)c * NW + wave) * 32 + lane),
+                                             (__attribute__((address_space(3))) void*)(ring + HRING + (slot * NW + wave) * 128), 4, 0, 0);
     };
     auto hdr_get = [&](int slot) -> Hdr {                   // (after the s_waitcnt vmcnt that covers its fetch)
         Hdr h;
         uint32_t elo, ehi;
-        const uint32_t addr = (uint32_t)(HRING + (slot * NW + wave) * 64) + (lane & 15) * 4;
+        const uint32_t addr = (uint32_t)(HRING + (slot * NW + wave) * 128) + (lane & 31) * 4;
         asm volatile("ds_read_b32 v28, %[addr]\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
                      "v_readlane_b32 %[c0], v28, 0\n\t"
@@ -242,12 +245,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                      "v_readlane_b32 %[c7], v28, 7\n\t"
                      "v_readlane_b32 %[c8], v28, 8\n\t"
                      "v_readlane_b32 %[c9], v28, 9\n\t"
-                     "v_readlane_b32 %[n], v28, 10\n\t"
-                     "v_readlane_b32 %[elo], v28, 11\n\t"
-                     "v_readlane_b32 %[ehi], v28, 12"
+                     "v_readlane_b32 %[c10], v28, 10\n\t"
+                     "v_readlane_b32 %[c11], v28, 11\n\t"
+                     "v_readlane_b32 %[c12], v28, 12\n\t"
+                     "v_readlane_b32 %[c13], v28, 13\n\t"
+                     "v_readlane_b32 %[c14], v28, 14\n\t"
+                     "v_readlane_b32 %[c15], v28, 15\n\t"
+                     "v_readlane_b32 %[n], v28, 16\n\t"
+                     "v_readlane_b32 %[elo], v28, 17\n\t"
+                     "v_readlane_b32 %[ehi], v28, 18"
                      : [c0] "=s"(h.col[0]), [c1] "=s"(h.col[1]), [c2] "=s"(h.col[2]), [c3] "=s"(h.col[3]), [c4] "=s"(h.col[4]),
                        [c5] "=s"(h.col[5]), [c6] "=s"(h.col[6]), [c7] "=s"(h.col[7]), [c8] "=s"(h.col[8]), [c9] "=s"(h.col[9]),
-                       [n] "=s"(h.n), [elo] "=s"(elo), [ehi] "=s"(ehi)
+                       [c10] "=s"(h.col[10]), [c11] "=s"(h.col[11]), [c12] "=s"(h.col[12]), [c13] "=s"(h.col[13]),
+                       [c14] "=s"(h.col[14]), [c15] "=s"(h.col[15]), [n] "=s"(h.n), [elo] "=s"(elo), [ehi] "=s"(ehi)
                      : [addr] "v"(addr)
                      : "v28", "memory");
         h.e = (int64_t)(((uint64_t)ehi << 32) | elo);
@@ -288,50 +298,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto stamp = [&]() -> unsigned long long { return a.prof ? __builtin_readcyclecounter() : 0ull; };
     t_all0 = stamp();
     if (nc > 0) {
-        uint32_t n0, n1 = 0, n2 = 0;
-        hdr_fetch(c0, 0);
-        if (nc > 1) hdr_fetch(c0 + 1, 1);
-        if (nc > 2) hdr_fetch(c0 + 2, 2);
+        uint32_t n0 = 0, n1 = 0, n2 = 0;
+        // headers of the first LA + 1 chunks, then the first LA chunks themselves
+#pragma unroll
+        for (int j = 0; j <= LA; j++)
+            if (j < nc) hdr_fetch(c0 + j, j);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         {
             const Hdr h = hdr_get(0);
             fill(0, h);
             n0 = h.n;
         }
-        if (nc > 1) {
+        if (LA == 2 && nc > 1) {
             const Hdr h = hdr_get(1);
             fill(1, h);
             n1 = h.n;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         t_pro = stamp() - t_all0;
-        int part = 0;                                       // k % 3: the ring part of chunk k
+        int part = 0;                                       // k % NPART: the ring part of chunk k
         for (int k = 0; k < nc; k++) {
             // chunk k has landed for everybody (each wave waited for its own fills below); everybody is past chunk k - 1.
             // A bare s_barrier: __syncthreads() would add a fence, i.e. wait for the fills just issued as well.
-            const bool more = k + 2 < nc;
-            const int p2 = part >= 1 ? part - 1 : 2;        // (k + 2) % 3: the part chunk k - 1 left
+            const bool more = k + LA < nc;
+            const int pn = part >= 1 ? part - 1 : NPART - 1;    // (k + LA) % NPART: the part chunk k - 1 left
             Hdr h;
-            if (more) h = hdr_get(p2);                      // chunk k + 2's header came in during the last iteration (it is
+            if (more) h = hdr_get(pn);                      // chunk k + LA's header came in during the last iteration (it is
             t_mark = stamp();                               // mine alone: read ahead of the barrier, its latency in the barrier's)
             asm volatile("s_barrier" ::: "memory");
             { const unsigned long long t = stamp(); t_bar += t - t_mark; t_mark = t; }
             if (more) {
-                n2 = h.n;
-                if (k + 3 < nc) hdr_fetch(c0 + k + 3, part);    // the next header goes first (older than the fills: see the wait)
+                if (LA == 2) n2 = h.n; else n1 = h.n;
+                if (k + LA + 1 < nc) hdr_fetch(c0 + k + LA + 1, part);  // the next header goes first (older than the fills: see the wait)
+                fill(pn, h);                                // chunk k + LA goes in flight into the part chunk k - 1 left
             }
-            // (tried: the two waves of a SIMD taking the iteration in opposite order -- one requests while its partner computes;
-            // no change, 1.71 vs 1.72 ms: a wave issuing global_load_lds does not leave its SIMD's ALU to the partner)
-            if (more) fill(p2, h);                          // chunk k + 2 goes in flight into the part chunk k - 1 left
             { const unsigned long long t = stamp(); t_fill += t - t_mark; t_mark = t; }
             if (n0 && !(a.dbg & 2))
                 lds_chunk<UNIT>(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off);
             { const unsigned long long t = stamp(); t_comp += t - t_mark; t_mark = t; }
             n0 = n1; n1 = n2;
-            part = part == 2 ? 0 : part + 1;
-            // chunk k + 1 was requested an iteration ago: everything older than this iteration's fills has to be here
-            // before the barrier (the header fetch was issued ahead of them: it is covered too)
-            if (more && !(a.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerChunk) : "memory");
+            part = part == NPART - 1 ? 0 : part + 1;
+            // chunk k + 1 has to be here before the barrier.  Three parts: it was requested an iteration ago -- everything
+            // older than THIS iteration's fills (the header fetch was issued ahead of them: covered too).  Two parts: it is
+            // this iteration's request.
+            if (LA == 2 && more && !(a.dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerChunk) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             { const unsigned long long t = stamp(); t_wait += t - t_mark; }
         }
@@ -432,8 +442,9 @@ extern "C" int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t 
                                  float* C, int64_t ldc, float beta, void* stream) {
     SGCN_REQUIRE(plan && M >= 0 && K >= 0 && d >= 0, "spmm_lds: bad argument");
     if (M == 0 || d == 0) return SGCN_OK;
-    SGCN_REQUIRE(plan->NW == 8 && plan->VW == 2 && plan->RW == 96 && plan->U == 8 && plan->S == 80,
-                 "spmm_lds: the plan must be built for 8 waves x 96 rows x float2, groups of 8 entries, 3 x 80 ring slots");
+    SGCN_REQUIRE(plan->NW == 8 && plan->VW == 2 && plan->RW == 96 && plan->U == 8 &&
+                 ((plan->S == 80 && plan->nparts == 3) || (plan->S == 128 && plan->nparts == 2)),
+                 "spmm_lds: the plan must be built for 8 waves x 96 rows x float2, groups of 8 entries, a ring of 3 x 80 or 2 x 128 slots");
     SGCN_REQUIRE(plan->dev_tile_chunk_ptr && plan->dev_chunk_hdr && plan->dev_words &&
                  plan->dev_tile_rows && plan->dev_tile_slots && B && C, "spmm_lds: null operand");
     SGCN_REQUIRE(plan->unit ? plan->dev_row_fold != nullptr : plan->dev_vals != nullptr,
@@ -466,17 +477,24 @@ extern "C" int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t 
     a.xcd_ptr[8] = plan->xcd_tile_ptr[8];
     const int64_t blocks = 8 * per_xcd * a.nslab;
     SGCN_REQUIRE(blocks < (1ll << 31), "spmm_lds: too many work items");
-    constexpr int lds = 3 * 80 * 512 + 512 + 3 * 8 * 1024 + 3 * 8 * 64;
+    const int lds = plan->nparts * (plan->S * 512 + 8 * 1024 + 8 * 128) + 512;       // pieces + entries + headers, zero piece
     static bool once = false;                   // (an attribute of the function, not of a launch)
     if (!once) {
-        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        constexpr int kMax = 160 * 1024;
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<128, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
         once = true;
     }
-    if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<80, true>), dim3((unsigned)blocks), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((lds_spmm_kernel<80, false>), dim3((unsigned)blocks), dim3(512), lds, st, a);
+    const dim3 grid((unsigned)blocks), block(512);
+    if (plan->S == 80) {
+        if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<80, 3, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((lds_spmm_kernel<80, 3, false>), grid, block, lds, st, a);
+    } else {
+        if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<128, 2, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((lds_spmm_kernel<128, 2, false>), grid, block, lds, st, a);
+    }
     SGCN_HIP_TRY(hipGetLastError());
     if (plan->nfix > 0) {
         const int nvec = (d + 3) / 4;

@@ -75,7 +75,8 @@ def plan_cache_paths(dataset):
 def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats=None):
     """train_feats = train_adj . feats, test_feats = full_adj . feats (gcn/utils.py:169-170,
     321-322).  Dense features: the column-sweep SpMM kernel on the GPU (K11; sgcn_spmm_cs_f32 -- the
-    kernel bench.py times), its host plan cached beside the dataset.  Sparse features: a
+    kernel bench.py times), its host plan cached beside the dataset; for a graph with communities the LDS-staged sweep
+    (ops.LdsSweepCSR.for_graph).  Sparse features: a
     sparse x sparse product, done once on the host with SciPy exactly like the reference."""
     if sp.issparse(features):
         return train_adj.dot(features).tocsr(), full_adj.dot(features).tocsr()
@@ -88,6 +89,15 @@ def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats
         X = Xp[:, :d]
     out = []
     for a, path in zip((train_adj, full_adj), cache):
+        # a large graph WITH communities (>= 90 % of its nonzeros inside tiles that share their columns): the LDS-staged
+        # sweep + the column sweep on the rest; anything else: the column sweep alone
+        L = ops.LdsSweepCSR.for_graph(a, device) if (path is None and a.nnz >= 2000000 and d >= 128) else None
+        if L is not None:
+            L.autotune(X)
+            if stats is not None:
+                stats.append(dict(plan_from_cache=False, pace=None, kernel=L.variant(d)))
+            out.append(ops.spmm_lds(L, X).contiguous())
+            continue
         A, hit = ops.ColumnSweepCSR.cached(a, device, path, G=ops.ColumnSweepCSR.choose_g(d, a.nnz / max(a.shape[0], 1)))
         if d not in A.pace:
             A.autotune(X)               # once per plan and width; stored with the cached plan

@@ -808,9 +808,9 @@ def test_lds_sweep_vs_oracle(dev, M, K, d, pad, min_reuse, unit):
     Bd = T(B, dev)[:, :d]
     ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
     lab = (rng.randint(0, 3, M).astype(np.int32), rng.randint(0, 3, K).astype(np.int32))
-    for labels, T_ in ((None, 0), (lab, 32)):
-        A = ops.LdsSweepCSR(a, dev, labels=labels, T=T_, min_reuse=min_reuse)
-        assert bool(A.unit) == unit
+    for labels, T_, slots in ((None, 0, 128), (lab, 32, 80), (lab, 32, 128)):     # ring: 2 x 128 slots or 3 x 80
+        A = ops.LdsSweepCSR(a, dev, labels=labels, T=T_, min_reuse=min_reuse, ring_slots=slots)
+        assert bool(A.unit) == unit and (A.S, A.nparts) == ((128, 2) if slots == 128 else (80, 3))
         if T_:
             assert A.nfix >= 1
         if min_reuse == 1:

@@ -18,9 +18,10 @@ def _matrix(m, k, dens, seed, long_rows=()):
     return a
 
 
-def _check(a, labels, min_reuse, T=0, general=True):
+def _check(a, labels, min_reuse, T=0, general=True, ring_slots=0):
     from stochastic_gcn_amd import ops
-    h = ops.LdsPlanHost(a, labels=labels, min_reuse=min_reuse, T=T, general=general)
+    h = ops.LdsPlanHost(a, labels=labels, min_reuse=min_reuse, T=T, general=general, ring_slots=ring_slots)
+    assert (h.S, h.nparts) == ((80, 3) if ring_slots == 80 else (128, 2))
     assert not (general and h.unit)
     r, c, v, s = h.decode()
     if h.unit:                                   # the values live once per row
@@ -49,6 +50,8 @@ def test_plan_is_the_matrix(m, k, dens):
     lab = (rng.randint(0, 3, m).astype(np.int32), rng.randint(0, 3, k).astype(np.int32))
     h = _check(a, lab, 2, T=16)
     assert h.nfix >= 1 and h.ntiles >= 3 or m < 10
+    h3 = _check(a, lab, 2, T=16, ring_slots=80)             # three ring parts of 80 slots: more, smaller chunks
+    assert h3.nchunks >= h.nchunks and h3.local_nnz == h.local_nnz
 
 
 def test_plan_edge_cases():

@@ -253,3 +253,26 @@ def test_det_dropout_model_trains_through_the_driver():
     assert all(len(h) == 2 for h in tr.train_model.history)
     assert all(float(h.abs().max()) > 0 for hs in tr.train_model.history for h in hs)
     assert np.isfinite(accs).all() and accs[-1] > 0.45 and accs[-1] > accs[0], accs
+
+
+def test_pp_products_pick_the_lds_sweep_for_a_graph_with_communities():
+    """train.pp_products on a graph whose nonzeros sit inside communities (p_in 0.95) runs the LDS-staged sweep + its
+    residual and agrees with SciPy (the reference's own library for this product, gcn/utils.py:321-322); on a graph
+    without structure it keeps the column sweep."""
+    import torch
+    from stochastic_gcn_amd import synthetic, train
+    dev = torch.device("cuda:0")
+    data = synthetic.reddit_sbm(n=60000, m=3000000, classes=12, splits=(40000, 8000, 12000), p_in=0.95, seed=4)
+    a = data[2]
+    rng = np.random.RandomState(0)
+    X = rng.standard_normal((a.shape[0], 130)).astype(np.float32)
+    stats = []
+    tf, ff = train.pp_products(data[1], a, X, dev, stats=stats)
+    assert "lds_spmm_kernel" in stats[1]["kernel"], stats
+    for got, m in ((tf, data[1]), (ff, a)):
+        ref = m.astype(np.float64).dot(X.astype(np.float64))
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    flat = synthetic.reddit_like(n=60000, m=3000000, f=8, classes=5, splits=(40000, 8000, 12000), seed=4, with_features=False)
+    stats = []
+    train.pp_products(flat[1], flat[2], X, dev, stats=stats)
+    assert all("cs_spmm" in s_["kernel"] for s_ in stats), stats
