@@ -615,6 +615,8 @@ def main(argv=None):
         dCp[:, :d] = torch.randn((n, d), device=dev, generator=gen)
         if args.kernel in ("cs", "lds") and not any(kv.startswith("cs_pace") for kv in args.tune):
             sh.autotune(X, None if args.no_backward else dC)
+            tuned = {"fwd_pace": sh.A.pace.get(d) if sh.A is not None else None,
+                     "bwd_pace": sh.AT.pace.get(d) if sh.AT is not None else None}
         C, dX = C[sh.lo:sh.hi], dX[sh.lo:sh.hi]
         Xl, dCl = X[sh.lo:sh.hi].contiguous(), dC[sh.lo:sh.hi].contiguous()
     elif args.kernel in ("cs", "lds") and not any(kv.startswith("cs_pace") for kv in args.tune):

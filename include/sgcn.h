@@ -140,7 +140,7 @@ int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const 
  * halves of a wave inside one L2 window); every tile's entry count is padded to a multiple of 64 (the pipelined kernel
  * has no tail code); the tile count is rounded up to whole launches of round_tiles waves (0: no rounding).
  * (Round 2 also built ngroups = 4 -- 64 rows per wavefront on 64-column slabs; its kernel was instruction-bound and is
- * not part of the product: profiles/experiments/) */
+ * not part of the product: profiles/HISTORY.md 3.1b.) */
 int sgcn_csplang_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
                        int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries,
                        int64_t* nfix, int64_t* nslots);
@@ -613,7 +613,7 @@ enum {
     SGCN_OP_AUX_SCATTER_ROWS = 16, /* sgcn_scatter_rows_f32 on the auxiliary stream (forked from `stream`) */
     SGCN_OP_AUX_MEMSET0 = 17, /* hipMemsetAsync on the auxiliary stream; joined before the first DENSE_BWD */
     /* 18, 19, 20: retired with ABI v6 (two dense layers as one launch; the loss / the lower layer's LayerNorm backward in
-     * a GEMM epilogue -- measured slower than the separate launches in round 2: DESIGN.md 3.6, profiles/experiments/) */
+     * a GEMM epilogue -- measured slower than the separate launches in round 2: profiles/HISTORY.md 3.6) */
     SGCN_OP_DW_FLUSH = 21,      /* no arguments.  A program that contains this op runs in DEFERRED weight-gradient mode: every
                                  * DENSE_BWD before it only records its dW GEMM (+ split-K and LayerNorm-parameter
                                  * reductions); this op issues all of them as ONE grouped GEMM launch + ONE reduction launch

@@ -17,14 +17,14 @@
 // waves of an XCD stay inside one L2-sized window of B.
 // Split rows / ordered fix-up exactly as in sgcn_spmm.hip (deterministic, no atomics).
 //
-// Where its time goes (profiles/gather_ceiling.*, DESIGN.md 3.1b): L2 hits and fabric misses do
+// Where its time goes (profiles/gather_ceiling.*, DESIGN.md 3.2): L2 hits and fabric misses do
 // not overlap in the vector memory path -- T ~ miss_bytes / 7.2 TB/s + hit_bytes / 30 TB/s -- and
 // the kernel sits on that line; the levers left are fewer fabric bytes (rows resident per XCD) and
 // graphs with locality (grouped plans, xcd_map).
 //
 // Kernels in this file (what the product dispatches; the forms measured and dropped on the way -- plain and unpacked
-// two-group kernels, four lane groups per wave, the compiler-indexed generic form with 32-row tiles -- are kept as text
-// under profiles/experiments/ with their measurements in DESIGN.md 3.1b):
+// two-group kernels, four lane groups per wave, the compiler-indexed generic form with 32-row tiles -- live in git history,
+// their measurements in profiles/HISTORY.md 3.1b):
 //   cs_spmm16_kernel<U, EXTRA>     one 16-row tile per wavefront, pinned accumulators, up to 320 columns per pass
 //   cs_spmm16g2k_kernel<U, WIDE>   two 16-row bins per wavefront on 128-column passes, software-pipelined, packed FMAs:
 //                                  what ColumnSweepCSR.choose_g selects for most widths (bench default at d = 602)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
 // 16 -- half the passes of B through every XCD per register byte.  The plan keeps the two bins' column positions within
 // `align` columns of each other (pads), so a wave gathers from ONE L2 window (profiles/l2_sweep_sim.py).
 //
-// History of the step (the earlier forms are kept as text under profiles/experiments/): plain form
+// History of the step (profiles/HISTORY.md 3.1b; the earlier forms live in git history): plain form
 // 4.4 ms per S-Reddit SpMM; software-pipelined, 8 half-wave v_fma + 15 scalar + 2 ds_bpermute per step: 3.5 ms; THIS
 // form, 3.2 ms.  profiles/issue_probe.hip says what a step costs on the instruction side of gfx950: a v_fma_f32 occupies
 // its SIMD for 4.4 clocks WHATEVER the execution mask (a half-wave update is not cheaper than a full one), a

@@ -245,6 +245,13 @@ class Model(object):
         self.history_join = None   # parallel.py: the exchange is asynchronous; every reader of the history joins it first
 
     # -- reference API --------------------------------------------------------------------
+    def _eval_out(self, vec):
+        """An evaluation batch's result vector [stats(4) | CE per row | hit per row | classes per row] on its way to the
+        host: straight into the caller's pinned buffer (``eval_sink``: a copy-engine transfer in stream order, no kernel --
+        the next batch may overwrite the program's arena behind it), else a device copy."""
+        sink = self.__dict__.get('eval_sink')
+        return sink.push(vec) if sink is not None else vec.clone()
+
     def join_history(self):
         """Data parallel: the history rows the ranks exchanged behind the last step land now (a no-op otherwise)."""
         if self.history_join is not None:
@@ -582,7 +589,7 @@ class GCN(Model):
         n = int(z.shape[0])
         self.eval_classes = stats[4 + 2 * n:4 + 3 * n] if (want_pred and not self.multitask) else None
         if self.__dict__.get('eval_light') and self.eval_classes is not None:
-            self.eval_vec, self.eval_rows = stats, n          # (Trainer.evaluate: the same vector the step program hands out)
+            self.eval_vec, self.eval_rows = self._eval_out(stats), n      # (Trainer.evaluate: the vector the step program hands out)
         if FLAGS.weight_decay and self._wd_range[1] > self._wd_range[0]:
             ops.l2_penalty(self.theta, self._wd_range[0], self._wd_range[1], FLAGS.weight_decay, loss=stats[2:3])
         return stats[2], stats[3], pred, dlogits
@@ -804,7 +811,7 @@ class GCN(Model):
                 # Trainer.evaluate's form: ONE copy out of the arena per batch -- [stats(4) | CE per row | hit per row |
                 # class indices per row] -- instead of prediction, labels and statistics as three tensors
                 so = prog.stats_off
-                self.eval_vec, self.eval_rows = prog.arena[so:so + 4 + 3 * nL].clone(), nL
+                self.eval_vec, self.eval_rows = self._eval_out(prog.arena[so:so + 4 + 3 * nL]), nL
                 if pb.slot is not None:
                     self._ring_step_queued(pb)
                 self.cur = self.eval_classes = None

@@ -444,13 +444,13 @@ class ColumnSweepCSR(object):
         of the slowest (the plan pads the bins that are ahead).  What ``choose_g(d)`` picks for most widths -- the
         bench and the training path call it: S-Reddit d = 602 3.51 vs 3.67 ms sustained, S-RMAT d = 256 2.61 vs
         2.82 ms.  G = 4 (four groups, 64-column passes) is parity-tested but instruction-bound (4.4 ms):
-        DESIGN.md 3.1b."""
+        profiles/HISTORY.md 3.1b."""
         a = a.tocsr()
         self.G = int(G)
         if R != 16:
             raise ValueError("the column-sweep kernels keep 16-row bins (R = 16)")
         if self.G not in (1, 2):
-            raise ValueError("G must be 1 or 2 (four lane groups per wave were instruction-bound: profiles/experiments/)")
+            raise ValueError("G must be 1 or 2 (four lane groups per wave were instruction-bound: profiles/HISTORY.md 3.1b)")
         if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
                 raise ValueError("G = 2 plans are ungrouped and use 16-row bins")

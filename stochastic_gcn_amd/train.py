@@ -328,11 +328,35 @@ class Trainer(object):
         self.last_epoch = {}
 
     # ---- evaluation (gcn/train.py:133-160) ------------------------------------------------------
+    class _EvalSink(object):
+        """Pinned host memory the evaluation batches' result vectors are copied into as they are produced (copy engine,
+        stream order): no torch arithmetic or concatenation kernel on the evaluation path, one synchronisation per sweep."""
+
+        def __init__(self, floats):
+            self.buf = torch.empty(max(int(floats), 1), dtype=torch.float32).pin_memory()
+            self.pos = 0
+
+        def push(self, vec):
+            n = int(vec.numel())
+            if self.pos + n > self.buf.numel():
+                raise RuntimeError("evaluation sink overflow")
+            out = self.buf[self.pos:self.pos + n]
+            out.copy_(vec, non_blocking=True)
+            self.pos += n
+            return out
+
     def evaluate(self, data):
         total_pred, total_labs, total_cls, stats = [], [], [], []
         t_test = time()
         N = len(data)
         chunks = [data[st:min(st + FLAGS.test_batch_size, N)] for st in range(0, N, FLAGS.test_batch_size)]
+        sink = None
+        if not self.multitask:
+            sink = getattr(self, '_eval_sink', None)
+            need = 4 * len(chunks) + 3 * N
+            if sink is None or sink.buf.numel() < need:
+                sink = self._eval_sink = Trainer._EvalSink(need)
+            sink.pos = 0
         if FLAGS.native_prefetch and (FLAGS.prefetch > 0 or len(self.eval_schs) > 1):
             pre = NativePrefetcher(self.eval_schs if len(self.eval_schs) > 1 else self.eval_sch, chunks,
                                    FLAGS.plan_t, depth=max(FLAGS.prefetch, 1))
@@ -351,10 +375,12 @@ class Trainer(object):
             if nxt is not None and pre is not None:      # its H2D copy starts one batch early (train_epoch)
                 self.test_model.stage(nxt)
             self.test_model.eval_light = not self.multitask       # (for this call only: models.py _run_program / loss)
+            self.test_model.eval_sink = sink
             try:
                 los, acc, prd = self.test_model.run_one_step(self.sess, batch, sync=False)
             finally:
                 self.test_model.eval_light = False
+                self.test_model.eval_sink = None
             vec = self.test_model.__dict__.pop('eval_vec', None)
             if vec is not None:                 # single-label: ONE vector per batch [stats | CE | hit | classes per row]
                 vecs.append(vec)
@@ -371,14 +397,16 @@ class Trainer(object):
             pre.close()
         assert not (vecs and stats), "evaluation batches took both result forms"
         if vecs:
-            # the same fp32 arithmetic as below, on the device: (loss, accuracy) x rows per batch, summed over the batches
-            w = torch.tensor(rows, dtype=torch.float32, device=vecs[0].device)
-            tot = (torch.stack([v[2:4] for v in vecs]) * w[:, None]).sum(dim=0).cpu().numpy() / max(N, 1)
-            allv = torch.cat(vecs).cpu().numpy()
-            v, pos = [], 0
-            for r in rows:
-                v.append(allv[pos + 4 + 2 * r:pos + 4 + 3 * r])
-                pos += 4 + 3 * r
+            # the vectors are already on their way to pinned host memory: ONE synchronisation, then (loss, accuracy) x rows
+            # per batch summed over the batches in fp32 on the host (no torch kernel on this path)
+            torch.cuda.current_stream().synchronize()
+            tot = np.zeros(2, dtype=np.float32)
+            v = []
+            for vec, r in zip(vecs, rows):
+                hv = vec.numpy() if not vec.is_cuda else vec.cpu().numpy()
+                tot += hv[2:4] * np.float32(r)
+                v.append(hv[4 + 2 * r:4 + 3 * r])
+            tot = tot / np.float32(max(N, 1))
             v = np.concatenate(v).astype(np.int64)
             micro, macro = f1_from_classes(v // 4096, v % 4096)
             return float(tot[0]), float(tot[1]), micro, macro, (time() - t_test)
