@@ -239,7 +239,7 @@ int sgcn_lds_profile_buffer(void* dev_buf);
  *   spmm_nv / spmm_unroll / spmm_slabmajor : row-gather kernel geometry (0 = auto)
  *   cs_round (tiles per launch), cs_unroll (4|8), cs_pace (ns per nonzero of the heaviest tile,
  *   0 = unpaced), cs_slack (columns), cs_noextra (no fifth fp32 accumulator plane), cs_g2_wide (G = 2 plans: force the
- *   64-bit row offsets), cs_last_pct (default 90: clock of a last pass that covers <= 3/4 of a slab, in percent of the
+ *   64-bit row offsets), cs_last_pct (default 80: clock of a last pass that covers <= 3/4 of a slab, in percent of the
  *   plan's pace; 0 = off) : column-sweep kernels
  *   step_overlap (library default 1; the step program sets it from its flags, 0 unless --agg_overlap or a non-lean mode):
  *   in sgcn_step_run the AUX_* / VR_AGG_PRE ops (and, without --group_dw / --lean_sync, weight-gradient GEMMs and loss

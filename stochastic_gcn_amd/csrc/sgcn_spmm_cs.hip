@@ -549,7 +549,8 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             if (pace_ns_per_nnz > 0 && plan->host_tile_nnz_hint) {
                 double launch_ns = (double)plan->host_tile_nnz_hint[t0 / round] * pace_ns_per_nnz;
                 // A last pass that covers at most 3/4 of a slab gathers fewer cache lines per step and holds the
-                // lock-step on a slightly faster clock (measured on d = 602, G = 2: 90 % holds, 80 % does not).
+                // lock-step on a faster clock (d = 602, G = 2, sustained: 3.16 ms per product at 80 %, 3.22 at 90, 3.28 at 100, 3.43 at 70:
+                // profiles/r27_headline_knobs.jsonl).
                 if (nslab > 1 && slab == nslab - 1 && tune_get("cs_last_pct") > 0 &&
                     4 * (((d + 3) / 4 * 4) - slab * var.slab_floats) <= 3 * var.slab_floats)
                     launch_ns *= tune_get("cs_last_pct") / 100.0;
