@@ -72,7 +72,7 @@ def parse(argv=None):
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-align", type=int, default=2048, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
-    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2, 4],
+    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2],
                    help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes; "
                         "0: what ops.ColumnSweepCSR.choose_g picks for d -- also what the training path uses)")
     p.add_argument("--cpu-sample-rows", type=int, default=40000)

@@ -1,5 +1,6 @@
 """Four lane groups per wave (one round of resident tiles) on the S-Reddit product: time against the sweep clock, with
-and without the arithmetic (lds_dbg bit 1: gathers + pacing only), by bin alignment.  One JSON line per setting."""
+and without the arithmetic (lds_dbg bit 1: gathers + pacing only), by bin alignment.  One JSON line per setting.
+Needs the kernel of commit af99d18 (cs_spmm16g4k_kernel, removed after this measurement: profiles/r29_g4k_probe.jsonl)."""
 import json
 import sys
 

@@ -449,8 +449,8 @@ class ColumnSweepCSR(object):
         self.G = int(G)
         if R != 16:
             raise ValueError("the column-sweep kernels keep 16-row bins (R = 16)")
-        if self.G not in (1, 2, 4):
-            raise ValueError("G must be 1, 2 or 4 lane groups per wavefront")
+        if self.G not in (1, 2):
+            raise ValueError("G must be 1 or 2 (four lane groups per wave were instruction-bound: profiles/HISTORY.md 3.1b)")
         if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
                 raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
