@@ -619,6 +619,9 @@ enum {
                                  * reductions); this op issues all of them as ONE grouped GEMM launch + ONE reduction launch
                                  * on `stream` (bit-identical to the layer-by-layer launches, 2 HIP calls instead of 4 per
                                  * layer) */
+    SGCN_OP_MODE = 23,          /* (overlap, fuse), constants, anywhere in the program: this RUN uses the auxiliary stream iff
+                                 * overlap != 0 and, when fuse >= 0, the fusion bits `fuse` -- instead of the process-wide
+                                 * knobs step_overlap / step_fuse (which stay the defaults of programs without this op) */
     SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD
                                  * writes its dW / doffset / dscale instead of adding to them, so the program zeroes nothing
                                  * (it must write every parameter gradient exactly once per step); and the statistics

@@ -933,10 +933,22 @@ static int bwd_scratch(const DenseBwdArgs& a, hipStream_t st, bool overlap, BwdS
 // One dense layer's backward.
 // `lower` / `slower`: the layer BELOW (its dy is this layer's dx), whose LayerNorm / ReLU backward pass rides behind this
 // layer's input-gradient tail when both fit the row pass (*lower_done = true: only its weight-gradient job is left to do)
+// Gradient-STORE mode (SGCN_OP_GRAD_STORE): a layer must WRITE its parameter gradients every step.  A degenerate call (an
+// empty minibatch level) has no GEMM to do that, so its gradient ranges are zeroed here -- otherwise the optimizer would apply
+// the previous step's values.
+static int store_mode_zero(const DenseBwdArgs& a, void* stream) {
+    if (!g_grad_store || a.N <= 0 || a.K <= 0) return SGCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.dW) SGCN_HIP_TRY(hipMemset2DAsync(a.dW, (size_t)a.lddw * sizeof(float), 0, (size_t)a.N * sizeof(float), (size_t)a.K, st));
+    if (a.doffset) SGCN_HIP_TRY(hipMemsetAsync(a.doffset, 0, (size_t)a.N * sizeof(float), st));
+    if (a.dscale) SGCN_HIP_TRY(hipMemsetAsync(a.dscale, 0, (size_t)a.N * sizeof(float), st));
+    return SGCN_OK;
+}
+
 static int dense_bwd_run(const DenseBwdArgs& a, const BwdScratch& s, void* stream, const DenseBwdArgs* lower = nullptr,
                          const BwdScratch* slower = nullptr, bool* lower_done = nullptr, int32_t* lower_nblk = nullptr) {
     SGCN_REQUIRE(a.n >= 0 && a.N >= 0 && a.K >= 0, "dense_bwd: negative size");
-    if (a.n == 0 || a.N == 0 || a.K == 0) return SGCN_OK;
+    if (a.n == 0 || a.N == 0 || a.K == 0) return store_mode_zero(a, stream);
     SGCN_REQUIRE(a.dy && a.x && a.W && a.dW, "dense_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
     const float* g = a.dy;
@@ -1026,7 +1038,8 @@ static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int6
                           float* g_tmp, float* ws, const int32_t* gidx, void* stream, bool overlap) {
     const DenseBwdArgs a{n, N, K, dy, lddy, y, ldy, xhat, rstd, scale, relu, x, ldx, W, ldw, dW, lddw, doffset, dscale,
                          dx, lddx, drop, g_tmp, ws, gidx};
-    if (n == 0 || N == 0 || K == 0) return n >= 0 && N >= 0 && K >= 0 ? SGCN_OK : fail(SGCN_ERR_INVALID, "dense_bwd: negative size");
+    if (n == 0 || N == 0 || K == 0)
+        return n >= 0 && N >= 0 && K >= 0 ? store_mode_zero(a, stream) : fail(SGCN_ERR_INVALID, "dense_bwd: negative size");
     BwdScratch s{};
     const int rc = bwd_scratch(a, (hipStream_t)stream, overlap, s);
     if (rc != SGCN_OK) return rc;
@@ -1037,8 +1050,11 @@ static int dense_bwd_impl(int32_t n, int32_t N, int32_t K, const float* dy, int6
 // behind the upper one's row pass when the shapes allow it (knob step_fuse bit 6); otherwise exactly the two calls.
 int dense_bwd_chain(const DenseBwdArgs& up, const DenseBwdArgs& lo, void* stream) {
     const bool overlap = tune_get("step_overlap") != 0;
-    if (up.n == 0 || up.N == 0 || up.K == 0 || lo.n == 0 || lo.N == 0 || lo.K == 0)
-        return SGCN_OK;                       // (degenerate: nothing to do for either -- the caller checked sizes are >= 0)
+    if (up.n == 0 || up.N == 0 || up.K == 0 || lo.n == 0 || lo.N == 0 || lo.K == 0) {
+        // degenerate (the caller checked sizes are >= 0): no GEMM for either layer; in gradient-STORE mode both still write
+        const int rz = store_mode_zero(up, stream);
+        return rz != SGCN_OK ? rz : store_mode_zero(lo, stream);
+    }
     BwdScratch su{}, sl{};
     int rc = bwd_scratch(up, (hipStream_t)stream, overlap, su);
     if (rc != SGCN_OK) return rc;

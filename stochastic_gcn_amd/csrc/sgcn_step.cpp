@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include "sgcn_host.h"
 #include "sgcn_fuse.h"
@@ -179,9 +180,27 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
                              void* stream) {
     if (nops < 0 || (nops > 0 && !ops) || nslots < 0 || (nslots > 0 && !slots))
         return sgcn::fail(SGCN_ERR_INVALID, "step_run: bad argument");
+    // a run keeps state in the library's singletons (deferred weight-gradient jobs, gradient-store mode, parked reductions,
+    // the auxiliary stream): runs of different models / threads of one process are serialised here
+    static std::mutex run_mutex;
+    std::lock_guard<std::mutex> run_lock(run_mutex);
     bool memset_on_aux = false;
-    const bool overlap = sgcn_tune_get("step_overlap") != 0;
-    const int fuse = (int)sgcn_tune_get("step_fuse");
+    // the process-wide knobs are the defaults; a program's own MODE op overrides them for this run (and for the entry points
+    // the run calls, which read the knobs: set here, put back by the guard below)
+    const int64_t knob_overlap = sgcn_tune_get("step_overlap"), knob_fuse = sgcn_tune_get("step_fuse");
+    int64_t run_overlap = knob_overlap, run_fuse = knob_fuse;
+    for (int32_t k = 0; k < nops; k++)
+        if (ops[k].op == SGCN_OP_MODE && ops[k].nargs >= 1) {
+            run_overlap = ops[k].add[0] != 0;
+            if (ops[k].nargs >= 2 && ops[k].add[1] >= 0) run_fuse = ops[k].add[1] & 127;
+        }
+    const bool overlap = run_overlap != 0;
+    const int fuse = (int)run_fuse;
+    struct KnobGuard {
+        int64_t ov, fu; bool on;
+        ~KnobGuard() { if (on) { sgcn_tune("step_overlap", ov); sgcn_tune("step_fuse", fu); } }
+    } knobs{knob_overlap, knob_fuse, run_overlap != knob_overlap || run_fuse != knob_fuse};
+    if (knobs.on) { sgcn_tune("step_overlap", run_overlap); sgcn_tune("step_fuse", run_fuse); }
     bool grouped = false, store = false, l2 = false;
     int ce_at = -1, adam_at = -1;
     for (int32_t k = 0; k < nops; k++) {
@@ -346,6 +365,7 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             rc = sgcn::dw_group_flush(stream, (fuse & 32) && k + 1 < nops && ops[k + 1].op == SGCN_OP_ADAM);
             break;
         case SGCN_OP_GRAD_STORE:         // (mode of the whole run: set before the loop)
+        case SGCN_OP_MODE:
             break;
         case SGCN_OP_VR_AGG: {
             const int32_t* arp = a.p<const int32_t>(); const int32_t* ac = a.p<const int32_t>(); const float* av = a.p<const float>();

@@ -671,9 +671,12 @@ class GCN(Model):
         key = (round(float(dropout), 9), self.history_hook is None, self.theta.data_ptr(), self.grad.data_ptr(),
                self.adam_m.data_ptr() if self.is_training else 0, self.adam_v.data_ptr() if self.is_training else 0,
                self.features_dev.data_ptr() if isinstance(self.features_dev, torch.Tensor) else 0,
-               tuple(h.data_ptr() for hs in self.history for h in hs))
+               tuple(h.data_ptr() for hs in self.history for h in hs),
+               bool(FLAGS.group_dw), bool(FLAGS.lean_sync), bool(FLAGS.agg_overlap))
         progs = self.__dict__.setdefault('_programs', {})
         if key not in progs:
+            while len(progs) >= 2:         # superseded programs (arenas of up to 2 GB each) go: oldest first
+                progs.pop(next(iter(progs)))
             from .step_program import StepProgram, Unsupported
             try:
                 progs[key] = StepProgram(self, dropout)

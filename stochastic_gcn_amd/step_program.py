@@ -28,7 +28,7 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22)       # 18-20: retired (include/sgcn.h)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22, MODE=23)       # 18-20: retired (include/sgcn.h)
 MAX_ARGS = 48
 GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
@@ -328,8 +328,9 @@ class StepProgram(object):
         # the library's auxiliary stream is used only on request: with the weight gradients grouped and the memset /
         # statistics / scatter gone from it (group_dw, lean_sync) the two events around the aggregator's history half cost
         # more than the overlap returns
-        from . import _ffi
-        _ffi.tune('step_overlap', int(bool(FLAGS.agg_overlap) or not (FLAGS.lean_sync and FLAGS.group_dw)))
+        # per-program state (SGCN_OP_MODE at the head of every run), not the process-wide knob: another program built later
+        # -- the test model's, another model's -- does not change how this one runs
+        self.overlap = int(bool(FLAGS.agg_overlap) or not (FLAGS.lean_sync and FLAGS.group_dw))
         local_hist = m.history_hook is None
         # the history scatter: beside the step on the auxiliary stream (one event pair, a barrier on the compute queue), or
         # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
@@ -544,6 +545,8 @@ class StepProgram(object):
         self.nslots = self.lr_slot + 1
 
         def pack(lst):
+            if lst:
+                lst = [(OP['MODE'], [K(self.overlap), K(-1)])] + list(lst)
             arr = (StepOp * max(len(lst), 1))()
             for k, (opc, args) in enumerate(lst):
                 o = arr[k]
@@ -552,9 +555,9 @@ class StepProgram(object):
                     o.mul[j], o.slot[j], o.add[j] = int(a[0]), int(a[1]), int(a[2])
             return arr
         self.c_fb, self.c_opt, self.c_hist = pack(self.ops_fb), pack(self.ops_opt), pack(self.ops_hist)
-        self.n_fb, self.n_opt, self.n_hist = len(self.ops_fb), len(self.ops_opt), len(self.ops_hist)
+        self.n_fb, self.n_opt, self.n_hist = (len(x) + (1 if x else 0) for x in (self.ops_fb, self.ops_opt, self.ops_hist))
         allops = self.ops_fb + self.ops_opt + self.ops_hist       # one contiguous program for the single-GPU case
-        self.c_all, self.n_all = pack(allops), len(allops)
+        self.c_all, self.n_all = pack(allops), len(allops) + (1 if allops else 0)
         f = np.array(self._fill, dtype=np.int64).reshape(-1, 3)
         self._f_idx, self._f_mul = f[:, 0].copy(), f[:, 1].copy()
         self._f_ip, self._f_fp = (f[:, 2] == 1).astype(np.int64), (f[:, 2] == 2).astype(np.int64)
