@@ -33,12 +33,13 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 10.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 11.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
  *   v9  sgcn_softmax_ce_f32: with a prediction output, rowstat has a third plane (the rows' class indices)
- *   v10 sgcn_ldsplan_* / sgcn_spmm_lds_f32: the LDS-staged column sweep for graphs with locality */
+ *   v10 sgcn_ldsplan_* / sgcn_spmm_lds_f32: the LDS-staged column sweep for graphs with locality
+ *   v11 sgcn_csr_slice_indptr_dev; step ops MODE and CSR_SLICE .. GATHER_F32 (sparse-input stacks as step programs) */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -312,6 +313,8 @@ int sgcn_scatter_rows_f32(float* dev_H, int64_t ldh, const int32_t* dev_r, int32
  * matrix in CSR; o_row (nullable) additionally receives the COO row ids. */
 int sgcn_csr_slice_indptr(int32_t n, const int32_t* host_r, const int32_t* host_a_p,
                           int32_t* host_o_p);
+/* the same prefix pass on the device (one workgroup), for the compiled step: o_p[n + 1] from device row ids */
+int sgcn_csr_slice_indptr_dev(int32_t n, const int32_t* dev_r, const int32_t* dev_a_p, int32_t* dev_o_p, void* stream);
 int sgcn_csr_slice_f32(int32_t n, const int32_t* dev_r, const float* dev_a_d,
                        const int32_t* dev_a_i, const int32_t* dev_a_p,
                        const int32_t* dev_o_p, float* dev_o_d, int32_t* dev_o_col,
@@ -622,6 +625,12 @@ enum {
     SGCN_OP_MODE = 23,          /* (overlap, fuse), constants, anywhere in the program: this RUN uses the auxiliary stream iff
                                  * overlap != 0 and, when fuse >= 0, the fusion bits `fuse` -- instead of the process-wide
                                  * knobs step_overlap / step_fuse (which stay the defaults of programs without this op) */
+    /* the sparse-input first layer (gcn/layers.py:125,401-402 with sparse_inputs), ABI v11: */
+    SGCN_OP_CSR_SLICE = 24,     /* sgcn_csr_slice_indptr_dev + sgcn_csr_slice_f32: (n, rows, a_val, a_col, a_rowptr, o_p, o_d, o_col, o_row) */
+    SGCN_OP_LN_ACT_FWD = 25,    /* sgcn_ln_act_fwd_f32 */
+    SGCN_OP_LN_ACT_BWD = 26,    /* sgcn_ln_act_bwd_f32 (ws, ws_capacity in floats) */
+    SGCN_OP_CSR_TRANSPOSE = 27, /* sgcn_csr_transpose_index (ws, ws_capacity in int32) */
+    SGCN_OP_GATHER_F32 = 28,    /* sgcn_gather_f32 */
     SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD
                                  * writes its dW / doffset / dscale instead of adding to them, so the program zeroes nothing
                                  * (it must write every parameter gradient exactly once per step); and the statistics

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 10         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 11         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -123,6 +123,7 @@ SIGNATURES = {
     "sgcn_gather_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_scatter_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),
+    "sgcn_csr_slice_indptr_dev": (C.c_int, [C.c_int32, P, P, P, P]),
     "sgcn_csr_slice_f32": (C.c_int, [C.c_int32, P, P, P, P, P, P, P, P, P]),
     "sgcn_ln_act_fwd_f32": (C.c_int, [P, C.c_int64, P, P, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                       P, C.c_int64, P, P, P]),

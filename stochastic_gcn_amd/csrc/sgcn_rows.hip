@@ -217,6 +217,37 @@ extern "C" int sgcn_scatter_rows_f32(float* H, int64_t ldh, const int32_t* r, in
     return launch_rows<true>(src, lds, r, n, d, H, ldh, (hipStream_t)stream);
 }
 
+// o_p of a row slice on the device (what sgcn_csr_slice_indptr computes on the host, gcn/history.cpp:50-58): ONE workgroup,
+// every thread a contiguous run of rows, run totals scanned through LDS.  For the compiled step (SGCN_OP_CSR_SLICE): the
+// minibatch's input vertices are on the device already and no host pass / copy sits in front of the step.
+__global__ __launch_bounds__(kBlock) void csr_slice_indptr_kernel(int32_t n, const int32_t* __restrict__ r,
+                                                                  const int32_t* __restrict__ a_p, int32_t* __restrict__ o_p) {
+    __shared__ int32_t part[kBlock];
+    const int t = threadIdx.x;
+    const int32_t per = (n + kBlock - 1) / kBlock;
+    const int32_t b = min(n, t * per), e = min(n, b + per);
+    int32_t s = 0;
+    for (int32_t i = b; i < e; i++) { const int32_t row = r[i]; s += a_p[row + 1] - a_p[row]; }
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int32_t acc = 0;
+        for (int k = 0; k < kBlock; k++) { const int32_t v = part[k]; part[k] = acc; acc += v; }
+        o_p[n] = acc;
+    }
+    __syncthreads();
+    int32_t acc = part[t];
+    for (int32_t i = b; i < e; i++) { o_p[i] = acc; const int32_t row = r[i]; acc += a_p[row + 1] - a_p[row]; }
+}
+
+extern "C" int sgcn_csr_slice_indptr_dev(int32_t n, const int32_t* r, const int32_t* a_p, int32_t* o_p, void* stream) {
+    SGCN_REQUIRE(n >= 0, "csr_slice_indptr_dev: negative size");
+    SGCN_REQUIRE(o_p && (n == 0 || (r && a_p)), "csr_slice_indptr_dev: null operand");
+    hipLaunchKernelGGL(csr_slice_indptr_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, n, r, a_p, o_p);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
 extern "C" int sgcn_csr_slice_f32(int32_t n, const int32_t* r, const float* a_d,
                                   const int32_t* a_i, const int32_t* a_p, const int32_t* o_p,
                                   float* o_d, int32_t* o_col, int32_t* o_row, void* stream) {

@@ -367,6 +367,52 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         case SGCN_OP_GRAD_STORE:         // (mode of the whole run: set before the loop)
         case SGCN_OP_MODE:
             break;
+        // ---- the sparse-input first layer: slice of the feature CSR, LayerNorm / ReLU passes around sparse products, the
+        // slice's transpose for the weight gradient (layers.Dense / AugmentedDropoutDense with sparse_inputs, call for call)
+        case SGCN_OP_CSR_SLICE: {
+            const int32_t n = a.i(); const int32_t* rows = a.p<const int32_t>();
+            const float* av = a.p<const float>(); const int32_t* ac = a.p<const int32_t>(); const int32_t* arp = a.p<const int32_t>();
+            int32_t* o_p = a.p<int32_t>(); float* o_d = a.p<float>(); int32_t* o_c = a.p<int32_t>(); int32_t* o_r = a.p<int32_t>();
+            rc = sgcn_csr_slice_indptr_dev(n, rows, arp, o_p, stream);
+            if (rc == SGCN_OK) rc = sgcn_csr_slice_f32(n, rows, av, ac, arp, o_p, o_d, o_c, o_r, stream);
+            break;
+        }
+        case SGCN_OP_LN_ACT_FWD: {
+            const float* x = a.p<const float>(); const int64_t ldx = a.next();
+            const float* off = a.p<const float>(); const float* sc = a.p<const float>();
+            const int32_t n = a.i(), d = a.i(); const float eps = a.f(); const int32_t relu = a.i();
+            float* y = a.p<float>(); const int64_t ldy = a.next(); float* xhat = a.p<float>(); float* rstd = a.p<float>();
+            rc = sgcn_ln_act_fwd_f32(x, ldx, off, sc, n, d, eps, relu, y, ldy, xhat, rstd, stream);
+            break;
+        }
+        case SGCN_OP_LN_ACT_BWD: {
+            const float* dy = a.p<const float>(); const int64_t lddy = a.next();
+            const float* y = a.p<const float>(); const int64_t ldy = a.next();
+            const float* xhat = a.p<const float>(); const float* rstd = a.p<const float>(); const float* sc = a.p<const float>();
+            const int32_t n = a.i(), d = a.i(), relu = a.i();
+            float* dx = a.p<float>(); const int64_t lddx = a.next(); float* doff = a.p<float>(); float* dsc = a.p<float>();
+            float* ws = a.p<float>(); const int64_t ws_cap = a.next();
+            if (sc && sgcn_ln_act_bwd_ws_floats(n, d) > ws_cap)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: LayerNorm-backward scratch too small at op %d", k);
+            rc = sgcn_ln_act_bwd_f32(dy, lddy, y, ldy, xhat, rstd, sc, n, d, relu, dx, lddx, doff, dsc, ws, stream);
+            break;
+        }
+        case SGCN_OP_CSR_TRANSPOSE: {
+            const int32_t ncols = a.i(); const int64_t nnz = a.next();
+            const int32_t* col = a.p<const int32_t>(); const int32_t* row = a.p<const int32_t>();
+            int32_t* trp = a.p<int32_t>(); int32_t* trow = a.p<int32_t>(); int32_t* tsrc = a.p<int32_t>();
+            int32_t* ws = a.p<int32_t>(); const int64_t ws_cap = a.next();
+            if (sgcn_csr_transpose_ws_ints(ncols, nnz) > ws_cap)
+                return sgcn::fail(SGCN_ERR_INVALID, "step_run: transpose scratch too small at op %d", k);
+            rc = sgcn_csr_transpose_index(ncols, nnz, col, row, trp, trow, tsrc, ws, stream);
+            break;
+        }
+        case SGCN_OP_GATHER_F32: {
+            const float* src = a.p<const float>(); const int32_t* idx = a.p<const int32_t>(); const int64_t n = a.next();
+            float* out = a.p<float>();
+            rc = sgcn_gather_f32(src, idx, n, out, stream);
+            break;
+        }
         case SGCN_OP_VR_AGG: {
             const int32_t* arp = a.p<const int32_t>(); const int32_t* ac = a.p<const int32_t>(); const float* av = a.p<const float>();
             const int32_t* frp = a.p<const int32_t>(); const int32_t* fc = a.p<const int32_t>(); const float* fv = a.p<const float>();

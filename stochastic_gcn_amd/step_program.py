@@ -28,7 +28,8 @@ from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
-          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22, MODE=23)       # 18-20: retired (include/sgcn.h)
+          AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22, MODE=23,
+          CSR_SLICE=24, LN_ACT_FWD=25, LN_ACT_BWD=26, CSR_TRANSPOSE=27, GATHER_F32=28)       # 18-20: retired (include/sgcn.h)
 MAX_ARGS = 48
 GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
@@ -98,6 +99,20 @@ class SGather(object):
         return self.src.cols
 
 
+class SSparse(object):
+    """the minibatch's row slice of the sparse feature matrix (layers.SparseInput): CSR arrays in the arena, sized for the
+    worst minibatch; ``nnz`` is a slot the host fills per step; the transpose index is emitted once, by the first consumer"""
+    __slots__ = ("o_p", "o_c", "o_d", "o_r", "rows", "nnz", "ncols", "cap", "vals", "tbox")
+
+    def __init__(self, o_p, o_c, o_d, o_r, rows, nnz, ncols, cap, vals=None, tbox=None):
+        self.o_p, self.o_c, self.o_d, self.o_r, self.rows, self.nnz, self.ncols, self.cap = o_p, o_c, o_d, o_r, rows, nnz, ncols, cap
+        self.vals = o_d if vals is None else vals          # the values in use (after a sparse dropout: a second vector)
+        self.tbox = [None] if tbox is None else tbox       # the transpose index, shared by the views of one slice
+
+    def with_vals(self, vals):
+        return SSparse(self.o_p, self.o_c, self.o_d, self.o_r, self.rows, self.nnz, self.ncols, self.cap, vals, self.tbox)
+
+
 class SDropped(object):
     """activation with a pending dropout (layers.Dropped)"""
     __slots__ = ("x", "site", "_m")
@@ -110,9 +125,11 @@ class StepProgram(object):
     def __init__(self, model, dropout):
         self.model = m = model
         self.dropout = float(dropout)
-        if m.sparse_input:
-            raise Unsupported("sparse input features")
-        if not isinstance(m.features_dev, torch.Tensor):
+        from . import ops as _ops
+        self.sparse = bool(m.sparse_input and m.sparse_mm)
+        if self.sparse and not (isinstance(m.features_dev, _ops.DeviceCSR) and m.features_dev.host_rowptr is not None):
+            raise Unsupported("sparse features are not a device CSR with its host row pointer")
+        if not self.sparse and not isinstance(m.features_dev, torch.Tensor):
             raise Unsupported("features are not a dense device tensor")
         self.dev = m.device
         self.L = m.L
@@ -126,6 +143,13 @@ class StepProgram(object):
         for l in range(self.L - 1, -1, -1):
             caps[l] = min(n, caps[l + 1] * (1 + int(deg)))
         self.caps = caps
+        if self.sparse:
+            # the slice's nonzeros: counted on the host per step (fill), bounded here by the caps[0] longest feature rows
+            self._rowlen = np.diff(np.asarray(m.features_dev.host_rowptr, dtype=np.int64))
+            k = min(caps[0], int(self._rowlen.shape[0]))
+            self.nnz_cap = int(np.sort(self._rowlen)[::-1][:k].sum()) if k else 0
+            if self.nnz_cap >= (1 << 31):
+                raise Unsupported("feature slice beyond 2^31 nonzeros")
         self._pb = PackedBatch(self.L, self.cv, np.zeros(int(lib.sgcn_sched_packed_meta_len(self.L)), np.int64),
                                None, None, 0, 0, None)          # only for its offsets
         self.plan_ws_floats = 8 << 20          # partial sums of split rows (checked per step)
@@ -201,6 +225,10 @@ class StepProgram(object):
 
     def _lr(self):
         return (1, self._n_meta + len(self._key_layers), 0)
+
+    def _nnz(self):
+        """the feature slice's nonzero count (sparse programs: the slot behind the step size)"""
+        return (1, self._n_meta + len(self._key_layers) + 1, 0)
 
     # ---- arena ------------------------------------------------------------------------------------
     def _alloc(self, rows, cols, ld=None):
@@ -305,6 +333,59 @@ class StepProgram(object):
                             self._p(B), K(B.ld), NULL, NULL, cscale, self._p(out), K(out.ld), K(_fbits(0.0))]
                    + self._plan(b, d) + [self._p(add), K(add.ld if add is not None else 0), add_rows])
 
+    def _sparse_dropout(self, xs, site):
+        """ops.dropout on the slice's value vector (one row of nnz elements)"""
+        out = self._alloc_vec(xs.cap)[0]
+        self._emit('DROPOUT', [xs.vals, xs.nnz, K(1), xs.nnz] + self._drop_args(site, K(-1), 0)[:4] + [xs.nnz, out, xs.nnz])
+        return out
+
+    def _sparse_fwd(self, xs, vals, W, off, sc, relu, post):
+        """ops.spmm(slice, W) [+ ops.ln_act_fwd]: returns (y, (xhat, rstd) or None)"""
+        n, N = xs.rows, W.cols
+        y0 = self._alloc(n, N)
+        self._emit('SPMM', [xs.o_p, xs.o_c, vals, n.op(), K(xs.ncols), K(N), self._p(W), K(W.ld), NULL, NULL, NULL,
+                            self._p(y0), K(N), K(_fbits(0.0)), K(0), NULL, K(0), NULL, K(0), K(0), NULL, K(0), NULL, K(0), K(0)])
+        if not post:
+            return y0, None
+        norm = off is not None
+        y = self._alloc(n, N)
+        xhat = self._alloc(n, N) if norm else None
+        rstd = self._alloc_vec(n.cap)[0] if norm else None
+        self._emit('LN_ACT_FWD', [self._p(y0), K(N), self._p(off), self._p(sc), n.op(), K(N), K(_fbits(1e-9)), K(int(bool(relu))),
+                                  self._p(y), K(N), self._p(xhat), self._p(rstd)])
+        return y, ((xhat, rstd) if norm else None)
+
+    def _sparse_bwd(self, g, rec):
+        """layers.Dense.backward with sparse_inputs: LayerNorm / ReLU backward, then dW += slice^T . g through the slice's
+        transpose index (built once per step) and the values gathered into its order"""
+        _, lay, xs, vals, y, ctx, relu, post = rec
+        n, N = g.rows, g.cols
+        if post:
+            norm = ctx is not None
+            need = (int(lib.sgcn_ln_act_bwd_ws_floats(n.cap, N)) + 3) // 4 * 4 if norm else 0
+            self._ws_need = max(self._ws_need, need + GEMM_WS_BOUND)
+            dx = self._alloc(n, N)
+            self._emit('LN_ACT_BWD', [self._p(g), K(g.ld), self._p(y), K(y.ld), self._p(ctx[0]) if norm else NULL,
+                                      self._p(ctx[1]) if norm else NULL, self._p(self._param(lay, 'scale')) if norm else NULL,
+                                      n.op(), K(N), K(int(bool(relu))), self._p(dx), K(N),
+                                      self._p(self._param(lay, 'offset', True)) if norm else NULL,
+                                      self._p(self._param(lay, 'scale', True)) if norm else NULL,
+                                      K(self._ws_gemm_ptr), K(self.gemm_ws_floats)])
+            g = dx
+        if xs.tbox[0] is None:
+            ws_ints = int(lib.sgcn_csr_transpose_ws_ints(xs.ncols, xs.cap))
+            trp, trow, tsrc = self._alloc_vec(xs.ncols + 1)[0], self._alloc_vec(xs.cap)[0], self._alloc_vec(xs.cap)[0]
+            ws = self._alloc_vec(max(ws_ints, 1))[0]
+            self._emit('CSR_TRANSPOSE', [K(xs.ncols), xs.nnz, xs.o_c, xs.o_r, trp, trow, tsrc, ws, K(ws_ints)])
+            xs.tbox[0] = (trp, trow, tsrc)
+        trp, trow, tsrc = xs.tbox[0]
+        tv = self._alloc_vec(xs.cap)[0]
+        self._emit('GATHER_F32', [vals, tsrc, xs.nnz, tv])
+        dW = self._param(lay, 'weights', True)
+        self._emit('SPMM', [trp, trow, tv, K(xs.ncols), n.op(), K(N), self._p(g), K(g.ld), NULL, NULL, NULL,
+                            self._p(dW), K(dW.ld), K(_fbits(1.0)), K(0), NULL, K(0), NULL, K(0), K(0), NULL, K(0), NULL, K(0), K(0)])
+        return None
+
     # ---- parameters -------------------------------------------------------------------------------
     def _param(self, layer, name, grad=False):
         t = (layer.grads if grad else layer.vars).get(name)
@@ -317,8 +398,17 @@ class StepProgram(object):
     def _build(self):
         m = self.model
         F = m.features_dev
-        feat = ST(K(F.data_ptr()), Rows(0, -1, int(F.shape[0]), int(F.shape[0])), int(F.shape[1]), int(F.stride(0)))
-        act = SGather(feat, self._field_ptr(0), self.rows[0])
+        if self.sparse:
+            # upload()'s csr_slice, as the program's first op: row pointer by a device prefix pass, then the copy
+            cap = max(self.nnz_cap, 1)
+            o_p = self._alloc_vec(self.caps[0] + 1)[0]
+            o_c, o_d, o_r = self._alloc_vec(cap)[0], self._alloc_vec(cap)[0], self._alloc_vec(cap)[0]
+            act = SSparse(o_p, o_c, o_d, o_r, self.rows[0], self._nnz(), int(F.shape[1]), cap)
+            self._emit('CSR_SLICE', [self.rows[0].op(), self._field_ptr(0), K(F.val.data_ptr()), K(F.col.data_ptr()),
+                                     K(F.rowptr.data_ptr()), o_p, o_d, o_c, o_r])
+        else:
+            feat = ST(K(F.data_ptr()), Rows(0, -1, int(F.shape[0]), int(F.shape[0])), int(F.shape[1]), int(F.stride(0)))
+            act = SGather(feat, self._field_ptr(0), self.rows[0])
         tape = []
         concat = FLAGS.normalization != 'gcn'
         self.new_history = {}
@@ -336,7 +426,11 @@ class StepProgram(object):
         # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
         self._hist_last = bool(FLAGS.lean_sync) and local_hist
         if m.is_training:
-            if FLAGS.lean_sync:
+            if self.sparse:
+                # the sparse layer's gradients are sums INTO the buffer (a transposed product with beta = 1, LayerNorm
+                # parameter sums): zeroed first, on the step's own stream
+                self._emit('MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
+            elif FLAGS.lean_sync:
                 # gradient-STORE mode (include/sgcn.h SGCN_OP_GRAD_STORE): every layer of a supported stack writes each of
                 # its parameter gradients exactly once per step, so nothing is zeroed (no memset, no join on it) and the
                 # loss statistics ride in the optimizer's launch
@@ -358,9 +452,31 @@ class StepProgram(object):
                                           self._p(buf)] + self._plan(bf, d))
                 accP[l] = buf
         for layer in m.layers:
-            if isinstance(layer, AugmentedDropoutDense):
-                if layer.sparse_inputs or layer.output_dim > 128:
-                    raise Unsupported("sparse / wide AugmentedDropoutDense")
+            if isinstance(layer, (AugmentedDropoutDense, Dense)) and layer.sparse_inputs:
+                # layers.Dense / AugmentedDropoutDense with sparse_inputs, call for call: (dropout of the slice's values) ->
+                # sparse product(s) with W -> LayerNorm + ReLU pass(es)
+                if not isinstance(act, SSparse):
+                    raise Unsupported("sparse layer behind a dense activation")
+                xs = act
+                aug = isinstance(layer, AugmentedDropoutDense)
+                site = self._site(layer) if aug else None
+                W = self._param(layer, 'weights')
+                off = self._param(layer, 'offset') if layer.norm else None
+                sc = self._param(layer, 'scale') if layer.norm else None
+                relu = True if aug else bool(layer.act)
+                vals = xs.vals
+                if site is not None:
+                    vals = self._sparse_dropout(xs, site)
+                hx, ctx = self._sparse_fwd(xs, vals, W, off, sc, relu, aug or layer.norm or layer.act)
+                tape.append(('sdense', layer, xs, vals, hx, ctx, relu, aug or layer.norm or layer.act))
+                if aug:
+                    hmu = hx if site is None else self._sparse_fwd(xs, xs.vals, W, off, sc, True, True)[0]
+                    act = (hx, hmu)
+                else:
+                    act = hx
+            elif isinstance(layer, AugmentedDropoutDense):
+                if layer.output_dim > 128:
+                    raise Unsupported("wide AugmentedDropoutDense")
                 x, mu = act if isinstance(act, tuple) else (act, act)
                 site = self._site(layer)
                 W, off, sc = self._param(layer, 'weights'), self._param(layer, 'offset') if layer.norm else None, \
@@ -379,6 +495,12 @@ class StepProgram(object):
                     hx = h2.head(n)
                     tape.append(('dense', layer, x, hx, ctx, site, True))
                     act = (hx, h2.tail(n))
+            elif isinstance(layer, Dropout) and isinstance(act, SSparse):
+                # layers.Dropout on the sparse slice: same structure, dropped values; nothing on the way back
+                site = self._site(layer)
+                if site is not None:
+                    act = act.with_vals(self._sparse_dropout(act, site))
+                tape.append(('dropout', None, False))
             elif isinstance(layer, Dropout):
                 site = self._site(layer)
                 inp = act[0] if (layer.cvd and isinstance(act, tuple)) else act
@@ -396,8 +518,6 @@ class StepProgram(object):
                     act = self._materialize(SDropped(inp, site))
                     tape.append(('dropout', site, False))
             elif isinstance(layer, Dense):
-                if layer.sparse_inputs:
-                    raise Unsupported("sparse Dense")
                 x, site = act, None
                 if isinstance(x, SDropped):
                     x, site = x.x, x.site
@@ -501,7 +621,9 @@ class StepProgram(object):
             g = dz
             first = m._first_param
             for layer, rec in reversed(list(zip(m.layers, tape))[first:]):
-                if rec[0] == 'dense':
+                if rec[0] == 'sdense':
+                    g = self._sparse_bwd(g, rec)
+                elif rec[0] == 'dense':
                     _, lay, x, y, ctx, site, relu = rec
                     g = self._dense_bwd(g, y, ctx, self._param(lay, 'scale') if lay.norm else None, relu, x,
                                         self._param(lay, 'weights'), self._param(lay, 'weights', True),
@@ -542,7 +664,8 @@ class StepProgram(object):
     def _finalize(self):
         self._key_slots = {li: self._n_meta + i for i, li in enumerate(self._key_layers)}
         self.lr_slot = self._n_meta + len(self._key_layers)
-        self.nslots = self.lr_slot + 1
+        self.nnz_slot = self.lr_slot + 1
+        self.nslots = self.lr_slot + (2 if self.sparse else 1)
 
         def pack(lst):
             if lst:
@@ -600,6 +723,12 @@ class StepProgram(object):
                                 self._slots_ptr, self.nslots)
         if rc < 0:
             check(rc)
+        if rc == 0 and self.sparse:
+            m = pb.m
+            nnz = int(self._rowlen[pb.ibuf[m[4]:m[4] + m[5]]].sum())
+            if nnz > self.nnz_cap:
+                return False
+            self.slots[self.nnz_slot] = nnz
         return rc == 0
 
     def run(self, which, stream):

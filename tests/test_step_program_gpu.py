@@ -1,7 +1,7 @@
 """The compiled step program (stochastic_gcn_amd/step_program.py + sgcn_step_run: ONE foreign call per
 training step) against the eager per-layer host path: same kernels, same arguments -> bit-identical
 weights, Adam moments, history, loss and accuracy over consecutive steps, for every layer stack the
-compiler supports; unsupported stacks (sparse input features, wide LayerNorm layers) fall back."""
+compiler supports (sparse input features included); unsupported stacks (wide LayerNorm layers) fall back."""
 import numpy as np
 import pytest
 import torch
@@ -92,7 +92,34 @@ def test_dropout_zero_and_weight_decay_variants():
         assert all(torch.equal(x[0], y[0]) for x, y in zip(la, lb))
 
 
-@pytest.mark.parametrize("name", ['pubmed_cvd_pp', 'cora_exact', 'reddit_cvd_pp_wide'])
+@pytest.mark.parametrize("name", ['pubmed_cvd_pp', 'cora_exact'])
+@pytest.mark.parametrize("slot,group", [(False, True), (True, True), (False, False)])
+def test_sparse_input_stacks_run_as_programs_bit_identical_to_the_eager_path(name, slot, group):
+    """BASELINE configs 1 and 2 (sparse feature matrices, gcn/layers.py:125,401-402 with sparse_inputs): the slice of the
+    feature CSR, the sparse dropout, the sparse products, their LayerNorm passes and the transposed product of the weight
+    gradient are ops of the step program (CSR_SLICE, DROPOUT, SPMM, LN_ACT_FWD / _BWD, CSR_TRANSPOSE, GATHER_F32) -- the
+    calls of the eager layers, in their order."""
+    case = mc.build_case(name)
+    a, la = _run(case, False, 4, slot)
+    b, lb = _run(case, True, 4, slot, group=group)
+    progs = getattr(b, '_programs', {})
+    assert progs and all(p is not None for p in progs.values()), getattr(b, '_program_note', 'no program was compiled')
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    for ha, hb in zip(a.history, b.history):
+        assert torch.equal(ha[0], hb[0])
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2)
+    assert a.amt_data == b.amt_data and np.array_equal(a.field_sizes, b.field_sizes)
+    prog = next(iter(progs.values()))
+    from stochastic_gcn_amd.step_program import OP
+    ops = [o for o, _ in prog.ops_fb]
+    assert prog.sparse and ops.count(OP['CSR_SLICE']) == 1 and ops.count(OP['CSR_TRANSPOSE']) == 1
+    assert ops.count(OP['MEMSET0']) == 1 and ops.count(OP['GRAD_STORE']) == 0      # sums into a zeroed gradient buffer
+    print("%s: %d ops per step, arena %.1f MB, slice capacity %d nonzeros" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20,
+                                                                              prog.nnz_cap))
+
+
+@pytest.mark.parametrize("name", ['reddit_cvd_pp_wide'])
 def test_unsupported_stacks_fall_back_to_the_eager_path(name):
     case = mc.build_case(name)
     b, lb = _run(case, True, 2, False)
@@ -161,9 +188,11 @@ def test_program_is_rebuilt_when_what_it_baked_in_changes():
     m.history_hook = hook
     step(m, sch), step(ref, sch2)
     assert len(m._programs) == 2 and len(calls) == 1          # a second program, whose history update went through the hook
+    seen = set(id(p) for p in m._programs.values())
     m.history[0][0] = m.history[0][0].clone()                  # the history tensor moves
     step(m, sch), step(ref, sch2)
-    assert len(m._programs) == 3
+    # a third program -- and the oldest (its arena with it) has been dropped: a model keeps two
+    assert len(m._programs) == 2 and sum(id(p) not in seen for p in m._programs.values()) == 1
     torch.cuda.synchronize()
     assert torch.equal(m.theta, ref.theta) and torch.equal(m.history[0][0], ref.history[0][0])
 
