@@ -188,11 +188,12 @@ def test_program_is_rebuilt_when_what_it_baked_in_changes():
     m.history_hook = hook
     step(m, sch), step(ref, sch2)
     assert len(m._programs) == 2 and len(calls) == 1          # a second program, whose history update went through the hook
-    seen = set(id(p) for p in m._programs.values())
+    for p in m._programs.values():
+        p._seen = True
     m.history[0][0] = m.history[0][0].clone()                  # the history tensor moves
     step(m, sch), step(ref, sch2)
     # a third program -- and the oldest (its arena with it) has been dropped: a model keeps two
-    assert len(m._programs) == 2 and sum(id(p) not in seen for p in m._programs.values()) == 1
+    assert len(m._programs) == 2 and sum(not getattr(p, '_seen', False) for p in m._programs.values()) == 1
     torch.cuda.synchronize()
     assert torch.equal(m.theta, ref.theta) and torch.equal(m.history[0][0], ref.history[0][0])
 
