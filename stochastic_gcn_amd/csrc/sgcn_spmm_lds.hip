@@ -26,6 +26,15 @@
 
 namespace sgcn {
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void lds_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        lds_static_for<N, I + 1>(f);
+    }
+}
+
 struct LdsArgs {
     const int32_t* tile_chunk_ptr;      // [ntiles + 1]
     const int32_t* chunk_hdr;           // [nchunks * NW * 16] per (chunk, wave): its S / NW column ids, entry groups, entry index
@@ -119,6 +128,49 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     SGCN_LDS_READ8(M, 0, EW, EX, 48, 49, 50, 51, 52, 53, 54, 55)       SGCN_LDS_APPLY8(M, 1, 8)                \
     SGCN_LDS_READ8(M, 1, EW, EX, 56, 57, 58, 59, 60, 61, 62, 63)       SGCN_LDS_APPLY8(M, 0, 8)                \
     SGCN_LDS_READ8(M, 0, NW, NX, 0, 1, 2, 3, 4, 5, 6, 7)               SGCN_LDS_APPLY8(M, 1, 8)
+// The NEXT chunk's piece requests ride inside the statement (two-part ring, 128 slots: 8 per wave): request J goes out
+// behind group J of the first block -- outside the indexing mode, M0 being both its index register and the LDS-DMA's
+// destination -- so that the vector L1 sees them spread over the chunk instead of as a burst in front of it (the burst was
+// 18 % of the sweep: profiles/lds_phase_probe.py).  Source address: lanes 0-31 the piece of column word A, lanes 32-63 that
+// of B (operand r<B> = the DIFFERENCE of the two row offsets, masked by hsel = ~0 in the upper half), + the lane's offset in the row.  A wave with fewer than 8 groups issues the rest on its
+// way out (labels Lf<J>).
+#define SGCN_LDS_FILL1(J, A, B)                                                                               \
+    "v_and_b32 v28, %[r" #B "], %[hsel]\n\t"                                                                   \
+    "v_add3_u32 v28, v28, %[r" #A "], %[boff]\n\t"                                                             \
+    "s_add_u32 m0, %[m0b], " #J "*1024\n\t"                                                                    \
+    "s_nop 0\n\t"                                                                                              \
+    "global_load_lds_dwordx4 v28, %[bb]\n\t"
+#define SGCN_LDS_APPLY8F(M, Q, WAIT, J, A, B, JN)                                                             \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                                        \
+    "s_set_gpr_idx_on s[36+8*" #Q "+0], " SGCN_LDS_MODE_##M "\n\t" SGCN_LDS_OP1_##M(Q, 0)                      \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" SGCN_LDS_OP1_##M(Q, 1)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" SGCN_LDS_OP1_##M(Q, 2)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" SGCN_LDS_OP1_##M(Q, 3)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" SGCN_LDS_OP1_##M(Q, 4)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" SGCN_LDS_OP1_##M(Q, 5)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_OP1_##M(Q, 6)                                            \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_OP1_##M(Q, 7)                                            \
+    "s_set_gpr_idx_off\n\t"                                                                                   \
+    SGCN_LDS_FILL1(J, A, B)                                                                                   \
+    "s_sub_u32 %[n], %[n], 1\n\t"                                                                             \
+    "s_cmp_eq_u32 %[n], 0\n\t"                                                                                \
+    "s_cbranch_scc1 Lf" #JN "_%=\n\t"
+#define SGCN_LDS_BLOCKF(M, EW, EX, NW, NX, ENEXT)                                                             \
+    ENEXT                                                                                                     \
+    SGCN_LDS_READ8(M, 1, EW, EX, 8, 9, 10, 11, 12, 13, 14, 15)         SGCN_LDS_APPLY8F(M, 0, 8, 0, 0, 1, 1)   \
+    SGCN_LDS_READ8(M, 0, EW, EX, 16, 17, 18, 19, 20, 21, 22, 23)       SGCN_LDS_APPLY8F(M, 1, 8, 1, 2, 3, 2)   \
+    SGCN_LDS_READ8(M, 1, EW, EX, 24, 25, 26, 27, 28, 29, 30, 31)       SGCN_LDS_APPLY8F(M, 0, 8, 2, 4, 5, 3)   \
+    SGCN_LDS_READ8(M, 0, EW, EX, 32, 33, 34, 35, 36, 37, 38, 39)       SGCN_LDS_APPLY8F(M, 1, 8, 3, 6, 7, 4)   \
+    SGCN_LDS_READ8(M, 1, EW, EX, 40, 41, 42, 43, 44, 45, 46, 47)       SGCN_LDS_APPLY8F(M, 0, 8, 4, 8, 9, 5)   \
+    SGCN_LDS_READ8(M, 0, EW, EX, 48, 49, 50, 51, 52, 53, 54, 55)       SGCN_LDS_APPLY8F(M, 1, 8, 5, 10, 11, 6) \
+    SGCN_LDS_READ8(M, 1, EW, EX, 56, 57, 58, 59, 60, 61, 62, 63)       SGCN_LDS_APPLY8F(M, 0, 8, 6, 12, 13, 7) \
+    SGCN_LDS_READ8(M, 0, NW, NX, 0, 1, 2, 3, 4, 5, 6, 7)               SGCN_LDS_APPLY8F(M, 1, 8, 7, 14, 15, 8)
+// the requests a short wave still owes, entered at Lf<J>; behind the last block (which jumps over them)
+#define SGCN_LDS_FILL_TAIL                                                                                    \
+    "s_branch Lx_%=\n\t"                                                                                      \
+    "Lf1_%=:\n\t" SGCN_LDS_FILL1(1, 2, 3) "Lf2_%=:\n\t" SGCN_LDS_FILL1(2, 4, 5) "Lf3_%=:\n\t" SGCN_LDS_FILL1(3, 6, 7)    \
+    "Lf4_%=:\n\t" SGCN_LDS_FILL1(4, 8, 9) "Lf5_%=:\n\t" SGCN_LDS_FILL1(5, 10, 11) "Lf6_%=:\n\t" SGCN_LDS_FILL1(6, 12, 13) \
+    "Lf7_%=:\n\t" SGCN_LDS_FILL1(7, 14, 15) "Lf8_%=:\n\t"
 #define SGCN_LDS_CLOBBER_V "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",   \
         "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", \
         "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
@@ -162,13 +214,37 @@ __device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2,
     }
 }
 
+// The same chunk with the next chunk's 8 piece requests inside (unit plans, two-part ring): r[2 J] = byte offset of the B row
+// of the first piece of request J, r[2 J + 1] = the second piece's minus that, hsel = ~0 in lanes 32-63, boff = the lane's offset in a row, m0b = LDS address of the wave's first
+// destination slot, bb = B.
+struct LdsFill { uint32_t r[16]; uint32_t boff, hsel, m0b; const char* bb; };
+__device__ __forceinline__ void lds_chunk_fill_u(acc32_t& a0, acc32_t& a1, acc32_t& a2, acc32_t& a3, acc32_t& a4, acc32_t& a5,
+                                                 uint32_t n, uint32_t ea, uint32_t mask, uint32_t lane_off, const LdsFill& F) {
+    asm volatile("ds_read_b32 v26, %[ea]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 SGCN_LDS_READ8(U, 0, v26, v26, 0, 1, 2, 3, 4, 5, 6, 7)
+                 SGCN_LDS_BLOCKF(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:256\n\t")
+                 SGCN_LDS_BLOCK(U, v27, v27, v26, v26, "ds_read_b32 v26, %[ea] offset:512\n\t")
+                 SGCN_LDS_BLOCK(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:768\n\t")
+                 SGCN_LDS_BLOCK(U, v27, v27, v27, v27, "ds_read_b32 v26, %[ea]\n\t")
+                 SGCN_LDS_FILL_TAIL
+                 "Lx_%=:\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : SGCN_LDS_ACC, [n] "+s"(n)
+                 : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off), [boff] "v"(F.boff), [hsel] "v"(F.hsel), [m0b] "s"(F.m0b), [bb] "s"(F.bb),
+                   [r0] "s"(F.r[0]), [r1] "s"(F.r[1]), [r2] "s"(F.r[2]), [r3] "s"(F.r[3]), [r4] "s"(F.r[4]), [r5] "s"(F.r[5]),
+                   [r6] "s"(F.r[6]), [r7] "s"(F.r[7]), [r8] "s"(F.r[8]), [r9] "s"(F.r[9]), [r10] "s"(F.r[10]), [r11] "s"(F.r[11]),
+                   [r12] "s"(F.r[12]), [r13] "s"(F.r[13]), [r14] "s"(F.r[14]), [r15] "s"(F.r[15])
+                 : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "memory");
+}
+
 // 128-column slabs: a lane holds a float2 of every row of its wave.  The piece ring has NPART parts of S slots
 // (512-byte pieces): chunk k is consumed from part k % NPART while the next NPART - 1 chunks are in flight into the
 // others.  Three parts of 80 slots give a fill two chunk times to land; two parts of 128 slots give it one, but
 // a third fewer chunks -- and a chunk costs ~1800 cycles of barrier, request issue and pipeline start whatever its size.
 // The waves' entries travel the same way, 1 KB per wave and chunk, into the entry ring behind the pieces; their
 // headers (128 bytes) into the header ring behind that.
-template <int S, int NPART, bool UNIT>
+template <int S, int NPART, bool UNIT, bool INL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lds_spmm_kernel(LdsArgs a) {
     constexpr int VW = 2, NW = 8;                       // floats per lane, waves per tile
     constexpr int RW = 192 / VW;                        // rows per wave: 192 accumulator registers
@@ -266,10 +342,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // chunk -> ring part p: its pieces (FPW instructions) and my entries of it (one instruction: 1 KB from the wave's
     // stream position -- unit plans 256 words; general plans 128 words by lanes 0-31 and their 128 values by lanes 32-63;
     // what lies behind the wave's count is fetched and never applied)
-    auto fill = [&](int p, const Hdr& h) {
+    auto fill = [&](int p, const Hdr& h, bool pieces = true) {
 #pragma unroll
         for (int g = 0; g < FPW; g++) {
-            if (a.dbg & 1) break;                           // (experiment: entries and headers only)
+            if ((a.dbg & 1) || !pieces) break;              // (experiment: entries and headers only; or: the chunk statement issues them)
             // (row offsets as scalars, picked per half-wave: a select between the two column ids themselves is turned into
             // a per-lane vector index by the compiler -- a dozen compares per fill)
             const char* src;
@@ -327,14 +403,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             t_mark = stamp();                               // mine alone: read ahead of the barrier, its latency in the barrier's)
             asm volatile("s_barrier" ::: "memory");
             { const unsigned long long t = stamp(); t_bar += t - t_mark; t_mark = t; }
+            // INL (unit plans on the two-part ring, B within 4 GB): the piece requests of chunk k + 1 go out from INSIDE chunk
+            // k's statement -- the ONLY chunk statement of this instantiation (two different statements on the pinned
+            // accumulators make the compiler copy them: 352 spills).  The last chunk of a tile requests row 0 eight times
+            // into the part nobody reads any more; a wave without entries in this chunk issues the requests the old way.
+            static_assert(!INL || (UNIT && NPART == 2 && FPW == 8), "inline requests: unit plans, two parts of 128 slots");
+            const bool inl = INL && n0;
             if (more) {
                 if (LA == 2) n2 = h.n; else n1 = h.n;
                 if (k + LA + 1 < nc) hdr_fetch(c0 + k + LA + 1, part);  // the next header goes first (older than the fills: see the wait)
-                fill(pn, h);                                // chunk k + LA goes in flight into the part chunk k - 1 left
+                fill(pn, h, !inl);                          // chunk k + LA goes in flight into the part chunk k - 1 left
             }
             { const unsigned long long t = stamp(); t_fill += t - t_mark; t_mark = t; }
-            if (n0 && !(a.dbg & 2))
-                lds_chunk<UNIT>(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off);
+            if constexpr (INL) {
+                if (n0) {
+                    LdsFill F;
+#pragma unroll
+                    for (int j = 0; j < 16; j += 2) {          // (even: the first piece's row offset; odd: second - first)
+                        F.r[j] = more ? (uint32_t)h.col[j] * (uint32_t)ldb_bytes : 0u;
+                        F.r[j + 1] = more ? (uint32_t)h.col[j + 1] * (uint32_t)ldb_bytes - F.r[j] : 0u;
+                    }
+                    F.boff = boff; F.hsel = second ? ~0u : 0u;
+                    F.m0b = (uint32_t)(pn * PART + wave * FPW * 1024); F.bb = Bb;
+                    lds_chunk_fill_u(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off, F);
+                }
+            } else {
+                if (n0 && !(a.dbg & 2))
+                    lds_chunk<UNIT>(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off);
+            }
             { const unsigned long long t = stamp(); t_comp += t - t_mark; t_mark = t; }
             n0 = n1; n1 = n2;
             part = part == NPART - 1 ? 0 : part + 1;
@@ -368,6 +464,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return __int_as_float(r < 64 ? __builtin_amdgcn_readlane(__float_as_int(lo), r) : __builtin_amdgcn_readlane(__float_as_int(hi), r - 64));
     };
     const int left_cols = a.d - f;
+    // The common case -- whole float2 columns (d even), nothing to add to (beta = 0) -- with every register of the wave's
+    // rows named at compile time: per row two v_readlane (row id, factor), a scalar address, one or two packed multiplies
+    // and ONE store with a scalar base.  (The general loop below costs ~530 cycles per row, 12 % of the sweep:
+    // profiles/lds_phase_probe.py; this one ~10x less.)
+    if (a.beta == 0.f && (a.d & 1) == 0 && !(a.dbg & 4)) {
+        const uint64_t valid_lo = __ballot(rows_lo >= 0), valid_hi = __ballot(rows_hi >= 0);
+        const uint64_t split_lo = __ballot(slots_lo >= 0), split_hi = __ballot(slots_hi >= 0);
+        int64_t ldc_bytes = a.ldc * 4, ldw_bytes = a.ldw * 4;
+        char* cbase = reinterpret_cast<char*>(a.C);
+        char* wsbase = reinterpret_cast<char*>(a.ws);
+        const uint32_t foff = (uint32_t)f * 4u;
+        const bool has_rs = a.rscale != nullptr;
+        // the bases as opaque scalars (otherwise re-read from the kernel arguments for every row: a scalar load and its wait
+        // per row), and the rows' factors consumed once here: the wait for their loads then sits in front of the loop and
+        // not, as an s_waitcnt vmcnt(0) that also waits for the previous row's STORE, inside every row
+        asm volatile("" : "+s"(cbase), "+s"(wsbase), "+s"(ldc_bytes), "+s"(ldw_bytes));
+        asm volatile("" ::"v"(fold_lo), "v"(fold_hi), "v"(rs_lo), "v"(rs_hi), "v"(rows_lo), "v"(rows_hi), "v"(slots_lo), "v"(slots_hi));
+        if (act) {
+            lds_static_for<RW>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int k = r / 16, e = (r % 16) * VW;
+                const bool valid = r < 64 ? ((valid_lo >> (r & 63)) & 1) : ((valid_hi >> ((r - 64) & 63)) & 1);
+                if (!valid) return;
+                const acc32_t& ak = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : k == 3 ? a3 : k == 4 ? a4 : a5;
+                VT res = {ak[e], ak[e + 1]};
+                const bool split = r < 64 ? ((split_lo >> (r & 63)) & 1) : ((split_hi >> ((r - 64) & 63)) & 1);
+                if (split) {                                    // a split row's piece: raw sum, scaled by the fix-up
+                    const int slot = r < 64 ? __builtin_amdgcn_readlane(slots_lo, r & 63) : __builtin_amdgcn_readlane(slots_hi, (r - 64) & 63);
+                    char* wsb = wsbase + (int64_t)slot * ldw_bytes;
+                    *(__attribute__((address_space(1))) VT*)(uintptr_t)(wsb + foff) = res;      // (a GLOBAL store: the opaque base lost its address space)
+                    return;
+                }
+                const int row = r < 64 ? __builtin_amdgcn_readlane(rows_lo, r & 63) : __builtin_amdgcn_readlane(rows_hi, (r - 64) & 63);
+                if (UNIT) res = res * lane_f(fold_lo, fold_hi, r);
+                if (has_rs) res = res * lane_f(rs_lo, rs_hi, r);
+                char* ob = cbase + (int64_t)row * ldc_bytes;
+                *(__attribute__((address_space(1))) VT*)(uintptr_t)(ob + foff) = res;
+            });
+        }
+    } else
     for (int r = 0; r < RW; r++) {
         const int row = r < 64 ? __builtin_amdgcn_readlane(rows_lo, r) : __builtin_amdgcn_readlane(rows_hi, r - 64);
         float x0, x1;
@@ -485,6 +621,7 @@ extern "C" int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t 
         SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<80, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
         SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<128, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
         SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
+        SGCN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_spmm_kernel<128, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax));
         once = true;
     }
     const dim3 grid((unsigned)blocks), block(512);
@@ -492,7 +629,10 @@ extern "C" int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t 
         if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<80, 3, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((lds_spmm_kernel<80, 3, false>), grid, block, lds, st, a);
     } else {
-        if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<128, 2, true>), grid, block, lds, st, a);
+        // unit plans with B inside 4 GB: the variant whose chunk statement carries the next chunk's piece requests
+        // (tune knob lds_dbg != 0: the plain variant, which the experiments' switches act on)
+        if (plan->unit && !a.wide && !a.dbg) hipLaunchKernelGGL((lds_spmm_kernel<128, 2, true, true>), grid, block, lds, st, a);
+        else if (plan->unit) hipLaunchKernelGGL((lds_spmm_kernel<128, 2, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((lds_spmm_kernel<128, 2, false>), grid, block, lds, st, a);
     }
     SGCN_HIP_TRY(hipGetLastError());
