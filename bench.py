@@ -66,13 +66,15 @@ def parse(argv=None):
                    help="rows = row-gather SpMM (sgcn_spmm.hip); cs = column-sweep (sgcn_spmm_cs.hip); lds = LDS-staged "
                         "sweep for graphs with communities (sgcn_spmm_lds.hip) + the column sweep on its residual; "
                         "default: lds for reddit-sbm, cs otherwise")
+    p.add_argument("--lds-residual-g", type=int, default=4, choices=[2, 4],
+                   help="--kernel lds: lane groups per wave of the column sweep that multiplies the residual (4: every row resident in one round)")
     p.add_argument("--lds-min-reuse", type=int, default=3,
                    help="--kernel lds: a column is staged for a tile only if the tile references it this often")
     p.add_argument("--cs-t", type=int, default=0)
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-align", type=int, default=2048, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
-    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2],
+    p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2, 4],
                    help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes; "
                         "0: what ops.ColumnSweepCSR.choose_g picks for d -- also what the training path uses)")
     p.add_argument("--cpu-sample-rows", type=int, default=40000)
@@ -585,9 +587,9 @@ def main(argv=None):
         if args.kernel == "lds":
             # planned nonzeros through the LDS ring, the rest (columns a tile references < min_reuse times) through the
             # two-lane-group column sweep into the same output
-            A = ops.LdsSweepCSR(full_adj, dev, labels=comm, min_reuse=args.lds_min_reuse)
+            A = ops.LdsSweepCSR(full_adj, dev, labels=comm, min_reuse=args.lds_min_reuse, residual_G=args.lds_residual_g)
             A.transpose = None if args.no_backward else ops.LdsSweepCSR(full_adj.T.tocsr(), dev, labels=comm,
-                                                                        min_reuse=args.lds_min_reuse)
+                                                                        min_reuse=args.lds_min_reuse, residual_G=args.lds_residual_g)
             mm = ops.spmm_lds
             reorder_info["lds_plan"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in A.host_stats.items()}
         else:

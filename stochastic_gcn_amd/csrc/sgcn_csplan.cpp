@@ -363,14 +363,14 @@ extern "C" {
 
 int sgcn_csplang_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles,
                        int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
-    if (ngroups != 2) return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: two lane groups per wavefront (ngroups = 2)");
+    if (ngroups != 2 && ngroups != 4) return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: two or four lane groups per wavefront");
     return gn_count(rowptr, col, M, T, round_tiles, align, ngroups, ntiles, nentries, nfix, nslots);
 }
 
 int sgcn_csplang_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T,
                       int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* tile_ptr, int32_t* colrow,
                       float* valout, int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
-    if (ngroups != 2) return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: two lane groups per wavefront (ngroups = 2)");
+    if (ngroups != 2 && ngroups != 4) return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: two or four lane groups per wavefront");
     return gn_fill(rowptr, col, val, M, T, round_tiles, align, ngroups, tile_ptr, colrow, valout, tile_rows, tile_slots, fix);
 }
 

@@ -425,6 +425,197 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
+// ---- four lane groups per wavefront (plan->G == 4): every row of the graph resident in ONE round of tiles ---------------
+// A tile is FOUR bins of 16 virtual rows; lanes 16 g .. 16 g + 15 hold bin g, each lane one float4 of a 64-column slab, and
+// one dwordx4 load per step gathers the 256-byte pieces of four different B rows ("x4 on 4 rows" in
+// profiles/gather_ceiling.json: 25 TB/s from L2 against 28.9 for two rows).  4,096 resident waves then hold 262,144 rows:
+// S-Reddit's 232,965 in ONE round, so every XCD fetches B once per product instead of twice -- the fabric bytes are what the
+// two-group kernel has left on the table.  The price is on the instruction side: a step is 8 packed FMAs
+// under four quarter masks + 4 v_readlane and 14 scalar instructions for the same 1 KiB of gathers, and ceil(d / 64)
+// passes.  Same structure as cs_spmm16g2k_kernel otherwise (entry l of a chunk: step l / 4, bin l % 4; the accumulator
+// offsets of a step are the four bytes of ONE scalar).  The unpacked round-2 form of this kernel was instruction-bound at
+// 4.4 ms (profiles/HISTORY.md 3.1b).
+template <int U, bool WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g4k_kernel(CsArgs a) {
+    typedef Vec<4>::type VT;
+    constexpr int kShift = 28;
+    constexpr uint32_t kColMask = (1u << kShift) - 1u;
+    constexpr int kSteps = kWave / 4;                 // steps per chunk of 64 entries
+    constexpr int kBatches = kSteps / U;
+    static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
+    const int lane = threadIdx.x & 63;
+    const int bin = lane >> 4;
+    const int li = lane & 15;
+    const int64_t tile = cs_first_tile(a) + threadIdx.x / kWave;
+    if (tile >= a.tile_end) return;
+    const int fbase = a.slab * 64;
+    const int f4 = fbase + li * 4;
+    const bool act = f4 < a.d;
+    const uint32_t off4 = (uint32_t)(act ? f4 : fbase) * 4u;
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const uint32_t ldb32 = (uint32_t)(a.ldb * 4);
+    const int sel0 = bin * 4;                         // ds_bpermute byte address of entry (4 j + bin) is sel0 + 16 j
+
+    typedef float accv_t __attribute__((ext_vector_type(32)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    accv_t axy = {}, azw = {};
+    const uint64_t q0 = 0x000000000000ffffull, q1 = 0x00000000ffff0000ull, q2 = 0x0000ffff00000000ull, q3 = 0xffff000000000000ull;
+
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t tnow = t0;
+    const uint32_t cpt16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.cols_per_tick * 65536.0f));
+    const uint32_t slack = (uint32_t)a.slack_cols;
+    const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
+
+    auto entries = [&](int64_t p, uint32_t& cr, float& v) {
+        cr = 0;
+        v = __int_as_float((int)0x80000000);                       // beyond the tile: pads on column 0
+        if (p < end) {
+            cr = a.colrow[p + lane];
+            v = a.val[p + lane];
+            uint32_t c = cr & kColMask;
+            if (a.cscale && __float_as_int(v) != (int)0x80000000) {
+                v *= a.cscale[c];
+                if (__float_as_int(v) == (int)0x80000000) v = 0.f;
+            }
+            if (a.gidx) { c = (uint32_t)a.gidx[c]; cr = (cr & ~kColMask) | c; }
+        }
+    };
+    // per-chunk scalars: word j = the register offsets (2 x local row id) of step j's four entries, one byte each
+    struct Meta { uint32_t lr[16]; uint32_t pad_lo, pad_hi; };
+    auto meta = [&](uint32_t cr, float v) -> Meta {
+        Meta m;
+        int x = (int)(((cr >> kShift) << 1) << (8 * (lane & 3)));
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+        x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2 -> lane 4j+3 holds step j
+#pragma unroll
+        for (int g = 0; g < 16; g++) m.lr[g] = (uint32_t)__builtin_amdgcn_readlane(x, 4 * g + 3);
+        const uint64_t pm = __ballot(__float_as_int(v) == (int)0x80000000);
+        m.pad_lo = (uint32_t)pm; m.pad_hi = (uint32_t)(pm >> 32);
+        return m;
+    };
+    auto pace = [&](uint32_t crs, int j) {
+        if (cpt16 != 0) {
+            const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 4 * j) & kColMask;
+            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
+            for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
+            }
+        }
+    };
+    auto gather = [&](uint32_t crs, int j) -> VT {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 16 * j, (int)crs);   // my bin's column word
+        if constexpr (WIDE) {
+            return *reinterpret_cast<const VT*>(Bb + (uint64_t)(c & kColMask) * ldb32 + off4);
+        } else {
+            const uint32_t off = __umul24(c, ldb32) + off4;
+            return *reinterpret_cast<const VT*>(Bb + off);
+        }
+    };
+    // step j: 4 v_readlane (the values, into fixed scalar pairs), then per bin: pad test -> quarter mask, the bin's
+    // accumulator offset (byte g of the step's word: one s_lshr between bins), two packed FMAs
+    auto fma4 = [&](const Meta& m, float vs, auto jc, VT b) {
+        constexpr int j = decltype(jc)::value;
+        const uint32_t lw = m.lr[j];
+        const uint32_t pw = j < 8 ? m.pad_lo : m.pad_hi;
+        const f2_t bxy = {b.x, b.y}, bzw = {b.z, b.w};
+        accv_t& rxy = axy;
+        accv_t& rzw = azw;
+        const uint64_t m0 = q0, m1 = q1, m2 = q2, m3 = q3;
+        asm volatile("v_readlane_b32 s20, %[vs], %[e0]\n\t"
+                     "v_readlane_b32 s22, %[vs], %[e0]+1\n\t"
+                     "v_readlane_b32 s24, %[vs], %[e0]+2\n\t"
+                     "v_readlane_b32 s26, %[vs], %[e0]+3\n\t"
+                     "s_bitcmp0_b32 %[pw], %[b0]\n\t"
+                     "s_cselect_b64 exec, %[m0], 0\n\t"
+                     "s_set_gpr_idx_on %[lw], 0xc\n\t"
+                     "v_pk_fma_f32 v[64:65], s[20:21], %[bxy], v[64:65] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[96:97], s[20:21], %[bzw], v[96:97] op_sel_hi:[0,1,1]\n\t"
+                     "s_lshr_b32 s28, %[lw], 8\n\t"
+                     "s_bitcmp0_b32 %[pw], %[b0]+1\n\t"
+                     "s_cselect_b64 exec, %[m1], 0\n\t"
+                     "s_set_gpr_idx_idx s28\n\t"
+                     "v_pk_fma_f32 v[64:65], s[22:23], %[bxy], v[64:65] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[96:97], s[22:23], %[bzw], v[96:97] op_sel_hi:[0,1,1]\n\t"
+                     "s_lshr_b32 s28, %[lw], 16\n\t"
+                     "s_bitcmp0_b32 %[pw], %[b0]+2\n\t"
+                     "s_cselect_b64 exec, %[m2], 0\n\t"
+                     "s_set_gpr_idx_idx s28\n\t"
+                     "v_pk_fma_f32 v[64:65], s[24:25], %[bxy], v[64:65] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[96:97], s[24:25], %[bzw], v[96:97] op_sel_hi:[0,1,1]\n\t"
+                     "s_lshr_b32 s28, %[lw], 24\n\t"
+                     "s_bitcmp0_b32 %[pw], %[b0]+3\n\t"
+                     "s_cselect_b64 exec, %[m3], 0\n\t"
+                     "s_set_gpr_idx_idx s28\n\t"
+                     "v_pk_fma_f32 v[64:65], s[26:27], %[bxy], v[64:65] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[96:97], s[26:27], %[bzw], v[96:97] op_sel_hi:[0,1,1]\n\t"
+                     "s_set_gpr_idx_off\n\t"
+                     "s_mov_b64 exec, -1"
+                     : "+{v[64:95]}"(rxy), "+{v[96:127]}"(rzw)
+                     : [vs] "v"(vs), [e0] "i"(4 * j), [pw] "s"(pw), [b0] "i"((4 * j) & 31),
+                       [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [lw] "s"(lw),
+                       [bxy] "v"(bxy), [bzw] "v"(bzw)
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "scc");
+    };
+
+    uint32_t ccr, ncr;
+    float cv, nv;
+    entries(start, ccr, cv);
+    entries(start + kWave, ncr, nv);
+    Meta cm = meta(ccr, cv);
+    VT buf[2][U];
+    pace(ccr, 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
+    if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    for (int64_t p0 = start; p0 < end; p0 += kWave) {
+        static_for<kBatches>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k + 1 < kBatches) {
+                pace(ccr, (k + 1) * U);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
+            } else {
+                pace(ncr, 0);
+#pragma unroll
+                for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
+            }
+            if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                fma4(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
+            });
+        });
+        ccr = ncr; cv = nv;
+        cm = meta(ccr, cv);
+        entries(p0 + 2 * kWave, ncr, nv);
+    }
+
+    const int32_t* rows = a.tile_rows + tile * 64 + bin * 16;
+    const int32_t* slots = a.tile_slots + tile * 64 + bin * 16;
+    const int left = a.d - f4;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rows[r];
+        const VT accv = {axy[2 * r], axy[2 * r + 1], azw[2 * r], azw[2 * r + 1]};
+        if (row < 0 || !act) continue;
+        const int slot = slots[r];
+        if (slot >= 0) {
+            vstore<4>(a.ws + (int64_t)slot * a.ldw + f4, accv);
+        } else {
+            float* out = a.C + (int64_t)row * a.ldc;
+            const float rs = a.rscale ? a.rscale[row] : 1.0f;
+            VT res = accv * rs;
+            if (a.beta != 0.f) {
+                if (left >= 4) res += a.beta * vload<4>(out + f4);
+                else for (int e = 0; e < left; e++) res[e] += a.beta * out[f4 + e];
+            }
+            if (left >= 4) vstore<4>(out + f4, res); else vstore_head<4>(out + f4, res, left);
+        }
+    }
+}
+
 // fix-up of split rows: ordered slot sum + epilogue (float4 path only)
 template <int VW>
 __global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix_t* fix, int64_t nfix) {
@@ -459,6 +650,14 @@ struct CsVariant { int nslab, slab_floats, U; bool extra; const char* name; };
 
 CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
     CsVariant v{};
+    if (plan->G == 4) {             // four lane groups per wave: 64-column passes, every row resident in one round
+        v.nslab = ((d + 3) / 4 * 4 + 63) / 64;
+        v.slab_floats = 64;
+        v.extra = false;
+        v.U = 4;
+        v.name = "sgcn::cs_spmm16g4k_kernel<4, false>";
+        return v;
+    }
     if (plan->G == 2) {             // two lane groups per wave: 128-column passes, one dwordx4 per step
         v.nslab = ((d + 3) / 4 * 4 + 127) / 128;
         v.slab_floats = 128;
@@ -491,7 +690,7 @@ CsVariant cs_variant(const sgcn_csplan_t* plan, int d) {
 
 extern "C" int sgcn_spmm_cs_variant(const sgcn_csplan_t* plan, int32_t d, char* buf, int32_t buflen) {
     SGCN_REQUIRE(plan && buf && buflen > 0 && d > 0, "spmm_cs_variant: bad argument");
-    SGCN_REQUIRE(plan->R == 16 && (plan->G == 1 || plan->G == 2 || plan->G == 0), "spmm_cs_variant: 16-row bins, one or two lane groups");
+    SGCN_REQUIRE(plan->R == 16 && (plan->G == 1 || plan->G == 2 || plan->G == 4 || plan->G == 0), "spmm_cs_variant: 16-row bins; one, two or four lane groups");
     const CsVariant v = cs_variant(plan, d);
     int64_t round = plan->round_tiles > 0 ? plan->round_tiles : (tune_get("cs_round") > 0 ? tune_get("cs_round") : 4096);
     snprintf(buf, (size_t)buflen, "%s x %d launches (%d passes of %d columns x %lld rounds of %lld tiles)", v.name,
@@ -506,8 +705,8 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
                                 float beta, void* stream) {
     SGCN_REQUIRE(plan && M >= 0 && K >= 0 && d >= 0, "spmm_cs: bad argument");
     if (M == 0 || d == 0) return SGCN_OK;
-    SGCN_REQUIRE(plan->R == 16 && (plan->G == 0 || plan->G == 1 || plan->G == 2),
-                 "spmm_cs: the plan must have 16-row bins and one or two lane groups per wavefront");
+    SGCN_REQUIRE(plan->R == 16 && (plan->G == 0 || plan->G == 1 || plan->G == 2 || plan->G == 4),
+                 "spmm_cs: the plan must have 16-row bins and one, two or four lane groups per wavefront");
     SGCN_REQUIRE(plan->dev_tile_ptr && plan->dev_tile_rows && plan->dev_tile_slots && B && C,
                  "spmm_cs: null operand");
     SGCN_REQUIRE(K < (1 << 28), "spmm_cs: K too large for the packed column word");
@@ -522,7 +721,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
     a.xcd_map = plan->xcd_map;
-    SGCN_REQUIRE(plan->G != 2 || ldb * 4 < (1ll << 32), "spmm_cs: row pitch of B must fit 32 bits");
+    SGCN_REQUIRE((plan->G != 2 && plan->G != 4) || ldb * 4 < (1ll << 32), "spmm_cs: row pitch of B must fit 32 bits");
     if (plan->nfix > 0) {
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
                      "spmm_cs: workspace missing or too small");
@@ -559,7 +758,12 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
             }
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
 #define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
-            if (plan->G == 2) {
+            if (plan->G == 4) {
+                const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
+                                  tune_get("cs_g2_wide") > 0;
+                if (wide) hipLaunchKernelGGL((cs_spmm16g4k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((cs_spmm16g4k_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+            } else if (plan->G == 2) {
                 const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
                                   tune_get("cs_g2_wide") > 0;
                 if (wide) hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);

@@ -443,14 +443,15 @@ class ColumnSweepCSR(object):
         the dense operand through every XCD per register byte; ``align``: columns one bin of a wave may run ahead
         of the slowest (the plan pads the bins that are ahead).  What ``choose_g(d)`` picks for most widths -- the
         bench and the training path call it: S-Reddit d = 602 3.51 vs 3.67 ms sustained, S-RMAT d = 256 2.61 vs
-        2.82 ms.  G = 4 (four groups, 64-column passes) is parity-tested but instruction-bound (4.4 ms):
-        profiles/HISTORY.md 3.1b."""
+        2.82 ms.  G = 4 (four groups, 64-column passes, every row of a 233 k-row graph resident in one round): instruction-
+        bound on a full graph (3.75 ms on S-Reddit; its gathers alone 3.21: DESIGN.md 3.2), but the better sweep for a SPARSE
+        matrix such as the LDS sweep's residual, which is what uses it."""
         a = a.tocsr()
         self.G = int(G)
         if R != 16:
             raise ValueError("the column-sweep kernels keep 16-row bins (R = 16)")
-        if self.G not in (1, 2):
-            raise ValueError("G must be 1 or 2 (four lane groups per wave were instruction-bound: profiles/HISTORY.md 3.1b)")
+        if self.G not in (1, 2, 4):
+            raise ValueError("G must be 1, 2 or 4 lane groups per wavefront")
         if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
                 raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
@@ -915,7 +916,8 @@ class LdsSweepCSR(object):
     nonzeros whose column a tile references fewer than ``min_reuse`` times are multiplied by the ordinary column sweep
     (``self.residual``: a ColumnSweepCSR) into the same output."""
 
-    def __init__(self, a, device, labels=None, VW=2, T=0, min_reuse=2, residual_G=2, host=None, general=False, ring_slots=0):
+    def __init__(self, a, device, labels=None, VW=2, T=0, min_reuse=2, residual_G=4, host=None, general=False, ring_slots=0,
+                 residual_align=8192):
         h = host if host is not None else LdsPlanHost(a, labels=labels, VW=VW, T=T, min_reuse=min_reuse, general=general,
                                                       ring_slots=ring_slots)
         self.host_stats = dict(ntiles=h.ntiles, nchunks=h.nchunks, nent=h.nent, staged=h.staged, nnz=h.nnz,
@@ -935,7 +937,10 @@ class LdsSweepCSR(object):
         self.ws = None
         self.residual = None
         if h.residual.nnz:
-            self.residual = ColumnSweepCSR(h.residual, device, G=residual_G) if residual_G else \
+            # four lane groups per wave: the residual's rows are all resident in ONE round of tiles, and a sparse residual is
+            # bound by the bytes each XCD pulls over the fabric, not by the step's instructions (S-Reddit-SBM p_in 0.8, 5.0 M
+            # nonzeros, sustained: 1.26 ms against 1.50 with two groups; bins aligned to 8,192 columns: profiles/r31_*)
+            self.residual = ColumnSweepCSR(h.residual, device, G=residual_G, align=residual_align) if residual_G else \
                 DeviceCSR.from_scipy(h.residual, device)
 
     def struct(self, d):

@@ -364,7 +364,7 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G=2):
     assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
     if pad:
         np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
-    assert "g2k" in A.variant(d)
+    assert ("g%dk" % G) in A.variant(d)
     # the kernel and its 64-bit-offset form apply every bin's entries in the same order: bit-identical products
     from stochastic_gcn_amd._ffi import lib
     try:
@@ -377,6 +377,13 @@ def test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G=2):
             lib.sgcn_tune(knob, 0)
     finally:
         lib.sgcn_tune(b"cs_g2_wide", 0)
+
+
+@pytest.mark.parametrize("M,K,d,pad", [(37, 53, 8, 0), (300, 200, 128, 0), (128, 400, 602, 6), (500, 500, 256, 0),
+                                         (64, 64, 130, 2), (90, 70, 30, 2), (5000, 3000, 602, 6)])
+def test_four_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad):
+    """G = 4 plan (four 16-row bins per wavefront, 64-column passes, quarter-wave execution masks)."""
+    test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G=4)
 
 
 def test_two_lane_group_full_size_vs_oracle_rows(dev):
