@@ -56,7 +56,8 @@ struct TileOut {
     std::vector<int32_t> chunk_cols;                // nchunks * S
     std::vector<std::vector<uint32_t>> wave_word;   // per wave: entry words, chunk after chunk
     std::vector<std::vector<float>> wave_val;       // ... and values
-    std::vector<std::vector<int64_t>> wave_cnt;     // per wave: entries per chunk (padded)
+    std::vector<std::vector<int64_t>> wave_cnt;     // per wave: entry words per chunk (padded)
+    std::vector<std::vector<int32_t>> wave_pairs;   // per wave: how many of them (the first ones) are PAIR words, per chunk
     std::vector<Edge> residual;
     int64_t staged = 0;
 };
@@ -211,7 +212,16 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         o.wave_word.assign((size_t)NW, {});
         o.wave_val.assign((size_t)NW, {});
         o.wave_cnt.assign((size_t)NW, {});
-        std::vector<int64_t> cnt((size_t)NW, 0), add((size_t)NW, 0);
+        o.wave_pairs.assign((size_t)NW, {});
+        // the open chunk, per wave: PAIR words (unit plans: two rows of the wave on one staged piece -- one LDS read, two
+        // updates; row offsets in bits 0-7 and 24-31) and single words (+ values); a chunk's words = pairs, padded to whole
+        // groups, then singles, padded
+        std::vector<std::vector<uint32_t>> pw((size_t)NW), sw((size_t)NW);
+        std::vector<std::vector<float>> sv((size_t)NW);
+        std::vector<int64_t> add((size_t)NW, 0);
+        const bool pairs = h->unit != 0;
+        constexpr int64_t kMaxPairWords = 128;             // the kernel's pair path covers the first 16 groups of a chunk
+        auto padded = [&](size_t n) { return (int64_t)((n + GE - 1) / GE * GE); };
         int32_t nslot = 0;                   // slots used in the open chunk
         int64_t nchunks = 0;
         auto close_chunk = [&]() {
@@ -219,13 +229,16 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             const int32_t last = o.chunk_cols.back();
             for (int32_t s = nslot; s < S; s++) o.chunk_cols.push_back(last);      // unused slots fetch a valid column
             for (int32_t wv = 0; wv < NW; wv++) {
-                while (cnt[(size_t)wv] % GE) {                                     // pads: value 0 on the zero piece
-                    o.wave_word[(size_t)wv].push_back(zero_addr);
-                    o.wave_val[(size_t)wv].push_back(0.f);
-                    cnt[(size_t)wv]++;
-                }
-                o.wave_cnt[(size_t)wv].push_back(cnt[(size_t)wv]);
-                cnt[(size_t)wv] = 0;
+                std::vector<uint32_t>& W = o.wave_word[(size_t)wv];
+                std::vector<float>& V = o.wave_val[(size_t)wv];
+                int64_t c = 0;
+                for (uint32_t x : pw[(size_t)wv]) { W.push_back(x); V.push_back(0.f); c++; }
+                while (c % GE) { W.push_back(zero_addr); V.push_back(0.f); c++; }   // pads: the zero piece (onto row 0)
+                o.wave_pairs[(size_t)wv].push_back((int32_t)c);
+                for (size_t q = 0; q < sw[(size_t)wv].size(); q++) { W.push_back(sw[(size_t)wv][q]); V.push_back(sv[(size_t)wv][q]); c++; }
+                while (c % GE) { W.push_back(zero_addr); V.push_back(0.f); c++; }
+                o.wave_cnt[(size_t)wv].push_back(c);
+                pw[(size_t)wv].clear(); sw[(size_t)wv].clear(); sv[(size_t)wv].clear();
             }
             nslot = 0;
             nchunks++;
@@ -237,23 +250,39 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             if ((int64_t)(j - i) < min_reuse) {
                 for (size_t q = i; q < j; q++) o.residual.push_back(e[q]);
             } else {
-                // a chunk holds at most S columns and at most CAP entries per wave (what the kernel loads per chunk)
+                // a chunk holds at most S columns and at most CAP entry words per wave (what the kernel loads per chunk),
+                // at most kMaxPairWords of them pairs
                 std::fill(add.begin(), add.end(), 0);
                 for (size_t q = i; q < j; q++) add[(size_t)e[q].w]++;
                 bool over = nslot == S;
                 for (int32_t wv = 0; wv < NW; wv++) {
-                    over = over || cnt[(size_t)wv] + add[(size_t)wv] > CAP;
-                    if (add[(size_t)wv] > CAP) overflow = 1;          // (one column, more entries of one wave than the ring holds: duplicates)
+                    const int64_t np2 = pairs ? add[(size_t)wv] / 2 : 0, ns2 = add[(size_t)wv] - 2 * np2;
+                    over = over || padded(pw[(size_t)wv].size() + (size_t)np2) + padded(sw[(size_t)wv].size() + (size_t)ns2) > CAP ||
+                           (int64_t)pw[(size_t)wv].size() + np2 > kMaxPairWords;
+                    if (np2 > kMaxPairWords || padded((size_t)np2) + padded((size_t)ns2) > CAP) overflow = 1;   // (one column, more entries of one wave than the ring holds: duplicates)
                 }
                 if (over) close_chunk();
                 const uint32_t addr = (uint32_t)(nchunks % NPART) * S * piece + (uint32_t)nslot * piece;
                 o.chunk_cols.push_back(e[i].col);
                 nslot++;
                 o.staged++;
-                for (size_t q = i; q < j; q++) {
-                    o.wave_word[(size_t)e[q].w].push_back(addr | (uint32_t)(e[q].lr * VW));
-                    o.wave_val[(size_t)e[q].w].push_back(e[q].val);
-                    cnt[(size_t)e[q].w]++;
+                // the column's entries wave by wave (they arrive sorted by position only): two at a time into a pair word
+                for (int32_t wv = 0; wv < NW; wv++) {
+                    if (!add[(size_t)wv]) continue;
+                    int32_t held = -1;
+                    for (size_t q = i; q < j; q++) {
+                        if (e[q].w != wv) continue;
+                        if (!pairs) {
+                            sw[(size_t)wv].push_back(addr | (uint32_t)(e[q].lr * VW));
+                            sv[(size_t)wv].push_back(e[q].val);
+                        } else if (held < 0) {
+                            held = e[q].lr;
+                        } else {
+                            pw[(size_t)wv].push_back(addr | (uint32_t)(held * VW) | ((uint32_t)(e[q].lr * VW) << 24));
+                            held = -1;
+                        }
+                    }
+                    if (held >= 0) { sw[(size_t)wv].push_back(addr | (uint32_t)(held * VW)); sv[(size_t)wv].push_back(0.f); }
                 }
             }
             i = j;
@@ -329,7 +358,8 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         h->xcd_tile_ptr[8] = (int32_t)ntiles;
     }
     // per (chunk, wave) header, 32 ints: what a wave needs to request a chunk, in ONE 128-byte load -- the column ids of
-    // its S / NW ring slots (words 0-15), its entry count in groups (16) and the position of its entries (17, 18)
+    // its S / NW ring slots (words 0-15), its entry count in groups (16), the position of its entries (17, 18) and how many of
+    // the groups hold pair words (19)
     {
         const int32_t per = S / NW;                          // slots a wave fetches per chunk
         h->chunk_hdr.assign((size_t)nchunks * NW * 32, 0);
@@ -341,6 +371,7 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
                     for (int32_t q = 0; q < per; q++) hd[q] = h->chunk_cols[(size_t)(cb + k) * S + (size_t)wv * per + q];
                     const int64_t a = h->ent_ptr[(size_t)(cb * NW + wv * nc + k)], b = h->ent_ptr[(size_t)(cb * NW + wv * nc + k) + 1];
                     hd[16] = (int32_t)((b - a) / GE);
+                    hd[19] = outs[(size_t)t].wave_pairs[(size_t)wv][(size_t)k] / GE;       // the first hd[19] groups are pair words
                     hd[17] = (int32_t)(uint32_t)(a & 0xffffffffll);
                     hd[18] = (int32_t)(a >> 32);
                 }

@@ -115,6 +115,56 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     "s_sub_u32 %[n], %[n], 1\n\t"                                                                             \
     "s_cmp_eq_u32 %[n], 0\n\t"                                                                                \
     "s_cbranch_scc1 Lx_%=\n\t"
+// Unit plans, the first 16 groups of a chunk: a group is 8 PAIR words while %[np] > 0 -- two rows of this wave on the same
+// staged piece: row offsets in bits 0-7 and 24-31 of the word, ONE LDS read, two updates -- and 8 single words after that
+// (the plan puts a chunk's pairs first).  On S-Reddit-SBM a wave's 138 entries of a chunk sit on 84 different pieces: pairs
+// take the LDS reads of a chunk from 138 to 97 per wave, and the chunk statement is bound by the LDS bandwidth.
+#define SGCN_LDS_PAIR1(Q, K)                                                                                  \
+    SGCN_LDS_OP1_U(Q, K)                                                                                      \
+    "s_lshr_b32 s[36+8*" #Q "+" #K "], s[36+8*" #Q "+" #K "], 24\n\t"                                          \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+" #K "]\n\t"                                                              \
+    SGCN_LDS_OP1_U(Q, K)
+#define SGCN_LDS_UBODY(Q)                                                                                     \
+    "s_cmp_eq_u32 %[np], 0\n\t"                                                                               \
+    "s_cbranch_scc1 1f\n\t"                                                                                   \
+    "s_set_gpr_idx_on s[36+8*" #Q "+0], 0x9\n\t" SGCN_LDS_PAIR1(Q, 0)                                          \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" SGCN_LDS_PAIR1(Q, 1)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" SGCN_LDS_PAIR1(Q, 2)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" SGCN_LDS_PAIR1(Q, 3)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" SGCN_LDS_PAIR1(Q, 4)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" SGCN_LDS_PAIR1(Q, 5)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_PAIR1(Q, 6)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_PAIR1(Q, 7)                                              \
+    "s_set_gpr_idx_off\n\t"                                                                                   \
+    "s_sub_u32 %[np], %[np], 1\n\t"                                                                           \
+    "s_branch 2f\n\t"                                                                                         \
+    "1:\n\t"                                                                                                  \
+    "s_set_gpr_idx_on s[36+8*" #Q "+0], 0x9\n\t" SGCN_LDS_OP1_U(Q, 0)                                          \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" SGCN_LDS_OP1_U(Q, 1)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" SGCN_LDS_OP1_U(Q, 2)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" SGCN_LDS_OP1_U(Q, 3)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" SGCN_LDS_OP1_U(Q, 4)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" SGCN_LDS_OP1_U(Q, 5)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_OP1_U(Q, 6)                                              \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_OP1_U(Q, 7)                                              \
+    "s_set_gpr_idx_off\n\t"                                                                                   \
+    "2:\n\t"
+#define SGCN_LDS_APPLY8P(Q, WAIT)                                                                             \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                                        \
+    SGCN_LDS_UBODY(Q)                                                                                         \
+    "s_sub_u32 %[n], %[n], 1\n\t"                                                                             \
+    "s_cmp_eq_u32 %[n], 0\n\t"                                                                                \
+    "s_cbranch_scc1 Lx_%=\n\t"
+#define SGCN_LDS_BLOCKP(EW, NW, ENEXT)                                                                        \
+    ENEXT                                                                                                     \
+    SGCN_LDS_READ8(U, 1, EW, EW, 8, 9, 10, 11, 12, 13, 14, 15)         SGCN_LDS_APPLY8P(0, 8)                  \
+    SGCN_LDS_READ8(U, 0, EW, EW, 16, 17, 18, 19, 20, 21, 22, 23)       SGCN_LDS_APPLY8P(1, 8)                  \
+    SGCN_LDS_READ8(U, 1, EW, EW, 24, 25, 26, 27, 28, 29, 30, 31)       SGCN_LDS_APPLY8P(0, 8)                  \
+    SGCN_LDS_READ8(U, 0, EW, EW, 32, 33, 34, 35, 36, 37, 38, 39)       SGCN_LDS_APPLY8P(1, 8)                  \
+    SGCN_LDS_READ8(U, 1, EW, EW, 40, 41, 42, 43, 44, 45, 46, 47)       SGCN_LDS_APPLY8P(0, 8)                  \
+    SGCN_LDS_READ8(U, 0, EW, EW, 48, 49, 50, 51, 52, 53, 54, 55)       SGCN_LDS_APPLY8P(1, 8)                  \
+    SGCN_LDS_READ8(U, 1, EW, EW, 56, 57, 58, 59, 60, 61, 62, 63)       SGCN_LDS_APPLY8P(0, 8)                  \
+    SGCN_LDS_READ8(U, 0, NW, NW, 0, 1, 2, 3, 4, 5, 6, 7)               SGCN_LDS_APPLY8P(1, 8)
 // a block = 64 entries in EW (/ EX); ENEXT fetches the next block's entries into NW (/ NX) first -- it is the OLDEST LDS
 // operation in flight when the first group waits (lgkmcnt(8) then covers it: LDS returns in order), so the block's last
 // group can read ahead from NW's first lanes
@@ -142,15 +192,7 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     "global_load_lds_dwordx4 v28, %[bb]\n\t"
 #define SGCN_LDS_APPLY8F(M, Q, WAIT, J, A, B, JN)                                                             \
     "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                                        \
-    "s_set_gpr_idx_on s[36+8*" #Q "+0], " SGCN_LDS_MODE_##M "\n\t" SGCN_LDS_OP1_##M(Q, 0)                      \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" SGCN_LDS_OP1_##M(Q, 1)                                            \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" SGCN_LDS_OP1_##M(Q, 2)                                            \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" SGCN_LDS_OP1_##M(Q, 3)                                            \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" SGCN_LDS_OP1_##M(Q, 4)                                            \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" SGCN_LDS_OP1_##M(Q, 5)                                            \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_OP1_##M(Q, 6)                                            \
-    "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_OP1_##M(Q, 7)                                            \
-    "s_set_gpr_idx_off\n\t"                                                                                   \
+    SGCN_LDS_UBODY(Q)                                                                                         \
     SGCN_LDS_FILL1(J, A, B)                                                                                   \
     "s_sub_u32 %[n], %[n], 1\n\t"                                                                             \
     "s_cmp_eq_u32 %[n], 0\n\t"                                                                                \
@@ -186,18 +228,18 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
 // the entry ring: unit plans 4 blocks of 64 words; general plans 2 blocks of words, then their values at + 512)
 template <bool UNIT>
 __device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2, acc32_t& a3, acc32_t& a4, acc32_t& a5,
-                                          uint32_t n, uint32_t ea, uint32_t mask, uint32_t lane_off) {
+                                          uint32_t n, uint32_t np, uint32_t ea, uint32_t mask, uint32_t lane_off) {
     if constexpr (UNIT) {
         asm volatile("ds_read_b32 v26, %[ea]\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
                      SGCN_LDS_READ8(U, 0, v26, v26, 0, 1, 2, 3, 4, 5, 6, 7)
-                     SGCN_LDS_BLOCK(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:256\n\t")
-                     SGCN_LDS_BLOCK(U, v27, v27, v26, v26, "ds_read_b32 v26, %[ea] offset:512\n\t")
+                     SGCN_LDS_BLOCKP(v26, v27, "ds_read_b32 v27, %[ea] offset:256\n\t")
+                     SGCN_LDS_BLOCKP(v27, v26, "ds_read_b32 v26, %[ea] offset:512\n\t")
                      SGCN_LDS_BLOCK(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:768\n\t")
                      SGCN_LDS_BLOCK(U, v27, v27, v27, v27, "ds_read_b32 v26, %[ea]\n\t")
                      "Lx_%=:\n\t"
                      "s_waitcnt lgkmcnt(0)"
-                     : SGCN_LDS_ACC, [n] "+s"(n)
+                     : SGCN_LDS_ACC, [n] "+s"(n), [np] "+s"(np)
                      : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off)
                      : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "memory");
     } else {
@@ -219,18 +261,18 @@ __device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2,
 // destination slot, bb = B.
 struct LdsFill { uint32_t r[16]; uint32_t boff, hsel, m0b; const char* bb; };
 __device__ __forceinline__ void lds_chunk_fill_u(acc32_t& a0, acc32_t& a1, acc32_t& a2, acc32_t& a3, acc32_t& a4, acc32_t& a5,
-                                                 uint32_t n, uint32_t ea, uint32_t mask, uint32_t lane_off, const LdsFill& F) {
+                                                 uint32_t n, uint32_t np, uint32_t ea, uint32_t mask, uint32_t lane_off, const LdsFill& F) {
     asm volatile("ds_read_b32 v26, %[ea]\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  SGCN_LDS_READ8(U, 0, v26, v26, 0, 1, 2, 3, 4, 5, 6, 7)
                  SGCN_LDS_BLOCKF(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:256\n\t")
-                 SGCN_LDS_BLOCK(U, v27, v27, v26, v26, "ds_read_b32 v26, %[ea] offset:512\n\t")
+                 SGCN_LDS_BLOCKP(v27, v26, "ds_read_b32 v26, %[ea] offset:512\n\t")
                  SGCN_LDS_BLOCK(U, v26, v26, v27, v27, "ds_read_b32 v27, %[ea] offset:768\n\t")
                  SGCN_LDS_BLOCK(U, v27, v27, v27, v27, "ds_read_b32 v26, %[ea]\n\t")
                  SGCN_LDS_FILL_TAIL
                  "Lx_%=:\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : SGCN_LDS_ACC, [n] "+s"(n)
+                 : SGCN_LDS_ACC, [n] "+s"(n), [np] "+s"(np)
                  : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off), [boff] "v"(F.boff), [hsel] "v"(F.hsel), [m0b] "s"(F.m0b), [bb] "s"(F.bb),
                    [r0] "s"(F.r[0]), [r1] "s"(F.r[1]), [r2] "s"(F.r[2]), [r3] "s"(F.r[3]), [r4] "s"(F.r[4]), [r5] "s"(F.r[5]),
                    [r6] "s"(F.r[6]), [r7] "s"(F.r[7]), [r8] "s"(F.r[8]), [r9] "s"(F.r[9]), [r10] "s"(F.r[10]), [r11] "s"(F.r[11]),
@@ -276,7 +318,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int f = fbase + lane * VW;                                     // my first column
     const bool act = f < a.d;
     const uint32_t lane_off = (uint32_t)lane * (VW * 4);
-    const uint32_t mask = ~(uint32_t)(PIECE - 1);
+    const uint32_t mask = 0x0003fe00u;                                   // the LDS address bits of an entry word (pieces of 512 bytes in a ring of < 256 KB)
 
     acc32_t a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {};
 
@@ -299,7 +341,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // scalar memory instruction in the loop (the chunk statement opens with s_waitcnt lgkmcnt(0), which would wait for an
     // outstanding s_load too: measured with the ids on the scalar path, 0.7 us of exposed latency per chunk) and no
     // compiler-visible load either (the compiler's own s_waitcnt for one would be vmcnt(0): the fills just issued).
-    struct Hdr { int32_t col[16]; uint32_t n; int64_t e; };
+    struct Hdr { int32_t col[16]; uint32_t n, np; int64_t e; };
     auto hdr_fetch = [&](int c, int slot) {                 // chunk c's header -> my slot of the header ring
         if (lane < 32)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.chunk_hdr + ((int64_t)c * NW + wave) * 32 + lane),
@@ -329,11 +371,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                      "v_readlane_b32 %[c15], v28, 15\n\t"
                      "v_readlane_b32 %[n], v28, 16\n\t"
                      "v_readlane_b32 %[elo], v28, 17\n\t"
-                     "v_readlane_b32 %[ehi], v28, 18"
+                     "v_readlane_b32 %[ehi], v28, 18\n\t"
+                     "v_readlane_b32 %[np], v28, 19"
                      : [c0] "=s"(h.col[0]), [c1] "=s"(h.col[1]), [c2] "=s"(h.col[2]), [c3] "=s"(h.col[3]), [c4] "=s"(h.col[4]),
                        [c5] "=s"(h.col[5]), [c6] "=s"(h.col[6]), [c7] "=s"(h.col[7]), [c8] "=s"(h.col[8]), [c9] "=s"(h.col[9]),
                        [c10] "=s"(h.col[10]), [c11] "=s"(h.col[11]), [c12] "=s"(h.col[12]), [c13] "=s"(h.col[13]),
-                       [c14] "=s"(h.col[14]), [c15] "=s"(h.col[15]), [n] "=s"(h.n), [elo] "=s"(elo), [ehi] "=s"(ehi)
+                       [c14] "=s"(h.col[14]), [c15] "=s"(h.col[15]), [n] "=s"(h.n), [elo] "=s"(elo), [ehi] "=s"(ehi), [np] "=s"(h.np)
                      : [addr] "v"(addr)
                      : "v28", "memory");
         h.e = (int64_t)(((uint64_t)ehi << 32) | elo);
@@ -374,7 +417,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto stamp = [&]() -> unsigned long long { return a.prof ? __builtin_readcyclecounter() : 0ull; };
     t_all0 = stamp();
     if (nc > 0) {
-        uint32_t n0 = 0, n1 = 0, n2 = 0;
+        uint32_t n0 = 0, n1 = 0, n2 = 0, p0 = 0, p1 = 0, p2 = 0;   // groups (and pair groups among them) of chunks k, k + 1, k + 2
         // headers of the first LA + 1 chunks, then the first LA chunks themselves
 #pragma unroll
         for (int j = 0; j <= LA; j++)
@@ -383,12 +426,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const Hdr h = hdr_get(0);
             fill(0, h);
-            n0 = h.n;
+            n0 = h.n; p0 = h.np;
         }
         if (LA == 2 && nc > 1) {
             const Hdr h = hdr_get(1);
             fill(1, h);
-            n1 = h.n;
+            n1 = h.n; p1 = h.np;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         t_pro = stamp() - t_all0;
@@ -410,7 +453,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             static_assert(!INL || (UNIT && NPART == 2 && FPW == 8), "inline requests: unit plans, two parts of 128 slots");
             const bool inl = INL && n0;
             if (more) {
-                if (LA == 2) n2 = h.n; else n1 = h.n;
+                if (LA == 2) { n2 = h.n; p2 = h.np; } else { n1 = h.n; p1 = h.np; }
                 if (k + LA + 1 < nc) hdr_fetch(c0 + k + LA + 1, part);  // the next header goes first (older than the fills: see the wait)
                 fill(pn, h, !inl);                          // chunk k + LA goes in flight into the part chunk k - 1 left
             }
@@ -425,14 +468,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     F.boff = boff; F.hsel = second ? ~0u : 0u;
                     F.m0b = (uint32_t)(pn * PART + wave * FPW * 1024); F.bb = Bb;
-                    lds_chunk_fill_u(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off, F);
+                    lds_chunk_fill_u(a0, a1, a2, a3, a4, a5, n0, p0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off, F);
                 }
             } else {
                 if (n0 && !(a.dbg & 2))
-                    lds_chunk<UNIT>(a0, a1, a2, a3, a4, a5, n0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off);
+                    lds_chunk<UNIT>(a0, a1, a2, a3, a4, a5, n0, p0, (uint32_t)(ERING + (part * NW + wave) * 1024) + lane * 4, mask, lane_off);
             }
             { const unsigned long long t = stamp(); t_comp += t - t_mark; t_mark = t; }
-            n0 = n1; n1 = n2;
+            n0 = n1; n1 = n2; p0 = p1; p1 = p2;
             part = part == NPART - 1 ? 0 : part + 1;
             // chunk k + 1 has to be here before the barrier.  Three parts: it was requested an iteration ago -- everything
             // older than THIS iteration's fills (the header fetch was issued ahead of them: covered too).  Two parts: it is

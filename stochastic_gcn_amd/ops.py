@@ -895,17 +895,27 @@ class LdsPlanHost(object):
                         continue
                     assert (e1 - e0) % self.U == 0 and e1 - e0 <= (256 if self.unit else 128)
                     word = self.words[e0:e1]
-                    addr = word & np.uint32(~np.uint32(piece - 1))
+                    addr = word & np.uint32(0x0003fe00)           # (the kernel's mask: LDS address bits of a 512-byte piece)
                     real = addr != self.nparts * part             # pads sit on the zero piece
-                    assert np.all(self.vals[e0:e1][~real] == 0)
+                    assert self.unit or np.all(self.vals[e0:e1][~real] == 0)
                     assert np.all(addr[real] // part == k % self.nparts), "entry in the wrong part of the ring"
-                    slot = (addr[real] % part) // piece
-                    lr = (word[real] & np.uint32(0xff)) // self.VW
-                    place = (t * self.NW + w) * self.RW + lr.astype(np.int64)
-                    rows.append(self.tile_rows[place])
-                    slots.append(self.tile_slots[place])
-                    cols.append(self.chunk_cols[(cb + k) * self.S + slot.astype(np.int64)])
-                    vals.append(self.vals[e0:e1][real])
+                    npair = int(hd[19]) * self.U                  # the first words of a unit plan's chunk carry TWO rows
+                    assert 0 <= npair <= min(e1 - e0, 128) and (self.unit or npair == 0)
+                    assert np.all(word[npair:] >> np.uint32(24) == 0)
+                    for second in (False, True):
+                        sel = real.copy()
+                        if second:
+                            sel[npair:] = False
+                        if not sel.any():
+                            continue
+                        slot = (addr[sel] % part) // piece
+                        lr = ((word[sel] >> np.uint32(24)) if second else (word[sel] & np.uint32(0xff))) // self.VW
+                        place = (t * self.NW + w) * self.RW + lr.astype(np.int64)
+                        rows.append(self.tile_rows[place])
+                        slots.append(self.tile_slots[place])
+                        cols.append(self.chunk_cols[(cb + k) * self.S + slot.astype(np.int64)])
+                        # (unit plans: the value lives once per row, row_fold -- the words' value slots are not used)
+                        vals.append(self.row_fold[self.tile_rows[place]] if self.unit else self.vals[e0:e1][sel])
         cat = lambda x, dt: np.concatenate(x) if x else np.zeros(0, dtype=dt)          # noqa: E731
         return cat(rows, np.int32), cat(cols, np.int32), cat(vals, np.float32), cat(slots, np.int32)
 
@@ -940,6 +950,8 @@ class LdsSweepCSR(object):
             # four lane groups per wave: the residual's rows are all resident in ONE round of tiles, and a sparse residual is
             # bound by the bytes each XCD pulls over the fabric, not by the step's instructions (S-Reddit-SBM p_in 0.8, 5.0 M
             # nonzeros, sustained: 1.26 ms against 1.50 with two groups; bins aligned to 8,192 columns: profiles/r31_*)
+            if residual_G == 4 and h.residual.nnz > 40 * max(h.shape[0], 1):
+                residual_G, residual_align = 2, 2048       # a DENSE residual (most of the graph) is the full-graph case: two groups
             self.residual = ColumnSweepCSR(h.residual, device, G=residual_G, align=residual_align) if residual_G else \
                 DeviceCSR.from_scipy(h.residual, device)
 
@@ -957,12 +969,12 @@ class LdsSweepCSR(object):
                             0 if self.ws is None else self.ws.numel())
 
     @classmethod
-    def for_graph(cls, a, device, min_local=0.9, min_gain=3.0, min_reuse=3):
+    def for_graph(cls, a, device, min_local=0.6, min_gain=3.0, min_reuse=3):
         """The LDS-sweep plan of a square adjacency IF the graph has the locality that pays for it, else None: communities
         from label propagation on the graph itself (``reorder_labels``), and a plan whose staged pieces serve at least
         ``min_gain`` nonzeros each while leaving at most 1 - ``min_local`` of the nonzeros to the residual sweep (measured
-        on S-Reddit-SBM: at 81 % planned the two-kernel product only draws level with the plain column sweep, at 93 % it is
-        1.2 x faster).  A graph without structure (S-Reddit: one label) costs the 0.3 s of the propagation."""
+        on S-Reddit-SBM, profiles/r31_*: with 74 % of the nonzeros planned the two-kernel product takes 2.60 ms against 3.20
+        for the plain column sweep, with 91 % 2.12 against 3.15; with 11 % it loses, 3.7 against 3.2).  A graph without structure (S-Reddit: one label) costs the 0.3 s of the propagation."""
         a = a.tocsr()
         if a.shape[0] != a.shape[1] or a.nnz == 0:
             return None
