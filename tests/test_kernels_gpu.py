@@ -256,6 +256,34 @@ def test_csr_slice_golden(dev):
         assert onp.rel_err(out.cpu().numpy(), a[r].dot(B)) <= TOL
 
 
+def test_csr_slice_row_pointer_on_the_device_equals_the_host_pass(dev):
+    """sgcn_csr_slice_indptr_dev (one workgroup, what the compiled step uses: SGCN_OP_CSR_SLICE) against
+    sgcn_csr_slice_indptr (the reference's c_indptr, gcn/history.cpp:50-58) on the reference's golden slices and on ragged /
+    empty / repeated / 20,000-row selections: bit-exact, and the slice built on it equals the host-prefixed one."""
+    from stochastic_gcn_amd import ops
+    from stochastic_gcn_amd._ffi import lib, check
+    z = gu.load("slice.npz")
+    a = sp.csr_matrix((z["a/data"], z["a/indices"], z["a/indptr"]), shape=tuple(z["a/shape"]))
+    rng = np.random.RandomState(5)
+    big = rand_csr(30000, 500, 0.01, 9, long_rows=[(0, 400), (17, 300)])
+    cases = [(a, z["slice/%s/r" % n]) for n in sorted({k.split("/")[1] for k in z.files if k.startswith("slice/")})]
+    cases += [(big, rng.randint(0, 30000, 20000).astype(np.int32)), (big, np.zeros(0, np.int32)), (big, np.array([0, 0, 17, 0], np.int32)),
+              (big, np.arange(255, dtype=np.int32)), (big, np.arange(257, dtype=np.int32))]
+    for m, r in cases:
+        A = ops.DeviceCSR.from_scipy(m, dev, with_plan=False)
+        r = np.ascontiguousarray(r, dtype=np.int32)
+        n = int(r.shape[0])
+        host = np.empty(n + 1, dtype=np.int32)
+        check(lib.sgcn_csr_slice_indptr(n, r.ctypes.data, A.host_rowptr.ctypes.data, host.ctypes.data))
+        rd = T(r, dev) if n else torch.zeros(1, dtype=torch.int32, device=dev)
+        o_p = torch.full((n + 1,), -7, dtype=torch.int32, device=dev)
+        check(lib.sgcn_csr_slice_indptr_dev(n, rd.data_ptr(), A.rowptr.data_ptr(), o_p.data_ptr(), None))
+        assert np.array_equal(o_p.cpu().numpy(), host)
+        if n:
+            s = ops.csr_slice(A, r, with_coo_rows=True)
+            assert np.array_equal(s.rowptr.cpu().numpy(), host) and s.nnz == int(host[-1])
+
+
 def test_full_size_reddit_shape_properties(dev):
     """BASELINE config 3 at full size (N=232,965, nnz~23.2 M, d=602): size-independent
     properties + oracle comparison on a row sample."""

@@ -198,6 +198,37 @@ def test_program_is_rebuilt_when_what_it_baked_in_changes():
     assert torch.equal(m.theta, ref.theta) and torch.equal(m.history[0][0], ref.history[0][0])
 
 
+def test_two_programs_of_one_process_keep_their_own_stream_mode():
+    """the auxiliary-stream / fusion mode is a program's own (SGCN_OP_MODE), not the process-wide knob the LAST
+    built program left behind: a model compiled for the auxiliary stream (agg_overlap) and one compiled for a single stream,
+    stepped alternately, each equal their own eager twin bit for bit; the knob itself is what it was."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd import _ffi
+    from stochastic_gcn_amd.step_program import OP
+    case = mc.build_case('reddit_cvd_pp')
+    params = mc.make_oracle_model(case, seed=3).params
+    models, refs, schs = [], [], []
+    for group in (False, True):                                   # (False: overlap on the auxiliary stream; True: one stream)
+        models.append(_model(case, {k: v.copy() for k, v in params.items()}, True, group))
+        refs.append(_model(case, {k: v.copy() for k, v in params.items()}, False, group))
+        schs.append((mc.make_scheduler(case, 1), mc.make_scheduler(case, 1)))
+    knob = int(_ffi.lib.sgcn_tune_get(b"step_overlap"))
+    for step in range(3):
+        for i, group in enumerate((False, True)):
+            for model, sch, native in ((models[i], schs[i][0], True), (refs[i], schs[i][1], False)):
+                FLAGS.update(native_step=native, group_dw=group, lean_sync=group, agg_overlap=not group)
+                pb = sch.minibatch_packed(case['cfg']['batch'], FLAGS.plan_t, None)
+                pb.dropout = case['flags']['dropout']
+                model.run_one_step(None, pb, sync=True)
+    torch.cuda.synchronize()
+    for m, r in zip(models, refs):
+        assert torch.equal(m.theta, r.theta) and torch.equal(m.history[0][0], r.history[0][0])
+    p0, p1 = (next(iter(m._programs.values())) for m in models)
+    assert (p0.overlap, p1.overlap) == (1, 0)
+    assert all(o == OP['MODE'] for o in (p0.c_fb[0].op, p1.c_fb[0].op))
+    assert int(_ffi.lib.sgcn_tune_get(b"step_overlap")) == knob
+
+
 def test_dense_scratch_is_sized_for_the_row_capacity():
     """The program's dense-layer scratch covers every op at its ROW CAPACITY (LayerNorm-backward partials grow with
     the rows; ADVICE r2: a fixed 4M-float buffer failed inside sgcn_step_run for narrow layers on large row caps)."""
