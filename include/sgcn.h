@@ -329,6 +329,11 @@ int64_t sgcn_csr_transpose_ws_ints(int32_t ncols, int64_t nnz);
 int sgcn_csr_transpose_index(int32_t ncols, int64_t nnz, const int32_t* dev_col, const int32_t* dev_coo_row,
                              int32_t* dev_t_rowptr, int32_t* dev_t_row, int32_t* dev_t_src, int32_t* dev_ws,
                              void* stream);
+/* out[r, :] = s[r] * x[r, :]  (16-byte aligned rows).  For products whose matrix carries one value per COLUMN -- the transpose
+ * of a row-normalised adjacency, the backward of gcn/layers.py:31-37 on D^-1 A: M . B = pattern(M) . (s (.) B), which lets
+ * the LDS sweep use its unit plan (ops.LdsSweepCSR). */
+int sgcn_scale_rows_f32(const float* dev_x, int64_t ldx, const float* dev_s, int32_t n, int32_t d, float* dev_out, int64_t ldo,
+                        void* stream);
 /* out[i] = src[idx[i]] */
 int sgcn_gather_f32(const float* dev_src, const int32_t* dev_idx, int64_t n, float* dev_out, void* stream);
 

@@ -124,6 +124,7 @@ SIGNATURES = {
     "sgcn_scatter_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),
     "sgcn_csr_slice_indptr_dev": (C.c_int, [C.c_int32, P, P, P, P]),
+    "sgcn_scale_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_csr_slice_f32": (C.c_int, [C.c_int32, P, P, P, P, P, P, P, P, P]),
     "sgcn_ln_act_fwd_f32": (C.c_int, [P, C.c_int64, P, P, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                       P, C.c_int64, P, P, P]),

@@ -191,6 +191,40 @@ extern "C" int sgcn_csr_transpose_index(int32_t ncols, int64_t nnz, const int32_
     return SGCN_OK;
 }
 
+// out[r, :] = s[r] * x[r, :]: the operand of a product whose matrix carries one value per COLUMN (the transpose of a
+// row-normalised adjacency, i.e. the backward of a mean aggregation): M . B = pattern(M) . (s (.) B).  float4 per lane.
+__global__ __launch_bounds__(kBlock) void scale_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ s,
+                                                            int32_t n, int32_t nvec, int32_t d, float* __restrict__ out, int64_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)n * nvec) return;
+    const int32_t r = (int32_t)(i / nvec), v = (int32_t)(i % nvec);
+    const float f = s[r];
+    const float* src = x + (int64_t)r * ldx + 4 * v;
+    float* dst = out + (int64_t)r * ldo + 4 * v;
+    if (4 * v + 4 <= d) {
+        float4 t = *reinterpret_cast<const float4*>(src);
+        t.x *= f; t.y *= f; t.z *= f; t.w *= f;
+        *reinterpret_cast<float4*>(dst) = t;
+    } else {
+        for (int e = 0; 4 * v + e < d; e++) dst[e] = f * src[e];
+    }
+}
+
+extern "C" int sgcn_scale_rows_f32(const float* x, int64_t ldx, const float* s, int32_t n, int32_t d, float* out, int64_t ldo,
+                                   void* stream) {
+    SGCN_REQUIRE(n >= 0 && d >= 0, "scale_rows: negative size");
+    if (n == 0 || d == 0) return SGCN_OK;
+    SGCN_REQUIRE(x && s && out && ldx >= d && ldo >= d, "scale_rows: bad operand");
+    SGCN_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                 "scale_rows: rows must be 16-byte aligned");
+    const int32_t nvec = (d + 3) / 4;
+    const int64_t blocks = ((int64_t)n * nvec + kBlock - 1) / kBlock;
+    SGCN_REQUIRE(blocks < (1ll << 31), "scale_rows: too large");
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, s, n, nvec, d, out, ldo);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
 extern "C" int sgcn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out, void* stream) {
     SGCN_REQUIRE(n >= 0, "gather: negative size");
     if (n == 0) return SGCN_OK;

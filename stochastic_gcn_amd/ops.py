@@ -819,6 +819,22 @@ class LdsPlanHost(object):
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
         val = np.ascontiguousarray(a.data, dtype=np.float32)
         M, K = int(a.shape[0]), int(a.shape[1])
+        # One value per COLUMN (the transpose of a row-normalised adjacency: the backward of a mean aggregation) and not one
+        # per row: the plan is built on the pattern -- a unit plan -- and the values become a scale of the operand's rows
+        # (``col_fold``; ops.spmm_lds multiplies B by it first: M . B = pattern(M) . (col_fold (.) B)).
+        self.col_fold = None
+        if not general and val.shape[0]:
+            vb = val.view(np.int32)
+            first = np.zeros(M, dtype=np.int32)
+            nz = np.diff(rowptr) > 0
+            first[nz] = vb[rowptr[:-1][nz]]
+            row_unit = bool(np.all(vb == np.repeat(first, np.diff(rowptr))))
+            if not row_unit:
+                cf = np.zeros(K, dtype=np.int32)
+                cf[col] = vb                                   # (any nonzero of the column: all equal, or the check fails)
+                if bool(np.all(cf[col] == vb)):
+                    self.col_fold = np.where(np.bincount(col, minlength=K) > 0, cf, np.float32(1.0).view(np.int32)).view(np.float32)
+                    val = np.ones_like(val)
         col_pos = row_group = None
         if labels is not None:
             row_labels, col_labels = labels if isinstance(labels, tuple) else (labels, labels)
@@ -873,6 +889,11 @@ class LdsPlanHost(object):
         self.nnz = int(a.nnz)
         self.residual = sp.csr_matrix((res_val, res_col, res_rowptr), shape=(M, K))
         self.local_nnz = self.nnz - rnnz
+
+    def planned(self):
+        """(row, column, value, workspace slot) as ``decode``, with the column values folded back in."""
+        r, c, v, sl = self.decode()
+        return (r, c, v * self.col_fold[c], sl) if self.col_fold is not None else (r, c, v, sl)
 
     def decode(self):
         """(row, column, value, workspace slot) of every non-pad entry, read back from the kernel's operands: the ring
@@ -945,6 +966,8 @@ class LdsSweepCSR(object):
         self.tile_rows, self.tile_slots = to(h.tile_rows), to(h.tile_slots)
         self.fix = to(h.fix) if h.nfix else None
         self.ws = None
+        self.col_fold = to(h.col_fold) if h.col_fold is not None else None       # scale of the operand's rows (see LdsPlanHost)
+        self._scaled = None
         self.residual = None
         if h.residual.nnz:
             # four lane groups per wave: the residual's rows are all resident in ONE round of tiles, and a sparse residual is
@@ -1017,6 +1040,13 @@ def spmm_lds(A, B, out=None, rscale=None, beta=0.0, d=None, local_only=False):
         pitch = (d + 3) // 4 * 4
         out = torch.empty((M, pitch), dtype=torch.float32, device=B.device)[:, :d]
     cptr, ldc = _rows2d(out, "out")
+    if A.col_fold is not None:               # one value per column: B's rows take it (one pass over B), the plan is a unit plan
+        pitch = (d + 31) // 32 * 32               # rows on 128-byte lines: a piece of a row never straddles one more line than it must
+        if A._scaled is None or A._scaled.shape[0] < K or A._scaled.shape[1] != pitch:
+            A._scaled = torch.empty((K, pitch), dtype=torch.float32, device=B.device)
+        check(lib.sgcn_scale_rows_f32(bptr, ldb, A.col_fold.data_ptr(), K, d, A._scaled.data_ptr(), pitch, _stream()))
+        B = A._scaled[:K, :d]
+        bptr, ldb = _rows2d(B, "B")
     plan = A.struct(d)
     check(lib.sgcn_spmm_lds_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(rscale, torch.float32, "rscale")),
                                 cptr, ldc, float(beta), _stream()))

@@ -894,6 +894,21 @@ def test_lds_sweep_on_communities_vs_oracle_and_column_sweep(dev):
     loc = ops.spmm_lds(A, Bd, local_only=True)
     res = ops.spmm_cs(A.residual, Bd)
     assert float((loc + res - c1).abs().max() / c1.abs().max()) <= 1e-5
+    # the transpose (one value per COLUMN: the backward product): a unit plan on the pattern + a row scale of the operand
+    at = a.T.tocsr().astype(np.float32)
+    at.sort_indices()
+    At = ops.LdsSweepCSR(at, dev, labels=comm, min_reuse=2)
+    assert At.unit and At.col_fold is not None
+    reft = onp.spmm(at.indptr, at.indices, at.data, B[:, :d])
+    rs = rng.rand(at.shape[0]).astype(np.float32)
+    c0t = T(rng.standard_normal((at.shape[0], 608)).astype(np.float32), dev)
+    keep = c0t.clone()
+    ct = ops.spmm_lds(At, Bd)
+    assert onp.rel_err(ct.cpu().numpy(), reft) <= TOL and torch.equal(ops.spmm_lds(At, Bd), ct)
+    ops.spmm_lds(At, Bd, out=c0t[:, :d], rscale=T(rs, dev), beta=0.5)
+    ref2 = onp.spmm(at.indptr, at.indices, at.data, B[:, :d], rscale=rs, C_in=keep[:, :d].cpu().numpy(), beta=0.5)
+    assert onp.rel_err(c0t[:, :d].cpu().numpy(), ref2) <= TOL and torch.equal(c0t[:, d:], keep[:, d:])
+    assert torch.equal(Bd, T(B, dev)[:, :d])                                    # the caller's operand is not touched
 
 
 def test_column_sweep_lost_lock_guard_retunes(dev):

@@ -54,6 +54,30 @@ def test_plan_is_the_matrix(m, k, dens):
     assert h3.nchunks >= h.nchunks and h3.local_nnz == h.local_nnz
 
 
+def test_one_value_per_column_becomes_a_unit_plan_and_a_row_scale_of_the_operand():
+    """The transpose of a row-normalised adjacency (the backward of a mean aggregation) carries one value per COLUMN: the
+    plan is built on the pattern (a unit plan, pair words and all), the values become ``col_fold``; planned() + residual
+    (x col_fold) is the matrix, exactly."""
+    from stochastic_gcn_amd import ops
+    a = _matrix(600, 600, 0.05, 11, long_rows=[(3, 300)])
+    a.data[:] = 1.0
+    deg = np.maximum(np.diff(a.indptr), 1).astype(np.float32)
+    a = sp.diags((1.0 / deg).astype(np.float32)).dot(a).tocsr().astype(np.float32)      # D^-1 A: one value per row
+    at = a.T.tocsr().astype(np.float32)
+    at.sort_indices()
+    for lab in (None, np.random.RandomState(2).randint(0, 4, 600).astype(np.int32)):
+        h = ops.LdsPlanHost(at, labels=lab, min_reuse=2, T=16)
+        assert h.unit and h.col_fold is not None and h.nfix >= 1
+        r, c, v, _ = h.planned()
+        loc = sp.coo_matrix((v.astype(np.float64), (r, c)), shape=at.shape).tocsr()
+        res = h.residual.astype(np.float64).dot(sp.diags(h.col_fold.astype(np.float64)))
+        diff = abs(loc + res - at.astype(np.float64))
+        assert r.shape[0] + h.residual.nnz == at.nnz and (diff.nnz == 0 or diff.max() == 0.0)
+        assert ops.LdsPlanHost(a, labels=lab, min_reuse=2).col_fold is None          # one value per ROW: the ordinary unit plan
+    g = ops.LdsPlanHost(_matrix(200, 200, 0.1, 5), min_reuse=2)
+    assert g.col_fold is None and not g.unit                                          # arbitrary values: a general plan
+
+
 def test_plan_edge_cases():
     _check(sp.csr_matrix((10, 10), dtype=np.float32), None, 1)        # no nonzeros at all
     _check(sp.csr_matrix((0, 5), dtype=np.float32), None, 1)          # no rows
