@@ -119,7 +119,10 @@ typedef struct {
                                        0 = library default knob, < 0 = unpaced                  */
     int32_t G;                      /* lane groups per wavefront: 0 / 1 = one 16-row tile per wave on 304-column
                                        slabs; 2 = two 16-row bins per wave (lanes 0-31 / 32-63) on 128-column
-                                       slabs, entries interleaved with pads (sgcn_csplang_*)               */
+                                       slabs, entries interleaved with pads (sgcn_csplang_*); 4 = four 16-row bins
+                                       per wave (16 lanes each) on 64-column slabs: 64 rows per wave, so a 233 k-row
+                                       graph is resident in ONE round -- the sweep of SPARSE matrices (the LDS plan's
+                                       residual), instruction-bound on a full graph                               */
     int32_t xcd_map;                /* != 0: consecutive tiles of a launch go to the SAME XCD (the
                                        dispatcher deals workgroups round-robin over the 8 XCDs):
                                        with a grouped plan the tiles that share B rows share an L2.
@@ -134,14 +137,13 @@ int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const 
                      int32_t M, int32_t R, int32_t T, const int32_t* host_row_group,
                      int64_t* host_tile_ptr, int32_t* host_colrow, float* host_valout,
                      int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
-/* Plan with TWO lane groups per wavefront (sgcn_csplan_t.G = 2, 16-row bins; `ngroups` must be 2): tile_rows / tile_slots
- * are [ntiles * 32] (bin 0's 16 rows, then bin 1's), colrow / val hold `nentries` interleaved entries (entry 2*step + g
- * is bin g's); pad entries carry the value bits 0x80000000 (-0.0f; real -0.0f values are stored as +0.0f) and are masked
+/* Plan with `ngroups` = 2 or 4 lane groups per wavefront (sgcn_csplan_t.G, 16-row bins): tile_rows / tile_slots are
+ * [ntiles * 16 * ngroups] (bin 0's 16 rows, then bin 1's, ...), colrow / val hold `nentries` interleaved entries (entry
+ * ngroups*step + g is bin g's); pad entries carry the value bits 0x80000000 (-0.0f; real -0.0f values are stored as +0.0f) and are masked
  * off by the kernel.  align > 0: a bin advances only while at most `align` columns ahead of the other (keeps the two
  * halves of a wave inside one L2 window); every tile's entry count is padded to a multiple of 64 (the pipelined kernel
  * has no tail code); the tile count is rounded up to whole launches of round_tiles waves (0: no rounding).
- * (Round 2 also built ngroups = 4 -- 64 rows per wavefront on 64-column slabs; its kernel was instruction-bound and is
- * not part of the product: profiles/HISTORY.md 3.1b.) */
+ * align > 0 with four groups: every bin stays within `align` columns of the slowest. */
 int sgcn_csplang_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
                        int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries,
                        int64_t* nfix, int64_t* nslots);
