@@ -756,8 +756,11 @@ def main(argv=None):
                     "T_model = miss_bytes/miss_rate + hit_bytes/hit_rate"}
         out["roofline"]["frac_of_gather_ceiling"] = t_floor / (fwd_ms * 1e-3)
     # the committed PMC record of exactly the kernel variant that was dispatched
-    tr = profiled_traffic(("void " + A.variant(d).split(" x ")[0]) if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
-        if not (args.tune or sh is not None or reorder != "none") else None
+    if args.kernel == "lds":         # (the whole two-kernel product: profiles/r32_lds_traffic.json is assembled from its PMC table)
+        tr = profiled_traffic("void sgcn::lds_spmm_kernel", nnz, d) if not (args.tune or sh is not None) else None
+    else:
+        tr = profiled_traffic(("void " + A.variant(d).split(" x ")[0]) if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
+            if not (args.tune or sh is not None or reorder != "none") else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model
@@ -769,7 +772,7 @@ def main(argv=None):
             miss_b = tr[0]["fetch_bytes_corrected"] * tr[0]["kernel_launches_per_spmm"]
             hit_b = max(nnz * (d * 4 + 8) - miss_b, 0)
             t_model = miss_b / (gc["miss"] * 1e12) + hit_b / (gc["hit"] * 1e12)
-            out["roofline"]["gather_ceiling"]["ms_model_for_profiled_traffic"] = t_model * 1e3
+            out["roofline"].setdefault("gather_ceiling", {})["ms_model_for_profiled_traffic"] = t_model * 1e3
             out["roofline"]["frac_of_traffic_model"] = t_model / (fwd_ms * 1e-3)
     def emit():
         if rank == 0:
