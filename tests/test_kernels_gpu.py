@@ -911,6 +911,40 @@ def test_lds_sweep_on_communities_vs_oracle_and_column_sweep(dev):
     assert torch.equal(Bd, T(B, dev)[:, :d])                                    # the caller's operand is not touched
 
 
+def test_lds_sweep_full_size_sbm_vs_oracle_rows(dev):
+    """What `bench.py --workload reddit-sbm` times -- the full-size graph (N = 232,965, 22.7 M nonzeros, p_in 0.8), d = 602,
+    communities from label propagation on the graph alone, the planned part through the LDS ring (pair words, requests from
+    inside the chunk statement) and the residual on the four-group column sweep at its autotuned clock -- against the CPU
+    oracle on sampled rows (the heaviest and the emptiest included); the same for the transpose (one value per column: a
+    unit plan + a row scale of the operand); reruns bit-identical."""
+    from stochastic_gcn_amd import ops, synthetic
+    n, _, a, *_ = synthetic.reddit_sbm(p_in=0.8)
+    d = 602
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    Bfull = torch.zeros((n, 608), device=dev)
+    Bfull[:, :d] = torch.randn((n, d), device=dev, generator=g)
+    B = Bfull[:, :d]
+    Bh = B.cpu().numpy()
+    at = a.T.tocsr().astype(np.float32)
+    at.sort_indices()
+    for m, want_fold in ((a, False), (at, True)):
+        A = ops.LdsSweepCSR.for_graph(m, dev)
+        assert A is not None and A.unit and (A.col_fold is not None) == want_fold
+        assert A.residual is not None and A.residual.G == 4 and "g4k" in A.variant(d)
+        A.autotune(B)
+        c = ops.spmm_lds(A, B)
+        deg = np.diff(m.indptr)
+        rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.argsort(deg)[:20],
+                                         np.random.RandomState(4).choice(n, 1500, replace=False)]))
+        sub = m[rows].tocsr()
+        ref = onp.spmm(sub.indptr, sub.indices, sub.data, Bh)
+        assert onp.rel_err(c[torch.from_numpy(rows).to(dev)].cpu().numpy(), ref) <= TOL
+        assert torch.equal(ops.spmm_lds(A, B), c)
+        assert torch.equal(B, Bfull[:, :d]) and float(Bfull[:, d:].abs().max()) == 0.0
+        print("LDS sweep, full size%s: %.1f %% of the nonzeros planned, %.1f nonzeros per staged piece"
+              % (" (transpose)" if want_fold else "", 100.0 * A.host_stats["local_nnz"] / m.nnz, A.host_stats["reuse"]))
+
+
 def test_column_sweep_lost_lock_guard_retunes(dev):
     """The clock-paced sweep watches itself: with a pace that is deliberately too fast (the lock-step is lost, the
     product costs ~2x) two timed samples in a row exceed 1.3 x the tuned time and the plan re-tunes on the spot; a
