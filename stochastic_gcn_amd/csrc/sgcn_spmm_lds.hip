@@ -624,7 +624,9 @@ extern "C" int sgcn_spmm_lds_f32(const sgcn_ldsplan_t* plan, int32_t M, int32_t 
     SGCN_REQUIRE(plan->NW == 8 && plan->VW == 2 && plan->RW == 96 && plan->U == 8 &&
                  ((plan->S == 80 && plan->nparts == 3) || (plan->S == 128 && plan->nparts == 2)),
                  "spmm_lds: the plan must be built for 8 waves x 96 rows x float2, groups of 8 entries, a ring of 3 x 80 or 2 x 128 slots");
-    SGCN_REQUIRE(plan->dev_tile_chunk_ptr && plan->dev_chunk_hdr && plan->dev_words &&
+    // (a plan without a single staged column -- an empty matrix, or everything in the residual -- has no chunk headers: its
+    // tiles still write their rows, rscale (.) 0 + beta C)
+    SGCN_REQUIRE(plan->dev_tile_chunk_ptr && (plan->dev_chunk_hdr || plan->nchunks == 0) && plan->dev_words &&
                  plan->dev_tile_rows && plan->dev_tile_slots && B && C, "spmm_lds: null operand");
     SGCN_REQUIRE(plan->unit ? plan->dev_row_fold != nullptr : plan->dev_vals != nullptr,
                  "spmm_lds: a unit plan needs its row values, a general plan its entry values");

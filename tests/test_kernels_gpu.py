@@ -911,6 +911,26 @@ def test_lds_sweep_on_communities_vs_oracle_and_column_sweep(dev):
     assert torch.equal(Bd, T(B, dev)[:, :d])                                    # the caller's operand is not touched
 
 
+def test_lds_sweep_edge_cases(dev):
+    """No nonzeros at all, a single row / column, and a plan whose every nonzero is residual (no column reaches min_reuse):
+    the tiles still write their rows (rscale (.) 0 + beta C), the pitch padding stays untouched."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(3)
+    for a, mr in ((sp.csr_matrix((5, 7), dtype=np.float32), 1), (sp.csr_matrix((700, 1), dtype=np.float32), 3),
+                  (rand_csr(1, 5, 0.9, 1), 1), (rand_csr(300, 4000, 0.001, 2), 3)):
+        M, K = a.shape
+        d, pitch = 30, 36
+        B = rng.standard_normal((K, pitch)).astype(np.float32)
+        c0 = rng.standard_normal((M, pitch)).astype(np.float32)
+        rs = rng.rand(M).astype(np.float32)
+        A = ops.LdsSweepCSR(a, dev, min_reuse=mr)
+        out = T(c0, dev)
+        ops.spmm_lds(A, T(B, dev)[:, :d], out=out[:, :d], rscale=T(rs, dev), beta=0.5)
+        ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d], rscale=rs, C_in=c0[:, :d], beta=0.5)
+        assert onp.rel_err(out[:, :d].cpu().numpy(), ref) <= TOL
+        np.testing.assert_array_equal(out[:, d:].cpu().numpy(), c0[:, d:])
+
+
 def test_lds_sweep_full_size_sbm_vs_oracle_rows(dev):
     """What `bench.py --workload reddit-sbm` times -- the full-size graph (N = 232,965, 22.7 M nonzeros, p_in 0.8), d = 602,
     communities from label propagation on the graph alone, the planned part through the LDS ring (pair words, requests from
