@@ -35,4 +35,5 @@ rec = {"items": int(p.shape[0]), "chunks_per_item": float(p[:, 0, 7].mean()),
        "cycles_per_item_mean": float(p[:, :, 6].mean()), "cycles_per_item_max": float(p[:, :, 6].max()),
        "share": {nm: round(float(p[:, :, i].sum() / tot), 4) for i, nm in enumerate(names[:6])},
        "cycles_per_chunk": {nm: round(float(p[:, :, i].sum() / p[:, :, 7].sum()), 1) for i, nm in enumerate(names[1:5], start=1)}}
+rec["by_wave"] = {nm: [round(float(p[:, w, i].mean()), 0) for w in range(8)] for i, nm in ((2, "chunk_statements"), (4, "barrier"), (1, "fill_issue"), (5, "epilogue"))}
 print(json.dumps(rec))

@@ -34,9 +34,11 @@ struct VRow { int32_t row, piece, npieces, nnz; };
 
 // Longest-processing-time dealing with a capacity: the next heaviest item goes to the lightest bin that still has a
 // free place.  Returns bin * cap + place -> item (or -1).
-std::vector<int64_t> deal(const std::vector<int64_t>& weight, int64_t nbins, int32_t cap) {
+// `speed` (nullable, per bin, per cent): a bin's load counts as load * 100 / speed -- bins that work faster get more.
+std::vector<int64_t> deal(const std::vector<int64_t>& weight, int64_t nbins, int32_t cap, const int32_t* speed = nullptr) {
     std::vector<int64_t> assign((size_t)nbins * cap, -1);
     std::vector<int32_t> fill((size_t)nbins, 0);
+    std::vector<int64_t> load((size_t)nbins, 0);
     typedef std::pair<int64_t, int64_t> WB;
     std::priority_queue<WB, std::vector<WB>, std::greater<WB>> heap;
     for (int64_t b = 0; b < nbins; b++) heap.push({0, b});
@@ -45,7 +47,8 @@ std::vector<int64_t> deal(const std::vector<int64_t>& weight, int64_t nbins, int
         heap.pop();
         const int64_t b = top.second;
         assign[(size_t)b * cap + fill[b]++] = (int64_t)i;
-        if (fill[b] < cap) heap.push({top.first + weight[i], b});
+        load[(size_t)b] += weight[i];
+        if (fill[b] < cap) heap.push({speed ? load[(size_t)b] * 10000 / speed[b] : load[(size_t)b], b});
     }
     return assign;
 }
@@ -169,7 +172,12 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             }
             std::vector<int64_t> ww(tr.vr.size());
             for (size_t i = 0; i < tr.vr.size(); i++) ww[i] = tr.vr[i].nnz;
-            const std::vector<int64_t> wa = deal(ww, NW, RW);
+            // waves 0-3 of a workgroup are the OLDER wave of their SIMD and issue first: with equal shares they finish a chunk
+            // 24 % ahead of waves 4-7 and wait at its barrier (231 k against 287 k cycles of chunk statements per item,
+            // profiles/lds_phase_probe.py by_wave) -- so they get that much more (knob lds_wave_bias, per cent)
+            int32_t speed[8];
+            for (int32_t wv = 0; wv < NW; wv++) speed[wv] = wv < NW / 2 ? (int32_t)sgcn_tune_get("lds_wave_bias") : 100;
+            const std::vector<int64_t> wa = deal(ww, NW, RW, speed);
             tr.wave.assign(tr.vr.size(), 0);
             tr.lr.assign(tr.vr.size(), 0);
             for (int32_t wv = 0; wv < NW; wv++)
