@@ -172,9 +172,9 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             }
             std::vector<int64_t> ww(tr.vr.size());
             for (size_t i = 0; i < tr.vr.size(); i++) ww[i] = tr.vr[i].nnz;
-            // waves 0-3 of a workgroup are the OLDER wave of their SIMD and issue first: with equal shares they finish a chunk
-            // 24 % ahead of waves 4-7 and wait at its barrier (231 k against 287 k cycles of chunk statements per item,
-            // profiles/lds_phase_probe.py by_wave) -- so they get that much more (knob lds_wave_bias, per cent)
+            // (knob lds_wave_bias, per cent, default 100 = even shares: waves 0-3 of a workgroup are the OLDER wave of their SIMD
+            // and issue first -- without the s_setprio around the kernel's update chain they finished a chunk 24 % ahead of
+            // waves 4-7 and waited at its barrier; with it the two are level and the bias buys nothing)
             int32_t speed[8];
             for (int32_t wv = 0; wv < NW; wv++) speed[wv] = wv < NW / 2 ? (int32_t)sgcn_tune_get("lds_wave_bias") : 100;
             const std::vector<int64_t> wa = deal(ww, NW, RW, speed);

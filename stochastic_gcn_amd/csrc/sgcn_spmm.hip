@@ -44,7 +44,7 @@ int g_tune_step_fuse = 127;           // bit 0: the output layer's forward as th
 int g_tune_cs_g2_wide = 0;
 int g_tune_cs_last_pct = 80;          // (round 4: 80 % holds the lock-step on the 90-column pass of d = 602: 3.16 vs 3.22 ms at 90, 3.43 at 70)
 int g_tune_gemm_min_steps = 0;
-int g_tune_lds_wave_bias = 124;    // LDS plan: entries of a tile's waves 0-3 per 100 of its waves 4-7 (the older wave of a SIMD issues first)
+int g_tune_lds_wave_bias = 100;    // LDS plan: entries of a tile's waves 0-3 per 100 of its waves 4-7 (100: even; made moot by the s_setprio around the update chain)
 int g_tune_lds_dbg = 0;             // experiments on the LDS sweep: bit 0 no ring fills after the first, bit 1 no arithmetic
 }  // namespace
 

@@ -125,6 +125,7 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     "s_set_gpr_idx_idx s[36+8*" #Q "+" #K "]\n\t"                                                              \
     SGCN_LDS_OP1_U(Q, K)
 #define SGCN_LDS_UBODY(Q)                                                                                     \
+    "s_setprio 2\n\t"                                                                                         \
     "s_cmp_eq_u32 %[np], 0\n\t"                                                                               \
     "s_cbranch_scc1 1f\n\t"                                                                                   \
     "s_set_gpr_idx_on s[36+8*" #Q "+0], 0x9\n\t" SGCN_LDS_PAIR1(Q, 0)                                          \
@@ -148,7 +149,8 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_OP1_U(Q, 6)                                              \
     "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_OP1_U(Q, 7)                                              \
     "s_set_gpr_idx_off\n\t"                                                                                   \
-    "2:\n\t"
+    "2:\n\t"                                                                                                  \
+    "s_setprio 0\n\t"
 #define SGCN_LDS_APPLY8P(Q, WAIT)                                                                             \
     "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                                        \
     SGCN_LDS_UBODY(Q)                                                                                         \
