@@ -103,6 +103,7 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     "v_pk_fma_f32 v[64:65], s[52+16*" #Q "+2*" #K ":52+16*" #Q "+2*" #K "+1], v[32+16*" #Q "+2*" #K ":32+16*" #Q "+2*" #K "+1], v[64:65] op_sel_hi:[0,1,1]\n\t"
 #define SGCN_LDS_APPLY8(M, Q, WAIT)                                                                           \
     "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                                        \
+    "s_setprio 2\n\t"                                                                                         \
     "s_set_gpr_idx_on s[36+8*" #Q "+0], " SGCN_LDS_MODE_##M "\n\t" SGCN_LDS_OP1_##M(Q, 0)                      \
     "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" SGCN_LDS_OP1_##M(Q, 1)                                            \
     "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" SGCN_LDS_OP1_##M(Q, 2)                                            \
@@ -112,6 +113,7 @@ typedef float acc32_t __attribute__((ext_vector_type(32)));
     "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" SGCN_LDS_OP1_##M(Q, 6)                                            \
     "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" SGCN_LDS_OP1_##M(Q, 7)                                            \
     "s_set_gpr_idx_off\n\t"                                                                                   \
+    "s_setprio 0\n\t"                                                                                         \
     "s_sub_u32 %[n], %[n], 1\n\t"                                                                             \
     "s_cmp_eq_u32 %[n], 0\n\t"                                                                                \
     "s_cbranch_scc1 Lx_%=\n\t"
