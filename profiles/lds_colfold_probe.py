@@ -1,5 +1,6 @@
+"""Forward (one value per row) and transposed (one value per column -> unit plan + row scale of the operand) LDS products on\nS-Reddit-SBM: total, planned part, residual.  usage: python profiles/lds_colfold_probe.py"""
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from stochastic_gcn_amd import ops, synthetic
 dev = torch.device("cuda:0"); d = 602
 n, _, a, _, _, _, labels, *_ = synthetic.reddit_sbm(p_in=0.8)
