@@ -570,7 +570,7 @@ def main(argv=None):
             r_, w_ = (int(x) for x in args.emulate_shard.split("/"))
             par = types.SimpleNamespace(rank=r_, world=w_, active=False)    # no peers: no collectives
         sh = ShardedSpMM(par, full_adj, dev, kernel="cs" if args.kernel == "lds" else args.kernel, with_transpose=not args.no_backward,
-                         d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d))
+                         d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d), G=args.cs_g if args.cs_g in (2, 4) else None)
         A = sh.A
     elif args.kernel in ("cs", "lds"):
         comm = None

@@ -214,9 +214,9 @@ class ShardedSpMM(object):
         layer activation sharded like C: the ranks all-gather their row blocks first
         (xGMI-bound for large operands; bench.py reports both variants)."""
 
-    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None):
+    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None, G=None):
         """d: width of the dense operand, when known up front -- picks the sweep's lane-group count for it
-        (ops.ColumnSweepCSR.choose_g); None: one group per wavefront."""
+        (ops.ColumnSweepCSR.choose_g); None: one group per wavefront.  G: that count given outright."""
         from . import ops
         adj = adj.tocsr()
         if adj.shape[0] != adj.shape[1]:
@@ -236,7 +236,8 @@ class ShardedSpMM(object):
         if self.hi == self.lo or kernel is None:   # more ranks than row blocks (this rank only joins collectives), or the
             pass                                   # partition + collectives alone (kernel=None: the CPU dry run of bench.py)
         elif kernel == "cs":
-            G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1)) if d else 1
+            if G is None:
+                G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1)) if d else 1
             self.A = ops.ColumnSweepCSR(blk, device, G=G)
             self.AT = ops.ColumnSweepCSR(blk_t, device, G=G) if with_transpose else None
             self._mm = ops.spmm_cs
