@@ -997,7 +997,8 @@ class LdsSweepCSR(object):
         from label propagation on the graph itself (``reorder_labels``), and a plan whose staged pieces serve at least
         ``min_gain`` nonzeros each while leaving at most 1 - ``min_local`` of the nonzeros to the residual sweep (measured
         on S-Reddit-SBM, profiles/r31_*: with 74 % of the nonzeros planned the two-kernel product takes 2.60 ms against 3.20
-        for the plain column sweep, with 91 % 2.12 against 3.15; with 11 % it loses, 3.7 against 3.2).  A graph without structure (S-Reddit: one label) costs the 0.3 s of the propagation."""
+        for the plain column sweep, with 91 % 2.09 against 3.15; with 40 % the two draw level, 3.21; with 11-14 % it loses,
+        3.6-3.7 against 3.2).  A graph without structure (S-Reddit: one label) costs the 0.3 s of the propagation."""
         a = a.tocsr()
         if a.shape[0] != a.shape[1] or a.nnz == 0:
             return None
