@@ -35,11 +35,14 @@ def sustained(A, reps=10):
 
 
 print(json.dumps({"residual_nnz": int(res.nnz), "nnz": int(a.nnz)}), flush=True)
-for G, align in ((2, 2048), (2, 8192), (4, 2048), (4, 4096), (4, 8192), (4, 16384), (4, 32768)):
-    A = ops.ColumnSweepCSR(res, dev, G=G, align=align)
+CASES = [(2, 2048, 0), (2, 8192, 0), (4, 2048, 0), (4, 4096, 0), (4, 8192, 0), (4, 16384, 0), (4, 32768, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "T":          # the split threshold of long rows (0: the plan's default, 4 x the mean row)
+    CASES = [(4, 8192, 0), (4, 8192, 128), (4, 8192, 256), (4, 8192, 512), (4, 8192, 2048)]
+for G, align, Tsplit in CASES:
+    A = ops.ColumnSweepCSR(res, dev, G=G, align=align, T=Tsplit)
     A._tuning = True
     t, pace = A.autotune(B[:, :d])
     A._tuning = True
     steps = int(A._tile_nnz.max())
-    print(json.dumps({"G": G, "align": align, "pad_fraction": round(A.pad_fraction, 4), "steps_heaviest_tile": steps,
+    print(json.dumps({"G": G, "align": align, "T": Tsplit, "split_rows": int(A.nfix), "pad_fraction": round(A.pad_fraction, 4), "steps_heaviest_tile": steps,
                       "autotuned_pace": pace, "autotune_ms": round(t, 4), "sustained_ms": round(sustained(A), 4)}), flush=True)
