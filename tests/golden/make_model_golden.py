@@ -7,6 +7,7 @@ tf.nn.batch_normalization, torch.autograd for tf.gradients -- sharing NO arithme
 oracle/model_np.py / oracle_c.c (hand-written forward and backward) or with the HIP path.
 
     python tests/golden/make_model_golden.py            # writes tests/golden/model_steps.npz
+    python tests/golden/make_model_golden.py --det      # writes tests/golden/model_steps_det.npz (the --det_dropout cases)
 
 What is shared, and why that is legitimate: the INPUTS -- the synthetic cases (tests/model_cases.py),
 the initial weights, the minibatches (the product's sampler, itself bit-exact against the real
@@ -20,6 +21,9 @@ Reference definitions followed (file:line under /root/reference):
   loss / accuracy        gcn/models.py:68-94            Adam              gcn/models.py:50-51 (TF: eps outside the sqrt,
                                                                             lr_t = lr sqrt(1-b2^t)/(1-b1^t))
   history alloc / update gcn/vrgcn.py:23-36, gcn/models.py:160-166,186-194
+  --det_dropout          DetDropoutFC gcn/layers.py:141-202 (torch.distributions.Normal for tf Normal), aggregators on
+                         (mu, var) :236-248, :320-349, Gaussian re-sampling :425-428, two histories gcn/vrgcn.py:28;
+                         shared input besides the masks: the N(0, 1) deviates of the re-sampling (a counter hash like them)
 """
 import os
 import sys
@@ -36,6 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import model_cases as mc                      # noqa: E402
 from oracle import model_np as mnp            # noqa: E402  (init_params + hash_mask only: inputs)
+from oracle import det_np                     # noqa: E402  (gauss_noise only: the re-sampling's deviates, an input)
 
 STEPS = 3
 SAMPLER_SEED = 1
@@ -60,6 +65,7 @@ class TorchRef(object):
         fl, c = case['flags'], case['cfg']
         self.fl, self.case = fl, case
         self.cv, self.cvd = bool(fl['cv']), bool(fl['cvd'])
+        self.det = bool(fl.get('det_dropout'))
         feats, nbr = case['feats'], case['nbr']
         self.sparse_input = sp.issparse(feats)
         input_dim = feats.shape[1]
@@ -87,7 +93,9 @@ class TorchRef(object):
             for l in range(nfc):
                 ind = input_dim * dim_s if l == 0 else H
                 last = self.L == 0 and l + 1 == nfc
-                if self.cvd:
+                if self.det:                                   # gcn/models.py:275-282
+                    st.append(('det', 'dense%d' % cnt, fl['layer_norm']))
+                elif self.cvd:
                     st.append(('add', 'dense%d' % cnt, self.sparse_mm and l == 0, fl['layer_norm']))
                 else:
                     st.append(('dropout',))
@@ -99,7 +107,9 @@ class TorchRef(object):
             for l2 in range(nfc):
                 last = l2 + 1 == nfc and l + 1 == self.L
                 norm = False if last else fl['layer_norm']
-                if self.cvd and l + 1 != self.L:
+                if self.det and l + 1 != self.L:               # gcn/models.py:312-318
+                    st.append(('det', 'dense%d' % cnt, norm))
+                elif self.cvd and l + 1 != self.L:
                     st.append(('add', 'dense%d' % cnt, False, norm))
                 else:
                     if not fl['reverse']:
@@ -114,6 +124,8 @@ class TorchRef(object):
         self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
         self.t = 0
         self.history = [torch.zeros((c['n'], agg0 if i == 0 else H)) for i in range(self.L)] if self.cv else []
+        self.history_var = [torch.zeros_like(h) for h in self.history] if self.det else []      # gcn/vrgcn.py:28
+        self.normal = torch.distributions.Normal(torch.tensor(0.0), torch.tensor(1.0))
 
     def _mask(self, li, step, shape, keep):
         key = mnp.dropout_key(DROPOUT_SEED, li, step)
@@ -147,7 +159,72 @@ class TorchRef(object):
         new_hist, rec = {}, {}
         for li, s in enumerate(self.stack):
             kind = s[0]
-            if kind == 'add':
+            if kind == 'det':                                      # DetDropoutFC._call, gcn/layers.py:163-202
+                _, name, norm = s
+                W = self.p[name + '/weights']
+                p_ = np.float32(keep)
+                if isinstance(act, tuple):
+                    mu, var = act
+                    mu2 = mu * mu
+                    var = (var + mu2) / p_ - mu2
+                else:
+                    mu = act
+                    var = (1 - p_) / p_ * (mu * mu)
+                mu = mu @ W
+                var = (var @ (W * W)) * np.float32(1.2)
+                if norm:
+                    mean = mu.mean(1, keepdim=True)
+                    variance = ((mu - mean) ** 2).mean(1, keepdim=True)
+                    sc, off = self.p[name + '/scale'], self.p[name + '/offset']
+                    mu = (mu - mean) * torch.rsqrt(variance + np.float32(1e-10)) * sc + off
+                    var = var * (sc * sc / variance)
+                sigma = torch.sqrt(var)
+                alpha = -mu / sigma
+                phi = torch.exp(self.normal.log_prob(alpha))
+                Phi = self.normal.cdf(alpha)
+                Z = self.normal.cdf(-alpha) + np.float32(1e-10)
+                phiZ = phi / Z
+                m = mu + sigma * phiZ
+                mu = Z * m
+                var = torch.relu(var * (1 + alpha * phiZ - phiZ * phiZ)) + np.float32(1e-10)
+                var = Z * var + Z * Phi * (mu * mu)
+                act = (mu, var)
+            elif kind == 'dropout' and self.det and isinstance(act, tuple):          # gcn/layers.py:425-428
+                mu, var = act
+                eps = torch.from_numpy(det_np.gauss_noise(mnp.dropout_key(DROPOUT_SEED, li + 4096, step), tuple(mu.shape)))
+                x = mu + eps * torch.sqrt(var + np.float32(1e-10))
+                act = x * (self._mask(li, step, x.shape, keep) * np.float32(1.0 / keep)) if on else x
+            elif kind == 'agg' and self.det and isinstance(act, tuple):              # gcn/layers.py:236-248, 320-349
+                l = s[1]
+                A = coo_to_torch(feed[ph['adj'][l]])
+                A2 = torch.sparse_coo_tensor(A.indices(), A.values() ** 2, size=A.shape).coalesce()
+                n1 = A.shape[0]
+                mu, var = act
+                if self.cv:
+                    P = coo_to_torch(feed[ph['fadj'][l]])
+                    P2 = torch.sparse_coo_tensor(P.indices(), P.values() ** 2, size=P.shape).coalesce()
+                    Mj = coo_to_torch(feed[ph['madj'][l]])
+                    ifield = torch.from_numpy(np.asarray(feed[ph['fields'][l]]).astype(np.int64))
+                    ffield = torch.from_numpy(np.asarray(feed[ph['ffields'][l]]).astype(np.int64))
+                    Hm, Hv = self.history[l], self.history_var[l]
+                    delta_mu = mu - Hm.index_select(0, ifield)
+                    mu_bar = Hm.index_select(0, ffield)
+                    sigma = torch.sqrt(var)
+                    sigma_bar = torch.sqrt(Hv.index_select(0, ifield))
+                    delta_sigma = sigma - sigma_bar
+                    var_bar = Hv.index_select(0, ffield)
+                    msigma = delta_sigma * sigma_bar
+                    mu_nbr = torch.sparse.mm(A, delta_mu) + torch.sparse.mm(P, mu_bar)
+                    var_nbr = torch.sparse.mm(A2, delta_sigma * delta_sigma) + torch.sparse.mm(P2, var_bar) \
+                        + 2 * torch.sparse.mm(Mj, msigma)
+                    var_nbr = torch.relu(var_nbr) + np.float32(1e-10)
+                    new_hist[l] = (ifield, mu.detach().clone(), var.detach().clone())
+                else:
+                    mu_nbr, var_nbr = torch.sparse.mm(A, mu), torch.sparse.mm(A2, var)
+                act = (torch.cat((mu[:n1], mu_nbr), 1), torch.cat((var[:n1], var_nbr), 1)) if concat else (mu_nbr, var_nbr)
+                rec['agg%d' % l] = act
+                rec['aggvar%d' % l] = act[1]
+            elif kind == 'add':
                 _, name, sparse_in, norm = s
                 W = self.p[name + '/weights']
                 x, mu = act if isinstance(act, tuple) else (act, act)
@@ -211,9 +288,9 @@ class TorchRef(object):
         logits = act
         labels = torch.from_numpy(np.asarray(feed[ph['labels']], np.float32))
         # gcn/models.py:68-83: weight decay on the vars of the first layer that has any
-        first = next(s for s in self.stack if s[0] in ('add', 'dense'))
+        first = next(s for s in self.stack if s[0] in ('add', 'dense', 'det'))
         wd_names = [k for k in (first[1] + '/weights', first[1] + '/offset', first[1] + '/scale') if k in self.p] \
-            if first[0] == 'add' else [first[1] + '/weights']
+            if first[0] in ('add', 'det') else [first[1] + '/weights']
         loss = sum(fl['weight_decay'] * 0.5 * (self.p[k] ** 2).sum() for k in wd_names) \
             + (-(labels * F.log_softmax(logits, dim=1)).sum(1)).mean()
         acc = (logits.argmax(1) == labels.argmax(1)).float().mean()
@@ -231,8 +308,10 @@ class TorchRef(object):
                 self.m[k] = b1 * self.m[k] + (1 - b1) * g
                 self.v[k] = b2 * self.v[k] + (1 - b2) * g * g
                 v -= np.float32(lr_t) * self.m[k] / (self.v[k].sqrt() + np.float32(1e-8))
-            for l, (ifield, rows) in new_hist.items():          # scatter AFTER the optimizer step
-                self.history[l].index_copy_(0, ifield, rows)
+            for l, nh in new_hist.items():                      # scatter AFTER the optimizer step
+                self.history[l].index_copy_(0, nh[0], nh[1])
+                if len(nh) == 3:
+                    self.history_var[l].index_copy_(0, nh[0], nh[2])
         out = dict(loss=np.float32(loss.item()), acc=np.float32(acc.item()), logits=logits.detach().numpy())
         for k, a in rec.items():
             a = a[0] if isinstance(a, tuple) else a
@@ -244,11 +323,11 @@ class TorchRef(object):
         return out
 
 
-def generate():
+def generate(det=False):
     torch.manual_seed(0)
     torch.set_num_threads(1)          # fixed reduction order -> reproducible file
     blob = {}
-    for name in sorted(mc.CASES):
+    for name in sorted(mc.DET_CASES if det else mc.CASES):
         case = mc.build_case(name)
         fl, c, ph = case['flags'], case['cfg'], case['ph']
         params = mnp.init_params(mc.make_oracle_model(case, seed=3).specs, 3)
@@ -262,11 +341,14 @@ def generate():
                 blob['%s/s%d/%s' % (name, step, k)] = np.asarray(v, np.float32)
         for l, h in enumerate(ref.history):
             blob['%s/history%d' % (name, l)] = h.numpy()
+        for l, h in enumerate(ref.history_var):
+            blob['%s/history_var%d' % (name, l)] = h.numpy()
     return blob
 
 
 if __name__ == "__main__":
-    blob = generate()
-    out = os.path.join(HERE, "model_steps.npz")
+    det = "--det" in sys.argv[1:]
+    blob = generate(det)
+    out = os.path.join(HERE, "model_steps_det.npz" if det else "model_steps.npz")
     np.savez_compressed(out, **blob)
     print("wrote %s: %d arrays, %.2f MB" % (out, len(blob), os.path.getsize(out) / 1e6))

@@ -105,8 +105,9 @@ CASES = {
 }
 
 
-# --det_dropout (moment propagation, gcn/layers.py:141-202,236-248,320-349,425-428): no golden vectors (the variant
-# came after the fixtures; its oracle is pinned by float64 autograd, tests/test_model_oracle.py), so not in CASES
+# --det_dropout (moment propagation, gcn/layers.py:141-202,236-248,320-349,425-428): its own golden file
+# (tests/golden/model_steps_det.npz, make_model_golden.py --det; round 4), and the float64-autograd pin of the oracle's
+# backward (tests/test_model_oracle.py) -- kept apart from CASES, whose golden file predates the variant
 DET_CASES = {
     # CV + PP, three layers: DetDropoutFC -> VR aggregator on (mu, var) with two histories -> DetDropoutFC on a tuple
     # -> second aggregator -> Gaussian re-sampling + dropout -> Dense

@@ -65,3 +65,51 @@ def test_oracle_matches_independent_golden(gold, name):
     for l, h in enumerate(om.history):
         assert onp.rel_err(h, gold["%s/history%d" % (name, l)]) <= ACT_TOL, (name, 'history', l)
     print("%s: worst rel err  activations %.1e  grads %.1e  params %.1e" % (name, worst['act'], worst['grad'], worst['param']))
+
+
+GOLD_DET = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_steps_det.npz")
+
+
+@pytest.mark.parametrize("name", sorted(mc.DET_CASES))
+def test_det_dropout_oracle_matches_independent_golden(name):
+    """--det_dropout (moment propagation, gcn/layers.py:141-202,236-248,320-349,425-428): oracle/det_np.py -- hand-written
+    forward AND backward in fp32 -- against the same definitions restated with PyTorch-CPU ops + autograd
+    (torch.distributions.Normal, torch.sparse.mm; tests/golden/make_model_golden.py --det): logits, both streams of every
+    aggregator output, loss, accuracy, every gradient, the Adam-updated weights over 3 steps, and BOTH histories."""
+    gold = np.load(GOLD_DET)
+    case = mc.build_case(name)
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    om = mc.make_oracle_model(case, seed=3)
+    sch = mc.make_scheduler(case, 1)
+    well, worst = {}, dict(act=0.0, grad=0.0, param=0.0)
+    agg_index = [i for i, s in enumerate(om.specs) if s[0] == 'agg']
+    for step in range(3):
+        feed = sch.minibatch(c['batch'])
+        key = "%s/s%d/" % (name, step)
+        assert np.array_equal(feed[ph['fields'][0]], gold[key + "field0"])
+        masks = mnp.HashMasks(1, step, 1.0 - fl['dropout'])
+        loss, acc, pred, acts, grads = om.run_one_step(feed, ph, fl['dropout'], masks)
+        e = onp.rel_err(acts[-1], gold[key + "logits"]); worst['act'] = max(worst['act'], e)
+        assert e <= ACT_TOL, (name, step, 'logits', e)
+        for l, li in enumerate(agg_index):
+            a = acts[li]
+            e = onp.rel_err(a[0] if isinstance(a, tuple) else a, gold[key + "agg%d" % l]); worst['act'] = max(worst['act'], e)
+            assert e <= ACT_TOL, (name, step, 'agg', l, e)
+            if isinstance(a, tuple):                                   # the variance stream
+                e = onp.rel_err(a[1], gold[key + "aggvar%d" % l]); worst['act'] = max(worst['act'], e)
+                assert e <= ACT_TOL, (name, step, 'agg variance', l, e)
+        assert abs(float(loss) - float(gold[key + "loss"])) <= 1e-5 * max(1.0, abs(float(loss)))
+        assert abs(float(acc) - float(gold[key + "acc"])) <= 1e-6
+        for k, g in grads.items():
+            e = onp.rel_err(g, gold[key + "grad/" + k]); worst['grad'] = max(worst['grad'], e)
+            assert e <= GRAD_TOL, (name, step, 'grad', k, e)
+            well[k] = well_conditioned(gold[key + "grad/" + k], well.get(k, True))
+        for k, v in om.params.items():
+            gv = gold[key + "param/" + k]
+            e = np.abs(v - gv)[well[k]].max() / np.abs(gv).max(); worst['param'] = max(worst['param'], e)
+            assert e <= PARAM_TOL, (name, step, 'param', k, e)
+    for l, h in enumerate(om.history):
+        assert onp.rel_err(h, gold["%s/history%d" % (name, l)]) <= ACT_TOL, (name, 'history', l)
+    for l, h in enumerate(om.history_var):
+        assert onp.rel_err(h, gold["%s/history_var%d" % (name, l)]) <= ACT_TOL, (name, 'variance history', l)
+    print("%s: worst rel err  activations %.1e  grads %.1e  params %.1e" % (name, worst['act'], worst['grad'], worst['param']))

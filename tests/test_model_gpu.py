@@ -197,6 +197,58 @@ def test_training_steps_match_independent_golden(name):
           % (name, worst['act'], worst['grad'], worst['param']))
 
 
+@pytest.mark.parametrize("name", sorted(mc.DET_CASES))
+def test_det_dropout_training_steps_match_independent_golden(name):
+    """--det_dropout on the HIP path (csrc/sgcn_det.hip, layers.DetDropoutFC, the aggregators on (mean, variance)) against the
+    INDEPENDENT fp32 golden (PyTorch-CPU ops + autograd of the reference's definitions, tests/golden/model_steps_det.npz) --
+    the second implementation VERDICT r3 found missing for this variant: logits, both streams of every aggregator output,
+    loss, accuracy, every gradient, the Adam-updated weights over 3 steps, both histories."""
+    import os
+    from stochastic_gcn_amd.layers import PlainAggregator, VRAggregator
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_steps_det.npz"))
+    case = mc.build_case(name)
+    fl, c, ph = case['flags'], case['cfg'], case['ph']
+    params = mc.make_oracle_model(case, seed=3).params
+    dmodel = _make_device_model(case, {k: v.copy() for k, v in params.items()})
+    sch = mc.make_scheduler(case, 1)
+    agg_index = [i for i, l in enumerate(dmodel.layers) if isinstance(l, (PlainAggregator, VRAggregator))]
+    well, worst = {}, dict(act=0.0, grad=0.0, param=0.0)
+    for step in range(3):
+        feed = sch.minibatch(c['batch'])
+        feed[ph['dropout']] = fl['dropout']
+        key = "%s/s%d/" % (name, step)
+        assert np.array_equal(feed[ph['fields'][0]], gold[key + "field0"])
+        outs = dmodel.run_one_step(None, feed)
+        acts = dmodel.activations[1:]
+        e = onp.rel_err(_np(acts[-1]), gold[key + "logits"]); worst['act'] = max(worst['act'], e)
+        assert e <= TOL, (name, step, 'logits', e)
+        for l, li in enumerate(agg_index):
+            a = _np(acts[li])
+            e = onp.rel_err(a[0] if isinstance(a, tuple) else a, gold[key + "agg%d" % l]); worst['act'] = max(worst['act'], e)
+            assert e <= TOL, (name, step, 'agg', l, e)
+            if isinstance(a, tuple):
+                e = onp.rel_err(a[1], gold[key + "aggvar%d" % l]); worst['act'] = max(worst['act'], e)
+                assert e <= TOL, (name, step, 'agg variance', l, e)
+        assert abs(outs[1] - float(gold[key + "loss"])) <= 1e-4 * max(1.0, abs(float(gold[key + "loss"])))
+        assert abs(outs[2] - float(gold[key + "acc"])) <= 1e-6
+        dg = dmodel.get_grads()
+        for k in params:
+            g = gold[key + "grad/" + k]
+            e = onp.rel_err(dg[k], g); worst['grad'] = max(worst['grad'], e)
+            assert e <= GRAD_TOL, (name, step, 'grad', k, e)
+            well[k] = well.get(k, True) & (np.abs(g) > 1e-6)
+        dp = dmodel.get_params()
+        for k in params:
+            gv = gold[key + "param/" + k]
+            e = np.abs(dp[k] - gv)[well[k]].max() / np.abs(gv).max(); worst['param'] = max(worst['param'], e)
+            assert e <= PARAM_TOL, (name, step, 'param', k, e)
+    for l in range(len(dmodel.history)):
+        assert onp.rel_err(dmodel.history[l][0].cpu().numpy(), gold["%s/history%d" % (name, l)]) <= TOL
+        assert onp.rel_err(dmodel.history[l][1].cpu().numpy(), gold["%s/history_var%d" % (name, l)]) <= TOL
+    print("%s vs independent golden: worst rel err  activations %.1e  grads %.1e  params %.1e"
+          % (name, worst['act'], worst['grad'], worst['param']))
+
+
 @pytest.mark.parametrize("which", ["cora", "pubmed"])
 def test_planetoid_configs_at_full_size_match_oracle(which):
     """BASELINE configs 1 and 2 at their SURVEY.md 8d sizes (S-Cora: N = 2,708, 1,433 sparse features,
