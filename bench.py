@@ -68,8 +68,8 @@ def parse(argv=None):
                         "default: lds for reddit-sbm, cs otherwise")
     p.add_argument("--lds-residual-g", type=int, default=4, choices=[2, 4],
                    help="--kernel lds: lane groups per wave of the column sweep that multiplies the residual (4: every row resident in one round)")
-    p.add_argument("--lds-min-reuse", type=int, default=3,
-                   help="--kernel lds: a column is staged for a tile only if the tile references it this often")
+    p.add_argument("--lds-min-reuse", type=int, default=0,
+                   help="--kernel lds: a column is staged for a tile only if the tile references it this often (0: 3, or 1 -- everything through the ring -- when that leaves under 16 % of the nonzeros to the residual)")
     p.add_argument("--cs-t", type=int, default=0)
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
@@ -587,9 +587,14 @@ def main(argv=None):
         if args.kernel == "lds":
             # planned nonzeros through the LDS ring, the rest (columns a tile references < min_reuse times) through the
             # two-lane-group column sweep into the same output
-            A = ops.LdsSweepCSR(full_adj, dev, labels=comm, min_reuse=args.lds_min_reuse, residual_G=args.lds_residual_g)
-            A.transpose = None if args.no_backward else ops.LdsSweepCSR(full_adj.T.tocsr(), dev, labels=comm,
-                                                                        min_reuse=args.lds_min_reuse, residual_G=args.lds_residual_g)
+            def lds_plan(m):
+                if args.lds_min_reuse > 0:
+                    return ops.LdsSweepCSR(m, dev, labels=comm, min_reuse=args.lds_min_reuse, residual_G=args.lds_residual_g)
+                # (0: what train.pp_products gets from LdsSweepCSR.for_graph -- min_reuse 3, or everything through the ring
+                # when that leaves a residual under 16 % of the nonzeros)
+                return ops.LdsSweepCSR(m, dev, host=ops.LdsSweepCSR.auto_host(m, comm), residual_G=args.lds_residual_g)
+            A = lds_plan(full_adj)
+            A.transpose = None if args.no_backward else lds_plan(full_adj.T.tocsr())
             mm = ops.spmm_lds
             reorder_info["lds_plan"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in A.host_stats.items()}
         else:

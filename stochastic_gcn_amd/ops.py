@@ -1011,7 +1011,22 @@ class LdsSweepCSR(object):
         host = LdsPlanHost(a, labels=labels, min_reuse=min_reuse)
         if host.local_nnz < min_local * a.nnz or host.local_nnz < min_gain * host.staged:
             return None
-        return cls(a, device, host=host)
+        return cls(a, device, host=cls.auto_host(a, labels, host))
+
+    # A residual costs ten launches and a sweep of B through every XCD however few nonzeros it has; below this share of the
+    # nonzeros it is cheaper to stage EVERY column through the ring, single-use pieces included (no residual, no second
+    # kernel).  Measured on S-Reddit-SBM, min_reuse 1 against 3 (profiles/r36_*): p_in 0.95 (9 % residual) 1.74 against
+    # 2.09 ms, 0.9 (13 %) 2.09 / 2.17, 0.85 (19 %) 2.40 / 2.31, 0.8 (26 %) 2.69 / 2.44.
+    ALL_STAGED_BELOW = 0.16
+
+    @classmethod
+    def auto_host(cls, a, labels, host=None, min_reuse=3):
+        """The host plan for ``a``: ``min_reuse`` 3, or 1 (everything through the ring) when that leaves a small residual."""
+        if host is None:
+            host = LdsPlanHost(a, labels=labels, min_reuse=min_reuse)
+        if 0 < host.residual.nnz < cls.ALL_STAGED_BELOW * max(a.nnz, 1):
+            host = LdsPlanHost(a, labels=labels, min_reuse=1)
+        return host
 
     def variant(self, d):
         """What spmm_lds dispatches for this plan and width, as text (bench.py: roofline.kernel)."""
