@@ -125,3 +125,27 @@ def test_plan_on_a_graph_with_communities_stages_shared_columns():
     assert h.local_nnz / h.staged > 4.0              # ... with real reuse per staged piece
     flat = _check(a, None, 2)                        # without labels the same matrix shares far less
     assert flat.local_nnz / max(flat.staged, 1) < h.local_nnz / h.staged
+
+
+def test_a_small_residual_is_folded_into_the_plan():
+    """LdsSweepCSR.auto_host: min_reuse 3 leaves the columns a tile uses once or twice to the residual sweep; when that is under
+    16 % of the nonzeros every column is staged instead (min_reuse 1: no residual at all, one kernel) -- and not otherwise."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(0)
+    n, nb = 3000, 3
+    lab = np.repeat(np.arange(nb), n // nb).astype(np.int32)
+    dense_blocks = sp.block_diag([sp.random(n // nb, n // nb, density=0.05, format='csr', random_state=rng, dtype=np.float32)
+                                  for _ in range(nb)]).tocsr()
+    for wide_nnz_per_row, want_all in ((0.5, True), (20, False)):
+        # out-of-block nonzeros over 200,000 extra columns: nearly all of them the only one of their column in a tile
+        m = int(wide_nnz_per_row * n)
+        wide = sp.coo_matrix((np.ones(m, np.float32), (rng.randint(0, n, m), rng.randint(0, 40000, m))), shape=(n, 40000)).tocsr()
+        a = sp.hstack((dense_blocks, wide)).tocsr()
+        a.data[:] = 1.0
+        a.sort_indices()
+        labels = (lab, np.concatenate([lab, np.full(40000, nb, np.int32)]))
+        h3 = ops.LdsPlanHost(a, labels=labels, min_reuse=3)
+        h = ops.LdsSweepCSR.auto_host(a, labels)
+        small = 0 < h3.residual.nnz < ops.LdsSweepCSR.ALL_STAGED_BELOW * a.nnz
+        assert small == want_all, (h3.residual.nnz, a.nnz)
+        assert (h.residual.nnz == 0 and h.local_nnz == a.nnz) if want_all else (h.residual.nnz == h3.residual.nnz > 0)
