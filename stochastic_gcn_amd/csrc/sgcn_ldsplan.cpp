@@ -228,6 +228,7 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
         std::vector<std::vector<float>> sv((size_t)NW);
         std::vector<int64_t> add((size_t)NW, 0);
         const bool pairs = h->unit != 0;
+        const bool mix = sgcn_tune_get("lds_mix") != 0;
         constexpr int64_t kMaxPairWords = 128;             // the kernel's pair path covers the first 16 groups of a chunk
         auto padded = [&](size_t n) { return (int64_t)((n + GE - 1) / GE * GE); };
         int32_t nslot = 0;                   // slots used in the open chunk
@@ -251,13 +252,43 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
             nslot = 0;
             nchunks++;
         };
-        size_t i = 0;
-        while (i < e.size()) {
+        // Staging order.  Columns the tile uses three times or more ("hot": its own community's) and the ones it uses once
+        // or twice ("cold": staged only by plans with min_reuse < 3, i.e. when there is no residual sweep) are DEALT into
+        // the chunks in proportion, each kind in sweep order: a chunk of cold columns alone has ~16 entries per wave and
+        // waits for its fabric-bound pieces (fill wait 9-17 % of the sweep of an all-staged plan), a chunk of hot ones has
+        // ~160 and hides them -- mixed, every chunk has the arithmetic to cover its requests.  (Which chunk a column is staged
+        // in changes the order of a row's additions, nothing else.)
+        std::vector<std::pair<size_t, size_t>> hot, cold, all, order;
+        for (size_t i = 0; i < e.size();) {
             size_t j = i;
             while (j < e.size() && e[j].pos == e[i].pos) j++;
             if ((int64_t)(j - i) < min_reuse) {
                 for (size_t q = i; q < j; q++) o.residual.push_back(e[q]);
             } else {
+                ((j - i) >= 3 || !mix ? hot : cold).push_back({i, j});
+                all.push_back({i, j});
+            }
+            i = j;
+        }
+        {
+            // Only a tile with no more cold columns than hot ones is mixed (knob lds_mix, 0 = never); any other keeps the plain
+            // sweep order.  Measured on S-Reddit-SBM, everything staged (profiles/r37_lds_mix.txt): 0.7 cold per hot (p_in
+            // 0.95) 1.74 -> 1.60 ms; at 1.25 per hot (p_in 0.9) and 2.45 (p_in 0.8) every form of mixing tried -- in
+            // proportion, capped with the rest behind or left in place -- loses 2-4 %.
+            if (!mix || cold.empty() || hot.empty() || cold.size() > hot.size()) {
+                order = all;
+            } else {
+                size_t ih = 0, ic = 0;
+                const size_t tot = hot.size() + cold.size();
+                for (size_t t = 0; t < tot; t++) {
+                    const bool take_cold = ic < cold.size() && (ih >= hot.size() || ic * tot < (t + 1) * cold.size());
+                    order.push_back(take_cold ? cold[ic++] : hot[ih++]);
+                }
+            }
+        }
+        for (const auto& grp : order) {
+            const size_t i = grp.first, j = grp.second;
+            {
                 // a chunk holds at most S columns and at most CAP entry words per wave (what the kernel loads per chunk),
                 // at most kMaxPairWords of them pairs
                 std::fill(add.begin(), add.end(), 0);
@@ -293,7 +324,6 @@ int sgcn_ldsplan_create(const int32_t* rowptr, const int32_t* col, const float* 
                     if (held >= 0) { sw[(size_t)wv].push_back(addr | (uint32_t)(held * VW)); sv[(size_t)wv].push_back(0.f); }
                 }
             }
-            i = j;
         }
         close_chunk();
     };

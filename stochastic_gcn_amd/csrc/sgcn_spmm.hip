@@ -45,6 +45,7 @@ int g_tune_cs_g2_wide = 0;
 int g_tune_cs_last_pct = 80;          // (round 4: 80 % holds the lock-step on the 90-column pass of d = 602: 3.16 vs 3.22 ms at 90, 3.43 at 70)
 int g_tune_gemm_min_steps = 0;
 int g_tune_lds_wave_bias = 100;    // LDS plan: entries of a tile's waves 0-3 per 100 of its waves 4-7 (100: even; made moot by the s_setprio around the update chain)
+int g_tune_lds_mix = 1;            // LDS plan: columns a tile uses once or twice dealt into the chunks among the reused ones (all-staged plans)
 int g_tune_lds_dbg = 0;             // experiments on the LDS sweep: bit 0 no ring fills after the first, bit 1 no arithmetic
 }  // namespace
 
@@ -63,6 +64,7 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_last_pct")) return g_tune_cs_last_pct;
     if (!strcmp(key, "gemm_min_steps")) return g_tune_gemm_min_steps;
     if (!strcmp(key, "lds_wave_bias")) return g_tune_lds_wave_bias;
+    if (!strcmp(key, "lds_mix")) return g_tune_lds_mix;
     if (!strcmp(key, "lds_dbg")) return g_tune_lds_dbg;
     return -1;
 }
@@ -293,6 +295,7 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
     if (!strcmp(key, "gemm_min_steps")) { g_tune_gemm_min_steps = (int)value; return SGCN_OK; }
     if (!strcmp(key, "lds_wave_bias")) { SGCN_REQUIRE(value >= 50 && value <= 300, "lds_wave_bias in 50..300 (per cent)"); g_tune_lds_wave_bias = (int)value; return SGCN_OK; }
+    if (!strcmp(key, "lds_mix")) { g_tune_lds_mix = value != 0; return SGCN_OK; }
     if (!strcmp(key, "lds_dbg")) { g_tune_lds_dbg = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_last_pct")) { SGCN_REQUIRE(value >= 0 && value <= 100, "cs_last_pct in [0, 100]"); g_tune_cs_last_pct = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_round")) { SGCN_REQUIRE(value >= 0, "cs_round >= 0"); g_tune_cs_round = (int)value; return SGCN_OK; }
