@@ -94,6 +94,8 @@ inline int pick_vw(int d, std::initializer_list<const void*> ptrs, std::initiali
 }
 
 int tune_get(const char* key);  // sgcn_spmm.hip
+// the calling thread's override of the step_overlap / step_fuse knobs (-1: none); sgcn_step_run sets it for one run
+void step_mode_override(int overlap, int fuse);
 
 // ---- counter-based dropout (include/sgcn.h sgcn_dropout_t) ---------------------------------------
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {      // murmur3 finaliser

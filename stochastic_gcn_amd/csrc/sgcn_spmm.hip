@@ -47,7 +47,11 @@ int g_tune_gemm_min_steps = 0;
 int g_tune_lds_wave_bias = 100;    // LDS plan: entries of a tile's waves 0-3 per 100 of its waves 4-7 (100: even; made moot by the s_setprio around the update chain)
 int g_tune_lds_mix = 1;            // LDS plan: columns a tile uses once or twice dealt into the chunks among the reused ones (all-staged plans)
 int g_tune_lds_dbg = 0;             // experiments on the LDS sweep: bit 0 no ring fills after the first, bit 1 no arithmetic
+// a step program's own MODE (sgcn_step_run): seen by the entry points that very thread calls during the run, by nobody else
+thread_local int tl_step_overlap = -1, tl_step_fuse = -1;
 }  // namespace
+
+void step_mode_override(int overlap, int fuse) { tl_step_overlap = overlap; tl_step_fuse = fuse; }
 
 int tune_get(const char* key) {
     if (!strcmp(key, "spmm_nv")) return g_tune_nv;
@@ -58,8 +62,8 @@ int tune_get(const char* key) {
     if (!strcmp(key, "cs_pace")) return g_tune_cs_pace;
     if (!strcmp(key, "cs_slack")) return g_tune_cs_slack;
     if (!strcmp(key, "cs_noextra")) return g_tune_cs_noextra;
-    if (!strcmp(key, "step_overlap")) return g_tune_step_overlap;
-    if (!strcmp(key, "step_fuse")) return g_tune_step_fuse;
+    if (!strcmp(key, "step_overlap")) return tl_step_overlap >= 0 ? tl_step_overlap : g_tune_step_overlap;
+    if (!strcmp(key, "step_fuse")) return tl_step_fuse >= 0 ? tl_step_fuse : g_tune_step_fuse;
     if (!strcmp(key, "cs_g2_wide")) return g_tune_cs_g2_wide;
     if (!strcmp(key, "cs_last_pct")) return g_tune_cs_last_pct;
     if (!strcmp(key, "gemm_min_steps")) return g_tune_gemm_min_steps;

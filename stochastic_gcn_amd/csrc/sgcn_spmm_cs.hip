@@ -30,6 +30,10 @@
 //   cs_spmm16g2k_kernel<U, WIDE>   two 16-row bins per wavefront on 128-column passes, software-pipelined, packed FMAs:
 //                                  what ColumnSweepCSR.choose_g selects for most widths (bench default at d = 602)
 //   cs_fix_kernel<VW>              ordered sum of a split row's workspace slots
+// Every asm statement that enters the VGPR-indexing mode (s_set_gpr_idx_*: the index lives in M0) or points M0 at an
+// LDS-DMA destination lists "m0" as a clobber, so that LLVM's M0-initialisation merging never carries a value across
+// it.  M0 is a reserved (non-allocatable) register, which makes clang warn about the entry; the entry is intended.
+#pragma clang diagnostic ignored "-Winline-asm"
 #include "sgcn_dev.h"
 
 namespace sgcn {
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
                              "s_set_gpr_idx_off"
                              : "+{v[48:63]}"(ax), "+{v[64:79]}"(ay), "+{v[80:95]}"(az), "+{v[96:111]}"(aw),
                                "+{v[112:127]}"(ae)
-                             : "s"(lr), "s"(v), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(be));
+                             : "s"(lr), "s"(v), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(be)
+                             : "m0");
             } else {
                 asm volatile("s_set_gpr_idx_on %4, 0xc\n\t"
                              "v_fma_f32 v64, %5, %6, v64\n\t"
@@ -150,7 +155,8 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
                              "v_fma_f32 v112, %5, %9, v112\n\t"
                              "s_set_gpr_idx_off"
                              : "+{v[64:79]}"(ax), "+{v[80:95]}"(ay), "+{v[96:111]}"(az), "+{v[112:127]}"(aw)
-                             : "s"(lr), "s"(v), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+                             : "s"(lr), "s"(v), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)
+                             : "m0");
             }
         };
         const int nb = n / U;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                      : [vs] "v"(vs), [e0] "i"(2 * j), [e1] "i"(2 * j + 1), [pw] "s"(pw), [b0] "i"((2 * j) & 31),
                        [b1] "i"(((2 * j) & 31) + 1), [lo] "s"(mlo), [hi] "s"(mhi), [l0] "s"(l0), [l1] "s"(l1),
                        [bxy] "v"(bxy), [bzw] "v"(bzw)
-                     : "s20", "s21", "s22", "s23", "scc");
+                     : "s20", "s21", "s22", "s23", "scc", "m0");
     };
 
     uint32_t ccr, ncr;
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                      : [vs] "v"(vs), [e0] "i"(4 * j), [pw] "s"(pw), [b0] "i"((4 * j) & 31),
                        [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [lw] "s"(lw),
                        [bxy] "v"(bxy), [bzw] "v"(bzw)
-                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "scc");
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "scc", "m0");
     };
 
     uint32_t ccr, ncr;

@@ -22,6 +22,10 @@
 //
 // Determinism: an accumulator receives its nonzeros in plan order; split rows meet in the ordered fix-up; no atomics.
 // Contract of sgcn_spmm_cs_f32 minus cscale and gidx.
+// Every asm statement that enters the VGPR-indexing mode (s_set_gpr_idx_*: the index lives in M0) or points M0 at an
+// LDS-DMA destination lists "m0" as a clobber, so that LLVM's M0-initialisation merging never carries a value across
+// it.  M0 is a reserved (non-allocatable) register, which makes clang warn about the entry; the entry is intended.
+#pragma clang diagnostic ignored "-Winline-asm"
 #include "sgcn_dev.h"
 
 namespace sgcn {
@@ -245,7 +249,7 @@ __device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2,
                      "s_waitcnt lgkmcnt(0)"
                      : SGCN_LDS_ACC, [n] "+s"(n), [np] "+s"(np)
                      : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off)
-                     : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "memory");
+                     : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "m0", "memory");
     } else {
         asm volatile("ds_read2_b32 v[24:25], %[ea] offset1:128\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
@@ -256,7 +260,7 @@ __device__ __forceinline__ void lds_chunk(acc32_t& a0, acc32_t& a1, acc32_t& a2,
                      "s_waitcnt lgkmcnt(0)"
                      : SGCN_LDS_ACC, [n] "+s"(n)
                      : [ea] "v"(ea), [mask] "v"(mask), [lane] "v"(lane_off)
-                     : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, SGCN_LDS_CLOBBER_SV, "scc", "memory");
+                     : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, SGCN_LDS_CLOBBER_SV, "scc", "m0", "memory");
     }
 }
 
@@ -281,7 +285,7 @@ __device__ __forceinline__ void lds_chunk_fill_u(acc32_t& a0, acc32_t& a1, acc32
                    [r0] "s"(F.r[0]), [r1] "s"(F.r[1]), [r2] "s"(F.r[2]), [r3] "s"(F.r[3]), [r4] "s"(F.r[4]), [r5] "s"(F.r[5]),
                    [r6] "s"(F.r[6]), [r7] "s"(F.r[7]), [r8] "s"(F.r[8]), [r9] "s"(F.r[9]), [r10] "s"(F.r[10]), [r11] "s"(F.r[11]),
                    [r12] "s"(F.r[12]), [r13] "s"(F.r[13]), [r14] "s"(F.r[14]), [r15] "s"(F.r[15])
-                 : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "memory");
+                 : SGCN_LDS_CLOBBER_V, SGCN_LDS_CLOBBER_SW, "scc", "m0", "memory");
 }
 
 // 128-column slabs: a lane holds a float2 of every row of its wave.  The piece ring has NPART parts of S slots
@@ -560,7 +564,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                      "s_set_gpr_idx_off"
                      : [x0] "=&v"(x0), [x1] "=&v"(x1)
                      : [i] "s"(r * VW), "{v[64:95]}"(a0), "{v[96:127]}"(a1), "{v[128:159]}"(a2),
-                       "{v[160:191]}"(a3), "{v[192:223]}"(a4), "{v[224:255]}"(a5));
+                       "{v[160:191]}"(a3), "{v[192:223]}"(a4), "{v[224:255]}"(a5)
+                     : "m0");
         const VT accv = {x0, x1};
         if (row < 0 || !act || (a.dbg & 4)) continue;
         const int slot = r < 64 ? __builtin_amdgcn_readlane(slots_lo, r) : __builtin_amdgcn_readlane(slots_hi, r - 64);

@@ -29,6 +29,7 @@ int dense_bwd_overlapped(int32_t n, int32_t N, int32_t K, const float* dy, int64
                          float* dscale, float* dx, int64_t lddx, const sgcn_dropout_t* drop, float* g_tmp, float* ws,
                          const int32_t* gidx, void* stream);
 int aux_join(void* stream);
+void step_mode_override(int overlap, int fuse);     // sgcn_spmm.hip: this thread's view of the step_overlap / step_fuse knobs
 int dense_bwd_chain(const DenseBwdArgs& up, const DenseBwdArgs& lo, void* stream);   // sgcn_gemm.hip
 int aux_fork(void* stream, void** aux_stream);
 int dw_group_begin();                    // sgcn_gemm.hip: record the weight-gradient GEMMs of the following DENSE_BWD ops ...
@@ -185,22 +186,24 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
     static std::mutex run_mutex;
     std::lock_guard<std::mutex> run_lock(run_mutex);
     bool memset_on_aux = false;
-    // the process-wide knobs are the defaults; a program's own MODE op overrides them for this run (and for the entry points
-    // the run calls, which read the knobs: set here, put back by the guard below)
-    const int64_t knob_overlap = sgcn_tune_get("step_overlap"), knob_fuse = sgcn_tune_get("step_fuse");
-    int64_t run_overlap = knob_overlap, run_fuse = knob_fuse;
+    // the process-wide knobs are the defaults; a program's own MODE op overrides them for this run -- as a thread-local
+    // override that the entry points this thread calls below read through tune_get: the process-wide values are never
+    // written, so other threads (and other entry points) keep seeing them
+    int64_t run_overlap = sgcn_tune_get("step_overlap"), run_fuse = sgcn_tune_get("step_fuse");
+    bool own_mode = false;
     for (int32_t k = 0; k < nops; k++)
         if (ops[k].op == SGCN_OP_MODE && ops[k].nargs >= 1) {
+            own_mode = true;
             run_overlap = ops[k].add[0] != 0;
             if (ops[k].nargs >= 2 && ops[k].add[1] >= 0) run_fuse = ops[k].add[1] & 127;
         }
     const bool overlap = run_overlap != 0;
     const int fuse = (int)run_fuse;
-    struct KnobGuard {
-        int64_t ov, fu; bool on;
-        ~KnobGuard() { if (on) { sgcn_tune("step_overlap", ov); sgcn_tune("step_fuse", fu); } }
-    } knobs{knob_overlap, knob_fuse, run_overlap != knob_overlap || run_fuse != knob_fuse};
-    if (knobs.on) { sgcn_tune("step_overlap", run_overlap); sgcn_tune("step_fuse", run_fuse); }
+    struct ModeGuard {
+        bool on;
+        ~ModeGuard() { if (on) sgcn::step_mode_override(-1, -1); }
+    } mode{own_mode};
+    if (own_mode) sgcn::step_mode_override(overlap ? 1 : 0, fuse);
     bool grouped = false, store = false, l2 = false;
     int ce_at = -1, adam_at = -1;
     for (int32_t k = 0; k < nops; k++) {

@@ -257,6 +257,28 @@ class Model(object):
         if self.history_join is not None:
             self.history_join()
 
+    # The history exchange of a data-parallel step is asynchronous (parallel.DataParallel.sync_history): until it is joined
+    # a replica's history lacks the rows of that step -- its own included.  So that no reader can forget the join, the
+    # public names ARE the join: ``history`` / ``history_vars`` hand the tensors out behind it (a no-op without a pending
+    # exchange).  Only the two places that ISSUE the exchange (update_history, _run_program) go to ``_history`` directly.
+    @property
+    def history(self):
+        self.join_history()
+        return self._history
+
+    @history.setter
+    def history(self, value):
+        self._history = value
+
+    @property
+    def history_vars(self):
+        self.join_history()
+        return self._history_vars
+
+    @history_vars.setter
+    def history_vars(self, value):
+        self._history_vars = value
+
     def save(self, sess=None, path=None):
         """Weights + history (gcn/models.py:204-209 saves self.vars + self.history_vars)."""
         self.join_history()
@@ -544,7 +566,7 @@ class GCN(Model):
 
     def upload(self, feed_dict):
         """feed-dict -> DevFeed (two H2D copies) and the input feature rows."""
-        cv = bool(self.history)
+        cv = bool(self._history)        # (structure only: no join, see ``history``)
         if isinstance(feed_dict, PackedBatch):
             cur = DevFeed.from_packed(feed_dict, self.device)
         else:
@@ -588,10 +610,12 @@ class GCN(Model):
         # the rows' classes for the F1 scores (sgcn_softmax_ce_f32: argmax(pred) + 4096 * argmax(labels)), single-label only
         n = int(z.shape[0])
         self.eval_classes = stats[4 + 2 * n:4 + 3 * n] if (want_pred and not self.multitask) else None
-        if self.__dict__.get('eval_light') and self.eval_classes is not None:
-            self.eval_vec, self.eval_rows = self._eval_out(stats), n      # (Trainer.evaluate: the vector the step program hands out)
         if FLAGS.weight_decay and self._wd_range[1] > self._wd_range[0]:
             ops.l2_penalty(self.theta, self._wd_range[0], self._wd_range[1], FLAGS.weight_decay, loss=stats[2:3])
+        # the snapshot Trainer.evaluate reads is taken BEHIND the weight-decay term (gcn/models.py:75: the reported loss
+        # includes it), as the step program's L2_PENALTY into stats[2] does
+        if self.__dict__.get('eval_light') and self.eval_classes is not None:
+            self.eval_vec, self.eval_rows = self._eval_out(stats), n      # (Trainer.evaluate: the vector the step program hands out)
         return stats[2], stats[3], pred, dlogits
 
     def backward(self, dlogits):
@@ -620,8 +644,8 @@ class GCN(Model):
         for l in range(self.L):
             agg = self.aggregators[l]
             nh = getattr(agg, 'new_history', None)
-            if nh is not None and self.history:
-                for h, v in zip(self.history[l], nh):
+            if nh is not None and self._history:
+                for h, v in zip(self._history[l], nh):      # (issuing side: no join, see ``history``)
                     if self.history_hook is not None:
                         self.history_hook(h, cur.fields[l], v, ops.scatter_rows)
                     else:
@@ -640,7 +664,7 @@ class GCN(Model):
 
     def _count_sizes(self, sizes):
         """The epoch counters of gcn/vrgcn.py:50-69 / gcn/plaingcn.py:41-50 from batch sizes."""
-        cv = bool(self.history)
+        cv = bool(self._history)        # (structure only: no join, see ``history``)
         for l in range(self.L):
             dim = self.agg0_dim if l == 0 else FLAGS.hidden1
             g_ops = ((sizes['fadj'][l] if cv else 0) + sizes['adj'][l]) * dim * 4
@@ -671,7 +695,7 @@ class GCN(Model):
         key = (round(float(dropout), 9), self.history_hook is None, self.theta.data_ptr(), self.grad.data_ptr(),
                self.adam_m.data_ptr() if self.is_training else 0, self.adam_v.data_ptr() if self.is_training else 0,
                self.features_dev.data_ptr() if isinstance(self.features_dev, torch.Tensor) else 0,
-               tuple(h.data_ptr() for hs in self.history for h in hs),
+               tuple(h.data_ptr() for hs in self._history for h in hs),
                bool(FLAGS.group_dw), bool(FLAGS.lean_sync), bool(FLAGS.agg_overlap))
         progs = self.__dict__.setdefault('_programs', {})
         if key not in progs:
@@ -851,7 +875,7 @@ class GCN(Model):
                 for l, nh in prog.new_history.items():
                     n = m[5 + 2 * l]
                     idx = words[m[4 + 2 * l]:m[4 + 2 * l] + n] if pb.slot is not None else ib[m[4 + 2 * l]:m[4 + 2 * l] + n]
-                    self.history_hook(self.history[l][0], idx, prog.tensor_of(nh, n), ops.scatter_rows)
+                    self.history_hook(self._history[l][0], idx, prog.tensor_of(nh, n), ops.scatter_rows)
         if pb.slot is not None:
             self._ring_step_queued(pb)
         self.dropout_step += 1

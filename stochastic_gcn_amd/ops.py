@@ -573,7 +573,11 @@ class ColumnSweepCSR(object):
                     round_tiles=self.round_tiles, tile_ptr=t(self.tile_ptr), colrow=t(self.colrow), val=t(self.val),
                     tile_rows=t(self.tile_rows), tile_slots=t(self.tile_slots),
                     fix=t(self.fix) if self.fix is not None else np.zeros((0, 3), np.int32),
-                    pace=np.array([[d, p] for d, p in sorted(self.pace.items())], np.int64).reshape(-1, 2))
+                    pace=np.array([[d, p] for d, p in sorted(self.pace.items())], np.int64).reshape(-1, 2),
+                    # the product's time at that pace: what the lost-lock guard compares against (a pace without it
+                    # -- a file of an older build -- is not restored: the guard could not watch it)
+                    tuned_ms=np.array([[d, self.tuned_ms[d]] for d in sorted(self.pace) if d in self.tuned_ms],
+                                      np.float64).reshape(-1, 2))
         import os
         import tempfile
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
@@ -620,8 +624,12 @@ class ColumnSweepCSR(object):
         self.ntiles, self.nfix = int(tile_ptr.shape[0] - 1), int(z["fix"].shape[0])
         self._tile_nnz = (np.diff(tile_ptr) // G).astype(np.int64)         # steps per tile (what the pace counts)
         self._hint, self._hint_round = None, None
-        self.pace = {int(d): int(p) for d, p in z["pace"]}
-        self.tuned_ms, self._guard, self._tuning = {}, {}, False
+        # a cached pace is only as good as the box and clock it was tuned on: it comes back WITH the time it gave there,
+        # so the run-time guard (_guard_before / _guard_after) is armed from the first product on; paces stored without
+        # that time (files of older builds) are dropped and tuned again
+        tuned = {int(d): float(ms) for d, ms in z["tuned_ms"]} if "tuned_ms" in z.files else {}
+        self.pace = {int(d): int(p) for d, p in z["pace"] if int(d) in tuned or int(p) <= 0}
+        self.tuned_ms, self._guard, self._tuning = {d: ms for d, ms in tuned.items() if d in self.pace}, {}, False
         to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)          # noqa: E731
         self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(z["colrow"]), to(z["val"])
         self.tile_rows, self.tile_slots = to(z["tile_rows"]), to(z["tile_slots"])
@@ -794,15 +802,19 @@ def spmm_cs(A, B, out=None, gidx=None, rscale=None, cscale=None, beta=0.0, d=Non
         if cscale is not None:
             raise ValueError("a grouped column-sweep plan does not take cscale (scale B instead)")
         gidx = A.pos2col if gidx is None else _dev(gidx, torch.int32, "gidx")[A.pos2col.long()]
+    gp, rp, cp = _ptr(_dev(gidx, torch.int32, "gidx")), _ptr(_dev(rscale, torch.float32, "rscale")), \
+        _ptr(_dev(cscale, torch.float32, "cscale"))
     ev = A._guard_before(d) if not A._tuning else None
     if ev is not None:
         ev[0].record()
-    check(lib.sgcn_spmm_cs_f32(C.byref(plan), M, K, d, bptr, ldb, _ptr(_dev(gidx, torch.int32, "gidx")),
-                               _ptr(_dev(rscale, torch.float32, "rscale")),
-                               _ptr(_dev(cscale, torch.float32, "cscale")), cptr, ldc, float(beta),
-                               _stream()))
-    if ev is not None:
-        ev[1].record()
+    try:
+        check(lib.sgcn_spmm_cs_f32(C.byref(plan), M, K, d, bptr, ldb, gp, rp, cp, cptr, ldc, float(beta), _stream()))
+        if ev is not None:
+            ev[1].record()
+    except BaseException:
+        if ev is not None:          # a sample whose second event was never recorded must not stay pending
+            A._guard[d]["pending"] = None
+        raise
     if not A._tuning and A._guard:
         A._guard_after(d, B)
     return out

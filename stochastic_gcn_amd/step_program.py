@@ -133,7 +133,7 @@ class StepProgram(object):
             raise Unsupported("features are not a dense device tensor")
         self.dev = m.device
         self.L = m.L
-        self.cv = bool(m.history)
+        self.cv = bool(m._history)
         # row bounds from the flags (same bound parallel.py uses for the history exchange)
         deg = FLAGS.degree if m.is_training else FLAGS.test_degree
         bs = FLAGS.batch_size if m.is_training else FLAGS.test_batch_size

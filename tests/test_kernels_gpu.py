@@ -806,11 +806,11 @@ def test_column_sweep_plan_cache_round_trip_both_group_counts(dev, tmp_path):
         path = str(tmp_path / ("plan%d.npz" % G))
         A, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=G)
         assert not hit and A.G == G
-        A.pace[160] = 300
+        A.pace[160], A.tuned_ms[160] = 300, 50.0       # (a pace travels with the product's time at it: the guard's yardstick)
         A.store_if_cached()
         ref = ops.spmm_cs(A, B)
         A2, hit2 = ops.ColumnSweepCSR.cached(a, dev, path, G=G)
-        assert hit2 and A2.G == G and A2.pace == {160: 300}
+        assert hit2 and A2.G == G and A2.pace == {160: 300} and A2.tuned_ms == {160: 50.0}
         assert torch.equal(ops.spmm_cs(A2, B), ref)
         assert A2.variant(160) == A.variant(160)
         other, hit3 = ops.ColumnSweepCSR.cached(a, dev, path, G=3 - G)          # same file, other group count: rebuilt
@@ -1000,3 +1000,49 @@ def test_column_sweep_lost_lock_guard_retunes(dev):
     assert abs(A.pace[d] - pace) <= 0.25 * pace
     e0.record(); out = ops.spmm_cs(A, Bd); e1.record(); e1.synchronize()
     assert e0.elapsed_time(e1) <= 1.2 * t_tuned and torch.equal(out, ref)
+
+
+def test_cached_column_sweep_pace_comes_back_with_its_time_and_arms_the_guard(dev, tmp_path):
+    """a pace restored from the plan cache was tuned on whatever box wrote the file -- exactly the case the
+    lost-lock guard exists for -- so the file carries the product's time at that pace and the guard samples the very
+    first products of a loaded plan; a file that holds paces without times (an older build's) gives its paces up."""
+    from stochastic_gcn_amd import ops, synthetic
+    _, _, a, *_ = synthetic.reddit_like(n=40000, m=1500000, f=8, classes=5, splits=(30000, 4000, 6000), seed=3,
+                                        with_features=False)
+    d = 256
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    B = torch.randn((a.shape[0], d), device=dev, generator=g)
+    path = str(tmp_path / "g.csplan.npz")
+    A, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=2)
+    assert not hit
+    t_tuned, pace = A.autotune(B)
+    if pace <= 0:                                   # a graph this small may run best unpaced: give it a (slow, safe) clock
+        A.pace[d] = pace = 400
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.spmm_cs(A, B); e0.record(); ops.spmm_cs(A, B); e1.record(); e1.synchronize()
+        A.tuned_ms[d] = t_tuned = e0.elapsed_time(e1)
+    A.store_if_cached()
+    ref = ops.spmm_cs(A, B).clone()
+    A2, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=2)
+    assert hit and A2.pace == A.pace and A2.tuned_ms == {d: t_tuned}
+    for _ in range(2 * A2.GUARD_EVERY):
+        out = ops.spmm_cs(A2, B)
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert A2._guard[d]["last_ms"] is not None and A2._guard[d]["retunes"] == 0        # armed, sampled, healthy
+    # an older file: paces, no times
+    z = dict(np.load(path))
+    z.pop("tuned_ms")
+    np.savez(path, **z)
+    A3, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=2)
+    assert hit and d not in A3.pace and not A3.tuned_ms
+    # a launch that fails between the guard's two events leaves no half-recorded sample behind
+    torch.cuda.synchronize()
+    A2._guard_after(d, B)                           # (reads the last finished sample: nothing pending now)
+    assert A2._guard[d]["pending"] is None
+    A2._guard[d]["calls"] = A2.GUARD_EVERY - 1      # the next product is a sampled one
+    bad = torch.empty((a.shape[0], d + 1), device=dev)[:, :d]        # row pitch 257 floats: refused by the foreign call
+    with pytest.raises(Exception, match="aligned"):
+        ops.spmm_cs(A2, B, out=bad)
+    assert A2._guard[d]["pending"] is None
+    ops.spmm_cs(A2, B)

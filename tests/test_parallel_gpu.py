@@ -366,6 +366,10 @@ def _rccl_worker(rank, world, port, force, out_dir):
     if force:
         assert dist.get_backend() == "nccl" and dist.get_world_size() == 1 and par.backend == "nccl"
         assert m.grad_hook is not None and m.history_hook is not None and len(par._pending) == 1
+        # the last step's exchange is still in flight -- and READING the history is what lands it (the public
+        # names join; nothing can see a replica that lacks this step's rows, its own included)
+        hist = m.history[0][0]
+        assert len(par._pending) == 0 and hist is m._history[0][0]
     m.join_history()
     # the collectives on their own: mean all-reduce (identity on one rank), padded row all-gather
     g = torch.Generator(device=trn.device); g.manual_seed(3)

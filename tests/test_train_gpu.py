@@ -147,17 +147,20 @@ def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monk
     assert len(list(tmp_path.glob("*.csplan.*.npz"))) == 2
 
 
-def test_evaluation_through_the_step_program_equals_the_eager_path():
+@pytest.mark.parametrize("weight_decay", [0.0, 5e-4])
+def test_evaluation_through_the_step_program_equals_the_eager_path(weight_decay):
     """Evaluation (gcn/train.py:133-160: forward + loss + prediction + the TEST model's own history scatter, with
     --test_cv warm-up sweeps reading what the previous sweep wrote) as compiled step programs -- one foreign call per
-    batch -- against the eager per-layer path: loss, accuracy, both F1 scores and the test history, bit for bit."""
+    batch -- against the eager per-layer path: loss, accuracy, both F1 scores and the test history, bit for bit.  With the
+    default weight decay (5e-4) the reported cost includes the L2 term of the first parametrised layer on BOTH paths
+    (gcn/models.py:75; the eager path once snapshotted its result vector in front of sgcn_l2_penalty_f32: ADVICE r4)."""
     import torch
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.train import Trainer
     res = {}
     for native in (False, True):
         FLAGS.reset()
-        FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
+        FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=weight_decay, dropout=0.1, layer_norm=True,
                      hidden1=64, num_fc_layers=2, batch_size=256, test_batch_size=512, learning_rate=0.01, seed=1,
                      prefetch=2, cv=True, cvd=True, test_cv=True, degree=1, test_degree=1, native_step=native)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -174,6 +177,22 @@ def test_evaluation_through_the_step_program_equals_the_eager_path():
     assert res[True][0] == res[False][0], (res[True][0], res[False][0])      # ... and gave the same numbers
     assert torch.equal(res[True][1], res[False][1]) and float(res[True][1].abs().sum()) > 0
     assert res[True][0][0] != res[True][0][1]         # the second sweep read the history the first one wrote
+    if weight_decay:
+        # the cost carries the L2 term of the first parametrised layer (the last trainer is the program one; its eager
+        # twin reported the same numbers above): one more eager batch read through BOTH result forms
+        m = tr.test_model
+        w = m.theta[m._wd_range[0]:m._wd_range[1]]
+        l2 = float(weight_decay * 0.5 * (w.double() ** 2).sum())
+        assert l2 > 0 and all(sw[0] > l2 for sw in res[False][0])
+        FLAGS.native_step = False
+        batch = tr.eval_sch.batch_packed(tr.val_d[:256], FLAGS.plan_t, tr.eval_slots[0])
+        m.eval_light, m.eval_sink = True, None
+        try:
+            los, acc, _ = m.run_one_step(None, batch, sync=True)
+        finally:
+            m.eval_light = False
+        vec = m.__dict__.pop('eval_vec')
+        assert float(vec[2]) == float(los) and float(vec[3]) == float(acc)
 
 
 def test_f1_scores_from_the_loss_kernels_class_indices_are_sklearns():
