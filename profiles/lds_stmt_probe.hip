@@ -7,6 +7,8 @@
 //   single    the shipped single-word group                     pair     the shipped pair-word group (one read, two updates)
 //   addtid    readlane + s_and m0 + 2 x ds_read_addtid_b32 + idx + pk_add (no VALU address)
 //   noread    the updates alone (no LDS reads): the VALU / scalar side of a group
+//   wide_b128 1 KB pieces, ds_read_b128, two packed adds per nonzero (a nonzero covers 256 columns); *_reads_only the read side alone
+//   *_words_in_sgprs   the entry words already in scalar registers (no v_readlane): what SMEM-delivered entries would cost
 // Output: one JSON line per (form, waves per SIMD): CU-clocks per nonzero (2.4 GHz nominal).
 // Build + run: hipcc -O3 --offload-arch=gfx950 profiles/lds_stmt_probe.hip -o /tmp/lds_stmt_probe && /tmp/lds_stmt_probe
 #include <hip/hip_runtime.h>
@@ -17,9 +19,9 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { SINGLE, PAIR, ADDTID, NOREAD, WIDE, WIDEONLY, B64ONLY, NFORM };
-static const char* kNames[NFORM] = {"single", "pair", "addtid", "noread", "wide_b128", "b128_reads_only", "b64_reads_only"};
-static const int kNnzPerGroup[NFORM] = {8, 16, 8, 8, 8, 8, 8};   // (wide: a nonzero covers 256 columns, not 128)
+enum { SINGLE, PAIR, ADDTID, NOREAD, WIDE, WIDEONLY, B64ONLY, SSINGLE, SPAIR, NFORM };
+static const char* kNames[NFORM] = {"single", "pair", "addtid", "noread", "wide_b128", "b128_reads_only", "b64_reads_only", "single_words_in_sgprs", "pair_words_in_sgprs"};
+static const int kNnzPerGroup[NFORM] = {8, 16, 8, 8, 8, 8, 8, 8, 16};   // (wide: a nonzero covers 256 columns, not 128)
 
 #define RD1(Q, K, LANE) "v_readlane_b32 s[36+8*" #Q "+" #K "], %[ew], " #LANE "\n\t"
 #define AD1(Q, K, T) "v_and_or_b32 v[28+" #T "], s[36+8*" #Q "+" #K "], %[mask], %[lane]\n\t"
@@ -28,6 +30,10 @@ static const int kNnzPerGroup[NFORM] = {8, 16, 8, 8, 8, 8, 8};   // (wide: a non
     RD1(Q, 0, L0) RD1(Q, 1, L1) RD1(Q, 2, L2) RD1(Q, 3, L3)                                        \
     AD1(Q, 0, 0) AD1(Q, 1, 1) AD1(Q, 2, 2) AD1(Q, 3, 3) DS1(Q, 0, 0) DS1(Q, 1, 1) DS1(Q, 2, 2) DS1(Q, 3, 3) \
     RD1(Q, 4, L4) RD1(Q, 5, L5) RD1(Q, 6, L6) RD1(Q, 7, L7)                                        \
+    AD1(Q, 4, 0) AD1(Q, 5, 1) AD1(Q, 6, 2) AD1(Q, 7, 3) DS1(Q, 4, 0) DS1(Q, 5, 1) DS1(Q, 6, 2) DS1(Q, 7, 3)
+// words already in scalar registers (what entries delivered by s_load_dwordx8 would look like): no v_readlane
+#define READ8S(Q, L0, L1, L2, L3, L4, L5, L6, L7)                                                  \
+    AD1(Q, 0, 0) AD1(Q, 1, 1) AD1(Q, 2, 2) AD1(Q, 3, 3) DS1(Q, 0, 0) DS1(Q, 1, 1) DS1(Q, 2, 2) DS1(Q, 3, 3) \
     AD1(Q, 4, 0) AD1(Q, 5, 1) AD1(Q, 6, 2) AD1(Q, 7, 3) DS1(Q, 4, 0) DS1(Q, 5, 1) DS1(Q, 6, 2) DS1(Q, 7, 3)
 // addtid: m0 = piece address (the word's upper bits), two dword reads: columns [0, 64) and [64, 128)
 #define AT1(Q, K)                                                                                   \
@@ -58,6 +64,17 @@ static const int kNnzPerGroup[NFORM] = {8, 16, 8, 8, 8, 8, 8};   // (wide: a non
     "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" PAIR1(Q, 3) "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" PAIR1(Q, 4)  \
     "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" PAIR1(Q, 5) "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" PAIR1(Q, 6)  \
     "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" PAIR1(Q, 7)                                             \
+    "s_set_gpr_idx_off\n\t"                                                                         \
+    "s_setprio 0\n\t"
+#define PAIR1S(Q, K) OP1(Q, K) "s_lshr_b32 s52, s[36+8*" #Q "+" #K "], 24\n\t" "s_set_gpr_idx_idx s52\n\t" OP1(Q, K)
+#define APPLY8PS(Q, WAIT)                                                                           \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                                              \
+    "s_setprio 2\n\t"                                                                               \
+    "s_set_gpr_idx_on s[36+8*" #Q "+0], 0x9\n\t" PAIR1S(Q, 0)                                        \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+1]\n\t" PAIR1S(Q, 1) "s_set_gpr_idx_idx s[36+8*" #Q "+2]\n\t" PAIR1S(Q, 2)  \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+3]\n\t" PAIR1S(Q, 3) "s_set_gpr_idx_idx s[36+8*" #Q "+4]\n\t" PAIR1S(Q, 4)  \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+5]\n\t" PAIR1S(Q, 5) "s_set_gpr_idx_idx s[36+8*" #Q "+6]\n\t" PAIR1S(Q, 6)  \
+    "s_set_gpr_idx_idx s[36+8*" #Q "+7]\n\t" PAIR1S(Q, 7)                                            \
     "s_set_gpr_idx_off\n\t"                                                                         \
     "s_setprio 0\n\t"
 #define CLOBBER_V "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
@@ -131,6 +148,20 @@ __global__ __launch_bounds__(1024) void probe(int reps, float* sink, const uint3
                 asm volatile(READ8W(0, 0, 1, 2, 3, 4, 5, 6, 7) BLOCK(READ8W, APPLY8X) "s_waitcnt lgkmcnt(0)"
                              : "+{v[64:95]}"(a0), "+{v[96:127]}"(a1) : [ew] "v"(ew), [mask] "v"(maskw), [lane] "v"(lane_w)
                              : CLOBBER_V, CLOBBER_W, CLOBBER_S, "scc", "m0", "memory");
+        } else if constexpr (F == SSINGLE || F == SPAIR) {
+            // the 16 words of the two group parities come down ONCE (outside the timed pattern's inner structure)
+            if constexpr (F == SSINGLE)
+                asm volatile(RD1(0, 0, 0) RD1(0, 1, 1) RD1(0, 2, 2) RD1(0, 3, 3) RD1(0, 4, 4) RD1(0, 5, 5) RD1(0, 6, 6) RD1(0, 7, 7)
+                             RD1(1, 0, 8) RD1(1, 1, 9) RD1(1, 2, 10) RD1(1, 3, 11) RD1(1, 4, 12) RD1(1, 5, 13) RD1(1, 6, 14) RD1(1, 7, 15)
+                             READ8S(0, 0, 1, 2, 3, 4, 5, 6, 7) BLOCK(READ8S, APPLY8) "s_waitcnt lgkmcnt(0)"
+                             : "+{v[64:95]}"(a0), "+{v[96:127]}"(a1) : [ew] "v"(ew), [mask] "v"(mask), [lane] "v"(lane_off)
+                             : CLOBBER_V, CLOBBER_S, "s52", "scc", "m0", "memory");
+            else
+                asm volatile(RD1(0, 0, 0) RD1(0, 1, 1) RD1(0, 2, 2) RD1(0, 3, 3) RD1(0, 4, 4) RD1(0, 5, 5) RD1(0, 6, 6) RD1(0, 7, 7)
+                             RD1(1, 0, 8) RD1(1, 1, 9) RD1(1, 2, 10) RD1(1, 3, 11) RD1(1, 4, 12) RD1(1, 5, 13) RD1(1, 6, 14) RD1(1, 7, 15)
+                             READ8S(0, 0, 1, 2, 3, 4, 5, 6, 7) BLOCK(READ8S, APPLY8PS) "s_waitcnt lgkmcnt(0)"
+                             : "+{v[64:95]}"(a0), "+{v[96:127]}"(a1) : [ew] "v"(ew), [mask] "v"(mask), [lane] "v"(lane_off)
+                             : CLOBBER_V, CLOBBER_S, "s52", "scc", "m0", "memory");
         } else if constexpr (F == B64ONLY) {
             asm volatile(READ8(0, 0, 1, 2, 3, 4, 5, 6, 7) BLOCK(READ8, APPLY8X) "s_waitcnt lgkmcnt(0)"
                          : "+{v[64:95]}"(a0), "+{v[96:127]}"(a1) : [ew] "v"(ew), [mask] "v"(mask), [lane] "v"(lane_off)
@@ -189,6 +220,8 @@ int main() {
         if (wps <= 2) run<WIDE>(wps, sink, words, e0, e1);          // (192 registers: two waves per SIMD at most)
         if (wps <= 2) run<WIDEONLY>(wps, sink, words, e0, e1);
         run<B64ONLY>(wps, sink, words, e0, e1);
+        run<SSINGLE>(wps, sink, words, e0, e1);
+        run<SPAIR>(wps, sink, words, e0, e1);
     }
     return 0;
 }
