@@ -622,19 +622,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
-// fix-up of split rows: ordered slot sum + epilogue (float4 path only)
+// fix-up of split rows: ordered slot sum + epilogue (float4 path only).  A workgroup owns 64 float4 columns of one split
+// row; its four waves take consecutive quarters of the row's workspace slots (a hub row of an R-MAT block has hundreds: one
+// thread walking them all was 0.35 ms of a 4.3 ms product), each sums its quarter in slot order, and wave 0 adds the
+// four partial sums in wave order -- a fixed association, so reruns stay bit-identical (rows of up to four slots: the plain
+// slot order).
 template <int VW>
 __global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix_t* fix, int64_t nfix) {
     typedef typename Vec<VW>::type VT;
-    const int nvblk = (a.nvec + kBlock - 1) / kBlock;
+    __shared__ VT part[kBlock / kWave - 1][kWave];
+    const int nvblk = (a.nvec + kWave - 1) / kWave;
     const int64_t f = blockIdx.x / nvblk;
     if (f >= nfix) return;
     const sgcn_fix_t fx = fix[f];
-    const int vi = (int)(blockIdx.x % nvblk) * kBlock + threadIdx.x;
-    if (vi >= a.nvec) return;
-    const float* w = a.ws + (int64_t)fx.first_slot * a.ldw + (int64_t)vi * VW;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    constexpr int NWV = kBlock / kWave;
+    const int vi = (int)(blockIdx.x % nvblk) * kWave + lane;
+    const bool live = vi < a.nvec;
+    const int q0 = (int)((int64_t)fx.nslots * w / NWV), q1 = (int)((int64_t)fx.nslots * (w + 1) / NWV);
     VT acc = vzero<VW>();
-    for (int q = 0; q < fx.nslots; q++) acc += vload<VW>(w + (int64_t)q * a.ldw);
+    if (live) {
+        const float* wp = a.ws + (int64_t)fx.first_slot * a.ldw + (int64_t)vi * VW;
+#pragma unroll 4
+        for (int q = q0; q < q1; q++) acc += vload<VW>(wp + (int64_t)q * a.ldw);
+    }
+    if (w > 0) part[w - 1][lane] = acc;
+    __syncthreads();
+    if (w > 0 || !live) return;
+#pragma unroll
+    for (int k = 0; k < NWV - 1; k++) acc += part[k][lane];
     float* out = a.C + (int64_t)fx.row * a.ldc + (int64_t)vi * VW;
     VT res = acc * (a.rscale ? a.rscale[fx.row] : 1.0f);
     const int left = a.d - vi * VW;
@@ -783,7 +799,7 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     }
     SGCN_HIP_TRY(hipGetLastError());
     if (plan->nfix > 0) {
-        const int64_t nfblk = (int64_t)((a.nvec + kBlock - 1) / kBlock) * plan->nfix;
+        const int64_t nfblk = (int64_t)((a.nvec + kWave - 1) / kWave) * plan->nfix;
         SGCN_REQUIRE(nfblk < (1ll << 31), "spmm_cs: too many split rows");
         hipLaunchKernelGGL(cs_fix_kernel<4>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
         SGCN_HIP_TRY(hipGetLastError());
