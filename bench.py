@@ -73,7 +73,9 @@ def parse(argv=None):
     p.add_argument("--cs-t", type=int, default=0)
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
-    p.add_argument("--cs-align", type=int, default=2048, help="--cs-g 2: columns one bin of a wave may run ahead of the other")
+    p.add_argument("--cs-align", type=int, default=-1, help="--cs-g 2 / 4: sweep positions one bin of a wave may run ahead of the slowest (-1: a third of the L2 window, ops.ColumnSweepCSR.auto_align)")
+    p.add_argument("--cs-warp", default="auto", choices=["auto", "on", "off"],
+                   help="the sweep clock in work coordinates (sgcn_csplan_t.dev_warp): auto = when the nonzeros are not spread evenly over the column ids")
     p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2, 4],
                    help="lane groups per wavefront of the column sweep (2: two 16-row bins on 128-column passes; "
                         "0: what ops.ColumnSweepCSR.choose_g picks for d -- also what the training path uses)")
@@ -570,7 +572,9 @@ def main(argv=None):
             r_, w_ = (int(x) for x in args.emulate_shard.split("/"))
             par = types.SimpleNamespace(rank=r_, world=w_, active=False)    # no peers: no collectives
         sh = ShardedSpMM(par, full_adj, dev, kernel="cs" if args.kernel == "lds" else args.kernel, with_transpose=not args.no_backward,
-                         d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d), G=args.cs_g if args.cs_g in (2, 4) else None)
+                         d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d), G=args.cs_g if args.cs_g in (2, 4) else None,
+                         plan_kw=dict(align=('auto' if args.cs_align < 0 else args.cs_align),
+                                      warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]))
         A = sh.A
     elif args.kernel in ("cs", "lds"):
         comm = None
@@ -598,8 +602,8 @@ def main(argv=None):
             mm = ops.spmm_lds
             reorder_info["lds_plan"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in A.host_stats.items()}
         else:
-            cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1)) if comm is None else 1)
-            gk = dict(G=cs_g, align=args.cs_align) if (cs_g != 1 and comm is None) else dict(col_labels=comm, row_labels=comm)
+            cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1), full_adj.shape[0]) if comm is None else 1)
+            gk = dict(G=cs_g, align=('auto' if args.cs_align < 0 else args.cs_align), warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]) if (cs_g != 1 and comm is None) else dict(col_labels=comm, row_labels=comm)
             A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
             A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
             mm = ops.spmm_cs
@@ -726,6 +730,10 @@ def main(argv=None):
             "kernel_launches_per_spmm": int(re.search(r" x (\d+) launches", A.variant(d)).group(1))
             if args.kernel == "cs" else 1,
             "lds_parts_ms": lds_parts,
+            "cs_plan": ({"G": int(getattr(A, "G", 1)), "align": getattr(A, "align", None),
+                         "pad_fraction": round(float(getattr(A, "pad_fraction", 0.0)), 4),
+                         "warp_table": None if getattr(A, "warp", None) is None else [int(A.warp.numel()), int(A.warp_shift)]}
+                        if args.kernel == "cs" else None),
             "cs_autotune_ms_pace": tuned},
         "roofline": {"bound": "hbm", "kernel": ((A.variant(d) + " + cs_fix_kernel: one SpMM") if args.kernel == "cs"
                                 else A.variant(d) if args.kernel == "lds"

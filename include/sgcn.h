@@ -33,13 +33,14 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 11.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 12.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
  *   v9  sgcn_softmax_ce_f32: with a prediction output, rowstat has a third plane (the rows' class indices)
  *   v10 sgcn_ldsplan_* / sgcn_spmm_lds_f32: the LDS-staged column sweep for graphs with locality
- *   v11 sgcn_csr_slice_indptr_dev; step ops MODE and CSR_SLICE .. GATHER_F32 (sparse-input stacks as step programs) */
+ *   v11 sgcn_csr_slice_indptr_dev; step ops MODE and CSR_SLICE .. GATHER_F32 (sparse-input stacks as step programs)
+ *   v12 sgcn_csplan_t: dev_warp / warp_shift (the column sweep's clock in work coordinates); sgcn_csplang_*: host_warp */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -127,6 +128,13 @@ typedef struct {
                                        dispatcher deals workgroups round-robin over the 8 XCDs):
                                        with a grouped plan the tiles that share B rows share an L2.
                                        Placement only -- results do not depend on it.            */
+    const uint32_t* dev_warp;       /* nullable, [((K - 1) >> warp_shift) + 1]: the sweep clock in WORK coordinates --
+                                       entry b = the share of the matrix's nonzeros in columns < (b << warp_shift),
+                                       scaled to [0, K).  A clock linear in the column id loses the lock-step where the
+                                       nonzeros are not spread evenly over the ids (R-MAT); with the table a wave holds
+                                       the POSITION of its column to the clock (G = 2 / 4 kernels; pace and slack keep
+                                       their units).  Pacing only -- results do not depend on it.                     */
+    int32_t warp_shift;
 } sgcn_csplan_t;
 /* row_group (nullable, [M], labels >= 0): tiles are formed inside groups, groups in label order
  * (locality-preserving reordering of a graph that has communities, e.g. from sgcn_reorder_lp);
@@ -143,12 +151,15 @@ int sgcn_csplan_fill(const int32_t* host_rowptr, const int32_t* host_col, const 
  * off by the kernel.  align > 0: a bin advances only while at most `align` columns ahead of the other (keeps the two
  * halves of a wave inside one L2 window); every tile's entry count is padded to a multiple of 64 (the pipelined kernel
  * has no tail code); the tile count is rounded up to whole launches of round_tiles waves (0: no rounding).
- * align > 0 with four groups: every bin stays within `align` columns of the slowest. */
+ * align > 0 with four groups: every bin stays within `align` columns of the slowest.
+ * host_warp (nullable, with warp_shift: the HOST copy of sgcn_csplan_t.dev_warp): `align` then counts sweep POSITIONS
+ * (warp[col >> warp_shift]) instead of column ids -- the bins are aligned in the coordinates the clock runs in. */
 int sgcn_csplang_count(const int32_t* host_rowptr, const int32_t* host_col, int32_t M, int32_t T,
-                       int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries,
-                       int64_t* nfix, int64_t* nslots);
+                       int32_t round_tiles, int32_t align, int32_t ngroups, const uint32_t* host_warp, int32_t warp_shift,
+                       int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots);
 int sgcn_csplang_fill(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
-                      int32_t T, int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* host_tile_ptr,
+                      int32_t T, int32_t round_tiles, int32_t align, int32_t ngroups, const uint32_t* host_warp,
+                      int32_t warp_shift, int64_t* host_tile_ptr,
                       int32_t* host_colrow, float* host_valout, int32_t* host_tile_rows, int32_t* host_tile_slots,
                       sgcn_fix_t* host_fix);
 /* Community labels of a square CSR pattern by seeded asynchronous label propagation (host, graph

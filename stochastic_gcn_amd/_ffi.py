@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 11         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 12         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -37,7 +37,8 @@ class CsPlan(C.Structure):
                 ("dev_tile_slots", C.c_void_p), ("dev_fix", C.c_void_p), ("nfix", C.c_int64),
                 ("nslots", C.c_int64), ("dev_ws", C.c_void_p), ("ws_elems", C.c_int64),
                 ("round_tiles", C.c_int64), ("host_tile_nnz_hint", C.c_void_p),
-                ("pace_ns_per_nnz", C.c_int32), ("G", C.c_int32), ("xcd_map", C.c_int32)]
+                ("pace_ns_per_nnz", C.c_int32), ("G", C.c_int32), ("xcd_map", C.c_int32),
+                ("dev_warp", C.c_void_p), ("warp_shift", C.c_int32)]
 
 
 class LdsPlan(C.Structure):
@@ -98,9 +99,10 @@ SIGNATURES = {
     "sgcn_csplan_count": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, P, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_csplan_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P]),
-    "sgcn_csplang_count": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
-                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "sgcn_csplang_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P]),
+    "sgcn_csplang_count": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int32,
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sgcn_csplang_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int32,
+                                    P, P, P, P, P, P]),
     "sgcn_reorder_lp": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, P, C.POINTER(C.c_int32)]),
     "sgcn_spmm_cs_variant": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_char_p, C.c_int32]),
     "sgcn_spmm_cs_f32": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,

@@ -199,7 +199,7 @@ namespace {
 constexpr int kG2R = 16;
 constexpr uint32_t kPadBits = 0x80000000u;
 
-struct G2Ent { int32_t col, lr; float val; };
+struct G2Ent { int32_t col, lr; float val; int64_t pos; };   // pos: the column's sweep position (the column id, or its warp table entry)
 
 struct G2Layout {
     std::vector<VRow> v;
@@ -221,28 +221,30 @@ void g2_layout(const int32_t* rowptr, int32_t M, int32_t T, int32_t round_tiles,
 
 // the column-sorted entries of one bin
 void g2_bin(const G2Layout& L, const int32_t* rowptr, const int32_t* col, const float* val, int64_t bin,
-            std::vector<G2Ent>& ents, std::vector<std::pair<int32_t, float>>& rowbuf) {
+            std::vector<G2Ent>& ents, std::vector<std::pair<int32_t, float>>& rowbuf, const uint32_t* warp, int32_t wshift) {
     ents.clear();
+    auto posof = [&](int32_t c) -> int64_t { return warp ? (int64_t)warp[c >> wshift] : (int64_t)c; };
     for (int32_t k = 0; k < kG2R; k++) {
         const int64_t vi = L.assign[(size_t)bin * kG2R + k];
         if (vi < 0) continue;
         const VRow& vr = L.v[vi];
         const int32_t b = rowptr[vr.row], e = rowptr[vr.row + 1];
         if (vr.npieces == 1) {
-            for (int32_t p = b; p < e; p++) ents.push_back({col[p], k, val ? val[p] : 0.f});
+            for (int32_t p = b; p < e; p++) ents.push_back({col[p], k, val ? val[p] : 0.f, posof(col[p])});
         } else {
             rowbuf.clear();
             for (int32_t p = b; p < e; p++) rowbuf.push_back({col[p], val ? val[p] : 0.f});
             std::stable_sort(rowbuf.begin(), rowbuf.end(),
                              [](const std::pair<int32_t, float>& a, const std::pair<int32_t, float>& c2) { return a.first < c2.first; });
-            for (int32_t i = vr.piece; i < e - b; i += vr.npieces) ents.push_back({rowbuf[i].first, k, rowbuf[i].second});
+            for (int32_t i = vr.piece; i < e - b; i += vr.npieces) ents.push_back({rowbuf[i].first, k, rowbuf[i].second, posof(rowbuf[i].first)});
         }
     }
     std::stable_sort(ents.begin(), ents.end(), [](const G2Ent& a, const G2Ent& b) { return a.col < b.col; });
 }
 
 // Aligned NG-bin schedule; emit(step, g, entry-or-null).  Returns the number of steps.  A bin applies its next
-// entry in a step only while that entry is at most `align` columns ahead of the slowest bin that still has
+// entry in a step only while that entry is at most `align` sweep positions (columns; with a warp table: the clock's work
+// coordinates, see sgcn_csplan_t.dev_warp) ahead of the slowest bin that still has
 // entries (the others get a pad): the bins of a wave then gather from one L2 window.  The step count is padded to
 // whole chunks of 64 entries (64 / NG steps): the pipelined kernels run without tail code.
 template <class Emit>
@@ -250,14 +252,14 @@ int64_t gn_schedule(const std::vector<G2Ent>* e, int NG, int32_t align, Emit emi
     size_t pos[4] = {0, 0, 0, 0};
     int64_t step = 0, window = 0;
     for (;;) {
-        int64_t lo = INT64_MAX;
+        int64_t lo = INT64_MAX, lo_col = 0;
         for (int g = 0; g < NG; g++)
-            if (pos[g] < e[g].size()) lo = std::min<int64_t>(lo, e[g][pos[g]].col);
+            if (pos[g] < e[g].size() && e[g][pos[g]].pos < lo) { lo = e[g][pos[g]].pos; lo_col = e[g][pos[g]].col; }
         if (lo == INT64_MAX) break;
-        window = lo;
+        window = lo_col;                      // (a pad gathers from the COLUMN the slowest bin is at)
         for (int g = 0; g < NG; g++) {
             const bool has = pos[g] < e[g].size();
-            const bool take = has && (align <= 0 || e[g][pos[g]].col <= lo + align);
+            const bool take = has && (align <= 0 || e[g][pos[g]].pos <= lo + align);
             emit(step, g, take ? &e[g][pos[g]] : nullptr, window);
             pos[g] += take;
         }
@@ -272,7 +274,7 @@ int64_t gn_schedule(const std::vector<G2Ent>* e, int NG, int32_t align, Emit emi
 }
 
 int gn_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles, int32_t align, int NG,
-             int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
+             const uint32_t* warp, int32_t wshift, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
     if (M < 0 || (M > 0 && (!rowptr || !col)) || !ntiles || !nentries || !nfix || !nslots || (NG != 2 && NG != 4))
         return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: bad argument");
     if (T <= 0) T = default_t(rowptr, M);
@@ -288,7 +290,7 @@ int gn_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, in
     std::vector<std::pair<int32_t, float>> rowbuf;
     int64_t entries = 0;
     for (int64_t t = 0; t < L.ntiles; t++) {
-        for (int g = 0; g < NG; g++) g2_bin(L, rowptr, col, nullptr, NG * t + g, e[g], rowbuf);
+        for (int g = 0; g < NG; g++) g2_bin(L, rowptr, col, nullptr, NG * t + g, e[g], rowbuf, warp, wshift);
         entries += NG * gn_schedule(e, NG, align, [](int64_t, int, const G2Ent*, int64_t) {});
     }
     *ntiles = L.ntiles; *nentries = entries; *nfix = f; *nslots = sl;
@@ -296,8 +298,8 @@ int gn_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, in
 }
 
 int gn_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T, int32_t round_tiles,
-            int32_t align, int NG, int64_t* tile_ptr, int32_t* colrow, float* valout, int32_t* tile_rows,
-            int32_t* tile_slots, sgcn_fix_t* fix) {
+            int32_t align, int NG, const uint32_t* warp, int32_t wshift, int64_t* tile_ptr, int32_t* colrow, float* valout,
+            int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
     if (M < 0 || (M > 0 && (!rowptr || !col || !val || !tile_ptr || !tile_rows || !tile_slots)) || (NG != 2 && NG != 4))
         return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: bad argument");
     if (T <= 0) T = default_t(rowptr, M);
@@ -330,7 +332,7 @@ int gn_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t
                 tile_rows[slot_idx] = vr.row;
                 tile_slots[slot_idx] = vr.npieces > 1 ? first_slot[vr.row] + vr.piece : -1;
             }
-            g2_bin(L, rowptr, col, val, NG * t + g, e[g], rowbuf);
+            g2_bin(L, rowptr, col, val, NG * t + g, e[g], rowbuf, warp, wshift);
         }
         // a pad gathers from the column the wave's slowest bin is at: inside the L2 window, never applied
         gn_schedule(e, NG, align, [&](int64_t, int, const G2Ent* en, int64_t window) {
@@ -362,16 +364,21 @@ int gn_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t
 extern "C" {
 
 int sgcn_csplang_count(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t T, int32_t round_tiles,
-                       int32_t align, int32_t ngroups, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
+                       int32_t align, int32_t ngroups, const uint32_t* host_warp, int32_t warp_shift,
+                       int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots) {
     if (ngroups != 2 && ngroups != 4) return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: two or four lane groups per wavefront");
-    return gn_count(rowptr, col, M, T, round_tiles, align, ngroups, ntiles, nentries, nfix, nslots);
+    if (host_warp && (warp_shift < 0 || warp_shift > 27)) return sgcn::fail(SGCN_ERR_INVALID, "csplang_count: bad warp_shift");
+    return gn_count(rowptr, col, M, T, round_tiles, align, ngroups, host_warp, warp_shift, ntiles, nentries, nfix, nslots);
 }
 
 int sgcn_csplang_fill(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t T,
-                      int32_t round_tiles, int32_t align, int32_t ngroups, int64_t* tile_ptr, int32_t* colrow,
+                      int32_t round_tiles, int32_t align, int32_t ngroups, const uint32_t* host_warp, int32_t warp_shift,
+                      int64_t* tile_ptr, int32_t* colrow,
                       float* valout, int32_t* tile_rows, int32_t* tile_slots, sgcn_fix_t* fix) {
     if (ngroups != 2 && ngroups != 4) return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: two or four lane groups per wavefront");
-    return gn_fill(rowptr, col, val, M, T, round_tiles, align, ngroups, tile_ptr, colrow, valout, tile_rows, tile_slots, fix);
+    if (host_warp && (warp_shift < 0 || warp_shift > 27)) return sgcn::fail(SGCN_ERR_INVALID, "csplang_fill: bad warp_shift");
+    return gn_fill(rowptr, col, val, M, T, round_tiles, align, ngroups, host_warp, warp_shift, tile_ptr, colrow, valout, tile_rows,
+                   tile_slots, fix);
 }
 
 // Graph-only locality labelling: asynchronous label propagation (Raghavan et al. 2007) on the

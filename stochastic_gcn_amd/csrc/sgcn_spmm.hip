@@ -42,6 +42,7 @@ int g_tune_step_fuse = 127;           // bit 0: the output layer's forward as th
                                      // layer as the pre-layer of the loss kernel's head, bit 5: the weight gradients' reductions in the
                                      // optimizer's launch, bit 6: the first layer's LayerNorm backward behind the second layer's row pass
 int g_tune_cs_g2_wide = 0;
+int g_tune_cs_nowarp = 0;            // experiments: ignore a plan's warp table (the sweep clock linear in the column id)
 int g_tune_cs_last_pct = 80;          // (round 4: 80 % holds the lock-step on the 90-column pass of d = 602: 3.16 vs 3.22 ms at 90, 3.43 at 70)
 int g_tune_gemm_min_steps = 0;
 int g_tune_lds_wave_bias = 100;    // LDS plan: entries of a tile's waves 0-3 per 100 of its waves 4-7 (100: even; made moot by the s_setprio around the update chain)
@@ -65,6 +66,7 @@ int tune_get(const char* key) {
     if (!strcmp(key, "step_overlap")) return tl_step_overlap >= 0 ? tl_step_overlap : g_tune_step_overlap;
     if (!strcmp(key, "step_fuse")) return tl_step_fuse >= 0 ? tl_step_fuse : g_tune_step_fuse;
     if (!strcmp(key, "cs_g2_wide")) return g_tune_cs_g2_wide;
+    if (!strcmp(key, "cs_nowarp")) return g_tune_cs_nowarp;
     if (!strcmp(key, "cs_last_pct")) return g_tune_cs_last_pct;
     if (!strcmp(key, "gemm_min_steps")) return g_tune_gemm_min_steps;
     if (!strcmp(key, "lds_wave_bias")) return g_tune_lds_wave_bias;
@@ -297,6 +299,7 @@ extern "C" int sgcn_tune(const char* key, int64_t value) {
     if (!strcmp(key, "step_overlap")) { g_tune_step_overlap = value != 0; return SGCN_OK; }
     if (!strcmp(key, "step_fuse")) { SGCN_REQUIRE(value >= 0 && value <= 127, "step_fuse in 0..127"); g_tune_step_fuse = (int)value; return SGCN_OK; }
     if (!strcmp(key, "cs_g2_wide")) { g_tune_cs_g2_wide = value != 0; return SGCN_OK; }
+    if (!strcmp(key, "cs_nowarp")) { g_tune_cs_nowarp = value != 0; return SGCN_OK; }
     if (!strcmp(key, "gemm_min_steps")) { g_tune_gemm_min_steps = (int)value; return SGCN_OK; }
     if (!strcmp(key, "lds_wave_bias")) { SGCN_REQUIRE(value >= 50 && value <= 300, "lds_wave_bias in 50..300 (per cent)"); g_tune_lds_wave_bias = (int)value; return SGCN_OK; }
     if (!strcmp(key, "lds_mix")) { g_tune_lds_mix = value != 0; return SGCN_OK; }

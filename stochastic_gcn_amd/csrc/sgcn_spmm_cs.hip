@@ -56,7 +56,20 @@ struct CsArgs {
     float cols_per_tick;   // pacing: columns the sweep may advance per 100 MHz tick (0 = unpaced)
     float slack_cols;      // how far ahead of the clock a wave may run
     int32_t xcd_map;       // consecutive tiles of the launch on the same XCD (grouped plans)
+    const uint32_t* warp;  // sweep position of column bucket (col >> warp_shift), in [0, K): the clock runs in WORK
+    int32_t warp_shift;    // coordinates (plan->dev_warp; null: positions are the column ids themselves)
 };
+
+// The sweep clock in work coordinates.  A clock that is linear in the COLUMN ID holds the lock-step only if the nonzeros are
+// spread evenly over the column ids (S-Reddit: hubs carry random ids).  Where they are not -- R-MAT: a third of the nonzeros
+// sit in the first sixteenth of the ids -- every wave falls behind such a clock in the dense ranges and free-runs, i.e. the
+// sweep is unpaced exactly where the sharing is to be had.  With a warp table the position of a column is the share of the
+// matrix's nonzeros that lie in front of its bucket (scaled to [0, K), so pace and slack keep their units): one scalar load
+// per batch of gathers, issued a batch ahead like the clock read, from a table of at most 64 KiB (scalar cache / L2).
+typedef const __attribute__((address_space(4))) uint32_t* cs_warp_ptr;
+__device__ __forceinline__ cs_warp_ptr cs_warp_table(const CsArgs& a) {
+    return (cs_warp_ptr)(uintptr_t)a.warp;
+}
 
 // Workgroup -> first tile of the launch.  The dispatcher deals workgroups round-robin over the 8
 // XCDs (workgroup b runs on XCD b % 8); with xcd_map the launch's tile range is cut into 8
@@ -92,7 +105,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // EXTRA every lane carries one more fp32 column next to its float4 -- a slab is 64 float4 + up to
 // 64 floats = up to 320 columns -- and d = 602 (pitch 608) is covered by TWO passes of 304.
 // Planes: x,y,z,w (+ e) of 16 registers each at v[64:127] (v[48:127] with EXTRA).
-template <int U, bool EXTRA>
+template <int U, bool EXTRA, bool WARP = false>
 __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     typedef Vec<4>::type VT;
     constexpr int kShift = 28;
@@ -121,6 +134,11 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
     // nonzeros jitters by ~N/(2 sqrt(nnz_tile)) columns, more than the window).
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     uint64_t tnow = t0;
+    // WARP: the clock in work coordinates -- a column's position is its warp table entry, looked up a batch ahead (the
+    // first batch of a block of 64 nonzeros waits for its own: one exposed scalar load per ~20 us of gathers)
+    const cs_warp_ptr wtab = cs_warp_table(a);
+    const uint32_t wshift = (uint32_t)a.warp_shift;
+    float pnext = 0.f;
     const int64_t start = a.tile_ptr[tile], end = a.tile_ptr[tile + 1];
     for (int64_t p0 = start; p0 < end; p0 += kWave) {
         const int n = (int)min((int64_t)kWave, end - p0);
@@ -165,7 +183,13 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
             // The clock read is a long-latency scalar memory op: issued right after a batch's
             // gathers, consumed before the NEXT batch (the stale reading only adds look-ahead).
             if (a.cols_per_tick > 0.f) {
-                const float mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj) & kColMask);
+                float mycol;
+                if constexpr (WARP) {
+                    if (k == 0) pnext = (float)wtab[((uint32_t)__builtin_amdgcn_readlane((int)mycr, 0) & kColMask) >> wshift];
+                    mycol = pnext;
+                } else {
+                    mycol = (float)((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj) & kColMask);
+                }
                 float allowed = (float)(tnow - t0) * a.cols_per_tick + a.slack_cols;
                 for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {   // bounded: never hangs
                     __builtin_amdgcn_s_sleep(8);
@@ -182,6 +206,10 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
                 be[u] = EXTRA ? *reinterpret_cast<const float*>(src + offe) : 0.f;
             }
             if (a.cols_per_tick > 0.f) tnow = __builtin_amdgcn_s_memrealtime();
+            if constexpr (WARP) {
+                if (a.cols_per_tick > 0.f && k + 1 < nb)
+                    pnext = (float)wtab[((uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + U) & kColMask) >> wshift];
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)mycr, jj + u);
@@ -254,12 +282,13 @@ __global__ __launch_bounds__(kBlock) void cs_spmm16_kernel(CsArgs a) {
 //  * the clock comparison is integer scalar arithmetic.
 // Requires every tile's entry count to be a multiple of 64 (the plan pads to that).  WIDE: K >= 2^24 or B beyond 4 GiB
 // -- 64-bit row offsets.
-template <int U, bool WIDE>
+template <int U, bool WIDE, bool WARP = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g2k_kernel(CsArgs a) {
     typedef Vec<4>::type VT;
     constexpr int kShift = 28;
     constexpr uint32_t kColMask = (1u << kShift) - 1u;
     constexpr int kSteps = kWave / 2;                 // steps per chunk of 64 entries
+    constexpr int kLanesPerStep = 2;
     constexpr int kBatches = kSteps / U;
     static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
     const int lane = threadIdx.x & 63;
@@ -328,6 +357,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
         }
     };
+    // WARP: the same wait on a POSITION that was looked up a batch earlier (wpos: the scalar load of the table entry of
+    // step j's first column; its latency lies under the batch that is applied in between)
+    const cs_warp_ptr wtab = cs_warp_table(a);
+    const uint32_t wshift = (uint32_t)a.warp_shift;
+    auto wpos = [&](uint32_t crs, int j) -> uint32_t {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)crs, kLanesPerStep * j) & kColMask;
+        return wtab[c >> wshift];
+    };
+    auto pace_at = [&](uint32_t pos) {
+        if (cpt16 != 0) {
+            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
+            for (int spin = 0; spin < 4096 && pos > allowed; spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
+            }
+        }
+    };
     auto gather = [&](uint32_t crs, int j) -> VT {
         const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel0 + 8 * j, (int)crs);   // my bin's column word
         if constexpr (WIDE) {
@@ -378,24 +424,32 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     entries(start + kWave, ncr, nv);
     Meta cm = meta(ccr, cv);
     VT buf[2][U];
-    pace(ccr, 0);
+    uint32_t pnext = 0;                             // WARP: position of the next batch's first column
+    if constexpr (WARP) { if (cpt16 != 0) pace_at(wpos(ccr, 0)); } else pace(ccr, 0);
 #pragma unroll
     for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
     if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if constexpr (WARP) { if (cpt16 != 0) pnext = wpos(ccr, U); }
     for (int64_t p0 = start; p0 < end; p0 += kWave) {
         static_for<kBatches>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             // batch k+1 goes in flight (the first batch of the NEXT chunk after this chunk's last) ...
             if constexpr (k + 1 < kBatches) {
-                pace(ccr, (k + 1) * U);
+                if constexpr (WARP) pace_at(pnext); else pace(ccr, (k + 1) * U);
 #pragma unroll
                 for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
             } else {
-                pace(ncr, 0);
+                if constexpr (WARP) pace_at(pnext); else pace(ncr, 0);
 #pragma unroll
                 for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
             }
             if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            if constexpr (WARP) {                  // batch k + 2's position: asked for now, waited on in the next iteration
+                if (cpt16 != 0) {
+                    if constexpr (k + 2 < kBatches) pnext = wpos(ccr, (k + 2) * U);
+                    else pnext = wpos(ncr, (k + 2 - kBatches) * U);
+                }
+            }
             // ... while batch k is applied
             static_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -441,12 +495,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 // passes.  Same structure as cs_spmm16g2k_kernel otherwise (entry l of a chunk: step l / 4, bin l % 4; the accumulator
 // offsets of a step are the four bytes of ONE scalar).  The unpacked round-2 form of this kernel was instruction-bound at
 // 4.4 ms (profiles/HISTORY.md 3.1b).
-template <int U, bool WIDE>
+template <int U, bool WIDE, bool WARP = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void cs_spmm16g4k_kernel(CsArgs a) {
     typedef Vec<4>::type VT;
     constexpr int kShift = 28;
     constexpr uint32_t kColMask = (1u << kShift) - 1u;
     constexpr int kSteps = kWave / 4;                 // steps per chunk of 64 entries
+    constexpr int kLanesPerStep = 4;
     constexpr int kBatches = kSteps / U;
     static_assert(kBatches % 2 == 0, "the two buffers alternate evenly over a chunk");
     const int lane = threadIdx.x & 63;
@@ -505,6 +560,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const uint32_t mycol = (uint32_t)__builtin_amdgcn_readlane((int)crs, 4 * j) & kColMask;
             uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
             for (int spin = 0; spin < 4096 && mycol > allowed; spin++) {
+                __builtin_amdgcn_s_sleep(8);
+                allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
+            }
+        }
+    };
+    // WARP: the same wait on a POSITION that was looked up a batch earlier (wpos: the scalar load of the table entry of
+    // step j's first column; its latency lies under the batch that is applied in between)
+    const cs_warp_ptr wtab = cs_warp_table(a);
+    const uint32_t wshift = (uint32_t)a.warp_shift;
+    auto wpos = [&](uint32_t crs, int j) -> uint32_t {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)crs, kLanesPerStep * j) & kColMask;
+        return wtab[c >> wshift];
+    };
+    auto pace_at = [&](uint32_t pos) {
+        if (cpt16 != 0) {
+            uint32_t allowed = (uint32_t)(((uint64_t)(tnow - t0) * cpt16) >> 16) + slack;
+            for (int spin = 0; spin < 4096 && pos > allowed; spin++) {
                 __builtin_amdgcn_s_sleep(8);
                 allowed = (uint32_t)(((uint64_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) * cpt16) >> 16) + slack;
             }
@@ -571,23 +643,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     entries(start + kWave, ncr, nv);
     Meta cm = meta(ccr, cv);
     VT buf[2][U];
-    pace(ccr, 0);
+    uint32_t pnext = 0;                             // WARP: position of the next batch's first column
+    if constexpr (WARP) { if (cpt16 != 0) pace_at(wpos(ccr, 0)); } else pace(ccr, 0);
 #pragma unroll
     for (int u = 0; u < U; u++) buf[0][u] = gather(ccr, u);
     if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if constexpr (WARP) { if (cpt16 != 0) pnext = wpos(ccr, U); }
     for (int64_t p0 = start; p0 < end; p0 += kWave) {
         static_for<kBatches>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             if constexpr (k + 1 < kBatches) {
-                pace(ccr, (k + 1) * U);
+                if constexpr (WARP) pace_at(pnext); else pace(ccr, (k + 1) * U);
 #pragma unroll
                 for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ccr, (k + 1) * U + u);
             } else {
-                pace(ncr, 0);
+                if constexpr (WARP) pace_at(pnext); else pace(ncr, 0);
 #pragma unroll
                 for (int u = 0; u < U; u++) buf[(k + 1) & 1][u] = gather(ncr, u);
             }
             if (cpt16 != 0) tnow = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            if constexpr (WARP) {                  // batch k + 2's position: asked for now, waited on in the next iteration
+                if (cpt16 != 0) {
+                    if constexpr (k + 2 < kBatches) pnext = wpos(ccr, (k + 2) * U);
+                    else pnext = wpos(ncr, (k + 2 - kBatches) * U);
+                }
+            }
             static_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 fma4(cm, cv, std::integral_constant<int, k * U + u>{}, buf[k & 1][u]);
@@ -743,6 +823,9 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     a.C = C; a.ldc = ldc; a.beta = beta; a.d = d; a.nvec = (d + VW - 1) / VW;
     a.ws = plan->dev_ws; a.ldw = ((int64_t)d + 3) / 4 * 4;
     a.xcd_map = plan->xcd_map;
+    a.warp = tune_get("cs_nowarp") <= 0 && !gidx ? plan->dev_warp : nullptr;
+    a.warp_shift = plan->warp_shift;
+    SGCN_REQUIRE(!a.warp || (plan->warp_shift >= 0 && plan->warp_shift < 28), "spmm_cs: bad warp_shift");
     SGCN_REQUIRE((plan->G != 2 && plan->G != 4) || ldb * 4 < (1ll << 32), "spmm_cs: row pitch of B must fit 32 bits");
     if (plan->nfix > 0) {
         SGCN_REQUIRE(plan->dev_fix && plan->dev_ws && plan->ws_elems >= plan->nslots * a.ldw,
@@ -779,22 +862,33 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
                 a.cols_per_tick = (float)((double)K / (launch_ns / 10.0));   // 100 MHz: 10 ns per tick
             }
             const unsigned blocks = (unsigned)((a.tile_end - t0 + 3) / 4);
-#define SGCN_CS16(UU, EE) hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE>), dim3(blocks), dim3(kBlock), 0, st, a)
+#define SGCN_CS16(UU, EE)                                                                                              \
+            do {                                                                                                        \
+                if (a.warp != nullptr && a.cols_per_tick > 0.f)                                                         \
+                    hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE, true>), dim3(blocks), dim3(kBlock), 0, st, a);         \
+                else hipLaunchKernelGGL((cs_spmm16_kernel<UU, EE, false>), dim3(blocks), dim3(kBlock), 0, st, a);       \
+            } while (0)
+            // the clock in work coordinates (plan->dev_warp): only a paced launch looks positions up
+            const bool warp = a.warp != nullptr && a.cols_per_tick > 0.f;
+#define SGCN_CSG(KERNEL, WIDE_)                                                                                         \
+            do {                                                                                                        \
+                if (warp) hipLaunchKernelGGL((KERNEL<4, WIDE_, true>), dim3(blocks), dim3(kBlock), 0, st, a);          \
+                else hipLaunchKernelGGL((KERNEL<4, WIDE_, false>), dim3(blocks), dim3(kBlock), 0, st, a);              \
+            } while (0)
             if (plan->G == 4) {
                 const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
                                   tune_get("cs_g2_wide") > 0;
-                if (wide) hipLaunchKernelGGL((cs_spmm16g4k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else hipLaunchKernelGGL((cs_spmm16g4k_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                if (wide) SGCN_CSG(cs_spmm16g4k_kernel, true); else SGCN_CSG(cs_spmm16g4k_kernel, false);
             } else if (plan->G == 2) {
                 const bool wide = K >= (1 << 24) || ldb * 4 >= (1 << 24) || (int64_t)K * ldb * 4 >= (1ll << 32) ||
                                   tune_get("cs_g2_wide") > 0;
-                if (wide) hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else hipLaunchKernelGGL((cs_spmm16g2k_kernel<4, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                if (wide) SGCN_CSG(cs_spmm16g2k_kernel, true); else SGCN_CSG(cs_spmm16g2k_kernel, false);
             } else {
                 if (extra) { if (U == 8) SGCN_CS16(8, true); else SGCN_CS16(4, true); }
                 else { if (U == 4) SGCN_CS16(4, false); else SGCN_CS16(8, false); }
             }
 #undef SGCN_CS16
+#undef SGCN_CSG
         }
     }
     SGCN_HIP_TRY(hipGetLastError());

@@ -438,10 +438,38 @@ class ColumnSweepCSR(object):
     what the clock pacing provides on a graph without structure).  Results equal the unlabelled
     plan's up to fp32 summation order."""
 
-    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align=2048):
+    WARP_BUCKETS = 16384      # the warp table's size bound (64 KiB: scalar cache / L2 resident)
+    WARP_AUTO_DEV = 0.01      # 'auto': a table is kept when some column's share of the work in front of it is off its
+                              # share of the ids by more than this (1 % of the sweep ~ a third of an L2 window)
+
+    @classmethod
+    def make_warp(cls, cols, K, mode='auto'):
+        """The sweep clock in work coordinates (include/sgcn.h sgcn_csplan_t.dev_warp): ``(table, shift)`` with
+        table[b] = share of the nonzeros in columns < (b << shift), scaled to [0, K) -- or ``(None, 0)`` when the nonzeros
+        are spread evenly enough over the column ids for the linear clock (S-Reddit: hubs carry random ids), or
+        ``mode`` is False.  R-MAT is the case it exists for: a third of the nonzeros in the first sixteenth of the ids."""
+        K = int(K)
+        if mode is False or K <= 0 or cols.shape[0] == 0:
+            return None, 0
+        shift = 0
+        while ((K - 1) >> shift) + 1 > cls.WARP_BUCKETS:
+            shift += 1
+        nb = ((K - 1) >> shift) + 1
+        hist = np.bincount(np.asarray(cols, dtype=np.int64) >> shift, minlength=nb)[:nb]
+        before = np.concatenate([[0], np.cumsum(hist)[:-1]]).astype(np.float64)
+        share = before / float(hist.sum())
+        if mode == 'auto':
+            ids = (np.arange(nb, dtype=np.float64) * (1 << shift)) / K
+            if np.abs(share - ids).max() <= cls.WARP_AUTO_DEV:
+                return None, 0
+        table = np.minimum(np.floor(share * K), K - 1).astype(np.uint32)
+        return table, shift
+
+    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align='auto', warp='auto'):
         """G = 2: two 16-row lane groups per wavefront on 128-column passes (sgcn_csplang_*), half the passes of
         the dense operand through every XCD per register byte; ``align``: columns one bin of a wave may run ahead
-        of the slowest (the plan pads the bins that are ahead).  What ``choose_g(d)`` picks for most widths -- the
+        of the slowest (the plan pads the bins that are ahead; 'auto': a third of the L2 window, ``auto_align``; with a
+        warp table -- ``warp``, ``make_warp`` -- it counts sweep positions).  What ``choose_g(d)`` picks for most widths -- the
         bench and the training path call it: S-Reddit d = 602 3.51 vs 3.67 ms sustained, S-RMAT d = 256 2.61 vs
         2.82 ms.  G = 4 (four groups, 64-column passes, every row of a 233 k-row graph resident in one round): instruction-
         bound on a full graph (3.75 ms on S-Reddit; its gathers alone 3.21: DESIGN.md 3.2), but the better sweep for a SPARSE
@@ -455,7 +483,7 @@ class ColumnSweepCSR(object):
         if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
                 raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
-            self._init_g2(a, device, T, round_tiles, int(align))
+            self._init_g2(a, device, T, round_tiles, align, warp)
             return
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
@@ -503,8 +531,25 @@ class ColumnSweepCSR(object):
         self.fix = to(fix) if nfix.value else None
         self.ws, self.device = None, device
         self.nnz = int(col.shape[0])
+        # the clock's coordinates (grouped plans run unpaced: no table)
+        wtab, self.warp_shift = (None, 0) if self.grouped else self.make_warp(col, self.shape[1], warp)
+        self.warp = None if wtab is None else torch.from_numpy(wtab.view(np.int32)).to(device)
 
-    def _init_g2(self, a, device, T, round_tiles, align):
+    @staticmethod
+    def auto_align(K, nnz, M, G, rnd, d_piece_bytes=None):
+        """How far (in sweep positions) one bin of a wave may run ahead of the slowest: a third of the L2 window.  An
+        XCD's 4 MiB hold 4 MiB / piece bytes of B (8,192 pieces of a 128-column pass); the window is that share of the
+        nonzeros an XCD gathers in one round of resident tiles, in positions.  S-Reddit: 1,300 positions -> the measured
+        default of 2,048 stays; a sparse block of a large graph (S-RMAT 10 M: 24.6 M nonzeros over 10 M columns in ten
+        rounds) gets ~90,000 -- aligned to 2,048 COLUMNS its bins were mostly pads."""
+        piece = d_piece_bytes or (512 if G == 2 else 256)
+        rows_round = max(rnd * 16 * G, 1)
+        rounds = max(-(-int(M) // rows_round), 1)
+        nnz_xcd_round = max(int(nnz) / rounds / 8.0, 1.0)
+        window = float(K) * ((4 << 20) / piece) / nnz_xcd_round
+        return int(max(2048, min(0.35 * window, K / 8.0)))
+
+    def _init_g2(self, a, device, T, round_tiles, align, warp='auto'):
         """G = 2 / 4 lane groups per wavefront (sgcn_csplang_*)"""
         G = self.G
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
@@ -512,16 +557,24 @@ class ColumnSweepCSR(object):
         val = np.ascontiguousarray(a.data, dtype=np.float32)
         M = rowptr.shape[0] - 1
         rnd = int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))
+        self.shape = (int(a.shape[0]), int(a.shape[1]))
+        # the clock's coordinates first: the bins of a wave are aligned in them
+        wtab, self.warp_shift = self.make_warp(col, self.shape[1], warp)
+        self.warp = None if wtab is None else torch.from_numpy(wtab.view(np.int32)).to(device)
+        wp = wtab.ctypes.data if wtab is not None else None
+        if align is None or align == 'auto':
+            align = self.auto_align(self.shape[1], col.shape[0], M, G, rnd)
+        self.align = align = int(align)
         nt, ne, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, T, rnd, align, G, C.byref(nt), C.byref(ne),
-                                     C.byref(nfix), C.byref(nslots)))
+        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, T, rnd, align, G, wp, self.warp_shift,
+                                     C.byref(nt), C.byref(ne), C.byref(nfix), C.byref(nslots)))
         tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
         colrow = np.empty(ne.value, dtype=np.int32)
         valout = np.empty(ne.value, dtype=np.float32)
         tile_rows = np.empty(nt.value * 16 * G, dtype=np.int32)
         tile_slots = np.empty(nt.value * 16 * G, dtype=np.int32)
         fix = np.empty((nfix.value, 3), dtype=np.int32)
-        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, T, rnd, align, G,
+        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, T, rnd, align, G, wp, self.warp_shift,
                                     tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data, tile_rows.ctypes.data,
                                     tile_slots.ctypes.data, fix.ctypes.data if nfix.value else None))
         self.pad_fraction = 1.0 - col.shape[0] / max(ne.value, 1)
@@ -553,14 +606,19 @@ class ColumnSweepCSR(object):
         return "%dx%d:%d:%08x" % (a.shape[0], a.shape[1], a.nnz, crc)
 
     @staticmethod
-    def choose_g(d, avg_degree=None):
-        """1 or 2 lane groups per wavefront for operands of width d: a G = 2 launch is ~0.73 of a G = 1 launch
+    def choose_g(d, avg_degree=None, rows=None):
+        """1, 2 or 4 lane groups per wavefront for operands of width d: a G = 2 launch is ~0.73 of a G = 1 launch
         (measured on S-Reddit: 0.323 ms with the packed-FMA kernel vs 0.445 ms) and a plan needs half the rounds of resident tiles, but
         ceil(d / 128) passes over the feature dimension instead of ceil(d / 320).  What two groups buy is fewer
         fabric misses; a graph dense enough to hit the L2 anyway (S-Reddit-114M, average degree 490: 15.1 vs
-        14.7 ms) keeps one group."""
+        14.7 ms) keeps one group.  A SPARSE matrix with more rows than one round of two-group tiles holds (a GPU's block of
+        S-RMAT 10 M / 200 M: 1.05 M rows of 23 nonzeros) takes four: twice the rows -- and nonzeros -- per sweep of B, which
+        is what its L2 hits come from (3.16 against 3.49 ms, profiles/r43_warp_probe.jsonl; the same rule as the LDS
+        plan's residual)."""
         if avg_degree is not None and avg_degree > 300:
             return 1
+        if avg_degree is not None and avg_degree <= 40 and rows is not None and rows > 4096 * 32:
+            return 4
         dp = (int(d) + 3) // 4 * 4
         return 2 if -(-dp // 128) * 0.73 <= -(-dp // 320) * 2 else 1
 
@@ -577,7 +635,9 @@ class ColumnSweepCSR(object):
                     # the product's time at that pace: what the lost-lock guard compares against (a pace without it
                     # -- a file of an older build -- is not restored: the guard could not watch it)
                     tuned_ms=np.array([[d, self.tuned_ms[d]] for d in sorted(self.pace) if d in self.tuned_ms],
-                                      np.float64).reshape(-1, 2))
+                                      np.float64).reshape(-1, 2),
+                    warp=t(self.warp) if getattr(self, 'warp', None) is not None else np.zeros(0, np.int32),
+                    warp_shift=int(getattr(self, 'warp_shift', 0)))
         import os
         import tempfile
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
@@ -636,6 +696,9 @@ class ColumnSweepCSR(object):
         self.fix = to(z["fix"]) if self.nfix else None
         self.ws, self.device = None, device
         self.nnz = int(z["colrow"].shape[0])
+        self.warp, self.warp_shift = None, 0
+        if "warp" in z.files and z["warp"].shape[0]:
+            self.warp, self.warp_shift = to(z["warp"]), int(z["warp_shift"])
         return self
 
     @classmethod
@@ -645,7 +708,7 @@ class ColumnSweepCSR(object):
         if path is None:
             return cls(a, device, G=G), False
         # the identity of the matrix AND of the build parameters the plan depends on (tiles per launch round)
-        key = "%s:r%d:T0:a2048" % (cls.matrix_key(a), int(_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))   # cached() builds with the default T / align
+        key = "%s:r%d:T0:a2048:w1" % (cls.matrix_key(a), int(_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))   # cached() builds with the default T / align
         hit = cls.load(path, device, key, g=G)
         if hit is not None:
             return hit, True
@@ -679,7 +742,7 @@ class ColumnSweepCSR(object):
                            _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
                            0 if self.ws is None else self.ws.numel(), rnd, self._hint.ctypes.data,
                            -1 if self.grouped else int(self.pace.get(d, 0)), int(getattr(self, 'G', 1)),
-                           1 if self.grouped else 0)
+                           1 if self.grouped else 0, _ptr(getattr(self, 'warp', None)), int(getattr(self, 'warp_shift', 0)))
 
     def variant(self, d):
         """The kernel variant / launch geometry sgcn_spmm_cs_f32 uses for this plan and width."""
@@ -722,6 +785,14 @@ class ColumnSweepCSR(object):
         for p in candidates:
             t = timed(p)
             if best is None or t < best[0]:
+                best = (t, p)
+        # a winner at the slow end of the list: the optimum may lie beyond it (sparse blocks of large graphs, whose steps
+        # mostly miss the L2: S-RMAT 10 M, 360 - 400 ns per step) -- keep slowing the clock while that pays
+        while refine and best[1] > 0 and best[1] == max(candidates) and best[1] < 2000:
+            p = int(best[1] * 1.15)
+            candidates = tuple(candidates) + (p,)
+            t = timed(p)
+            if t < best[0]:
                 best = (t, p)
         if refine and best[1] > 0:
             # The optimum sits right above a cliff (too fast a clock and the waves lose the lock-step for good),

@@ -214,9 +214,10 @@ class ShardedSpMM(object):
         layer activation sharded like C: the ranks all-gather their row blocks first
         (xGMI-bound for large operands; bench.py reports both variants)."""
 
-    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None, G=None):
+    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None, G=None, plan_kw=None):
         """d: width of the dense operand, when known up front -- picks the sweep's lane-group count for it
-        (ops.ColumnSweepCSR.choose_g); None: one group per wavefront.  G: that count given outright."""
+        (ops.ColumnSweepCSR.choose_g); None: one group per wavefront.  G: that count given outright.  plan_kw: further
+        arguments of the blocks' ops.ColumnSweepCSR plans (align, warp)."""
         from . import ops
         adj = adj.tocsr()
         if adj.shape[0] != adj.shape[1]:
@@ -237,9 +238,10 @@ class ShardedSpMM(object):
             pass                                   # partition + collectives alone (kernel=None: the CPU dry run of bench.py)
         elif kernel == "cs":
             if G is None:
-                G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1)) if d else 1
-            self.A = ops.ColumnSweepCSR(blk, device, G=G)
-            self.AT = ops.ColumnSweepCSR(blk_t, device, G=G) if with_transpose else None
+                G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1), blk.shape[0]) if d else 1
+            kw = dict(plan_kw or {}) if G != 1 else {}
+            self.A = ops.ColumnSweepCSR(blk, device, G=G, **kw)
+            self.AT = ops.ColumnSweepCSR(blk_t, device, G=G, **kw) if with_transpose else None
             self._mm = ops.spmm_cs
         else:
             self.A = ops.DeviceCSR.from_scipy(blk, device)

@@ -98,7 +98,7 @@ def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats
                 stats.append(dict(plan_from_cache=False, pace=None, kernel=L.variant(d)))
             out.append(ops.spmm_lds(L, X).contiguous())
             continue
-        A, hit = ops.ColumnSweepCSR.cached(a, device, path, G=ops.ColumnSweepCSR.choose_g(d, a.nnz / max(a.shape[0], 1)))
+        A, hit = ops.ColumnSweepCSR.cached(a, device, path, G=ops.ColumnSweepCSR.choose_g(d, a.nnz / max(a.shape[0], 1), a.shape[0]))
         if d not in A.pace:
             A.autotune(X)               # once per plan and width; stored with the cached plan
         A.store_if_cached()

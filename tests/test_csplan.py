@@ -114,7 +114,7 @@ def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
     M = a.shape[0]
     for rnd in (0, 8):
         nt, ne, nf, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, 64, rnd, align, 2, C.byref(nt), C.byref(ne),
+        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, 64, rnd, align, 2, None, 0, C.byref(nt), C.byref(ne),
                                      C.byref(nf), C.byref(ns)))
         if rnd:
             assert nt.value % rnd == 0
@@ -122,7 +122,7 @@ def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
         cr, vo = np.empty(ne.value, np.int32), np.empty(ne.value, np.float32)
         tr, ts = np.empty(nt.value * 32, np.int32), np.empty(nt.value * 32, np.int32)
         fx = np.empty((nf.value, 3), np.int32)
-        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, 64, rnd, align, 2, tp.ctypes.data,
+        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, 64, rnd, align, 2, None, 0, tp.ctypes.data,
                                     cr.ctypes.data, vo.ctypes.data, tr.ctypes.data, ts.ctypes.data, fx.ctypes.data))
         assert tp[-1] == ne.value and nf.value >= 1 and (np.diff(tp) % 2 == 0).all()
         u = cr.view(np.uint32)
@@ -144,3 +144,100 @@ def test_two_lane_group_plan_encodes_the_matrix_exactly(align):
                 s0, s1 = (tile == t) & (g == 0), (tile == t) & (g == 1)
                 both = real[s0] & real[s1]
                 assert (np.abs(cols[s0][both] - cols[s1][both]) <= align).all()
+
+
+def _skewed_csr(M, K, nnz, seed):
+    """columns drawn with an R-MAT-like skew: a third of the nonzeros in the first sixteenth of the ids"""
+    rng = np.random.RandomState(seed)
+    bits = max(int(np.ceil(np.log2(K))), 1)
+    c = np.zeros(nnz, np.int64)
+    for _ in range(bits):
+        c = (c << 1) | (rng.random_sample(nnz) >= 0.76)
+    c %= K
+    r = rng.randint(0, M, nnz)
+    a = sp.coo_matrix((rng.rand(nnz).astype(np.float32) + 0.1, (r, c)), shape=(M, K)).tocsr()
+    a.sort_indices()
+    return a
+
+
+def test_warp_table_is_the_cumulative_share_of_the_work():
+    """ops.ColumnSweepCSR.make_warp: entry b = share of the nonzeros in columns < b << shift, scaled to [0, K); 'auto' keeps
+    the linear clock for evenly spread columns and builds a table for skewed ones; the table never exceeds its bound."""
+    from stochastic_gcn_amd import ops
+    a = _skewed_csr(3000, 70000, 400000, 1)
+    tab, sh = ops.ColumnSweepCSR.make_warp(a.indices, a.shape[1])
+    assert tab is not None and tab.dtype == np.uint32
+    nb = ((a.shape[1] - 1) >> sh) + 1
+    assert tab.shape[0] == nb <= ops.ColumnSweepCSR.WARP_BUCKETS < 2 * nb
+    assert tab[0] == 0 and (np.diff(tab.astype(np.int64)) >= 0).all() and tab[-1] < a.shape[1]
+    hist = np.bincount(a.indices >> sh, minlength=nb)
+    before = np.concatenate([[0], np.cumsum(hist)[:-1]])
+    np.testing.assert_array_equal(tab, np.minimum(np.floor(before / a.nnz * a.shape[1]), a.shape[1] - 1).astype(np.uint32))
+    assert tab[nb // 16] > 0.2 * a.shape[1]                   # the skew: the first sixteenth of the ids is > 20 % of the sweep
+    rng = np.random.RandomState(0)
+    even = rng.randint(0, 70000, 400000)
+    assert ops.ColumnSweepCSR.make_warp(even, 70000) == (None, 0)
+    assert ops.ColumnSweepCSR.make_warp(even, 70000, True)[0] is not None
+    assert ops.ColumnSweepCSR.make_warp(a.indices, a.shape[1], False) == (None, 0)
+    assert ops.ColumnSweepCSR.make_warp(np.zeros(0, np.int32), 10) == (None, 0)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_lane_group_plan_aligns_its_bins_in_sweep_positions(G):
+    """sgcn_csplang_* with a warp table: the plan still encodes the matrix exactly (every nonzero once, in its row, columns
+    ascending per bin), pads gather from a column of the tile, and the bins of a tile stay within `align` POSITIONS -- with
+    far fewer pads than the same bound in column ids costs on a skewed matrix."""
+    from stochastic_gcn_amd import ops
+    a = _skewed_csr(2000, 60000, 60000, 2)
+    rowptr = np.ascontiguousarray(a.indptr, np.int32)
+    col, val = np.ascontiguousarray(a.indices, np.int32), np.ascontiguousarray(a.data, np.float32)
+    M, K = a.shape
+    tab, sh = ops.ColumnSweepCSR.make_warp(col, K, True)
+    align = 3000
+
+    def build(warp):
+        wp = tab.ctypes.data if warp else None
+        nt, ne, nf, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, 0, 0, align, G, wp, sh, C.byref(nt), C.byref(ne),
+                                     C.byref(nf), C.byref(ns)))
+        tp = np.empty(nt.value + 1, np.int64)
+        cr, vo = np.empty(ne.value, np.int32), np.empty(ne.value, np.float32)
+        tr, ts = np.empty(nt.value * 16 * G, np.int32), np.empty(nt.value * 16 * G, np.int32)
+        fx = np.empty((max(nf.value, 1), 3), np.int32)
+        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, 0, 0, align, G, wp, sh,
+                                    tp.ctypes.data, cr.ctypes.data, vo.ctypes.data, tr.ctypes.data, ts.ctypes.data, fx.ctypes.data))
+        return nt.value, ne.value, tp, cr.view(np.uint32), vo, tr
+
+    nt, ne, tp, u, vo, tr = build(True)
+    real = vo.view(np.uint32) != 0x80000000
+    assert real.sum() == a.nnz
+    e = np.arange(ne)
+    tile = np.repeat(np.arange(nt), np.diff(tp))
+    g = (e - tp[tile]) % G
+    cols = (u & 0x0FFFFFFF).astype(np.int64)
+    rows = tr[tile * 16 * G + g * 16 + (u >> 28).astype(np.int64)]
+    got = sp.coo_matrix((vo[real], (rows[real], cols[real])), shape=a.shape).tocsr()
+    got.sort_indices()
+    assert (got != a).nnz == 0
+    pos = tab[cols >> sh].astype(np.int64)
+    for t in range(nt):
+        sl = slice(tp[t], tp[t + 1])
+        steps = (e[sl] - tp[t]) // G
+        for b in range(G):
+            m = real[sl] & (g[sl] == b)
+            assert (np.diff(cols[sl][m]) >= 0).all()
+        # within a step, the entries that are applied lie within `align` positions of the slowest bin's
+        p_t, r_t = pos[sl], real[sl]
+        lo = np.full(steps.max() + 1, np.iinfo(np.int64).max)
+        np.minimum.at(lo, steps[r_t], p_t[r_t])
+        assert (p_t[r_t] <= lo[steps[r_t]] + align).all()
+    ne_cols = build(False)[1]
+    assert ne < ne_cols                                       # the same bound in column ids pads more
+
+
+def test_auto_align_is_a_third_of_the_l2_window():
+    from stochastic_gcn_amd import ops
+    f = ops.ColumnSweepCSR.auto_align
+    assert f(232965, 23173306, 232965, 2, 4096) == 2048       # S-Reddit: the measured default stays
+    assert 60000 < f(10_000_000, 24_613_381, 1_053_273, 2, 4096) < 120000      # one GPU's block of S-RMAT 10 M
+    assert f(1000, 10, 50, 2, 4096) <= max(2048, 1000 // 8) and f(1000, 10, 50, 2, 4096) >= 2048

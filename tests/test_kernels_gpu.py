@@ -414,6 +414,66 @@ def test_four_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad):
     test_two_lane_group_column_sweep_vs_oracle(dev, M, K, d, pad, G=4)
 
 
+@pytest.mark.parametrize("G", [1, 2, 4])
+@pytest.mark.parametrize("d,pad", [(256, 0), (602, 6), (40, 0)])
+def test_column_sweep_clock_in_work_coordinates(dev, G, d, pad):
+    """A matrix whose nonzeros are NOT spread evenly over the column ids (R-MAT-like skew): the plan carries a warp table
+    (sgcn_csplan_t.dev_warp), the bins of a wave are aligned in positions, the paced kernels look positions up -- and the
+    product is the oracle's, bit-identical at every pace and with the table ignored (pacing is timing only)."""
+    from stochastic_gcn_amd import ops
+    from stochastic_gcn_amd._ffi import lib
+    from test_csplan import _skewed_csr
+    M, K = 6000, 50000
+    a = _skewed_csr(M, K, 150000, 7 + G)
+    a = sp.vstack([a[:M - 1], sp.csr_matrix(np.ones((1, K), np.float32))]).tocsr()       # + one row that must be split
+    a.sort_indices()
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((K, d + pad)).astype(np.float32)
+    A = ops.ColumnSweepCSR(a, dev, G=G, T=4096)
+    assert A.warp is not None and A.warp.numel() == ((K - 1) >> A.warp_shift) + 1 and A.nfix >= 1
+    Alin = ops.ColumnSweepCSR(a, dev, G=G, T=4096, warp=False, align=getattr(A, 'align', 2048))
+    assert Alin.warp is None
+    Bd = T(B, dev)[:, :d]
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    outs = []
+    for p in (-1, 60, 150, 400, 2000):                        # unpaced, too fast, plausible, slow: the same bits
+        A.pace[d] = p
+        outs.append(ops.spmm_cs(A, Bd))
+        assert onp.rel_err(outs[-1].cpu().numpy(), ref) <= TOL
+        assert torch.equal(outs[-1], outs[0])
+    try:                                                       # the table ignored: the linear clock on the same plan
+        lib.sgcn_tune(b"cs_nowarp", 1)
+        assert torch.equal(ops.spmm_cs(A, Bd), outs[0])
+    finally:
+        lib.sgcn_tune(b"cs_nowarp", 0)
+    Alin.pace[d] = 150
+    assert onp.rel_err(ops.spmm_cs(Alin, Bd).cpu().numpy(), ref) <= TOL
+    # fusions on the warped plan
+    rs, cs = rng.rand(M).astype(np.float32), rng.rand(K).astype(np.float32)
+    c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
+    o2 = T(c0, dev)
+    A.pace[d] = 150
+    ops.spmm_cs(A, Bd, out=o2[:, :d], rscale=T(rs, dev), cscale=T(cs, dev), beta=0.5)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, B[:, :d], rscale=rs, cscale=cs, C_in=c0[:, :d], beta=0.5)
+    assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
+    if pad:
+        np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
+
+
+def test_column_sweep_plan_cache_keeps_the_warp_table(dev, tmp_path):
+    from stochastic_gcn_amd import ops
+    from test_csplan import _skewed_csr
+    a = _skewed_csr(3000, 40000, 90000, 3)
+    path = str(tmp_path / "plan.npz")
+    A, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=2)
+    assert not hit and A.warp is not None
+    A.store_if_cached()
+    A2, hit = ops.ColumnSweepCSR.cached(a, dev, path, G=2)
+    assert hit and A2.warp is not None and A2.warp_shift == A.warp_shift and torch.equal(A2.warp, A.warp)
+    B = torch.randn((40000, 64), device=dev)
+    assert torch.equal(ops.spmm_cs(A, B), ops.spmm_cs(A2, B))
+
+
 def test_two_lane_group_full_size_vs_oracle_rows(dev):
     from stochastic_gcn_amd import ops, synthetic
     n, _, full_adj, *_ = synthetic.reddit_like(with_features=False)
