@@ -74,6 +74,8 @@ def parse(argv=None):
     p.add_argument("--colmod", type=int, default=0,
                    help="[experiment] fold column ids modulo this (makes B L2-resident: all-hit ceiling)")
     p.add_argument("--cs-align", type=int, default=-1, help="--cs-g 2 / 4: sweep positions one bin of a wave may run ahead of the slowest (-1: a third of the L2 window, ops.ColumnSweepCSR.auto_align)")
+    p.add_argument("--shard-row-weight", type=int, default=-1,
+                   help="--shard: nonzero-equivalents a row adds to its block's load (-1: parallel.ShardedSpMM.ROW_WEIGHT)")
     p.add_argument("--cs-warp", default="auto", choices=["auto", "on", "off"],
                    help="the sweep clock in work coordinates (sgcn_csplan_t.dev_warp): auto = when the nonzeros are not spread evenly over the column ids")
     p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2, 4],
@@ -574,7 +576,8 @@ def main(argv=None):
         sh = ShardedSpMM(par, full_adj, dev, kernel="cs" if args.kernel == "lds" else args.kernel, with_transpose=not args.no_backward,
                          d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d), G=args.cs_g if args.cs_g in (2, 4) else None,
                          plan_kw=dict(align=('auto' if args.cs_align < 0 else args.cs_align),
-                                      warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]))
+                                      warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]),
+                         row_weight=None if args.shard_row_weight < 0 else args.shard_row_weight)
         A = sh.A
     elif args.kernel in ("cs", "lds"):
         comm = None

@@ -615,12 +615,13 @@ class ColumnSweepCSR(object):
         S-RMAT 10 M / 200 M: 1.05 M rows of 23 nonzeros) takes four: twice the rows -- and nonzeros -- per sweep of B, which
         is what its L2 hits come from (3.16 against 3.49 ms, profiles/r43_warp_probe.jsonl; the same rule as the LDS
         plan's residual)."""
-        if avg_degree is not None and avg_degree > 300:
-            return 1
         if avg_degree is not None and avg_degree <= 40 and rows is not None and rows > 4096 * 32:
             return 4
         dp = (int(d) + 3) // 4 * 4
-        return 2 if -(-dp // 128) * 0.73 <= -(-dp // 320) * 2 else 1
+        # (a dense graph gives two groups less of an edge: S-Reddit-114M at d = 602, five passes against two, stays with one;
+        # the hub block of S-RMAT 10 M -- 334 nonzeros per row, d = 256, two passes against one -- takes two: 2.04 vs 2.59 ms)
+        edge = 0.85 if (avg_degree is not None and avg_degree > 300) else 1.0
+        return 2 if -(-dp // 128) * 0.73 <= -(-dp // 320) * 2 * edge else 1
 
     def save(self, path, key):
         if self.grouped:

@@ -214,10 +214,16 @@ class ShardedSpMM(object):
         layer activation sharded like C: the ranks all-gather their row blocks first
         (xGMI-bound for large operands; bench.py reports both variants)."""
 
-    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None, G=None, plan_kw=None):
+    ROW_WEIGHT = 7       # a row of a block costs the column sweep what ~7 of its nonzeros do (its line of C, its share of
+                         # the rounds of resident tiles): blocks of S-RMAT 10 M with EQUAL nonzeros took 4.1 ms per fwd + bwd
+                         # (74 k hub rows) to 9.2 ms (3.7 M sparse rows); least squares over 16 blocks of two partitions:
+                         # t = 0.193 ms per M nonzeros + 1.32 ms per M rows (profiles/r43_rmat10m_blocks.json)
+
+    def __init__(self, par, adj, device, kernel="cs", with_transpose=True, d=None, G=None, plan_kw=None, row_weight=None):
         """d: width of the dense operand, when known up front -- picks the sweep's lane-group count for it
         (ops.ColumnSweepCSR.choose_g); None: one group per wavefront.  G: that count given outright.  plan_kw: further
-        arguments of the blocks' ops.ColumnSweepCSR plans (align, warp)."""
+        arguments of the blocks' ops.ColumnSweepCSR plans (align, warp).  row_weight: nonzero-equivalents a row adds to
+        its block's load (None: ROW_WEIGHT for the column sweep, 0 otherwise)."""
         from . import ops
         adj = adj.tocsr()
         if adj.shape[0] != adj.shape[1]:
@@ -226,6 +232,11 @@ class ShardedSpMM(object):
         self.shape = (int(adj.shape[0]), int(adj.shape[1]))
         adj_t = adj.T.tocsr() if with_transpose else None
         load = adj.indptr.astype(np.int64) + (adj_t.indptr.astype(np.int64) if with_transpose else 0)
+        if row_weight is None:
+            row_weight = self.ROW_WEIGHT if kernel == "cs" else 0
+        self.row_weight = int(row_weight)
+        if self.row_weight:              # (prefix sums: row r adds its nonzeros in both directions + the weight per direction)
+            load = load + np.arange(load.shape[0], dtype=np.int64) * (self.row_weight * (2 if with_transpose else 1))
         self.bounds = partition_rows_by_nnz(load, par.world)
         self.lo, self.hi = int(self.bounds[par.rank]), int(self.bounds[par.rank + 1])
         self.row_counts = [int(self.bounds[r + 1] - self.bounds[r]) for r in range(par.world)]
