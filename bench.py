@@ -575,7 +575,7 @@ def main(argv=None):
             par = types.SimpleNamespace(rank=r_, world=w_, active=False)    # no peers: no collectives
         sh = ShardedSpMM(par, full_adj, dev, kernel="cs" if args.kernel == "lds" else args.kernel, with_transpose=not args.no_backward,
                          d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d), G=args.cs_g if args.cs_g in (2, 4) else None,
-                         plan_kw=dict(align=('auto' if args.cs_align < 0 else args.cs_align),
+                         plan_kw=dict(align=('auto' if args.cs_align < 0 else args.cs_align), T=args.cs_t,
                                       warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]),
                          row_weight=None if args.shard_row_weight < 0 else args.shard_row_weight)
         A = sh.A
@@ -734,7 +734,7 @@ def main(argv=None):
             if args.kernel == "cs" else 1,
             "lds_parts_ms": lds_parts,
             "cs_plan": ({"G": int(getattr(A, "G", 1)), "align": getattr(A, "align", None),
-                         "pad_fraction": round(float(getattr(A, "pad_fraction", 0.0)), 4),
+                         "pad_fraction": round(float(getattr(A, "pad_fraction", 0.0)), 4), "T": getattr(A, "T", None),
                          "warp_table": None if getattr(A, "warp", None) is None else [int(A.warp.numel()), int(A.warp_shift)]}
                         if args.kernel == "cs" else None),
             "cs_autotune_ms_pace": tuned},

@@ -506,6 +506,9 @@ class ColumnSweepCSR(object):
             if rg.shape[0] != M:
                 raise ValueError("row_labels must have one label per row")
         rgp = rg.ctypes.data if rg is not None else None
+        if not T and not self.grouped:
+            T = self.auto_t(rowptr, 1, int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096)))
+        self.T = int(T)
         nt, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64()
         check(lib.sgcn_csplan_count(rowptr.ctypes.data, M, R, T, rgp, C.byref(nt), C.byref(nfix), C.byref(nslots)))
         tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
@@ -549,6 +552,36 @@ class ColumnSweepCSR(object):
         window = float(K) * ((4 << 20) / piece) / nnz_xcd_round
         return int(max(2048, min(0.35 * window, K / 8.0)))
 
+    @staticmethod
+    def auto_t(rowptr, G, rnd):
+        """The split threshold for a matrix that does not fill its rounds of resident tiles: rows longer than T become
+        strided virtual rows, and a block with few rows (an eighth of S-Reddit: 29 k rows against the 65 k / 131 k a round
+        holds) leaves most wavefront slots of its launches empty -- its sweep is latency-bound.  0 = the library's default
+        (4 x the mean degree, sgcn_csplan.cpp default_t) when the virtual rows it gives fill >= 3/4 of the rounds they
+        need; otherwise the smallest T >= 24 whose virtual rows fill 70 % of those rounds (an eighth of S-Reddit, one
+        group: T = 400 -> 1.34 ms per fwd + bwd, 100 -> 1.21, 61 (a full round) -> 1.25)."""
+        deg = np.diff(np.asarray(rowptr, dtype=np.int64))
+        if deg.shape[0] == 0:
+            return 0
+        avg = int(deg.sum()) // deg.shape[0]
+        t0 = int(min(512, max(64, 4 * avg)))
+        cap_round = int(rnd) * 16 * max(int(G), 1)
+
+        def vrows(t):
+            return int(np.maximum(1, -(-deg // t)).sum())
+        v0 = vrows(t0)
+        cap = -(-v0 // cap_round) * cap_round
+        if v0 >= 0.75 * cap:
+            return 0
+        lo, hi = 24, t0
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if vrows(mid) <= 0.7 * cap:
+                hi = mid
+            else:
+                lo = mid + 1
+        return lo
+
     def _init_g2(self, a, device, T, round_tiles, align, warp='auto'):
         """G = 2 / 4 lane groups per wavefront (sgcn_csplang_*)"""
         G = self.G
@@ -557,6 +590,9 @@ class ColumnSweepCSR(object):
         val = np.ascontiguousarray(a.data, dtype=np.float32)
         M = rowptr.shape[0] - 1
         rnd = int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))
+        if not T:
+            T = self.auto_t(rowptr, G, rnd)
+        self.T = int(T)
         self.shape = (int(a.shape[0]), int(a.shape[1]))
         # the clock's coordinates first: the bins of a wave are aligned in them
         wtab, self.warp_shift = self.make_warp(col, self.shape[1], warp)
@@ -621,7 +657,15 @@ class ColumnSweepCSR(object):
         # (a dense graph gives two groups less of an edge: S-Reddit-114M at d = 602, five passes against two, stays with one;
         # the hub block of S-RMAT 10 M -- 334 nonzeros per row, d = 256, two passes against one -- takes two: 2.04 vs 2.59 ms)
         edge = 0.85 if (avg_degree is not None and avg_degree > 300) else 1.0
-        return 2 if -(-dp // 128) * 0.73 <= -(-dp // 320) * 2 * edge else 1
+        # rounds of resident tiles: one group holds 65,536 rows per round, two hold 131,072 -- half the rounds for a full
+        # graph, but no fewer for a block that fits one round either way (an eighth of S-Reddit, 29 k rows, d = 602: two
+        # passes of one group 1.34 ms per fwd + bwd, five passes of two groups 1.72)
+        r1 = r2 = None
+        if rows is not None and rows > 0:
+            r1, r2 = -(-int(rows) // (4096 * 16)), -(-int(rows) // (4096 * 32))
+        if r1 is None:
+            r1, r2 = 2, 1
+        return 2 if -(-dp // 128) * 0.73 * r2 <= -(-dp // 320) * r1 * edge else 1
 
     def save(self, path, key):
         if self.grouped:

@@ -250,7 +250,9 @@ class ShardedSpMM(object):
         elif kernel == "cs":
             if G is None:
                 G = ops.ColumnSweepCSR.choose_g(d, blk.nnz / max(blk.shape[0], 1), blk.shape[0]) if d else 1
-            kw = dict(plan_kw or {}) if G != 1 else {}
+            kw = dict(plan_kw or {})
+            if G == 1:
+                kw.pop('align', None)
             self.A = ops.ColumnSweepCSR(blk, device, G=G, **kw)
             self.AT = ops.ColumnSweepCSR(blk_t, device, G=G, **kw) if with_transpose else None
             self._mm = ops.spmm_cs

@@ -241,3 +241,25 @@ def test_auto_align_is_a_third_of_the_l2_window():
     assert f(232965, 23173306, 232965, 2, 4096) == 2048       # S-Reddit: the measured default stays
     assert 60000 < f(10_000_000, 24_613_381, 1_053_273, 2, 4096) < 120000      # one GPU's block of S-RMAT 10 M
     assert f(1000, 10, 50, 2, 4096) <= max(2048, 1000 // 8) and f(1000, 10, 50, 2, 4096) >= 2048
+
+
+def test_auto_t_fills_the_rounds_a_small_block_needs_and_choose_g_counts_rounds():
+    """ops.ColumnSweepCSR.auto_t: a block with few rows splits them further (T down from the library's 4 x mean degree) until
+    its virtual rows fill 70 % of the round it occupies anyway; a matrix that fills its rounds keeps the default (0).
+    choose_g compares passes x ROUNDS: a block that fits one round of single-group tiles takes one group."""
+    from stochastic_gcn_amd import ops
+    Cs = ops.ColumnSweepCSR
+    rng = np.random.RandomState(0)
+    deg = rng.poisson(100, 29000)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    for G in (1, 2):
+        T = Cs.auto_t(rowptr, G, 4096)
+        cap = 4096 * 16 * G
+        v = lambda t: int(np.maximum(1, -(-deg // t)).sum())       # noqa: E731
+        assert 24 <= T < 400 and v(T) <= 0.7 * cap and (T == 24 or v(T - 1) > 0.7 * cap)
+    big = np.concatenate([[0], np.cumsum(rng.poisson(100, 60000))])
+    assert Cs.auto_t(big, 1, 4096) == 0                            # 60 k of 65 k slots: the library default stays
+    assert Cs.auto_t(np.zeros(1, np.int64), 1, 4096) == 0
+    assert Cs.choose_g(602, 100, 29000) == 1 and Cs.choose_g(602, 100, 58000) == 1
+    assert Cs.choose_g(602, 100, 116000) == 2 and Cs.choose_g(602, 100, 232965) == 2
+    assert Cs.choose_g(256, 23, 1053273) == 4 and Cs.choose_g(256, 334, 73793) == 2 and Cs.choose_g(602, 490, 232965) == 1

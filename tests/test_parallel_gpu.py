@@ -147,7 +147,7 @@ def _sampled_rows_vs_oracle(blk, rows, X, got, dev):
 
 def test_rmat_10m_one_block_of_eight_full_size_vs_oracle():
     """BASELINE config 5 at its REAL size (SURVEY.md 8d S-RMAT: 10 M vertices, 200 M R-MAT edges, d = 256): one GPU's
-    block of the 8-way nnz-balanced sharding -- the block an 8-GPU job's rank 3 owns, built by the same ShardedSpMM
+    block of the 8-way load-balanced sharding -- the block an 8-GPU job's rank 3 owns, built by the same ShardedSpMM
     code path (emulated rank 3 of 8), the 10.24 GB dense operand resident -- forward C[lo:hi] = A[lo:hi,:] . B and
     backward dB[lo:hi] = A^T[lo:hi,:] . dC on the autotuned column sweep, against the CPU oracle on 1,540 sampled rows
     of the block including its heaviest, plus size-independent properties on ALL rows (A . 1 = row sums, linearity)."""
@@ -159,9 +159,13 @@ def test_rmat_10m_one_block_of_eight_full_size_vs_oracle():
     adj = synthetic.cached_graph("rmat_10m_200m_seed1", lambda: synthetic.rmat_like(n, 200_000_000, seed=1))
     assert adj.shape == (n, n) and adj.nnz == 196_949_452
     sh = ShardedSpMM(types.SimpleNamespace(rank=3, world=8, active=False), adj, dev, d=d)
-    assert abs(sh.local_nnz - adj.nnz / 8) <= 0.02 * adj.nnz / 8 and sh.A.G == 2
     adj_t = adj.T.tocsr()
     blk, blk_t = adj[sh.lo:sh.hi].tocsr(), adj_t[sh.lo:sh.hi].tocsr()
+    # the blocks are balanced by LOAD: nonzeros of both directions + ShardedSpMM.ROW_WEIGHT per row and direction; a sparse
+    # block with more rows than a round of two-group tiles takes four lane groups and the clock in work coordinates
+    load, total = blk.nnz + blk_t.nnz + 2 * sh.row_weight * (sh.hi - sh.lo), 2 * adj.nnz + 2 * sh.row_weight * n
+    assert sh.row_weight == ShardedSpMM.ROW_WEIGHT > 0 and abs(load - total / 8) <= 0.02 * total / 8
+    assert sh.A.G == 4 and sh.A.warp is not None and sh.AT.warp is not None
     del adj, adj_t
     g = torch.Generator(device=dev); g.manual_seed(5)
     B = torch.empty((n, d), device=dev).uniform_(-1, 1, generator=g)
