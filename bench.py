@@ -86,7 +86,7 @@ def parse(argv=None):
     p.add_argument("--emulate-shard", default=None, metavar="R/W",
                    help="with --shard resident on ONE GPU: build and time rank R's block of a W-way sharding")
     p.add_argument("--shard", choices=["resident", "allgather"], default=None,
-                   help="STRONG scaling: ONE graph row-block sharded over the ranks (nnz-balanced), dense "
+                   help="STRONG scaling: ONE graph row-block sharded over the ranks (load-balanced: nonzeros + a weight per row), dense "
                         "operand resident on every GPU or all-gathered per product (SURVEY.md 8e)")
     p.add_argument("--dry-run", action="store_true",
                    help="[test hook] no GPU work: only the launch / rendezvous / collective skeleton of "
@@ -401,7 +401,7 @@ def sampler_baseline(data10):
 
 def strong_leg(args, dev, world, rank, full_adj0, d, pitch, steps):
     """STRONG scaling beside the weak step: ONE S-Reddit graph (rank 0's) row-block sharded over
-    the ranks by nonzeros (parallel.ShardedSpMM), forward A.X + backward A^T.dC per step, with the dense operand
+    the ranks by load (nonzeros + a weight per row: parallel.ShardedSpMM), forward A.X + backward A^T.dC per step, with the dense operand
     (a) resident on every GPU -- no collective on the data path -- and (b) sharded like the output and all-gathered
     before each product (7/8 of it crosses xGMI per GPU).  Barrier + synchronize on both sides, max over ranks."""
     import torch
@@ -446,7 +446,7 @@ def strong_leg(args, dev, world, rank, full_adj0, d, pitch, steps):
         res[name + "_ms"] = el / steps * 1e3
     nnz = int(full_adj0.nnz)
     res["edges_per_s"] = {"resident": 2 * nnz / (res["resident_ms"] * 1e-3), "allgather": 2 * nnz / (res["allgather_ms"] * 1e-3)}
-    res["what"] = ("ONE S-Reddit graph (%d nnz), nnz-balanced row blocks over %d rank(s), fwd A.X + bwd A^T.dC per step, d=%d; "
+    res["what"] = ("ONE S-Reddit graph (%d nnz), load-balanced row blocks (nonzeros + ShardedSpMM.ROW_WEIGHT per row) over %d rank(s), fwd A.X + bwd A^T.dC per step, d=%d; "
                    "resident: dense operand on every GPU, no data-path collective; allgather: operand sharded like the "
                    "output, all-gathered (RCCL) before each product" % (nnz, world, d))
     res["steps"] = steps
@@ -725,8 +725,8 @@ def main(argv=None):
             (", + all-gather of the dense operand per product" if args.shard == "allgather" else "") if sh is not None
             else (", + RCCL all-reduce of %d grad floats" % gfl if pg else "")),
             "N": n, "nnz": nnz, "d": d,
-            "per_gpu": ("nnz-balanced row block of ONE graph, dense operand %s; rank 0 rows [%d, %d), %d nnz"
-                        % (args.shard, sh.lo, sh.hi, sh.local_nnz)) if sh is not None
+            "per_gpu": ("load-balanced row block (nonzeros + %d per row) of ONE graph, dense operand %s; rank 0 rows [%d, %d), %d nnz"
+                        % (sh.row_weight, args.shard, sh.lo, sh.hi, sh.local_nnz)) if sh is not None
             else "one S-Reddit vertex-range shard",
             "kernel": args.kernel, "tune": args.tune, "grad_allreduce_ms": ar_ms,
             # column sweep: passes over the feature dimension x rounds of resident tiles, as the library reports it

@@ -195,3 +195,33 @@ def test_partition_rows_by_nnz_balances_power_law_rows():
     # more ranks than rows: empty ranges, still a partition
     b = partition_rows_by_nnz(np.array([0, 3, 4]), 5)
     assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
+
+
+def test_sharded_spmm_balances_load_not_nonzeros_alone():
+    """ShardedSpMM's row blocks (kernel=None: the partition alone, no device): with the column sweep a row costs what
+    ROW_WEIGHT of its nonzeros do, so the blocks of a skewed graph carry equal LOAD (nonzeros of both directions + the weight
+    per row and direction) -- the hub block gets more nonzeros, the sparse tail fewer rows; row_weight = 0 is the plain
+    nonzero balance."""
+    import types
+    from stochastic_gcn_amd import synthetic
+    from stochastic_gcn_amd.parallel import ShardedSpMM
+    a = synthetic.rmat_like(1 << 14, 30 << 14, seed=4)
+    at = a.T.tocsr()
+    world = 8
+    both = np.diff(a.indptr) + np.diff(at.indptr)
+    for w in (0, ShardedSpMM.ROW_WEIGHT):
+        bounds, loads, nnzs = [0], [], []
+        for r in range(world):
+            sh = ShardedSpMM(types.SimpleNamespace(rank=r, world=world, active=False), a, 'cpu', kernel=None, row_weight=w)
+            assert sh.row_weight == w and sh.lo == bounds[-1]
+            bounds.append(sh.hi)
+            loads.append(int(both[sh.lo:sh.hi].sum()) + 2 * w * (sh.hi - sh.lo))
+            nnzs.append(int(both[sh.lo:sh.hi].sum()))
+        assert bounds[-1] == a.shape[0]
+        ideal = (int(both.sum()) + 2 * w * a.shape[0]) / world
+        assert max(loads) <= ideal + int(both.max()) + 2 * w
+        if w:
+            assert nnzs[0] > 1.1 * nnzs[-2]           # the hub block takes more nonzeros than a sparse one
+    # the default: the weight for the column sweep, none for the row-gather kernel's blocks
+    ns = types.SimpleNamespace(rank=0, world=2, active=False)
+    assert ShardedSpMM(ns, a, 'cpu', kernel=None).row_weight == 0
