@@ -1,0 +1,50 @@
+"""S-Reddit headline product: bin alignment beyond 2,048 columns (pads 4.4 % -> 1.3 % at 8,192), the split threshold T and the clock's
+slack -- sustained forward products per setting, each at its own autotuned clock.  One JSON line per setting."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stochastic_gcn_amd import ops, synthetic, _ffi  # noqa: E402
+
+dev = torch.device("cuda:0")
+d = 602
+n, _, a, *_ = synthetic.reddit_like(with_features=False)
+B = torch.zeros((n, 608), device=dev)
+B[:, :d] = torch.randn((n, d), device=dev)
+out = torch.empty((n, 608), device=dev)[:, :d]
+
+
+def sustained(A, reps=20):
+    ops.spmm_cs(A, B[:, :d], out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.spmm_cs(A, B[:, :d], out=out)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def run(tag, **kw):
+    A = ops.ColumnSweepCSR(a, dev, G=2, **kw)
+    A._tuning = True
+    t, pace = A.autotune(B[:, :d])
+    A._tuning = True
+    best = min((sustained(A), p) for p in (pace,) if not A.pace.__setitem__(d, p))
+    print(json.dumps(dict(tag=tag, kw={k: str(v) for k, v in kw.items()}, pace=pace, burst_ms=round(t, 4), sustained_ms=round(best[0], 4),
+                          pad_fraction=round(A.pad_fraction, 4), ntiles=int(A.ntiles), nfix=int(A.nfix))), flush=True)
+    return A
+
+
+for align in (2048, 4096, 8192, 16384):
+    run("align", align=align)
+for T in (200, 800):
+    run("T", T=T)
+for slack in (256, 1024, 2048):
+    _ffi.tune("cs_slack", slack)
+    run("slack%d" % slack)
+_ffi.tune("cs_slack", 0)
