@@ -230,7 +230,7 @@ def step_chain_probe(trn, reps=20):
     import torch
     m = trn.train_model
     progs = [p for p in getattr(m, '_programs', {}).values() if p is not None]
-    if not progs or (m.grad_hook is not None) or (m.history_hook is not None):
+    if not progs or (((m.grad_hook is not None) or (m.history_hook is not None)) and not getattr(progs[-1], 'native_world', 0)):
         return {"note": "no single-GPU step program to replay"}
     prog = progs[-1]
     dev = m.device

@@ -33,14 +33,15 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 12.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 13.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
  *   v9  sgcn_softmax_ce_f32: with a prediction output, rowstat has a third plane (the rows' class indices)
  *   v10 sgcn_ldsplan_* / sgcn_spmm_lds_f32: the LDS-staged column sweep for graphs with locality
  *   v11 sgcn_csr_slice_indptr_dev; step ops MODE and CSR_SLICE .. GATHER_F32 (sparse-input stacks as step programs)
- *   v12 sgcn_csplan_t: dev_warp / warp_shift (the column sweep's clock in work coordinates); sgcn_csplang_*: host_warp */
+ *   v12 sgcn_csplan_t: dev_warp / warp_shift (the column sweep's clock in work coordinates); sgcn_csplang_*: host_warp
+ *   v13 sgcn_coll_* (own RCCL communicator), sgcn_hist_pack / _apply, step ops ALLREDUCE_AVG .. HIST_APPLY */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -318,6 +319,25 @@ int sgcn_gather_rows_f32(const float* dev_in, int64_t ldi, const int32_t* dev_r,
  * r[i] < 0 skips row i (padding of the fixed-capacity multi-GPU history exchange). */
 int sgcn_scatter_rows_f32(float* dev_H, int64_t ldh, const int32_t* dev_r, int32_t n,
                           int32_t d, const float* dev_src, int64_t lds, void* stream);
+
+/* ---- multi-GPU (the reference is single-process, gcn/train.py:130) ---------------------------------------
+ * The library's own RCCL communicator (librccl.so by dlopen), so that the data-parallel step's collectives are stream-
+ * ordered calls of sgcn_step_run (SGCN_OP_ALLREDUCE_AVG / _ALLGATHER_I32) rather than host-language calls between program
+ * runs.  Rank 0 draws the id, the host side carries its 128 bytes to every rank (any channel: the job's process group),
+ * every rank calls _init on its device.  One communicator per process. */
+int sgcn_coll_unique_id(void* host_out128);
+int sgcn_coll_init(const void* host_id128, int32_t world, int32_t rank);
+int sgcn_coll_world(void);                      /* ranks of the communicator, 0 = none */
+int sgcn_coll_destroy(void);
+int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream);                      /* in place, mean over ranks */
+int sgcn_coll_allgather_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream); /* recv = world x n */
+/* History exchange (policy H-a): send = [cap ids | cap x d row bits], ids[n..cap) = -1;  apply = every rank's block of the
+ * gathered buffer (world x cap x (d + 1) words) scattered into H in rank order (sgcn_scatter_rows_f32 per rank: ids < 0
+ * skipped; a vertex two ranks updated keeps the higher rank's row on every replica). */
+int sgcn_hist_pack_f32(const int32_t* dev_ids, int32_t n, const float* dev_rows, int64_t ld, int32_t d, int32_t cap,
+                       int32_t* dev_send, void* stream);
+int sgcn_hist_apply_f32(float* dev_H, int64_t ldh, const int32_t* dev_recv, int32_t world, int32_t cap, int32_t d,
+                        void* stream);
 
 /* CSR row slice -> CSR of the n selected rows.          replaces history.slice / c_indptr +
  *   phase 1 (host): o_p[0..n] prefix over deg(r[i])      c_slice  gcn/_history.pyx:25-51,
@@ -649,6 +669,14 @@ enum {
     SGCN_OP_LN_ACT_BWD = 26,    /* sgcn_ln_act_bwd_f32 (ws, ws_capacity in floats) */
     SGCN_OP_CSR_TRANSPOSE = 27, /* sgcn_csr_transpose_index (ws, ws_capacity in int32) */
     SGCN_OP_GATHER_F32 = 28,    /* sgcn_gather_f32 */
+    /* the data-parallel step's exchanges (ABI v13): */
+    SGCN_OP_ALLREDUCE_AVG = 29, /* sgcn_coll_allreduce_avg_f32 (buf, n) -- behind every gradient write of the run (joins the
+                                 * auxiliary stream, flushes parked reductions) */
+    SGCN_OP_HIST_PACK = 30,     /* sgcn_hist_pack_f32 (ids, n, rows, ld, d, cap, send, aux) */
+    SGCN_OP_ALLGATHER_I32 = 31, /* sgcn_coll_allgather_i32 (send, recv, n, aux) */
+    SGCN_OP_HIST_APPLY = 32,    /* sgcn_hist_apply_f32 (H, ldh, recv, world, cap, d, aux); aux != 0 (30 - 32): on the auxiliary
+                                 * stream, forked from `stream` at the op -- an exchange issued right behind the aggregator that
+                                 * read the history runs beside the rest of the step */
     SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD
                                  * writes its dW / doffset / dscale instead of adding to them, so the program zeroes nothing
                                  * (it must write every parameter gradient exactly once per step); and the statistics

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 12         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 13         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -124,6 +124,14 @@ SIGNATURES = {
                                              P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
     "sgcn_gather_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_scatter_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
+    "sgcn_coll_unique_id": (C.c_int, [P]),
+    "sgcn_coll_init": (C.c_int, [P, C.c_int32, C.c_int32]),
+    "sgcn_coll_world": (C.c_int, []),
+    "sgcn_coll_destroy": (C.c_int, []),
+    "sgcn_coll_allreduce_avg_f32": (C.c_int, [P, C.c_int64, P]),
+    "sgcn_coll_allgather_i32": (C.c_int, [P, P, C.c_int64, P]),
+    "sgcn_hist_pack_f32": (C.c_int, [P, C.c_int32, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
+    "sgcn_hist_apply_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, C.c_int32, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),
     "sgcn_csr_slice_indptr_dev": (C.c_int, [C.c_int32, P, P, P, P]),
     "sgcn_scale_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),

@@ -1,0 +1,130 @@
+// RCCL from inside the library: the data-parallel step's two collectives as stream-ordered calls of the native launch
+// loop (sgcn_step_run ops ALLREDUCE_AVG / ALLGATHER_I32) instead of Python calls between three program runs.
+//
+// Why: with torch.distributed the launching thread pays ~80 us per step for the collectives' bookkeeping (c10d call, work
+// objects, three slice assignments to pack the history rows, one scatter call per rank) -- measured with a forced ONE-rank
+// process group: 0.130 -> 0.211 ms per Reddit CVD+PP step, host-bound (profiles/r44_epoch_fixed_cost.jsonl).  An 8-GPU
+// epoch is 38 such steps.  The reference has nothing here (single session, gcn/train.py:130); SURVEY.md 8e.
+//
+// The library is loaded at run time (dlopen: the process usually has torch's own librccl.so mapped already, and the same
+// soname resolves to that copy), the communicator is the library's own: rank 0 draws the id (sgcn_coll_unique_id), the
+// host side broadcasts its 128 bytes over the job's existing process group, every rank calls sgcn_coll_init.
+#include "sgcn_host.h"
+#include "../../include/sgcn.h"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void* rcclComm_t;
+enum { kNcclSuccess = 0, kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0, kNcclAvg = 4 };
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rcclUniqueId*) = nullptr;
+    int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    rcclComm_t comm = nullptr;
+    int world = 0, rank = -1;
+};
+
+Rccl& R() { static Rccl r; return r; }
+std::mutex& mu() { static std::mutex m; return m; }
+
+int load() {
+    Rccl& r = R();
+    if (r.lib) return SGCN_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) {                           // the copy the process has mapped already, if any
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+    }
+    for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) return sgcn::fail(SGCN_ERR_INVALID, "coll: librccl.so not found (%s)", dlerror());
+#define SGCN_SYM(field, name)                                                                               \
+    *(void**)(&r.field) = dlsym(h, name);                                                                   \
+    if (!r.field) { dlclose(h); return sgcn::fail(SGCN_ERR_INVALID, "coll: librccl.so lacks %s", name); }
+    SGCN_SYM(GetUniqueId, "ncclGetUniqueId")
+    SGCN_SYM(CommInitRank, "ncclCommInitRank")
+    SGCN_SYM(CommDestroy, "ncclCommDestroy")
+    SGCN_SYM(AllReduce, "ncclAllReduce")
+    SGCN_SYM(AllGather, "ncclAllGather")
+    SGCN_SYM(GetErrorString, "ncclGetErrorString")
+#undef SGCN_SYM
+    r.lib = h;
+    return SGCN_OK;
+}
+
+int check(int rc, const char* what) {
+    if (rc == kNcclSuccess) return SGCN_OK;
+    return sgcn::fail(SGCN_ERR_HIP, "coll: %s: %s", what, R().GetErrorString ? R().GetErrorString(rc) : "?");
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgcn_coll_unique_id(void* out128) {
+    if (!out128) return sgcn::fail(SGCN_ERR_INVALID, "coll_unique_id: null buffer");
+    std::lock_guard<std::mutex> lk(mu());
+    const int rc = load();
+    if (rc != SGCN_OK) return rc;
+    rcclUniqueId id;
+    const int e = check(R().GetUniqueId(&id), "ncclGetUniqueId");
+    if (e != SGCN_OK) return e;
+    std::memcpy(out128, &id, sizeof(id));
+    return SGCN_OK;
+}
+
+int sgcn_coll_init(const void* id128, int32_t world, int32_t rank) {
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return sgcn::fail(SGCN_ERR_INVALID, "coll_init: bad argument");
+    std::lock_guard<std::mutex> lk(mu());
+    const int rc = load();
+    if (rc != SGCN_OK) return rc;
+    Rccl& r = R();
+    if (r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_init: a communicator exists (sgcn_coll_destroy first)");
+    rcclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    rcclComm_t c = nullptr;
+    const int e = check(r.CommInitRank(&c, world, id, rank), "ncclCommInitRank");
+    if (e != SGCN_OK) return e;
+    r.comm = c; r.world = world; r.rank = rank;
+    return SGCN_OK;
+}
+
+int sgcn_coll_world(void) { return R().comm ? R().world : 0; }
+
+int sgcn_coll_destroy(void) {
+    std::lock_guard<std::mutex> lk(mu());
+    Rccl& r = R();
+    if (!r.comm) return SGCN_OK;
+    const int e = check(r.CommDestroy(r.comm), "ncclCommDestroy");
+    r.comm = nullptr; r.world = 0; r.rank = -1;
+    return e;
+}
+
+int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream) {
+    Rccl& r = R();
+    if (!r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_allreduce: no communicator (sgcn_coll_init)");
+    if (n < 0 || (n > 0 && !dev_buf)) return sgcn::fail(SGCN_ERR_INVALID, "coll_allreduce: bad argument");
+    if (n == 0) return SGCN_OK;
+    return check(r.AllReduce(dev_buf, dev_buf, (size_t)n, kNcclFloat32, kNcclAvg, r.comm, stream), "ncclAllReduce");
+}
+
+int sgcn_coll_allgather_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream) {
+    Rccl& r = R();
+    if (!r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_allgather: no communicator (sgcn_coll_init)");
+    if (n < 0 || (n > 0 && (!dev_send || !dev_recv))) return sgcn::fail(SGCN_ERR_INVALID, "coll_allgather: bad argument");
+    if (n == 0) return SGCN_OK;
+    return check(r.AllGather(dev_send, dev_recv, (size_t)n, kNcclInt32, r.comm, stream), "ncclAllGather");
+}
+
+}  // extern "C"

@@ -251,6 +251,49 @@ extern "C" int sgcn_scatter_rows_f32(float* H, int64_t ldh, const int32_t* r, in
     return launch_rows<true>(src, lds, r, n, d, H, ldh, (hipStream_t)stream);
 }
 
+// ---- the multi-GPU history exchange (policy H-a) as two launches around one all-gather ---------------------
+// pack : send = [cap ids | cap x d row bits] of this rank's update -- ids[0..n) and their rows, ids[n..cap) = -1
+// apply: every rank's block of the gathered buffer scattered into the local replica, in RANK ORDER (a vertex that two
+//        ranks updated in one step keeps the higher rank's row on every replica: W scatter launches, stream-ordered)
+__global__ __launch_bounds__(kBlock) void hist_pack_kernel(const int32_t* __restrict__ ids, int32_t n, const float* __restrict__ rows,
+                                                           int64_t ld, int32_t d, int32_t cap, int32_t* __restrict__ send) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (i >= cap) return;
+    if (i >= n) {
+        if (lane == 0) send[i] = -1;
+        return;
+    }
+    if (lane == 0) send[i] = ids[i];
+    const float* src = rows + i * ld;
+    float* dst = reinterpret_cast<float*>(send + cap) + i * d;
+    for (int c = lane; c < d; c += kWave) dst[c] = src[c];
+}
+
+extern "C" int sgcn_hist_pack_f32(const int32_t* ids, int32_t n, const float* rows, int64_t ld, int32_t d, int32_t cap,
+                                  int32_t* send, void* stream) {
+    SGCN_REQUIRE(n >= 0 && d >= 0 && cap >= n, "hist_pack: %d rows do not fit the capacity %d", n, cap);
+    if (cap == 0) return SGCN_OK;
+    SGCN_REQUIRE(send && (n == 0 || (ids && rows && ld >= d)), "hist_pack: bad operand");
+    const int64_t blocks = ((int64_t)cap + (kBlock / kWave) - 1) / (kBlock / kWave);
+    hipLaunchKernelGGL(hist_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, ids, n, rows, ld, d, cap, send);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
+
+extern "C" int sgcn_hist_apply_f32(float* H, int64_t ldh, const int32_t* recv, int32_t world, int32_t cap, int32_t d, void* stream) {
+    SGCN_REQUIRE(world >= 1 && cap >= 0 && d >= 0, "hist_apply: bad size");
+    if (cap == 0 || d == 0) return SGCN_OK;
+    SGCN_REQUIRE(H && recv && ldh >= d, "hist_apply: bad operand");
+    const int64_t per = (int64_t)cap * (d + 1);
+    for (int32_t r = 0; r < world; r++) {
+        const int32_t* blk = recv + r * per;
+        const int rc = launch_rows<true>(reinterpret_cast<const float*>(blk + cap), d, blk, cap, d, H, ldh, (hipStream_t)stream);
+        if (rc != SGCN_OK) return rc;
+    }
+    return SGCN_OK;
+}
+
 // o_p of a row slice on the device (what sgcn_csr_slice_indptr computes on the host, gcn/history.cpp:50-58): ONE workgroup,
 // every thread a contiguous run of rows, run totals scanned through LDS.  For the compiled step (SGCN_OP_CSR_SLICE): the
 // minibatch's input vertices are on the device already and no host pass / copy sits in front of the step.

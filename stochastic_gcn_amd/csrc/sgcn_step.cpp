@@ -502,6 +502,39 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             rc = sgcn::adam_with_stats(th, g, m, v, n, lr, b1, b2, eps, stream);
             break;
         }
+        case SGCN_OP_ALLREDUCE_AVG: {
+            // every gradient of the run is in the buffer: deferred weight-gradient work joined, parked reductions issued
+            rc = sgcn::aux_join(stream);
+            if (rc == SGCN_OK) rc = sgcn::reduce_flush(stream);
+            if (rc != SGCN_OK) break;
+            float* buf = a.p<float>(); const int64_t n = a.next();
+            rc = sgcn_coll_allreduce_avg_f32(buf, n, stream);
+            break;
+        }
+        case SGCN_OP_HIST_PACK: {
+            const int32_t* ids = a.p<const int32_t>(); const int32_t n = a.i();
+            const float* rows = a.p<const float>(); const int64_t ld = a.next();
+            const int32_t d = a.i(), cap = a.i();
+            int32_t* send = a.p<int32_t>();
+            // (last argument != 0: on the auxiliary stream, forked here -- the exchange then runs beside the rest of the
+            // step and is joined with the other auxiliary work in front of the gradient all-reduce / the optimizer)
+            if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
+            rc = sgcn_hist_pack_f32(ids, n, rows, ld, d, cap, send, side);
+            break;
+        }
+        case SGCN_OP_ALLGATHER_I32: {
+            const int32_t* send = a.p<const int32_t>(); int32_t* recv = a.p<int32_t>(); const int64_t n = a.next();
+            if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
+            rc = sgcn_coll_allgather_i32(send, recv, n, side);
+            break;
+        }
+        case SGCN_OP_HIST_APPLY: {
+            float* H = a.p<float>(); const int64_t ldh = a.next();
+            const int32_t* recv = a.p<const int32_t>(); const int32_t world = a.i(), cap = a.i(), d = a.i();
+            if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
+            rc = sgcn_hist_apply_f32(H, ldh, recv, world, cap, d, side);
+            break;
+        }
         case SGCN_OP_SCATTER_ROWS:
         case SGCN_OP_AUX_SCATTER_ROWS: {
             float* H = a.p<float>(); const int64_t ldh = a.next();

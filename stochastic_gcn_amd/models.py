@@ -692,7 +692,8 @@ class GCN(Model):
         # a program bakes in raw addresses (weights, gradients, Adam moments, history, features) and whether the
         # history update is local: all of that is part of its identity, so a tensor re-allocated or a hook
         # attached after the first step builds a NEW program instead of leaving a stale one in use
-        key = (round(float(dropout), 9), self.history_hook is None, self.theta.data_ptr(), self.grad.data_ptr(),
+        key = (round(float(dropout), 9), self.history_hook is None, int(getattr(self, 'native_coll', 0) or 0),
+               self.theta.data_ptr(), self.grad.data_ptr(),
                self.adam_m.data_ptr() if self.is_training else 0, self.adam_v.data_ptr() if self.is_training else 0,
                self.features_dev.data_ptr() if isinstance(self.features_dev, torch.Tensor) else 0,
                tuple(h.data_ptr() for hs in self._history for h in hs),
@@ -861,8 +862,8 @@ class GCN(Model):
                 loss, acc, pred = float(loss), float(acc), pred.cpu().numpy()
             self.run_t += time() - t
             return [loss, acc, pred]
-        if self.grad_hook is None and self.history_hook is None:
-            prog.run('all', stream)
+        if (self.grad_hook is None and self.history_hook is None) or prog.native_world:
+            prog.run('all', stream)       # (data parallel on the library's own communicator: the collectives are ops of the program)
         else:                                 # data parallel: collectives between the program's phases
             prog.run('fb', stream)
             if self.grad_hook is not None:

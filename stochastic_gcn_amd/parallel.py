@@ -20,6 +20,12 @@ The reference is single-process (one tf.Session, gcn/train.py:130); this module 
     history's next reader -- the next step's aggregator (``join_history``) -- so it rides beside the
     host's work on the next batch instead of on the step's dependent chain.
 
+On RCCL the two collectives of a step run on the LIBRARY's own communicator (``native``: ``sgcn_coll_*``, created from an
+id that rank 0 draws and the process group broadcasts) as ops of the compiled step program -- one foreign call per step,
+as on one GPU.  As torch.distributed calls between the program's phases they cost the launching thread ~80 us per step
+(0.130 -> 0.211 ms per Reddit step with a one-rank group, host-bound: profiles/r44_epoch_fixed_cost.jsonl); the
+torch path stays for gloo (the CPU tests) and behind ``SGCN_NATIVE_COLL=0``.
+
 ``SGCN_FORCE_PG=1`` makes a one-rank job take the collective paths as well (a real process group
 of one rank): the RCCL smoke test, and ``bench.py --gpus 1`` printing its all-reduce time.
 """
@@ -54,6 +60,41 @@ class DataParallel(object):
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
         if dist.is_initialized():
             self.backend = dist.get_backend()
+        self.native = False              # the library's own RCCL communicator carries the step's collectives
+        if self.active and self.backend == "nccl" and os.environ.get("SGCN_NATIVE_COLL", "1") != "0":
+            self._init_native()
+
+    def _init_native(self):
+        """The library's communicator: every rank probes that it can load RCCL (a rank that cannot would leave the others
+        hanging in the collective initialisation), rank 0's id travels over the process group, every rank initialises.  Any
+        failure, on any rank, leaves ALL ranks on the torch.distributed path."""
+        import sys
+        from ._ffi import lib
+        dev = self.device
+        ident = torch.zeros(128, dtype=torch.uint8)
+        ok = 1.0 if lib.sgcn_coll_unique_id(ident.data_ptr()) == 0 else 0.0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            if self.rank == 0:
+                print("stochastic_gcn_amd: RCCL is not loadable from libsgcn.so on every rank; collectives through "
+                      "torch.distributed", file=sys.stderr)
+            return
+        t = ident.to(dev)
+        dist.broadcast(t, src=0)
+        ident = t.cpu().contiguous()
+        if dev is not None and dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        rc = lib.sgcn_coll_init(ident.data_ptr(), self.world, self.rank)
+        flag = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            lib.sgcn_coll_destroy()
+            if self.rank == 0:
+                print("stochastic_gcn_amd: the library's RCCL communicator did not come up on every rank; collectives "
+                      "through torch.distributed", file=sys.stderr)
+            return
+        self.native = True
 
     @property
     def active(self):
@@ -79,7 +120,10 @@ class DataParallel(object):
         """Mean over the ranks, in place.  RCCL averages inside the collective (ReduceOp.AVG: no extra kernel on the
         step's dependent chain); gloo has no AVG: sum, then one division."""
         if self.active:
-            if self.backend == "nccl":
+            if self.native:               # (a step that runs layer by layer: the same communicator as the programs' ops)
+                from ._ffi import check, lib
+                check(lib.sgcn_coll_allreduce_avg_f32(flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream))
+            elif self.backend == "nccl":
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG)
             else:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -122,6 +166,7 @@ class DataParallel(object):
         model.grad_hook = self.allreduce_mean_
         model.history_hook = self.sync_history
         model.history_join = self.join_history
+        model.native_coll = self.world if self.native else 0      # step programs carry the collectives themselves
         model.dropout_seed = int(getattr(model, "dropout_seed", 0)) + 7919 * self.rank   # independent masks per rank
         self.broadcast_(model.theta)
 
@@ -140,6 +185,8 @@ class DataParallel(object):
             return
         dev = rows.device
         n, d = int(rows.shape[0]), int(rows.shape[1])
+        if self.native:
+            return self._sync_history_native(history, idx, rows, n, d, dev)
         cap = self.history_cap
         if cap is not None and n > cap:      # a rank-local branch here would desynchronise the ranks
             raise RuntimeError("history exchange: %d rows exceed history_cap=%d" % (n, cap))
@@ -166,6 +213,30 @@ class DataParallel(object):
         work = dist.all_gather_into_tensor(recv, send, async_op=True)
         self._pending.append((work, recv, history, cap, d, scatter_fn))
 
+    def _sync_history_native(self, history, idx, rows, n, d, dev):
+        """The exchange of a step that runs layer by layer, on the library's communicator and the step's stream (what the
+        compiled program does with its HIST_PACK / ALLGATHER_I32 / HIST_APPLY ops): nothing stays pending."""
+        from ._ffi import check, lib
+        cap = self.history_cap
+        if cap is None:
+            raise RuntimeError("history exchange: the trainer sets history_cap (the rows a step can update) first")
+        if n > cap:
+            raise RuntimeError("history exchange: %d rows exceed history_cap=%d" % (n, cap))
+        cap = (cap + 3) // 4 * 4
+        key = ("native", cap, d, dev)
+        bufs = self._hist_bufs.get(key)
+        if bufs is None:
+            bufs = self._hist_bufs[key] = (torch.empty(cap * (d + 1), dtype=torch.int32, device=dev),
+                                           torch.empty(self.world * cap * (d + 1), dtype=torch.int32, device=dev))
+        send, recv = bufs
+        ids = idx.tensor() if hasattr(idx, "tensor") and not torch.is_tensor(idx) else idx
+        ids = ids.to(torch.int32)
+        rows = rows if rows.stride(1) == 1 else rows.contiguous()
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib.sgcn_hist_pack_f32(ids.data_ptr(), n, rows.data_ptr(), int(rows.stride(0)), d, cap, send.data_ptr(), st))
+        check(lib.sgcn_coll_allgather_i32(send.data_ptr(), recv.data_ptr(), cap * (d + 1), st))
+        check(lib.sgcn_hist_apply_f32(history.data_ptr(), int(history.stride(0)), recv.data_ptr(), self.world, cap, d, st))
+
     def join_history(self):
         """Wait for the history exchanges in flight and apply them (rank order, issue order).  On RCCL the wait is a
         stream dependency, not a host block."""
@@ -181,6 +252,12 @@ class DataParallel(object):
 
     def shutdown(self):
         self.join_history()
+        if self.native:
+            from ._ffi import lib
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            lib.sgcn_coll_destroy()
+            self.native = False
         if self.active and dist.is_initialized():
             dist.destroy_process_group()
 

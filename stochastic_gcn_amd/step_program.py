@@ -29,7 +29,8 @@ from .scheduler import CSR_DESC, PackedBatch
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
           AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22, MODE=23,
-          CSR_SLICE=24, LN_ACT_FWD=25, LN_ACT_BWD=26, CSR_TRANSPOSE=27, GATHER_F32=28)       # 18-20: retired (include/sgcn.h)
+          CSR_SLICE=24, LN_ACT_FWD=25, LN_ACT_BWD=26, CSR_TRANSPOSE=27, GATHER_F32=28,       # 18-20: retired (include/sgcn.h)
+          ALLREDUCE_AVG=29, HIST_PACK=30, ALLGATHER_I32=31, HIST_APPLY=32)
 MAX_ARGS = 48
 GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
@@ -333,6 +334,21 @@ class StepProgram(object):
                             self._p(B), K(B.ld), NULL, NULL, cscale, self._p(out), K(out.ld), K(_fbits(0.0))]
                    + self._plan(b, d) + [self._p(add), K(add.ld if add is not None else 0), add_rows])
 
+    def _native_exchange(self, l, nh, aux=0):
+        """Policy H-a (parallel.py) as ops of the program: [cap ids | cap x d row bits] per rank, all-gathered on the
+        library's communicator, applied in rank order -- on the step's own stream behind the optimizer, where the reference
+        orders the update (gcn/models.py:186-194).  aux = 1 would put the three ops on the auxiliary stream right behind the
+        aggregator that read the history, beside the rest of the step: measured SLOWER with a one-rank communicator (0.177
+        against 0.144 ms per Reddit step, and erratic: a communicator that alternates between two streams synchronises them
+        itself; profiles/HISTORY.md round 5)."""
+        hist = self.model.history[l][0]
+        d, cap = int(nh.cols), (self.caps[l] + 3) // 4 * 4
+        send = self._alloc_vec(cap * (d + 1))[0]
+        recv = self._alloc_vec(self.native_world * cap * (d + 1))[0]
+        self._emit('HIST_PACK', [self._field_ptr(l), self.rows[l].op(), self._p(nh), K(nh.ld), K(d), K(cap), send, K(aux)])
+        self._emit('ALLGATHER_I32', [send, recv, K(cap * (d + 1)), K(aux)])
+        self._emit('HIST_APPLY', [K(hist.data_ptr()), K(hist.stride(0)), recv, K(self.native_world), K(cap), K(d), K(aux)])
+
     def _sparse_dropout(self, xs, site):
         """ops.dropout on the slice's value vector (one row of nnz elements)"""
         out = self._alloc_vec(xs.cap)[0]
@@ -421,7 +437,11 @@ class StepProgram(object):
         # per-program state (SGCN_OP_MODE at the head of every run), not the process-wide knob: another program built later
         # -- the test model's, another model's -- does not change how this one runs
         self.overlap = int(bool(FLAGS.agg_overlap) or not (FLAGS.lean_sync and FLAGS.group_dw))
-        local_hist = m.history_hook is None
+        # data parallel with the library's own RCCL communicator (parallel.DataParallel.native): the gradient all-reduce
+        # and the history exchange are ops of THIS program -- one foreign call per step, as on one GPU -- instead of Python
+        # calls between its phases
+        self.native_world = int(getattr(m, 'native_coll', 0) or 0) if m.is_training else 0
+        local_hist = m.history_hook is None and not self.native_world
         # the history scatter: beside the step on the auxiliary stream (one event pair, a barrier on the compute queue), or
         # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
         self._hist_last = bool(FLAGS.lean_sync) and local_hist
@@ -651,12 +671,17 @@ class StepProgram(object):
                 self._emit('DW_FLUSH', [])
             if wd and hi > lo:
                 self._emit('L2_PENALTY', [K(m.theta.data_ptr()), K(lo), K(hi), K(_fbits(wd)), K(m.grad.data_ptr()), NULL])
+            if self.native_world:
+                self._emit('ALLREDUCE_AVG', [K(m.grad.data_ptr()), K(m.grad.numel())])
             self._cur = self.ops_opt
             self._emit('ADAM', [K(m.theta.data_ptr()), K(m.grad.data_ptr()), K(m.adam_m.data_ptr()), K(m.adam_v.data_ptr()),
                                 K(m.theta.numel()), self._lr(), K(_fbits(FLAGS.beta1)), K(_fbits(FLAGS.beta2)), K(_fbits(1e-8))])
         self._cur = self.ops_hist
         for l, nh in ({} if (local_hist and not self._hist_last) else self.new_history).items():
             hist = m.history[l][0]
+            if self.native_world:
+                self._native_exchange(l, nh)
+                continue
             self._emit('SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                         K(nh.cols), self._p(nh), K(nh.ld)])
 

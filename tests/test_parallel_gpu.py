@@ -342,11 +342,12 @@ def test_two_rank_cvd_pp_training_steps_match_the_two_rank_oracle(tmp_path):
 
 
 # ---- RCCL itself: one rank (SGCN_FORCE_PG=1) ---------------------------------------------------------------------------
-def _rccl_worker(rank, world, port, force, out_dir):
-    """Three program-path training steps + an all-gathered sharded product, with a REAL one-rank RCCL process group
-    (force) or without any process group (not force): the same numbers, bit for bit."""
+def _rccl_worker(rank, world, port, force, out_dir, native=True, program=True):
+    """Three training steps + an all-gathered sharded product, with a REAL one-rank RCCL process group (force; the step's
+    collectives on the library's own communicator -- native -- or as torch.distributed calls) or without any process group
+    (not force): the same numbers, bit for bit."""
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      SGCN_FORCE_PG="1" if force else "0")
+                      SGCN_FORCE_PG="1" if force else "0", SGCN_NATIVE_COLL="1" if native else "0")
     os.environ.pop("SGCN_DIST_BACKEND", None)
     import contextlib
     import io
@@ -361,15 +362,21 @@ def _rccl_worker(rank, world, port, force, out_dir):
     FLAGS.reset()
     FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
                  hidden1=64, num_fc_layers=2, batch_size=256, test_batch_size=512, cv=True, cvd=True, test_cv=True,
-                 degree=1, test_degree=1, seed=1, native_step=True, max_steps=3)
+                 degree=1, test_degree=1, seed=1, native_step=program, max_steps=3)
     with contextlib.redirect_stdout(io.StringIO()):
         trn = Trainer(data=data, verbose=False)
         trn.train_epoch()
     m, par = trn.train_model, trn.par
     assert par.active == force and dist.is_initialized() == force
     if force:
+        from stochastic_gcn_amd._ffi import lib
         assert dist.get_backend() == "nccl" and dist.get_world_size() == 1 and par.backend == "nccl"
-        assert m.grad_hook is not None and m.history_hook is not None and len(par._pending) == 1
+        assert par.native == native and lib.sgcn_coll_world() == (1 if native else 0) and m.native_coll == (1 if native else 0)
+        if native and program:                 # the collectives were ops of the step program: one foreign call per step
+            progs = [p for p in m._programs.values() if p is not None]
+            assert progs and all(p.native_world == 1 for p in progs)
+            assert all(any(op == 29 for op, _ in p.ops_fb) and all(any(op == o for op, _ in p.ops_hist) for o in (30, 31, 32)) for p in progs)
+        assert m.grad_hook is not None and m.history_hook is not None and len(par._pending) == (0 if native else 1)
         # the last step's exchange is still in flight -- and READING the history is what lands it (the public
         # names join; nothing can see a replica that lacks this step's rows, its own included)
         hist = m.history[0][0]
@@ -385,8 +392,8 @@ def _rccl_worker(rank, world, port, force, out_dir):
     full = sh.allgather_rows(X[sh.lo:sh.hi].contiguous())
     c = sh.forward_allgather(X[sh.lo:sh.hi].contiguous())
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "rccl%d.npz" % int(force)), theta=m.theta.cpu().numpy(), hist=m.history[0][0].cpu().numpy(),
-             used_program=np.array([bool(getattr(m, '_programs', {}))]), steps=np.array([m.adam_t]),
+    np.savez(os.path.join(out_dir, "rccl%d%d%d.npz" % (int(force), int(native), int(program))), theta=m.theta.cpu().numpy(), hist=m.history[0][0].cpu().numpy(),
+             used_program=np.array([bool([p for p in getattr(m, '_programs', {}).values() if p is not None])]), steps=np.array([m.adam_t]),
              allreduce_ok=np.array([bool(torch.equal(flat, ref))]), gathered_ok=np.array([bool(torch.equal(full, X))]),
              c=c.cpu().numpy())
     par.shutdown()
@@ -400,13 +407,50 @@ def test_rccl_one_rank_training_steps_and_allgather_equal_the_single_process_pat
     products (gloo stages through the host and synchronises; only RCCL can show a stream-ordering bug)."""
     import torch.multiprocessing as mp
     res = {}
-    for force in (True, False):
-        mp.spawn(_rccl_worker, args=(1, tg._free_port(), force, str(tmp_path)), nprocs=1, join=True)
-        res[force] = np.load(os.path.join(str(tmp_path), "rccl%d.npz" % int(force)))
-    for force in (True, False):
-        assert res[force]["used_program"][0] and res[force]["steps"][0] == 3
-        assert res[force]["allreduce_ok"][0] and res[force]["gathered_ok"][0]
-    np.testing.assert_array_equal(res[True]["theta"], res[False]["theta"])
-    np.testing.assert_array_equal(res[True]["hist"], res[False]["hist"])
-    np.testing.assert_array_equal(res[True]["c"], res[False]["c"])
-    assert np.abs(res[True]["hist"]).sum() > 0
+    # (process group, the library's own communicator, step programs): native and torch collectives, compiled and eager
+    # steps, against the run without a process group
+    modes = [(True, True, True), (True, False, True), (True, True, False), (False, True, True)]
+    for mode in modes:
+        mp.spawn(_rccl_worker, args=(1, tg._free_port(), mode[0], str(tmp_path), mode[1], mode[2]), nprocs=1, join=True)
+        res[mode] = np.load(os.path.join(str(tmp_path), "rccl%d%d%d.npz" % tuple(int(x) for x in mode)))
+    ref = res[(False, True, True)]
+    for mode in modes:
+        assert res[mode]["used_program"][0] == mode[2] and res[mode]["steps"][0] == 3
+        assert res[mode]["allreduce_ok"][0] and res[mode]["gathered_ok"][0]
+        np.testing.assert_array_equal(res[mode]["c"], ref["c"])
+        if mode[2]:                                # (the eager path sums in another order than the program: its own check below)
+            np.testing.assert_array_equal(res[mode]["theta"], ref["theta"])
+            np.testing.assert_array_equal(res[mode]["hist"], ref["hist"])
+    eager = res[(True, True, False)]
+    assert np.abs(eager["theta"] - ref["theta"]).max() <= 1e-5 and np.abs(eager["hist"] - ref["hist"]).max() <= 1e-4
+    assert np.abs(ref["hist"]).sum() > 0
+
+
+def test_history_exchange_pack_and_apply_in_rank_order():
+    """sgcn_hist_pack_f32 / sgcn_hist_apply_f32 with THREE ranks' blocks in the gathered buffer (the all-gather itself is
+    the one call that needs three GPUs): padded ids are skipped, and a vertex that several ranks updated keeps the highest
+    rank's row -- what DataParallel.join_history does with one scatter call per rank."""
+    from stochastic_gcn_amd._ffi import check, lib
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(0)
+    N, d, cap, world = 500, 37, 64, 3
+    H0 = rng.standard_normal((N, 40)).astype(np.float32)          # history with a pitch
+    H = torch.from_numpy(H0).to(dev)
+    want = H0.copy()
+    recv = torch.empty(world * cap * (d + 1), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        n = [64, 17, 0][r]
+        ids = rng.choice(N // 4, n, replace=False).astype(np.int32)              # a quarter of the vertices: ranks collide
+        rows = rng.standard_normal((max(n, 1), 48)).astype(np.float32)           # rows with a pitch
+        send = recv[r * cap * (d + 1):(r + 1) * cap * (d + 1)]
+        idt, rt = torch.from_numpy(ids).to(dev), torch.from_numpy(rows).to(dev)
+        check(lib.sgcn_hist_pack_f32(idt.data_ptr(), n, rt.data_ptr(), 48, d, cap, send.data_ptr(), st))
+        got = send.cpu().numpy()
+        np.testing.assert_array_equal(got[:n], ids)
+        assert (got[n:cap] == -1).all()
+        np.testing.assert_array_equal(got[cap:].view(np.float32).reshape(cap, d)[:n], rows[:n, :d])
+        want[ids, :d] = rows[:n, :d]
+    check(lib.sgcn_hist_apply_f32(H.data_ptr(), 40, recv.data_ptr(), world, cap, d, st))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(H.cpu().numpy(), want)
