@@ -333,11 +333,13 @@ int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream);       
 int sgcn_coll_allgather_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream); /* recv = world x n */
 /* History exchange (policy H-a): send = [cap ids | cap x d row bits], ids[n..cap) = -1;  apply = every rank's block of the
  * gathered buffer (world x cap x (d + 1) words) scattered into H in rank order (sgcn_scatter_rows_f32 per rank: ids < 0
- * skipped; a vertex two ranks updated keeps the higher rank's row on every replica). */
+ * skipped; a vertex two ranks updated keeps the higher rank's row on every replica).  dev_owner (nullable): one int32 per
+ * history row, ZERO on entry and on return -- with it, more than two ranks are applied in two launches instead of `world`
+ * (per vertex the highest (rank, slot) claims it by an integer atomicMax, then the owners copy): the same result. */
 int sgcn_hist_pack_f32(const int32_t* dev_ids, int32_t n, const float* dev_rows, int64_t ld, int32_t d, int32_t cap,
                        int32_t* dev_send, void* stream);
 int sgcn_hist_apply_f32(float* dev_H, int64_t ldh, const int32_t* dev_recv, int32_t world, int32_t cap, int32_t d,
-                        void* stream);
+                        int32_t* dev_owner, void* stream);
 
 /* CSR row slice -> CSR of the n selected rows.          replaces history.slice / c_indptr +
  *   phase 1 (host): o_p[0..n] prefix over deg(r[i])      c_slice  gcn/_history.pyx:25-51,
@@ -674,7 +676,7 @@ enum {
                                  * auxiliary stream, flushes parked reductions) */
     SGCN_OP_HIST_PACK = 30,     /* sgcn_hist_pack_f32 (ids, n, rows, ld, d, cap, send, aux) */
     SGCN_OP_ALLGATHER_I32 = 31, /* sgcn_coll_allgather_i32 (send, recv, n, aux) */
-    SGCN_OP_HIST_APPLY = 32,    /* sgcn_hist_apply_f32 (H, ldh, recv, world, cap, d, aux); aux != 0 (30 - 32): on the auxiliary
+    SGCN_OP_HIST_APPLY = 32,    /* sgcn_hist_apply_f32 (H, ldh, recv, world, cap, d, owner, aux); aux != 0 (30 - 32): on the auxiliary
                                  * stream, forked from `stream` at the op -- an exchange issued right behind the aggregator that
                                  * read the history runs beside the rest of the step */
     SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD

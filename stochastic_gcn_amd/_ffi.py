@@ -131,7 +131,7 @@ SIGNATURES = {
     "sgcn_coll_allreduce_avg_f32": (C.c_int, [P, C.c_int64, P]),
     "sgcn_coll_allgather_i32": (C.c_int, [P, P, C.c_int64, P]),
     "sgcn_hist_pack_f32": (C.c_int, [P, C.c_int32, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
-    "sgcn_hist_apply_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, C.c_int32, P]),
+    "sgcn_hist_apply_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),
     "sgcn_csr_slice_indptr_dev": (C.c_int, [C.c_int32, P, P, P, P]),
     "sgcn_scale_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),

@@ -281,11 +281,48 @@ extern "C" int sgcn_hist_pack_f32(const int32_t* ids, int32_t n, const float* ro
     return SGCN_OK;
 }
 
-extern "C" int sgcn_hist_apply_f32(float* H, int64_t ldh, const int32_t* recv, int32_t world, int32_t cap, int32_t d, void* stream) {
+// The same result in TWO launches whatever the number of ranks (eight scatter launches are ~25 us of an 8-GPU step's dependent
+// chain): `owner` (one word per history row, zero between calls) first takes, per vertex, the highest (rank, slot) that updates it
+// -- an integer atomicMax, order-independent --, then every (rank, slot) that owns its vertex copies its row and clears the word.
+__global__ __launch_bounds__(kBlock) void hist_claim_kernel(const int32_t* __restrict__ recv, int32_t world, int32_t cap, int64_t per,
+                                                            int32_t* __restrict__ owner) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= (int64_t)world * cap) return;
+    const int32_t r = (int32_t)(k / cap), i = (int32_t)(k % cap);
+    const int32_t id = recv[r * per + i];
+    if (id >= 0) atomicMax(&owner[id], (int32_t)k + 1);
+}
+
+__global__ __launch_bounds__(kBlock) void hist_write_kernel(float* __restrict__ H, int64_t ldh, const int32_t* __restrict__ recv,
+                                                            int32_t world, int32_t cap, int32_t d, int64_t per,
+                                                            int32_t* __restrict__ owner) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t k = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (k >= (int64_t)world * cap) return;
+    const int32_t r = (int32_t)(k / cap), i = (int32_t)(k % cap);
+    const int32_t id = recv[r * per + i];
+    if (id < 0 || owner[id] != (int32_t)k + 1) return;
+    const float* src = reinterpret_cast<const float*>(recv + r * per + cap) + (int64_t)i * d;
+    float* dst = H + (int64_t)id * ldh;
+    for (int c = lane; c < d; c += kWave) dst[c] = src[c];
+    if (lane == 0) owner[id] = 0;                     // (only the owner of a vertex touches its word in this launch)
+}
+
+extern "C" int sgcn_hist_apply_f32(float* H, int64_t ldh, const int32_t* recv, int32_t world, int32_t cap, int32_t d,
+                                   int32_t* owner, void* stream) {
     SGCN_REQUIRE(world >= 1 && cap >= 0 && d >= 0, "hist_apply: bad size");
     if (cap == 0 || d == 0) return SGCN_OK;
     SGCN_REQUIRE(H && recv && ldh >= d, "hist_apply: bad operand");
     const int64_t per = (int64_t)cap * (d + 1);
+    if (owner && world > 2) {
+        const int64_t n = (int64_t)world * cap;
+        hipLaunchKernelGGL(hist_claim_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                           recv, world, cap, per, owner);
+        hipLaunchKernelGGL(hist_write_kernel, dim3((unsigned)((n + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0,
+                           (hipStream_t)stream, H, ldh, recv, world, cap, d, per, owner);
+        SGCN_HIP_TRY(hipGetLastError());
+        return SGCN_OK;
+    }
     for (int32_t r = 0; r < world; r++) {
         const int32_t* blk = recv + r * per;
         const int rc = launch_rows<true>(reinterpret_cast<const float*>(blk + cap), d, blk, cap, d, H, ldh, (hipStream_t)stream);

@@ -531,8 +531,9 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         case SGCN_OP_HIST_APPLY: {
             float* H = a.p<float>(); const int64_t ldh = a.next();
             const int32_t* recv = a.p<const int32_t>(); const int32_t world = a.i(), cap = a.i(), d = a.i();
+            int32_t* owner = a.p<int32_t>();
             if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
-            rc = sgcn_hist_apply_f32(H, ldh, recv, world, cap, d, side);
+            rc = sgcn_hist_apply_f32(H, ldh, recv, world, cap, d, owner, side);
             break;
         }
         case SGCN_OP_SCATTER_ROWS:

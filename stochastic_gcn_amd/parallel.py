@@ -61,8 +61,14 @@ class DataParallel(object):
         if dist.is_initialized():
             self.backend = dist.get_backend()
         self.native = False              # the library's own RCCL communicator carries the step's collectives
-        if self.active and self.backend == "nccl" and os.environ.get("SGCN_NATIVE_COLL", "1") != "0":
-            self._init_native()
+        self._native_owner = False
+        if self.active and self.backend == "nccl" and os.environ.get("SGCN_NATIVE_COLL", "1") != "0" and \
+                device is not None and device.type == "cuda":
+            from ._ffi import lib
+            if lib.sgcn_coll_world() == self.world:       # one communicator per process: a later object of the job shares it
+                self.native = True
+            elif init:
+                self._init_native()
 
     def _init_native(self):
         """The library's communicator: every rank probes that it can load RCCL (a rank that cannot would leave the others
@@ -94,7 +100,7 @@ class DataParallel(object):
                 print("stochastic_gcn_amd: the library's RCCL communicator did not come up on every rank; collectives "
                       "through torch.distributed", file=sys.stderr)
             return
-        self.native = True
+        self.native = self._native_owner = True
 
     @property
     def active(self):
@@ -235,7 +241,12 @@ class DataParallel(object):
         st = torch.cuda.current_stream().cuda_stream
         check(lib.sgcn_hist_pack_f32(ids.data_ptr(), n, rows.data_ptr(), int(rows.stride(0)), d, cap, send.data_ptr(), st))
         check(lib.sgcn_coll_allgather_i32(send.data_ptr(), recv.data_ptr(), cap * (d + 1), st))
-        check(lib.sgcn_hist_apply_f32(history.data_ptr(), int(history.stride(0)), recv.data_ptr(), self.world, cap, d, st))
+        okey = ("owner", int(history.shape[0]), dev)
+        owner = self._hist_bufs.get(okey)
+        if owner is None:
+            owner = self._hist_bufs[okey] = torch.zeros(int(history.shape[0]), dtype=torch.int32, device=dev)
+        check(lib.sgcn_hist_apply_f32(history.data_ptr(), int(history.stride(0)), recv.data_ptr(), self.world, cap, d,
+                                      owner.data_ptr(), st))
 
     def join_history(self):
         """Wait for the history exchanges in flight and apply them (rank order, issue order).  On RCCL the wait is a
@@ -252,12 +263,12 @@ class DataParallel(object):
 
     def shutdown(self):
         self.join_history()
-        if self.native:
+        if self.native and self._native_owner:
             from ._ffi import lib
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             lib.sgcn_coll_destroy()
-            self.native = False
+        self.native = self._native_owner = False
         if self.active and dist.is_initialized():
             dist.destroy_process_group()
 

@@ -334,6 +334,13 @@ class StepProgram(object):
                             self._p(B), K(B.ld), NULL, NULL, cscale, self._p(out), K(out.ld), K(_fbits(0.0))]
                    + self._plan(b, d) + [self._p(add), K(add.ld if add is not None else 0), add_rows])
 
+    def _owner_words(self, hist):
+        """one zeroed int32 per history row (sgcn_hist_apply_f32's claim table), shared by the program's exchanges"""
+        ow = self.__dict__.get('_owner')
+        if ow is None or ow.numel() < int(hist.shape[0]):
+            ow = self._owner = torch.zeros(int(hist.shape[0]), dtype=torch.int32, device=self.dev)
+        return ow
+
     def _native_exchange(self, l, nh, aux=0):
         """Policy H-a (parallel.py) as ops of the program: [cap ids | cap x d row bits] per rank, all-gathered on the
         library's communicator, applied in rank order -- on the step's own stream behind the optimizer, where the reference
@@ -347,7 +354,9 @@ class StepProgram(object):
         recv = self._alloc_vec(self.native_world * cap * (d + 1))[0]
         self._emit('HIST_PACK', [self._field_ptr(l), self.rows[l].op(), self._p(nh), K(nh.ld), K(d), K(cap), send, K(aux)])
         self._emit('ALLGATHER_I32', [send, recv, K(cap * (d + 1)), K(aux)])
-        self._emit('HIST_APPLY', [K(hist.data_ptr()), K(hist.stride(0)), recv, K(self.native_world), K(cap), K(d), K(aux)])
+        owner = self._owner_words(hist)
+        self._emit('HIST_APPLY', [K(hist.data_ptr()), K(hist.stride(0)), recv, K(self.native_world), K(cap), K(d),
+                                  K(owner.data_ptr()), K(aux)])
 
     def _sparse_dropout(self, xs, site):
         """ops.dropout on the slice's value vector (one row of nnz elements)"""

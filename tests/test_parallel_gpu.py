@@ -451,6 +451,15 @@ def test_history_exchange_pack_and_apply_in_rank_order():
         assert (got[n:cap] == -1).all()
         np.testing.assert_array_equal(got[cap:].view(np.float32).reshape(cap, d)[:n], rows[:n, :d])
         want[ids, :d] = rows[:n, :d]
-    check(lib.sgcn_hist_apply_f32(H.data_ptr(), 40, recv.data_ptr(), world, cap, d, st))
+    H2 = H.clone()
+    check(lib.sgcn_hist_apply_f32(H.data_ptr(), 40, recv.data_ptr(), world, cap, d, None, st))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(H.cpu().numpy(), want)
+    # ... and the two-launch form (a claim table: one zeroed word per history row, zero again afterwards), twice
+    owner = torch.zeros(N, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        H3 = H2.clone()
+        check(lib.sgcn_hist_apply_f32(H3.data_ptr(), 40, recv.data_ptr(), world, cap, d, owner.data_ptr(), st))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(H3.cpu().numpy(), want)
+        assert int(owner.abs().sum()) == 0
