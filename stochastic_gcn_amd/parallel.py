@@ -173,6 +173,7 @@ class DataParallel(object):
         model.history_hook = self.sync_history
         model.history_join = self.join_history
         model.native_coll = self.world if self.native else 0      # step programs carry the collectives themselves
+        model._par = self                                         # (for the exchange's block capacity: history_cap)
         model.dropout_seed = int(getattr(model, "dropout_seed", 0)) + 7919 * self.rank   # independent masks per rank
         self.broadcast_(model.theta)
 

@@ -349,7 +349,10 @@ class StepProgram(object):
         against 0.144 ms per Reddit step, and erratic: a communicator that alternates between two streams synchronises them
         itself; profiles/HISTORY.md round 5)."""
         hist = self.model.history[l][0]
-        d, cap = int(nh.cols), (self.caps[l] + 3) // 4 * 4
+        # the capacity of a rank's block: the job-wide bound the layer-by-layer path uses too (DataParallel.history_cap,
+        # >= every field's own bound) -- a rank whose minibatch did not fit its program exchanges blocks of the same size
+        hc = getattr(getattr(self.model, '_par', None), 'history_cap', None)
+        d, cap = int(nh.cols), (max(int(hc or 0), self.caps[l]) + 3) // 4 * 4
         send = self._alloc_vec(cap * (d + 1))[0]
         recv = self._alloc_vec(self.native_world * cap * (d + 1))[0]
         self._emit('HIST_PACK', [self._field_ptr(l), self.rows[l].op(), self._p(nh), K(nh.ld), K(d), K(cap), send, K(aux)])
