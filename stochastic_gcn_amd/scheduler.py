@@ -412,6 +412,23 @@ def _minibatch_packed(self, batch_size, plan_T=0, slot=None):
     return self.batch_packed(batch, plan_T, slot)
 
 
+def default_packers():
+    """Packer threads beside the sampler's core thread: three when the process has the cores for them.  A data-parallel job
+    runs one process per GPU on ONE host: with 8 ranks on a box whose container grants 16 cores, 8 x (launching thread +
+    core + 3 packers) = 40 runnable threads would time-slice -- each rank then gets what is left of its share after the
+    launching thread and the core (the sample sequence does not depend on the count: sgcn_prefetch_start)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    return int(min(3, max(0, n // ranks - 2)))
+
+
 class NativePrefetcher(object):
     """An epoch's minibatches from the C++ sampler thread(s) of libsgcn.so (sgcn_prefetch_*).
 
@@ -428,7 +445,7 @@ class NativePrefetcher(object):
     def __init__(self, sch, batches, plan_T=0, depth=2, pin=True, lag=2, packers=None):
         schs = list(sch) if isinstance(sch, (list, tuple)) else [sch]
         if packers is None:       # one sampler: its core on one thread, the packing on three others (same bits)
-            packers = 3 if len(schs) == 1 else 0
+            packers = default_packers() if len(schs) == 1 else 0
         if len(schs) > 1:
             packers = 0
         self.packers = int(packers)
