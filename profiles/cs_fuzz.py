@@ -16,7 +16,12 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     dens = float(rng.choice([0.002, 0.02, 0.1, 0.4]))
     a = sp.random(M, K, density=dens, format='csr', random_state=rng, dtype=np.float32)
     a.data[:] = rng.standard_normal(a.nnz).astype(np.float32)
+    if rng.rand() < 0.4 and a.nnz:            # skewed columns (the clock in work coordinates: a warp table by itself)
+        coo = a.tocoo()
+        a = sp.coo_matrix((coo.data, (coo.row, (coo.col.astype(np.int64) ** 2 // max(K, 1)).astype(np.int32))), shape=(M, K)).tocsr()
+        a.sum_duplicates()
     a.sort_indices()
+    warp = [True, False, 'auto'][int(rng.randint(3))]
     G = int(rng.choice([1, 2, 4]))
     d = int(rng.choice([4, 30, 64, 66, 128, 130, 320, 602])); pad = (-d) % 4 + int(rng.choice([0, 4]))
     T = int(rng.choice([0, 8, 64])); align = int(rng.choice([0, 64, 2048]))
@@ -27,7 +32,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     beta = float(rng.choice([0.0, 0.5, 1.0]))
     c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
     try:
-        A = ops.ColumnSweepCSR(a, dev, T=T, G=G, **({} if G == 1 else {"align": align}))
+        A = ops.ColumnSweepCSR(a, dev, T=T, G=G, warp=warp, **({} if G == 1 else {"align": align if rng.rand() < 0.7 else 'auto'}))
         A.pace[d] = int(rng.choice([-1, 100, 300]))
         t = lambda x: None if x is None else torch.from_numpy(x).to(dev)     # noqa: E731
         out = t(c0.copy())
