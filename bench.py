@@ -53,7 +53,7 @@ def parse(argv=None):
                    help="locality-preserving column-sweep plan: communities from label propagation on the graph "
                         "(lp) or from the dataset's labels; default: lp for reddit-sbm, none otherwise")
     p.add_argument("--p-in", type=float, default=0.8, help="reddit-sbm: fraction of a vertex's edges inside its community")
-    p.add_argument("--d", type=int, default=602)
+    p.add_argument("--d", type=int, default=0, help="width of the dense operand (0: 602 for the Reddit shapes, 256 for S-RMAT -- BASELINE configs 3 / 5)")
     p.add_argument("--pitch", type=int, default=0, help="row pitch of X/C in floats (0: d rounded up to 32)")
     p.add_argument("--plan-t", type=int, default=0)
     p.add_argument("--tune", action="append", default=[], help="key=value passed to sgcn_tune")
@@ -559,7 +559,7 @@ def main(argv=None):
         full_adj = sp.csr_matrix((coo.data, (coo.row, coo.col % args.colmod)), shape=full_adj.shape)
         full_adj.sort_indices()
         wname += " [columns folded mod %d]" % args.colmod
-    d = args.d
+    d = args.d or (256 if args.workload.startswith("rmat") else 602)
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
     sh = None
