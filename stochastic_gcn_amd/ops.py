@@ -753,7 +753,7 @@ class ColumnSweepCSR(object):
         if path is None:
             return cls(a, device, G=G), False
         # the identity of the matrix AND of the build parameters the plan depends on (tiles per launch round)
-        key = "%s:r%d:T0:a2048:w1" % (cls.matrix_key(a), int(_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))   # cached() builds with the default T / align
+        key = "%s:r%d:Tauto:aauto:w1" % (cls.matrix_key(a), int(_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))   # cached() builds with the default T / align
         hit = cls.load(path, device, key, g=G)
         if hit is not None:
             return hit, True
