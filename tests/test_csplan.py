@@ -263,3 +263,22 @@ def test_auto_t_fills_the_rounds_a_small_block_needs_and_choose_g_counts_rounds(
     assert Cs.choose_g(602, 100, 29000) == 1 and Cs.choose_g(602, 100, 58000) == 1
     assert Cs.choose_g(602, 100, 116000) == 2 and Cs.choose_g(602, 100, 232965) == 2
     assert Cs.choose_g(256, 23, 1053273) == 4 and Cs.choose_g(256, 334, 73793) == 2 and Cs.choose_g(602, 490, 232965) == 1
+
+
+def test_warp_table_edge_cases():
+    """one column, every nonzero in one column, fewer columns than buckets, the largest column id: the table has one entry
+    per bucket, stays below K and never decreases; the plans built with it still encode the matrix."""
+    from stochastic_gcn_amd import ops
+    Cs = ops.ColumnSweepCSR
+    tab, sh = Cs.make_warp(np.zeros(5, np.int32), 1, True)
+    assert sh == 0 and tab.tolist() == [0]
+    tab, sh = Cs.make_warp(np.full(1000, 7, np.int32), 50, True)
+    assert sh == 0 and tab.shape[0] == 50 and tab[7] == 0 and (tab[8:] == 49).all()       # everything in front of column 8
+    K = 3 * Cs.WARP_BUCKETS + 5
+    cols = np.array([0, K - 1, K - 1, 17], np.int32)
+    tab, sh = Cs.make_warp(cols, K, True)
+    assert sh == 2 and tab.shape[0] == ((K - 1) >> 2) + 1 and tab[-1] < K and (np.diff(tab.astype(np.int64)) >= 0).all()
+    a = sp.csr_matrix((np.ones(4, np.float32), (np.array([0, 1, 2, 3]), cols)), shape=(4, K))
+    for G in (1, 2, 4):
+        A = Cs(a, 'cpu', G=G, warp=True)
+        assert A.warp is not None and A.warp.numel() == tab.shape[0] and A.nnz >= 4
