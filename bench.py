@@ -775,8 +775,10 @@ def main(argv=None):
     if args.kernel == "lds":         # (the whole two-kernel product: profiles/r32_lds_traffic.json is assembled from its PMC table)
         tr = profiled_traffic("void sgcn::lds_spmm_kernel", nnz, d) if not (args.tune or sh is not None) else None
     else:
-        tr = profiled_traffic(("void " + A.variant(d).split(" x ")[0]) if args.kernel == "cs" else "void sgcn::spmm", nnz, d) \
-            if not (args.tune or sh is not None or reorder != "none") else None
+        # (a block of a sharded graph: the committed passes of exactly that block -- its nonzero count identifies it)
+        tr = profiled_traffic(("void " + A.variant(d).split(" x ")[0].replace("false>", "").replace("true>", "").rstrip(", "))
+                              if args.kernel == "cs" else "void sgcn::spmm", sh.local_nnz if sh is not None else nnz, d) \
+            if not (args.tune or reorder != "none") else None
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model
@@ -786,7 +788,7 @@ def main(argv=None):
             tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
         if gc is not None:      # the two-rate model of this kernel's own traffic
             miss_b = tr[0]["fetch_bytes_corrected"] * tr[0]["kernel_launches_per_spmm"]
-            hit_b = max(nnz * (d * 4 + 8) - miss_b, 0)
+            hit_b = max((sh.local_nnz if sh is not None else nnz) * (d * 4 + 8) - miss_b, 0)
             t_model = miss_b / (gc["miss"] * 1e12) + hit_b / (gc["hit"] * 1e12)
             out["roofline"].setdefault("gather_ceiling", {})["ms_model_for_profiled_traffic"] = t_model * 1e3
             out["roofline"]["frac_of_traffic_model"] = t_model / (fwd_ms * 1e-3)
