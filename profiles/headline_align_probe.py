@@ -40,6 +40,12 @@ def run(tag, **kw):
     return A
 
 
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] == "T":
+    for rep in range(2):
+        for T in (1600, 2000, 2400, 3200, 4800):
+            run("T", T=T)
+    raise SystemExit(0)
 for align in (2048, 4096, 8192, 16384):
     run("align", align=align)
 for T in (200, 800):

@@ -33,11 +33,13 @@ void bucket_rows(const int32_t* row_group, int32_t M, std::vector<int32_t>& orde
     for (int32_t r = 0; r < M; r++) order[(size_t)fill[row_group[r]]++] = r;
 }
 
-// default split threshold: a few times the mean degree, so that no single (virtual) row
-// dominates a 16-row tile, within [64, 512]
+// default split threshold: 8 x the mean degree -- half the load of a 16-row bin, so that no single (virtual) row
+// dominates its bin -- within [64, 1024].  (Round 5, S-Reddit at d = 602, sustained: T = 400 3.13 - 3.17 ms, 800 3.12, 1,600
+// 3.10 - 3.15, 2,000 3.40: fewer split rows mean fewer workspace slots and a shorter fix-up launch until a row outweighs
+// its bin; profiles/r45_headline_T_probe.jsonl.)
 inline int32_t default_t(const int32_t* rowptr, int32_t M) {
     const int64_t avg = M > 0 ? ((int64_t)rowptr[M] - rowptr[0]) / M : 0;
-    return (int32_t)std::min<int64_t>(512, std::max<int64_t>(64, 4 * avg));
+    return (int32_t)std::min<int64_t>(1024, std::max<int64_t>(64, 8 * avg));
 }
 
 // virtual rows: a row with n <= T nonzeros is one; a longer row becomes ceil(n/T) strided pieces

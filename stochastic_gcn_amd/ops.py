@@ -557,14 +557,14 @@ class ColumnSweepCSR(object):
         """The split threshold for a matrix that does not fill its rounds of resident tiles: rows longer than T become
         strided virtual rows, and a block with few rows (an eighth of S-Reddit: 29 k rows against the 65 k / 131 k a round
         holds) leaves most wavefront slots of its launches empty -- its sweep is latency-bound.  0 = the library's default
-        (4 x the mean degree, sgcn_csplan.cpp default_t) when the virtual rows it gives fill >= 3/4 of the rounds they
+        (8 x the mean degree, sgcn_csplan.cpp default_t) when the virtual rows it gives fill >= 3/4 of the rounds they
         need; otherwise the smallest T >= 24 whose virtual rows fill 70 % of those rounds (an eighth of S-Reddit, one
         group: T = 400 -> 1.34 ms per fwd + bwd, 100 -> 1.21, 61 (a full round) -> 1.25)."""
         deg = np.diff(np.asarray(rowptr, dtype=np.int64))
         if deg.shape[0] == 0:
             return 0
         avg = int(deg.sum()) // deg.shape[0]
-        t0 = int(min(512, max(64, 4 * avg)))
+        t0 = int(min(1024, max(64, 8 * avg)))                   # (sgcn_csplan.cpp default_t)
         cap_round = int(rnd) * 16 * max(int(G), 1)
 
         def vrows(t):
