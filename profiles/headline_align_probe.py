@@ -41,6 +41,14 @@ def run(tag, **kw):
 
 
 import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] == "combo":
+    for rep in range(3):
+        for slack in (0, 256, 128):
+            _ffi.tune("cs_slack", slack)
+            for align in (2048, 4096):
+                run("slack%d" % slack, align=align)
+    _ffi.tune("cs_slack", 0)
+    raise SystemExit(0)
 if len(_sys.argv) > 1 and _sys.argv[1] == "T":
     for rep in range(2):
         for T in (1600, 2000, 2400, 3200, 4800):
