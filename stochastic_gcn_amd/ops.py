@@ -1103,7 +1103,7 @@ class LdsSweepCSR(object):
             # nonzeros, sustained: 1.26 ms against 1.50 with two groups; bins aligned to 8,192 columns: profiles/r31_*)
             if residual_G == 4 and h.residual.nnz > 40 * max(h.shape[0], 1):
                 residual_G, residual_align = 2, 2048       # a DENSE residual (most of the graph) is the full-graph case: two groups
-            # (long residual rows are split at 256 nonzeros, not at the plan's default 4 x the mean row = 84: fewer fix-up slots,
+            # (long residual rows are split at 256 nonzeros, not at the plan's default 8 x the mean row: fewer fix-up slots,
             # the same heaviest bin -- 1.275 -> 1.242 ms, profiles/lds_residual_probe.py 0.8 T)
             self.residual = ColumnSweepCSR(h.residual, device, G=residual_G, align=residual_align,
                                            T=256 if residual_G == 4 else 0) if residual_G else \
