@@ -646,17 +646,16 @@ class ColumnSweepCSR(object):
         """1, 2 or 4 lane groups per wavefront for operands of width d: a G = 2 launch is ~0.73 of a G = 1 launch
         (measured on S-Reddit: 0.323 ms with the packed-FMA kernel vs 0.445 ms) and a plan needs half the rounds of resident tiles, but
         ceil(d / 128) passes over the feature dimension instead of ceil(d / 320).  What two groups buy is fewer
-        fabric misses; a graph dense enough to hit the L2 anyway (S-Reddit-114M, average degree 490: 15.1 vs
-        14.7 ms) keeps one group.  A SPARSE matrix with more rows than one round of two-group tiles holds (a GPU's block of
+        fabric misses.  A SPARSE matrix with more rows than one round of two-group tiles holds (a GPU's block of
         S-RMAT 10 M / 200 M: 1.05 M rows of 23 nonzeros) takes four: twice the rows -- and nonzeros -- per sweep of B, which
         is what its L2 hits come from (3.16 against 3.49 ms, profiles/r43_warp_probe.jsonl; the same rule as the LDS
         plan's residual)."""
         if avg_degree is not None and avg_degree <= 40 and rows is not None and rows > 4096 * 32:
             return 4
         dp = (int(d) + 3) // 4 * 4
-        # (a dense graph gives two groups less of an edge: S-Reddit-114M at d = 602, five passes against two, stays with one;
-        # the hub block of S-RMAT 10 M -- 334 nonzeros per row, d = 256, two passes against one -- takes two: 2.04 vs 2.59 ms)
-        edge = 0.85 if (avg_degree is not None and avg_degree > 300) else 1.0
+        # (dense graphs follow the same rule since the split threshold doubled: S-Reddit-114M, degree 490, d = 602: two groups
+        # 13.0 ms, one 14.0 -- with the old threshold 15.1 vs 14.7; the hub block of S-RMAT 10 M, 334 nonzeros per row,
+        # d = 256: 2.04 vs 2.59 ms)
         # rounds of resident tiles: one group holds 65,536 rows per round, two hold 131,072 -- half the rounds for a full
         # graph, but no fewer for a block that fits one round either way (an eighth of S-Reddit, 29 k rows, d = 602: two
         # passes of one group 1.34 ms per fwd + bwd, five passes of two groups 1.72)
@@ -665,7 +664,7 @@ class ColumnSweepCSR(object):
             r1, r2 = -(-int(rows) // (4096 * 16)), -(-int(rows) // (4096 * 32))
         if r1 is None:
             r1, r2 = 2, 1
-        return 2 if -(-dp // 128) * 0.73 * r2 <= -(-dp // 320) * r1 * edge else 1
+        return 2 if -(-dp // 128) * 0.73 * r2 <= -(-dp // 320) * r1 else 1
 
     def save(self, path, key):
         if self.grouped:

@@ -262,7 +262,7 @@ def test_auto_t_fills_the_rounds_a_small_block_needs_and_choose_g_counts_rounds(
     assert Cs.auto_t(np.zeros(1, np.int64), 1, 4096) == 0
     assert Cs.choose_g(602, 100, 29000) == 1 and Cs.choose_g(602, 100, 58000) == 1
     assert Cs.choose_g(602, 100, 116000) == 2 and Cs.choose_g(602, 100, 232965) == 2
-    assert Cs.choose_g(256, 23, 1053273) == 4 and Cs.choose_g(256, 334, 73793) == 2 and Cs.choose_g(602, 490, 232965) == 1
+    assert Cs.choose_g(256, 23, 1053273) == 4 and Cs.choose_g(256, 334, 73793) == 2 and Cs.choose_g(602, 490, 232965) == 2
 
 
 def test_warp_table_edge_cases():
