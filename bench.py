@@ -288,6 +288,43 @@ def gather_ceiling():
         return None
 
 
+def setup_report(setup, full_adj, X, C, dev, cs_ms, ops):
+    """What the headline kernel's plan costs before its first product, next to the kernel that needs no such plan.
+
+    The reference runs this product once per matrix (gcn/utils.py:169-170, 321-322: train_adj . feats and full_adj . feats,
+    cached in the dataset's .npz); a full-batch model runs it every layer of every step.  The column sweep pays a host
+    plan (all cores), its upload and a clock autotune; the row-gather kernel (sgcn_spmm_csr_f32) pays the CSR's upload
+    and a row-pointer pass.  `products_to_break_even_vs_rows_kernel` = the number of products from which the column
+    sweep is the faster choice end to end (train.pp_products decides by the same arithmetic)."""
+    def _round(x):
+        return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in x.items()}
+    rep = {k: (_round(v) if isinstance(v, dict) else round(v, 4)) for k, v in setup.items()}
+    import torch
+    torch.cuda.synchronize()
+    t_s = time.perf_counter()
+    R = ops.DeviceCSR.from_scipy(full_adj, dev, with_transpose=False)
+    torch.cuda.synchronize()
+    rows_setup = time.perf_counter() - t_s
+    ops.spmm(R, X, out=C)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        ops.spmm(R, X, out=C)
+    e1.record()
+    e1.synchronize()
+    rows_ms = e0.elapsed_time(e1) / 3
+    cs_setup = sum(setup["fwd"].get(k, 0.0) for k in ("plan_total_s", "autotune_s"))
+    rep["fwd"]["setup_total_s"] = round(cs_setup, 4)
+    if "bwd" in setup:
+        rep["bwd"]["setup_total_s"] = round(setup.get("transpose_s", 0.0) + sum(setup["bwd"].get(k, 0.0) for k in ("plan_total_s", "autotune_s")), 4)
+    rep["rows_kernel"] = {"setup_s": round(rows_setup, 4), "ms_per_product": round(rows_ms, 4),
+                          "what": "sgcn_spmm_csr_f32 (spmm_seg_kernel): CSR upload + row plan, no autotune"}
+    gain = (rows_ms - cs_ms) * 1e-3
+    rep["products_to_break_even_vs_rows_kernel"] = (int(np.ceil(max(cs_setup - rows_setup, 0.0) / gain)) if gain > 0 else None)
+    rep["first_product_s"] = {"column_sweep": round(cs_setup + cs_ms * 1e-3, 4), "rows_kernel": round(rows_setup + rows_ms * 1e-3, 4)}
+    return rep
+
+
 def reddit_grad_floats(d_in=602, hidden=128, classes=41):
     """Weight count of the Reddit CVD+PP stack:
     [2*602 -> 128] -> [128 -> 128] -> agg -> [256 -> 128] -> [128 -> 41] + LN offset/scale."""
@@ -563,6 +600,7 @@ def main(argv=None):
     pitch = args.pitch or (d + 31) // 32 * 32
     nnz = int(full_adj.nnz)
     sh = None
+    setup = None
     reorder = args.reorder or ("lp" if args.workload == "reddit-sbm" else "none")
     reorder_info = None
     if args.shard:
@@ -607,8 +645,23 @@ def main(argv=None):
         else:
             cs_g = args.cs_g or (ops.ColumnSweepCSR.choose_g(d, nnz / max(full_adj.shape[0], 1), full_adj.shape[0]) if comm is None else 1)
             gk = dict(G=cs_g, align=('auto' if args.cs_align < 0 else args.cs_align), warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]) if (cs_g != 1 and comm is None) else dict(col_labels=comm, row_labels=comm)
+            # the plans' setup is timed: the reference runs this product ONCE per matrix (gcn/utils.py:321-322), so what a
+            # plan costs to build is user-visible time there; reported as "setup" beside the line
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
             A = ops.ColumnSweepCSR(full_adj, dev, T=args.cs_t, **gk)
-            A.transpose = None if args.no_backward else ops.ColumnSweepCSR(full_adj.T.tocsr(), dev, T=args.cs_t, **gk)
+            torch.cuda.synchronize()
+            setup = {"fwd": dict(A.setup_s, plan_total_s=time.perf_counter() - t_s)}
+            A.transpose = None
+            if not args.no_backward:
+                t_s = time.perf_counter()
+                full_adj_t = ops.transpose_host(full_adj)          # (until round 5: SciPy's single-threaded csr -> csc pass)
+                setup["transpose_s"] = time.perf_counter() - t_s
+                t_s = time.perf_counter()
+                A.transpose = ops.ColumnSweepCSR(full_adj_t, dev, T=args.cs_t, **gk)
+                torch.cuda.synchronize()
+                setup["bwd"] = dict(A.transpose.setup_s, plan_total_s=time.perf_counter() - t_s)
+                del full_adj_t
             mm = ops.spmm_cs
     else:
         A = ops.DeviceCSR.from_scipy(full_adj, dev, plan_T=args.plan_t, with_transpose=not args.no_backward)
@@ -634,9 +687,18 @@ def main(argv=None):
         C, dX = C[sh.lo:sh.hi], dX[sh.lo:sh.hi]
         Xl, dCl = X[sh.lo:sh.hi].contiguous(), dC[sh.lo:sh.hi].contiguous()
     elif args.kernel in ("cs", "lds") and not any(kv.startswith("cs_pace") for kv in args.tune):
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
         tuned = {"fwd": A.autotune(X)}                  # untimed setup, once per plan and width (lds: its residual's clock)
+        torch.cuda.synchronize()
+        if setup is not None:
+            setup["fwd"]["autotune_s"] = time.perf_counter() - t_s
         if not args.no_backward:
+            t_s = time.perf_counter()
             tuned["bwd"] = A.transpose.autotune(dC)
+            torch.cuda.synchronize()
+            if setup is not None:
+                setup["bwd"]["autotune_s"] = time.perf_counter() - t_s
     gfl = args.grad_floats or reddit_grad_floats()
     grad = torch.randn(gfl, device=dev, generator=gen)
 
@@ -758,6 +820,8 @@ def main(argv=None):
     }
     if reorder_info:
         out["config"]["reorder"] = reorder_info
+    if setup is not None:
+        out["setup"] = setup_report(setup, full_adj, X, C, dev, fwd_ms, ops)
     gc = gather_ceiling()
     if gc is not None and args.kernel == "cs":
         # every edge moves one d-float row of B from an L2 into VGPRs whatever else happens; the pure

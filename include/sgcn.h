@@ -33,7 +33,7 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 13.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 14.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
@@ -41,7 +41,9 @@ const char* sgcn_last_error(void);
  *   v10 sgcn_ldsplan_* / sgcn_spmm_lds_f32: the LDS-staged column sweep for graphs with locality
  *   v11 sgcn_csr_slice_indptr_dev; step ops MODE and CSR_SLICE .. GATHER_F32 (sparse-input stacks as step programs)
  *   v12 sgcn_csplan_t: dev_warp / warp_shift (the column sweep's clock in work coordinates); sgcn_csplang_*: host_warp
- *   v13 sgcn_coll_* (own RCCL communicator), sgcn_hist_pack / _apply, step ops ALLREDUCE_AVG .. HIST_APPLY */
+ *   v13 sgcn_coll_* (own RCCL communicator), sgcn_hist_pack / _apply, step ops ALLREDUCE_AVG .. HIST_APPLY
+ *   v14 sgcn_csplan_build / sgcn_csbuild_* (the column-sweep plan in one parallel pass), sgcn_cs_warp_table,
+ *       sgcn_csr_transpose_host, sgcn_host_threads */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -163,6 +165,36 @@ int sgcn_csplang_fill(const int32_t* host_rowptr, const int32_t* host_col, const
                       int32_t warp_shift, int64_t* host_tile_ptr,
                       int32_t* host_colrow, float* host_valout, int32_t* host_tile_rows, int32_t* host_tile_slots,
                       sgcn_fix_t* host_fix);
+/* The plan in ONE pass on `nthreads` host threads (0: every core the process may use -- affinity mask, cgroup quota,
+ * SGCN_PLAN_THREADS --, at most 64).  The reference runs the product this plan serves once per matrix
+ * (gcn/utils.py:321-322), so the plan's build time is part of the product's user-visible time.  ngroups = 1: the
+ * sgcn_csplan_count / _fill plan (R rows per tile, optional row groups); 2 / 4: the sgcn_csplang_* plan (R ignored,
+ * host_row_group must be NULL).  The plan does not depend on the thread count.  The builder owns the plan until
+ * sgcn_csbuild_free; sgcn_csbuild_export copies it (in parallel) into arrays sized by sgcn_csbuild_sizes:
+ * tile_ptr [ntiles + 1], colrow / val [nentries], tile_rows / tile_slots [ntiles * R * ngroups], fix [nfix]. */
+typedef struct sgcn_csbuild sgcn_csbuild_t;
+int sgcn_csplan_build(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
+                      int32_t ngroups, int32_t R, int32_t T, int32_t round_tiles, int32_t align,
+                      const int32_t* host_row_group, const uint32_t* host_warp, int32_t warp_shift,
+                      int32_t nthreads, sgcn_csbuild_t** out);
+int sgcn_csbuild_sizes(const sgcn_csbuild_t* b, int64_t* ntiles, int64_t* nentries, int64_t* nfix, int64_t* nslots,
+                       int32_t* T_used, int32_t* threads_used);
+int sgcn_csbuild_export(const sgcn_csbuild_t* b, int64_t* host_tile_ptr, int32_t* host_colrow, float* host_valout,
+                        int32_t* host_tile_rows, int32_t* host_tile_slots, sgcn_fix_t* host_fix);
+void sgcn_csbuild_free(sgcn_csbuild_t* b);
+/* sgcn_csplan_t.dev_warp's HOST copy from the matrix's column array (parallel histogram): table[b] = share of the
+ * nonzeros in columns < (b << *shift), scaled to [0, K), for the smallest shift that gives <= max_buckets entries
+ * (table must hold max_buckets).  mode 0 ("auto"): *nbuckets = 0 (no table: the clock stays linear in the column id)
+ * when no bucket's share of the work in front of it is off its share of the ids by more than auto_dev; mode 1: always. */
+int sgcn_cs_warp_table(const int32_t* host_col, int64_t nnz, int32_t K, int32_t max_buckets, int32_t mode,
+                       double auto_dev, int32_t nthreads, uint32_t* host_table, int32_t* nbuckets, int32_t* shift);
+/* A^T of an M x K CSR as a CSR on the host (stable parallel counting sort by column: rows ascend inside a column,
+ * as in SciPy's csr -> csc pass): the backward product's plan is built from it (the autodiff of gcn/layers.py:31-37).
+ * t_rowptr [K + 1], t_col / t_val [nnz]; host_val / host_t_val nullable together (pattern only). */
+int sgcn_csr_transpose_host(const int32_t* host_rowptr, const int32_t* host_col, const float* host_val, int32_t M,
+                            int32_t K, int32_t nthreads, int32_t* host_t_rowptr, int32_t* host_t_col, float* host_t_val);
+/* The number of host threads the plan builders use by default (see sgcn_csplan_build). */
+int32_t sgcn_host_threads(void);
 /* Community labels of a square CSR pattern by seeded asynchronous label propagation (host, graph
  * only; new -- the reference has no reordering).  comm[n] in [0, *ncomm), numbered by decreasing
  * size; communities smaller than min_size share the last label.  max_iters <= 0: 12 sweeps. */

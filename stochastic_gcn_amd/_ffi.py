@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 13         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 14         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -103,6 +103,16 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sgcn_csplang_fill": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int32,
                                     P, P, P, P, P, P]),
+    "sgcn_csplan_build": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_int32,
+                                    C.c_int32, C.POINTER(P)]),
+    "sgcn_csbuild_sizes": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sgcn_csbuild_export": (C.c_int, [P, P, P, P, P, P, P]),
+    "sgcn_csbuild_free": (None, [P]),
+    "sgcn_cs_warp_table": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, P,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sgcn_csr_transpose_host": (C.c_int, [P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
+    "sgcn_host_threads": (C.c_int32, []),
     "sgcn_reorder_lp": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, P, C.POINTER(C.c_int32)]),
     "sgcn_spmm_cs_variant": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_char_p, C.c_int32]),
     "sgcn_spmm_cs_f32": (C.c_int, [C.POINTER(CsPlan), C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P,

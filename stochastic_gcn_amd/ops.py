@@ -14,6 +14,7 @@ Reference seams replaced:
   spmm_cs         the same product as spmm for a STATIC graph (column sweep, ColumnSweepCSR)
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -152,7 +153,7 @@ class DeviceCSR(object):
         a = a.tocsr()
         m = DeviceCSR.from_arrays(a.shape, a.indptr, a.indices, a.data, device, plan_T, with_plan)
         if with_transpose:
-            at = a.T.tocsr()
+            at = transpose_host(a)
             m.transpose = DeviceCSR.from_arrays(at.shape, at.indptr, at.indices, at.data, device,
                                                 plan_T, with_plan)
         return m
@@ -410,6 +411,26 @@ def adam_step(theta, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
 
 
 # ---- column-sweep SpMM for static graphs (sgcn_spmm_cs.hip) --------------------------------------
+def transpose_host(a, threads=0):
+    """A^T of a SciPy CSR as a SciPy CSR with sorted rows, by the library's parallel counting sort
+    (sgcn_csr_transpose_host): what the plan of a backward product (the autodiff of gcn/layers.py:31-37) is built from.
+    Same arrays as ``a.T.tocsr()`` (rows ascend inside a column), in a fraction of its single-threaded time."""
+    import scipy.sparse as sp
+    a = a.tocsr()
+    M, K = int(a.shape[0]), int(a.shape[1])
+    rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+    col = np.ascontiguousarray(a.indices, dtype=np.int32)
+    val = np.ascontiguousarray(a.data, dtype=np.float32)
+    trp = np.empty(K + 1, dtype=np.int32)
+    tc = np.empty(col.shape[0], dtype=np.int32)
+    tv = np.empty(col.shape[0], dtype=np.float32)
+    check(lib.sgcn_csr_transpose_host(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, K, int(threads),
+                                      trp.ctypes.data, tc.ctypes.data, tv.ctypes.data))
+    t = sp.csr_matrix((tv, tc, trp), shape=(K, M), copy=False)
+    t.has_sorted_indices = True
+    return t
+
+
 def reorder_labels(a, max_iters=0, seed=1, min_size=64):
     """Community label per vertex of a square sparse matrix's pattern (sgcn_reorder_lp: seeded
     asynchronous label propagation on the host, graph only).  Returns (comm int32[n], ncomm)."""
@@ -451,19 +472,14 @@ class ColumnSweepCSR(object):
         K = int(K)
         if mode is False or K <= 0 or cols.shape[0] == 0:
             return None, 0
-        shift = 0
-        while ((K - 1) >> shift) + 1 > cls.WARP_BUCKETS:
-            shift += 1
-        nb = ((K - 1) >> shift) + 1
-        hist = np.bincount(np.asarray(cols, dtype=np.int64) >> shift, minlength=nb)[:nb]
-        before = np.concatenate([[0], np.cumsum(hist)[:-1]]).astype(np.float64)
-        share = before / float(hist.sum())
-        if mode == 'auto':
-            ids = (np.arange(nb, dtype=np.float64) * (1 << shift)) / K
-            if np.abs(share - ids).max() <= cls.WARP_AUTO_DEV:
-                return None, 0
-        table = np.minimum(np.floor(share * K), K - 1).astype(np.uint32)
-        return table, shift
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        table = np.empty(cls.WARP_BUCKETS, dtype=np.uint32)
+        nb, shift = C.c_int32(), C.c_int32()
+        check(lib.sgcn_cs_warp_table(cols.ctypes.data, cols.shape[0], K, cls.WARP_BUCKETS, 0 if mode == 'auto' else 1,
+                                     cls.WARP_AUTO_DEV, 0, table.ctypes.data, C.byref(nb), C.byref(shift)))
+        if nb.value == 0:
+            return None, 0
+        return np.ascontiguousarray(table[:nb.value]), int(shift.value)
 
     def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align='auto', warp='auto'):
         """G = 2: two 16-row lane groups per wavefront on 128-column passes (sgcn_csplang_*), half the passes of
@@ -509,34 +525,30 @@ class ColumnSweepCSR(object):
         if not T and not self.grouped:
             T = self.auto_t(rowptr, 1, int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096)))
         self.T = int(T)
-        nt, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplan_count(rowptr.ctypes.data, M, R, T, rgp, C.byref(nt), C.byref(nfix), C.byref(nslots)))
-        tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
-        colrow = np.empty(col.shape[0], dtype=np.int32)
-        valout = np.empty(col.shape[0], dtype=np.float32)
-        tile_rows = np.empty(nt.value * R, dtype=np.int32)
-        tile_slots = np.empty(nt.value * R, dtype=np.int32)
-        fix = np.empty((nfix.value, 3), dtype=np.int32)
-        check(lib.sgcn_csplan_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, R, T, rgp,
-                                   tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data,
-                                   tile_rows.ctypes.data, tile_slots.ctypes.data,
-                                   fix.ctypes.data if nfix.value else None))
+        t_build = time.perf_counter()
+        tile_ptr, colrow, valout, tile_rows, tile_slots, fix, nt, nfix, nslots = self._build(
+            rowptr, col, val, M, 1, R, T, 0, 0, rgp, None, 0)
+        t_build = time.perf_counter() - t_build
         self.shape = (int(a.shape[0]), int(a.shape[1]))
-        self.R, self.ntiles, self.nfix, self.nslots = R, nt.value, nfix.value, nslots.value
+        self.R, self.ntiles, self.nfix, self.nslots = R, nt, nfix, nslots
         self.round_tiles = round_tiles
         self._tile_nnz = np.diff(tile_ptr).astype(np.int64)
         self._hint, self._hint_round = None, None
         self.pace = {}          # d -> ns per nonzero of the heaviest tile (autotuned), -1 = unpaced
         self.tuned_ms, self._guard, self._tuning = {}, {}, False
+        t_up = time.perf_counter()
         to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731
         self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
         self.tile_rows, self.tile_slots = to(tile_rows), to(tile_slots)
-        self.fix = to(fix) if nfix.value else None
+        self.fix = to(fix) if nfix else None
         self.ws, self.device = None, device
         self.nnz = int(col.shape[0])
         # the clock's coordinates (grouped plans run unpaced: no table)
         wtab, self.warp_shift = (None, 0) if self.grouped else self.make_warp(col, self.shape[1], warp)
         self.warp = None if wtab is None else torch.from_numpy(wtab.view(np.int32)).to(device)
+        # what the plan cost to set up (the product it serves may run once: gcn/utils.py:321-322)
+        self.setup_s = {"host_plan_s": t_build, "upload_s": time.perf_counter() - t_up,
+                        "host_threads": int(lib.sgcn_host_threads())}
 
     @staticmethod
     def auto_align(K, nnz, M, G, rnd, d_piece_bytes=None):
@@ -601,33 +613,51 @@ class ColumnSweepCSR(object):
         if align is None or align == 'auto':
             align = self.auto_align(self.shape[1], col.shape[0], M, G, rnd)
         self.align = align = int(align)
-        nt, ne, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.sgcn_csplang_count(rowptr.ctypes.data, col.ctypes.data, M, T, rnd, align, G, wp, self.warp_shift,
-                                     C.byref(nt), C.byref(ne), C.byref(nfix), C.byref(nslots)))
-        tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
-        colrow = np.empty(ne.value, dtype=np.int32)
-        valout = np.empty(ne.value, dtype=np.float32)
-        tile_rows = np.empty(nt.value * 16 * G, dtype=np.int32)
-        tile_slots = np.empty(nt.value * 16 * G, dtype=np.int32)
-        fix = np.empty((nfix.value, 3), dtype=np.int32)
-        check(lib.sgcn_csplang_fill(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, T, rnd, align, G, wp, self.warp_shift,
-                                    tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data, tile_rows.ctypes.data,
-                                    tile_slots.ctypes.data, fix.ctypes.data if nfix.value else None))
-        self.pad_fraction = 1.0 - col.shape[0] / max(ne.value, 1)
+        t_build = time.perf_counter()
+        tile_ptr, colrow, valout, tile_rows, tile_slots, fix, nt, nfix, nslots = self._build(
+            rowptr, col, val, M, G, 16, T, rnd, align, None, wp, self.warp_shift)
+        t_build = time.perf_counter() - t_build
+        ne = int(colrow.shape[0])
+        self.pad_fraction = 1.0 - col.shape[0] / max(ne, 1)
         self.grouped, self.pos2col = False, None
         self.shape = (int(a.shape[0]), int(a.shape[1]))
-        self.R, self.ntiles, self.nfix, self.nslots = 16, nt.value, nfix.value, nslots.value
+        self.R, self.ntiles, self.nfix, self.nslots = 16, nt, nfix, nslots
         self.round_tiles = round_tiles
         self._tile_nnz = (np.diff(tile_ptr) // G).astype(np.int64)       # steps per tile (what the pace counts)
         self._hint, self._hint_round = None, None
         self.pace = {}
         self.tuned_ms, self._guard, self._tuning = {}, {}, False
+        t_up = time.perf_counter()
         to = lambda x: torch.from_numpy(x).to(device)          # noqa: E731
         self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
         self.tile_rows, self.tile_slots = to(tile_rows), to(tile_slots)
-        self.fix = to(fix) if nfix.value else None
+        self.fix = to(fix) if nfix else None
         self.ws, self.device = None, device
         self.nnz = int(col.shape[0])
+        self.setup_s = {"host_plan_s": t_build, "upload_s": time.perf_counter() - t_up,
+                        "host_threads": int(lib.sgcn_host_threads())}
+
+    @staticmethod
+    def _build(rowptr, col, val, M, G, R, T, rnd, align, rgp, wp, warp_shift, threads=0):
+        """sgcn_csplan_build + export: the plan's host arrays, built in one pass on every core the process may use."""
+        h = C.c_void_p()
+        check(lib.sgcn_csplan_build(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, M, G, R, int(T), int(rnd), int(align),
+                                    rgp, wp, int(warp_shift), int(threads), C.byref(h)))
+        try:
+            nt, ne, nfix, nslots = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+            check(lib.sgcn_csbuild_sizes(h, C.byref(nt), C.byref(ne), C.byref(nfix), C.byref(nslots), None, None))
+            tile_ptr = np.empty(nt.value + 1, dtype=np.int64)
+            colrow = np.empty(ne.value, dtype=np.int32)
+            valout = np.empty(ne.value, dtype=np.float32)
+            tile_rows = np.empty(nt.value * R * G, dtype=np.int32)
+            tile_slots = np.empty(nt.value * R * G, dtype=np.int32)
+            fix = np.empty((nfix.value, 3), dtype=np.int32)
+            check(lib.sgcn_csbuild_export(h, tile_ptr.ctypes.data, colrow.ctypes.data, valout.ctypes.data,
+                                          tile_rows.ctypes.data, tile_slots.ctypes.data,
+                                          fix.ctypes.data if nfix.value else None))
+        finally:
+            lib.sgcn_csbuild_free(h)
+        return tile_ptr, colrow, valout, tile_rows, tile_slots, fix, nt.value, nfix.value, nslots.value
 
     # ---- on-disk plan cache (beside the dataset's .npz, SURVEY.md 8f f-3) -------------------------
     @staticmethod

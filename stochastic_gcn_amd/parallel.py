@@ -319,7 +319,7 @@ class ShardedSpMM(object):
             raise ValueError("ShardedSpMM shards one vertex set: the matrix must be square")
         self.par, self.device, self.kernel = par, device, kernel
         self.shape = (int(adj.shape[0]), int(adj.shape[1]))
-        adj_t = adj.T.tocsr() if with_transpose else None
+        adj_t = ops.transpose_host(adj) if with_transpose else None      # (parallel counting sort; SciPy's pass until round 5)
         load = adj.indptr.astype(np.int64) + (adj_t.indptr.astype(np.int64) if with_transpose else 0)
         if row_weight is None:
             row_weight = self.ROW_WEIGHT if kernel == "cs" else 0

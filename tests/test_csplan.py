@@ -282,3 +282,139 @@ def test_warp_table_edge_cases():
     for G in (1, 2, 4):
         A = Cs(a, 'cpu', G=G, warp=True)
         assert A.warp is not None and A.warp.numel() == tab.shape[0] and A.nnz >= 4
+
+
+def _build(a, G, threads, T=0, rnd=0, align=0, R=16, row_group=None, warp=None, shift=0):
+    """sgcn_csplan_build + export on `threads` host threads -> the plan's arrays"""
+    a = a.tocsr()
+    rowptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+    col = np.ascontiguousarray(a.indices, dtype=np.int32)
+    val = np.ascontiguousarray(a.data, dtype=np.float32)
+    rg = None if row_group is None else np.ascontiguousarray(row_group, dtype=np.int32)
+    h = C.c_void_p()
+    check(lib.sgcn_csplan_build(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, a.shape[0], G, R, T, rnd, align,
+                                None if rg is None else rg.ctypes.data, None if warp is None else warp.ctypes.data, shift,
+                                threads, C.byref(h)))
+    try:
+        nt, ne, nf, ns, tu, th = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        check(lib.sgcn_csbuild_sizes(h, C.byref(nt), C.byref(ne), C.byref(nf), C.byref(ns), C.byref(tu), C.byref(th)))
+        assert th.value == threads and tu.value > 0
+        out = [np.empty(nt.value + 1, np.int64), np.empty(ne.value, np.int32), np.empty(ne.value, np.float32),
+               np.empty(nt.value * R * G, np.int32), np.empty(nt.value * R * G, np.int32), np.empty((nf.value, 3), np.int32)]
+        check(lib.sgcn_csbuild_export(h, *[x.ctypes.data if x.size else None for x in out]))
+    finally:
+        lib.sgcn_csbuild_free(h)
+    return out + [np.array([ns.value])]
+
+
+def _unsorted_with_duplicates(seed):
+    """a CSR whose rows are NOT column-sorted and hold repeated (row, column) entries"""
+    rng = np.random.RandomState(seed)
+    coo = sp.random(3000, 2000, density=0.02, random_state=rng, format='coo', dtype=np.float32)
+    r = np.concatenate([coo.row, coo.row[:500]])
+    c = np.concatenate([coo.col, coo.col[:500]])
+    v = np.concatenate([coo.data, coo.data[:500] * 2])
+    perm = rng.permutation(len(r))
+    order = np.argsort(r[perm], kind='stable')
+    r, c, v = r[perm][order], c[perm][order], v[perm][order]
+    ip = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=3000))]).astype(np.int32)
+    return sp.csr_matrix((v, c.astype(np.int32), ip), shape=(3000, 2000))
+
+
+def test_parallel_plan_is_bit_identical_to_the_serial_one_and_to_the_two_call_form():
+    """sgcn_csplan_build (ABI v14): the plan does not depend on the number of building threads, equals what the count / fill
+    pair returns, handles rows that are not column-sorted (stable: duplicates keep their order), and a hub row's pieces."""
+    from stochastic_gcn_amd import ops
+    mats = [_skewed_csr(20000, 30000, 400000, 5), _unsorted_with_duplicates(2)]
+    a = sp.random(700, 500, density=0.05, random_state=np.random.RandomState(3), format='csr', dtype=np.float32)
+    a = sp.vstack([a, sp.csr_matrix(np.ones((1, 500), np.float32))]).tocsr()
+    a.sort_indices()
+    mats.append(a)
+    for a in mats:
+        rg = np.random.RandomState(1).randint(0, 5, a.shape[0])
+        for T in (0, 64):
+            for kw in (dict(G=1), dict(G=1, row_group=rg), dict(G=1, R=32), dict(G=2, rnd=64, align=500), dict(G=4, rnd=64, align=2048),
+                       dict(G=2, align=0)):
+                one = _build(a, threads=1, T=T, **kw)
+                for threads in (3, 8):
+                    many = _build(a, threads=threads, T=T, **kw)
+                    assert all(np.array_equal(x.view(np.int32) if x.dtype == np.float32 else x,
+                                              y.view(np.int32) if y.dtype == np.float32 else y) for x, y in zip(one, many)), (T, kw)
+            # the two-call form of the header is the same plan
+            p = _plan(a, T=T, row_group=rg)
+            one = _build(a, G=1, threads=2, T=T, row_group=rg)
+            assert np.array_equal(p['tile_ptr'], one[0]) and np.array_equal(p['colrow'], one[1])
+            assert np.array_equal(p['val'].view(np.int32), one[2].view(np.int32)) and np.array_equal(p['rows'].ravel(), one[3])
+        wt, sh = ops.ColumnSweepCSR.make_warp(a.indices, a.shape[1], True)
+        one = _build(a, G=2, threads=1, rnd=64, align=300, warp=wt, shift=sh)
+        many = _build(a, G=2, threads=5, rnd=64, align=300, warp=wt, shift=sh)
+        assert all(np.array_equal(x, y) for x, y in zip(one[:2], many[:2]))
+    # the encoded matrix of an unsorted input: exactly the input (duplicates summed by both sides)
+    a = mats[1]
+    one = _build(a, G=1, threads=4, T=64)
+    p = dict(nt=len(one[0]) - 1, tile_ptr=one[0], colrow=one[1], val=one[2], rows=one[3].reshape(-1, 16), R=16)
+    b = _rebuild(p, a.shape)
+    ac = a.copy()
+    ac.sum_duplicates()
+    assert abs(ac - b).max() < 1e-6
+
+
+def test_build_rejects_bad_arguments():
+    a = sp.identity(8, format='csr', dtype=np.float32)
+    rp, col, val = (np.ascontiguousarray(x) for x in (a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data))
+    h = C.c_void_p()
+    assert lib.sgcn_csplan_build(rp.ctypes.data, col.ctypes.data, val.ctypes.data, 8, 3, 16, 0, 0, 0, None, None, 0, 1, C.byref(h)) == -1
+    g = np.zeros(8, np.int32)
+    assert lib.sgcn_csplan_build(rp.ctypes.data, col.ctypes.data, val.ctypes.data, 8, 2, 16, 0, 0, 0, g.ctypes.data, None, 0, 1, C.byref(h)) == -1
+    bad = col.copy()
+    bad[3] = -1
+    assert lib.sgcn_csplan_build(rp.ctypes.data, bad.ctypes.data, val.ctypes.data, 8, 1, 16, 0, 0, 0, None, None, 0, 2, C.byref(h)) == -1
+    assert b"does not fit" in lib.sgcn_last_error() and not h.value
+    assert lib.sgcn_host_threads() >= 1
+
+
+def test_host_transpose_equals_scipy():
+    """sgcn_csr_transpose_host: the stable parallel counting sort gives SciPy's csr -> csc arrays, whatever the thread count;
+    rectangular matrices, empty rows / columns, duplicates."""
+    from stochastic_gcn_amd import ops
+    rng = np.random.RandomState(7)
+    for a in (_skewed_csr(5000, 9000, 300000, 3), _unsorted_with_duplicates(4),
+              sp.csr_matrix((50, 70), dtype=np.float32), sp.random(400, 30, density=0.3, random_state=rng, format='csr', dtype=np.float32)):
+        want = a.T.tocsr()
+        for threads in (1, 2, 7):
+            got = ops.transpose_host(a, threads=threads)
+            assert got.shape == want.shape
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+            assert np.array_equal(got.data.view(np.int32), want.data.astype(np.float32).view(np.int32))
+    bad = sp.csr_matrix((np.ones(2, np.float32), np.array([0, 9], np.int32), np.array([0, 2], np.int32)), shape=(1, 10))
+    bad.indices[1] = 11
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.transpose_host(bad)
+
+
+def test_warp_table_in_c_equals_the_numpy_expression():
+    """sgcn_cs_warp_table against the NumPy form ops.ColumnSweepCSR.make_warp had until round 5 (float64, same order)."""
+    from stochastic_gcn_amd import ops
+
+    def numpy_form(cols, K, mode):
+        shift = 0
+        while ((K - 1) >> shift) + 1 > ops.ColumnSweepCSR.WARP_BUCKETS:
+            shift += 1
+        nb = ((K - 1) >> shift) + 1
+        hist = np.bincount(np.asarray(cols, dtype=np.int64) >> shift, minlength=nb)[:nb]
+        before = np.concatenate([[0], np.cumsum(hist)[:-1]]).astype(np.float64)
+        share = before / float(hist.sum())
+        if mode == 'auto':
+            ids = (np.arange(nb, dtype=np.float64) * (1 << shift)) / K
+            if np.abs(share - ids).max() <= ops.ColumnSweepCSR.WARP_AUTO_DEV:
+                return None, 0
+        return np.minimum(np.floor(share * K), K - 1).astype(np.uint32), shift
+
+    for a in (_skewed_csr(3000, 100000, 200000, 1), _skewed_csr(2000, 777, 50000, 2),
+              sp.random(3000, 50000, density=0.002, random_state=np.random.RandomState(5), format='csr', dtype=np.float32)):
+        for mode in ('auto', True):
+            w0, s0 = numpy_form(a.indices, a.shape[1], mode)
+            w1, s1 = ops.ColumnSweepCSR.make_warp(a.indices, a.shape[1], mode)
+            assert (w0 is None) == (w1 is None) and s0 == s1
+            if w0 is not None:
+                assert np.array_equal(w0, w1)
