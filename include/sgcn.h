@@ -43,7 +43,8 @@ const char* sgcn_last_error(void);
  *   v12 sgcn_csplan_t: dev_warp / warp_shift (the column sweep's clock in work coordinates); sgcn_csplang_*: host_warp
  *   v13 sgcn_coll_* (own RCCL communicator), sgcn_hist_pack / _apply, step ops ALLREDUCE_AVG .. HIST_APPLY
  *   v14 sgcn_csplan_build / sgcn_csbuild_* (the column-sweep plan in one parallel pass), sgcn_cs_warp_table,
- *       sgcn_csr_transpose_host, sgcn_host_threads */
+ *       sgcn_csr_transpose_host, sgcn_host_threads; sgcn_coll_available / _retain / _abort / _async_error,
+ *       sgcn_coll_destroy counts users */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -356,11 +357,21 @@ int sgcn_scatter_rows_f32(float* dev_H, int64_t ldh, const int32_t* dev_r, int32
  * The library's own RCCL communicator (librccl.so by dlopen), so that the data-parallel step's collectives are stream-
  * ordered calls of sgcn_step_run (SGCN_OP_ALLREDUCE_AVG / _ALLGATHER_I32) rather than host-language calls between program
  * runs.  Rank 0 draws the id, the host side carries its 128 bytes to every rank (any channel: the job's process group),
- * every rank calls _init on its device.  One communicator per process. */
+ * every rank calls _init on its device.  One communicator per process, shared by reference count: _init = 1 user,
+ * _retain adds one, _destroy drops one and destroys the communicator with the last.
+ * sgcn_coll_available: a pure probe (library found, symbols bound, ncclGetVersion >= 2.10 -- ncclAvg); every rank calls it
+ * before rank 0 draws the id (ncclGetUniqueId starts a listener that lives as long as the process).
+ * sgcn_coll_abort: a rank that fails ahead of a collective aborts the communicator so that its peers' collectives return
+ * an error instead of blocking for good (there is no watchdog on this communicator); sgcn_coll_async_error polls for
+ * such an error (0 = healthy). */
+int sgcn_coll_available(int32_t* nccl_version_code);
 int sgcn_coll_unique_id(void* host_out128);
 int sgcn_coll_init(const void* host_id128, int32_t world, int32_t rank);
 int sgcn_coll_world(void);                      /* ranks of the communicator, 0 = none */
+int sgcn_coll_retain(void);
 int sgcn_coll_destroy(void);
+int sgcn_coll_abort(void);
+int sgcn_coll_async_error(void);
 int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream);                      /* in place, mean over ranks */
 int sgcn_coll_allgather_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream); /* recv = world x n */
 /* History exchange (policy H-a): send = [cap ids | cap x d row bits], ids[n..cap) = -1;  apply = every rank's block of the

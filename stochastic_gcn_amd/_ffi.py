@@ -134,6 +134,10 @@ SIGNATURES = {
                                              P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
     "sgcn_gather_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "sgcn_scatter_rows_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int64, P]),
+    "sgcn_coll_available": (C.c_int, [C.POINTER(C.c_int32)]),
+    "sgcn_coll_retain": (C.c_int, []),
+    "sgcn_coll_abort": (C.c_int, []),
+    "sgcn_coll_async_error": (C.c_int, []),
     "sgcn_coll_unique_id": (C.c_int, [P]),
     "sgcn_coll_init": (C.c_int, [P, C.c_int32, C.c_int32]),
     "sgcn_coll_world": (C.c_int, []),

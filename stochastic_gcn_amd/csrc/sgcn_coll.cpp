@@ -19,9 +19,13 @@
 
 namespace {
 
+// The handful of RCCL declarations this file needs, restated (rccl.h is not included: the library is bound at run time).
+// They are ABI constants of NCCL >= 2.10 -- ncclAvg = 4 arrived with 2.10, NCCL_UNIQUE_ID_BYTES = 128 and the data type
+// codes are older -- and load() refuses a library whose ncclGetVersion reports less.
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void* rcclComm_t;
-enum { kNcclSuccess = 0, kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0, kNcclAvg = 4 };
+enum { kNcclSuccess = 0, kNcclInProgress = 7, kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0, kNcclAvg = 4 };
+constexpr int kMinNcclVersion = 21000;        // NCCL_VERSION(2, 10, 0) = 2 * 10000 + 10 * 100
 
 struct Rccl {
     void* lib = nullptr;
@@ -31,8 +35,11 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*CommAbort)(rcclComm_t) = nullptr;
+    int (*CommGetAsyncError)(rcclComm_t, int*) = nullptr;
     rcclComm_t comm = nullptr;
-    int world = 0, rank = -1;
+    int world = 0, rank = -1, users = 0, version = 0;
 };
 
 Rccl& R() { static Rccl r; return r; }
@@ -58,7 +65,16 @@ int load() {
     SGCN_SYM(AllReduce, "ncclAllReduce")
     SGCN_SYM(AllGather, "ncclAllGather")
     SGCN_SYM(GetErrorString, "ncclGetErrorString")
+    SGCN_SYM(GetVersion, "ncclGetVersion")
+    SGCN_SYM(CommAbort, "ncclCommAbort")
+    SGCN_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
 #undef SGCN_SYM
+    int v = 0;
+    if (r.GetVersion(&v) != kNcclSuccess || v < kMinNcclVersion) {
+        dlclose(h);
+        return sgcn::fail(SGCN_ERR_INVALID, "coll: librccl.so reports NCCL version code %d; ncclAvg needs >= %d (2.10)", v, kMinNcclVersion);
+    }
+    r.version = v;
     r.lib = h;
     return SGCN_OK;
 }
@@ -71,6 +87,16 @@ int check(int rc, const char* what) {
 }  // namespace
 
 extern "C" {
+
+// Pure probe: can this process bind RCCL (library found, every symbol present, version >= 2.10)?  No unique id is drawn --
+// ncclGetUniqueId starts a bootstrap listener thread and socket that live as long as the process -- so every
+// rank may call this; only rank 0 calls sgcn_coll_unique_id.
+int sgcn_coll_available(int32_t* version_code) {
+    std::lock_guard<std::mutex> lk(mu());
+    const int rc = load();
+    if (version_code) *version_code = rc == SGCN_OK ? R().version : 0;
+    return rc;
+}
 
 int sgcn_coll_unique_id(void* out128) {
     if (!out128) return sgcn::fail(SGCN_ERR_INVALID, "coll_unique_id: null buffer");
@@ -96,19 +122,53 @@ int sgcn_coll_init(const void* id128, int32_t world, int32_t rank) {
     rcclComm_t c = nullptr;
     const int e = check(r.CommInitRank(&c, world, id, rank), "ncclCommInitRank");
     if (e != SGCN_OK) return e;
-    r.comm = c; r.world = world; r.rank = rank;
+    r.comm = c; r.world = world; r.rank = rank; r.users = 1;
     return SGCN_OK;
 }
 
 int sgcn_coll_world(void) { return R().comm ? R().world : 0; }
 
+// The communicator is process-global; a second user of it (another DataParallel object of the same job) retains it and
+// the LAST sgcn_coll_destroy destroys it (the owner's shutdown used to destroy it under the others).
+int sgcn_coll_retain(void) {
+    std::lock_guard<std::mutex> lk(mu());
+    Rccl& r = R();
+    if (!r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_retain: no communicator (sgcn_coll_init)");
+    r.users++;
+    return SGCN_OK;
+}
+
 int sgcn_coll_destroy(void) {
     std::lock_guard<std::mutex> lk(mu());
     Rccl& r = R();
     if (!r.comm) return SGCN_OK;
+    if (--r.users > 0) return SGCN_OK;
     const int e = check(r.CommDestroy(r.comm), "ncclCommDestroy");
-    r.comm = nullptr; r.world = 0; r.rank = -1;
+    r.comm = nullptr; r.world = 0; r.rank = -1; r.users = 0;
     return e;
+}
+
+// A rank that fails ahead of a collective leaves its peers blocked inside RCCL for good (no watchdog on this
+// communicator, unlike c10d's): the failing rank ABORTS the communicator -- the peers' pending and later collectives then
+// return an error instead of hanging -- whatever the user count.  Called by the host side on any failing step.
+int sgcn_coll_abort(void) {
+    std::lock_guard<std::mutex> lk(mu());
+    Rccl& r = R();
+    if (!r.comm) return SGCN_OK;
+    const int e = check(r.CommAbort(r.comm), "ncclCommAbort");
+    r.comm = nullptr; r.world = 0; r.rank = -1; r.users = 0;
+    return e;
+}
+
+// 0 = the communicator is healthy; an asynchronous error a peer's abort or a network fault left behind otherwise.
+int sgcn_coll_async_error(void) {
+    Rccl& r = R();
+    if (!r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_async_error: no communicator (sgcn_coll_init)");
+    int err = kNcclSuccess;
+    const int e = check(r.CommGetAsyncError(r.comm, &err), "ncclCommGetAsyncError");
+    if (e != SGCN_OK) return e;
+    if (err == kNcclSuccess || err == kNcclInProgress) return SGCN_OK;
+    return check(err, "asynchronous error on the communicator");
 }
 
 int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream) {

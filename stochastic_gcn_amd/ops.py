@@ -862,8 +862,10 @@ class ColumnSweepCSR(object):
                 best = (t, p)
         # a winner at the slow end of the list: the optimum may lie beyond it (sparse blocks of large graphs, whose steps
         # mostly miss the L2: S-RMAT 10 M, 360 - 400 ns per step) -- keep slowing the clock while that pays
-        while refine and best[1] > 0 and best[1] == max(candidates) and best[1] < 2000:
-            p = int(best[1] * 1.15)
+        ext = 0
+        while refine and best[1] > 0 and best[1] == max(candidates) and best[1] < 2000 and ext < 8:
+            ext += 1                                  # (bounded: timing noise must not decide when this ends)
+            p = max(best[1] + 1, int(best[1] * 1.15))
             candidates = tuple(candidates) + (p,)
             t = timed(p)
             if t < best[0]:

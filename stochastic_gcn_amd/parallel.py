@@ -66,9 +66,10 @@ class DataParallel(object):
                 device is not None and device.type == "cuda":
             from ._ffi import lib
             if lib.sgcn_coll_world() == self.world:       # one communicator per process: a later object of the job shares it
-                self.native = True
+                self.native = lib.sgcn_coll_retain() == 0  # (by reference count: the last shutdown() destroys it)
             elif init:
                 self._init_native()
+        self.native_history = self.native                  # the history exchange too (set_history_cap may say no)
 
     def _init_native(self):
         """The library's communicator: every rank probes that it can load RCCL (a rank that cannot would leave the others
@@ -78,13 +79,17 @@ class DataParallel(object):
         from ._ffi import lib
         dev = self.device
         ident = torch.zeros(128, dtype=torch.uint8)
-        ok = 1.0 if lib.sgcn_coll_unique_id(ident.data_ptr()) == 0 else 0.0
+        # every rank PROBES (library, symbols, NCCL >= 2.10); only rank 0 draws an id -- ncclGetUniqueId leaves a bootstrap
+        # listener thread and socket behind for the life of the process
+        ok = 1.0 if lib.sgcn_coll_available(None) == 0 else 0.0
+        if ok and self.rank == 0:
+            ok = 1.0 if lib.sgcn_coll_unique_id(ident.data_ptr()) == 0 else 0.0
         flag = torch.tensor([ok], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag.item()) < 1.0:
             if self.rank == 0:
-                print("stochastic_gcn_amd: RCCL is not loadable from libsgcn.so on every rank; collectives through "
-                      "torch.distributed", file=sys.stderr)
+                print("stochastic_gcn_amd: RCCL (>= 2.10) is not loadable from libsgcn.so on every rank; collectives "
+                      "through torch.distributed", file=sys.stderr)
             return
         t = ident.to(dev)
         dist.broadcast(t, src=0)
@@ -172,10 +177,32 @@ class DataParallel(object):
         model.grad_hook = self.allreduce_mean_
         model.history_hook = self.sync_history
         model.history_join = self.join_history
-        model.native_coll = self.world if self.native else 0      # step programs carry the collectives themselves
+        # step programs carry the collectives themselves -- unless the history exchange's fixed block is too large for
+        # that (set_history_cap): then every rank runs both collectives between the program's phases
+        model.native_coll = self.world if (self.native and self.native_history) else 0
         model._par = self                                         # (for the exchange's block capacity: history_cap)
         model.dropout_seed = int(getattr(model, "dropout_seed", 0)) + 7919 * self.rank   # independent masks per rank
         self.broadcast_(model.theta)
+
+    def set_history_cap(self, cap, d_max):
+        """The job-wide bound of the rows a step can update (``cap``, or None) and the widest history (``d_max`` floats).
+        The library's exchange (HIST_PACK / ALLGATHER_I32 / HIST_APPLY) always moves a FIXED block of cap x (d + 1) words
+        per rank and layer; above HISTORY_FIXED_LIMIT_BYTES per rank -- a bound that saturates at the graph's size: Reddit
+        with 8 GPUs and d = 128 would receive ~1 GB per layer and step -- or without a bound, the history exchange of
+        EVERY rank goes through torch.distributed instead (a size exchange + a gather padded to the largest block).  The
+        decision depends on job-wide constants only, so all ranks take it alike."""
+        self.history_cap = None if cap is None else int(cap)
+        fits = cap is not None and (int(cap) + 3) // 4 * 4 * (int(d_max) + 1) * 4 <= self.HISTORY_FIXED_LIMIT_BYTES
+        self.native_history = bool(self.native and fits)
+        return self.native_history
+
+    def abort(self):
+        """A rank-local failure ahead of a collective: abort the library's communicator so that the peers' collectives
+        fail instead of blocking for good (there is no watchdog on it; torch's process group has its own timeout)."""
+        if self.native:
+            from ._ffi import lib
+            lib.sgcn_coll_abort()
+            self.native = self.native_history = self._native_owner = False
 
     def sync_history(self, history, idx, rows, scatter_fn):
         """All-gather this step's (idx[n], rows[n x d]) and apply every rank's update to the local
@@ -192,8 +219,12 @@ class DataParallel(object):
             return
         dev = rows.device
         n, d = int(rows.shape[0]), int(rows.shape[1])
-        if self.native:
-            return self._sync_history_native(history, idx, rows, n, d, dev)
+        if self.native and self.native_history:
+            try:
+                return self._sync_history_native(history, idx, rows, n, d, dev)
+            except BaseException:
+                self.abort()                 # (this rank will not reach the collective: do not leave the peers in it)
+                raise
         cap = self.history_cap
         if cap is not None and n > cap:      # a rank-local branch here would desynchronise the ranks
             raise RuntimeError("history exchange: %d rows exceed history_cap=%d" % (n, cap))
@@ -264,12 +295,12 @@ class DataParallel(object):
 
     def shutdown(self):
         self.join_history()
-        if self.native and self._native_owner:
+        if self.native:                   # (every user drops its reference; the last one destroys the communicator)
             from ._ffi import lib
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             lib.sgcn_coll_destroy()
-        self.native = self._native_owner = False
+        self.native = self.native_history = self._native_owner = False
         if self.active and dist.is_initialized():
             dist.destroy_process_group()
 

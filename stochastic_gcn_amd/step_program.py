@@ -337,8 +337,13 @@ class StepProgram(object):
     def _owner_words(self, hist):
         """one zeroed int32 per history row (sgcn_hist_apply_f32's claim table), shared by the program's exchanges"""
         ow = self.__dict__.get('_owner')
-        if ow is None or ow.numel() < int(hist.shape[0]):
-            ow = self._owner = torch.zeros(int(hist.shape[0]), dtype=torch.int32, device=self.dev)
+        if ow is None:
+            # sized ONCE, for the tallest history of the model: HIST_APPLY ops bake the table's address in, so it must
+            # never be replaced by a larger one while an earlier op still points at it (ADVICE r5)
+            rows = max(int(h.shape[0]) for hs in self.model.history for h in hs)
+            ow = self._owner = torch.zeros(max(rows, int(hist.shape[0])), dtype=torch.int32, device=self.dev)
+        if ow.numel() < int(hist.shape[0]):
+            raise Unsupported("history exchange: a history taller than the claim table")
         return ow
 
     def _native_exchange(self, l, nh, aux=0):
@@ -771,7 +776,16 @@ class StepProgram(object):
     def run(self, which, stream):
         arr, n = self._runs[which]
         if n:
-            check(lib.sgcn_step_run(arr, n, self._slots_ptr, self.nslots, stream))
+            rc = lib.sgcn_step_run(arr, n, self._slots_ptr, self.nslots, stream)
+            if rc != 0 and self.native_world:
+                # a step that failed on THIS rank may have stopped ahead of a collective op its peers are in: abort the
+                # library's communicator so that they fail too instead of blocking for good (no watchdog on it)
+                par = getattr(self.model, '_par', None)
+                if par is not None:
+                    par.abort()
+                else:
+                    lib.sgcn_coll_abort()
+            check(rc)
 
     def tensor_of(self, t, n):
         """torch view of the first n rows of an arena activation under the CURRENT slot table (multi-GPU history

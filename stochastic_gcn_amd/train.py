@@ -72,12 +72,36 @@ def plan_cache_paths(dataset):
     return base + ".csplan.train.npz", base + ".csplan.full.npz"
 
 
-def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats=None):
+# What the static-graph kernels cost end to end on the MI355X (profiles/r60_bench_setup.json, S-Reddit: 23.2 M nonzeros,
+# d = 602, 16 host cores): the row-gather kernel needs the CSR in HBM and a row-pointer pass (5 ms) and takes 7.66 ms per
+# product; the column sweep needs its host plan + upload (0.185 s: 8 ns per nonzero), a clock autotune worth ~62 products,
+# and takes 0.40 of the row kernel's time per product.
+CS_PLAN_S_PER_NNZ = 8.0e-9
+CS_AUTOTUNE_PRODUCTS = 62
+CS_TIME_RATIO = 0.40
+ROWS_S_PER_NNZ_FLOAT = 7.66e-3 / (23173306 * 602.0)
+
+
+def static_kernel_for(nnz, d, products):
+    """'rows' or 'cs': the kernel with the lower expected END-TO-END time for `products` products of one static matrix
+    with a d-wide dense operand -- setup included.  The reference computes each PP product once (gcn/utils.py:321-322, the
+    result cached in the dataset's .npz), and for one product no plan pays: the column sweep breaks even at ~83 products of
+    S-Reddit (a full-batch model's layers over a few epochs), which is what bench.py reports as
+    setup.products_to_break_even_vs_rows_kernel."""
+    t_rows = ROWS_S_PER_NNZ_FLOAT * nnz * d
+    rows = products * t_rows
+    cs = CS_PLAN_S_PER_NNZ * nnz + (CS_AUTOTUNE_PRODUCTS + products) * CS_TIME_RATIO * t_rows
+    return 'cs' if cs < rows else 'rows'
+
+
+def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats=None, products=1):
     """train_feats = train_adj . feats, test_feats = full_adj . feats (gcn/utils.py:169-170,
-    321-322).  Dense features: the column-sweep SpMM kernel on the GPU (K11; sgcn_spmm_cs_f32 -- the
-    kernel bench.py times), its host plan cached beside the dataset; for a graph with communities the LDS-staged sweep
-    (ops.LdsSweepCSR.for_graph).  Sparse features: a
-    sparse x sparse product, done once on the host with SciPy exactly like the reference."""
+    321-322).  Dense features: an SpMM kernel on the GPU (K11), chosen by expected end-to-end time for the number of
+    times the product will run with one plan (``products``; ``static_kernel_for``): once, as in the reference -- the
+    row-gather kernel sgcn_spmm_csr_f32, no plan; many times -- the column sweep (sgcn_spmm_cs_f32, the kernel bench.py
+    times), its host plan cached beside the dataset, or for a graph with communities the LDS-staged sweep
+    (ops.LdsSweepCSR.for_graph).  Sparse features: a sparse x sparse product, done once on the host with SciPy exactly
+    like the reference."""
     if sp.issparse(features):
         return train_adj.dot(features).tocsr(), full_adj.dot(features).tocsr()
     X = features.to(device) if isinstance(features, torch.Tensor) else \
@@ -89,13 +113,22 @@ def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats
         X = Xp[:, :d]
     out = []
     for a, path in zip((train_adj, full_adj), cache):
+        t0 = time()
+        if static_kernel_for(a.nnz, d, products) == 'rows':
+            R = ops.DeviceCSR.from_scipy(a, device)
+            out.append(ops.spmm(R, X).contiguous())
+            if stats is not None:
+                torch.cuda.synchronize()
+                stats.append(dict(plan_from_cache=False, pace=None, kernel="sgcn::spmm_seg_kernel", products=products,
+                                  end_to_end_s=time() - t0))
+            continue
         # a large graph WITH communities (>= 90 % of its nonzeros inside tiles that share their columns): the LDS-staged
         # sweep + the column sweep on the rest; anything else: the column sweep alone
         L = ops.LdsSweepCSR.for_graph(a, device) if (path is None and a.nnz >= 2000000 and d >= 128) else None
         if L is not None:
             L.autotune(X)
             if stats is not None:
-                stats.append(dict(plan_from_cache=False, pace=None, kernel=L.variant(d)))
+                stats.append(dict(plan_from_cache=False, pace=None, kernel=L.variant(d), products=products))
             out.append(ops.spmm_lds(L, X).contiguous())
             continue
         A, hit = ops.ColumnSweepCSR.cached(a, device, path, G=ops.ColumnSweepCSR.choose_g(d, a.nnz / max(a.shape[0], 1), a.shape[0]))
@@ -103,7 +136,7 @@ def pp_products(train_adj, full_adj, features, device, cache=(None, None), stats
             A.autotune(X)               # once per plan and width; stored with the cached plan
         A.store_if_cached()
         if stats is not None:
-            stats.append(dict(plan_from_cache=hit, pace=A.pace.get(d), kernel=A.variant(d)))
+            stats.append(dict(plan_from_cache=hit, pace=A.pace.get(d), kernel=A.variant(d), products=products))
         out.append(ops.spmm_cs(A, X).contiguous())
     return out[0], out[1]
 
@@ -249,7 +282,8 @@ class Trainer(object):
         self.pp_stats = []
         if train_features is None:
             train_features, test_features = pp_products(train_adj, full_adj, features, device,
-                                                        cache=plan_cache_paths(FLAGS.dataset), stats=self.pp_stats)
+                                                        cache=plan_cache_paths(FLAGS.dataset), stats=self.pp_stats,
+                                                        products=FLAGS.pp_products)
         if FLAGS.gradvar:
             log('Analyze mode...')
             full_adj = train_adj.copy()
@@ -295,7 +329,8 @@ class Trainer(object):
             bound = int(FLAGS.batch_size)
             for _ in range(L):
                 bound = min(int(num_data), bound * (1 + int(FLAGS.degree)))
-            par.history_cap = bound
+            par.set_history_cap(bound, max([int(h.shape[1]) for hs in self.train_model.history for h in hs] or [1]))
+            self.train_model.native_coll = par.world if (par.native and par.native_history) else 0
 
         train_degrees = np.array([FLAGS.degree] * L, dtype=np.int32)
         test_degrees = np.array([FLAGS.test_degree] * test_L, dtype=np.int32)

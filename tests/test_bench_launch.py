@@ -39,6 +39,21 @@ def test_gpus_2_spawns_two_distinct_ranks_that_share_an_allreduce(monkeypatch, c
     assert len(printed) == 1 and printed[0]["n_gpus"] == 2   # ONE line, from rank 0
 
 
+def test_gpus_8_dry_run_meets_eight_ranks(monkeypatch, capfd):
+    """The driver's widest launch (`--gpus 8`) over gloo: eight distinct ranks, one line, an eight-way strong partition."""
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SGCN_DIST_BACKEND", "gloo")
+    line = bench.main(["--gpus", "8", "--steps", "2", "--warmup", "0", "--dry-run"])
+    assert line["n_gpus"] == 8 and sorted(line["ranks"]) == list(range(8))
+    assert line["allreduce_of_rank_plus_1"] == 36.0
+    st = line["strong"]
+    assert st["allgather_ok"] is True and abs(st["local_nnz"] - st["nnz"] / 8) < 0.2 * st["nnz"]
+    printed = [json.loads(l) for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(printed) == 1 and printed[0]["n_gpus"] == 8
+
+
 def test_gpus_2_without_two_gpus_fails_loudly():
     """On a box with fewer than N GPUs (this container has none) the nccl launcher must refuse --
     never run one rank and print n_gpus: 1."""

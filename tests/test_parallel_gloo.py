@@ -137,7 +137,121 @@ def w_stop_verdict(par):
     return dict(v=np.array([v1, v2, v3, v4]))
 
 
+def w_eight(par):
+    """World size 8 (the node the driver's scaling run uses): sharding, the fixed-capacity history exchange with cap x 8
+    receive blocks, duplicates that several ranks write in one step, the collective stop decision, the sampler's packer
+    count under a shared host."""
+    from oracle import oracle_np as onp
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.scheduler import default_packers
+    from stochastic_gcn_amd.train import stop_verdict
+    W, r = par.world, par.rank
+    n = 10007
+    ids = np.random.RandomState(0).permutation(n)[:6000]
+    mine = par.shard_ids(ids, n)
+    flat = torch.arange(12, dtype=torch.float32) * (r + 1)
+    par.allreduce_mean_(flat)
+    # history: 40 rows per rank; vertex 5 is written by EVERY rank, vertex 6 by ranks 2 and 6, vertex 7 by ranks 0 and 7
+    N, d = 400, 5
+    rng = np.random.RandomState(100 + r)
+    idx = (8 + r * 40 + np.arange(40)).astype(np.int32)          # disjoint ranges ...
+    idx[0] = 5
+    if r in (2, 6):
+        idx[1] = 6
+    if r in (0, 7):
+        idx[2] = 7
+    nrow = 40 - (r % 3)                                          # ... of ragged sizes
+    idx, rows = idx[:nrow], rng.standard_normal((nrow, d)).astype(np.float32)
+
+    def scatter(h, i, rr):
+        onp.scatter_rows(h.numpy(), i.numpy(), rr.numpy())
+    assert par.set_history_cap(48, d) is False                   # (gloo: never the library's communicator)
+    H = torch.zeros((N, d))
+    par.sync_history(H, torch.from_numpy(idx), torch.from_numpy(rows), scatter)
+    par.sync_history(H, torch.from_numpy(idx), torch.from_numpy(rows * 2), scatter)     # two exchanges in flight
+    assert not H.any()
+    par.join_history()
+    recv_words = max(b[1].numel() for b in par._hist_bufs.values())
+    # the unbounded form (size exchange + padded gather) gives the same history
+    par.history_cap = None
+    H2 = torch.zeros((N, d))
+    par.sync_history(H2, torch.from_numpy(idx), torch.from_numpy(rows * 2), scatter)
+    par.join_history()
+    FLAGS.reset()
+    FLAGS.update(early_stopping=2, epochs=100, data=0)
+    falling, rising = [1.0, 0.9, 0.8, 0.7, 0.6], [1.0, 0.9, 0.8, 0.9, 1.0]
+    v1 = stop_verdict(par, 4, falling if r == 0 else rising, 10)            # rank 0 decides: go on
+    v2 = stop_verdict(par, 4, rising if r == 0 else falling, 10)            # ... stop
+    FLAGS.update(epochs=3, data=100)
+    v3 = stop_verdict(par, 4, falling, 12)                                  # job-wide data 96 < 100
+    v4 = stop_verdict(par, 4, falling, 13)                                  # 104 >= 100
+    os.environ["LOCAL_WORLD_SIZE"] = str(W)
+    return dict(mine=mine, flat=flat.numpy(), lo_hi=np.array(par.vertex_range(n)), H=H.numpy(), H2=H2.numpy(), idx=idx,
+                rows=rows, recv_words=np.array([recv_words]), v=np.array([v1, v2, v3, v4]),
+                packers=np.array([default_packers()]), seed=np.array([par.sampler_seed(123)]))
+
+
 # ---- tests -----------------------------------------------------------------------------------
+def test_eight_ranks_sharding_history_exchange_and_collective_decisions(tmp_path):
+    """The paths the driver's 8-GPU run takes, at world size 8 on CPU (gloo) -- so that its first contact with eight ranks
+    is RCCL itself and nothing of ours."""
+    W = 8
+    r = _run("w_eight", tmp_path, world=W)
+    ids = np.random.RandomState(0).permutation(10007)[:6000]
+    assert sorted(np.concatenate([x["mine"] for x in r]).tolist()) == sorted(ids.tolist())
+    for k, x in enumerate(r):
+        lo, hi = x["lo_hi"]
+        assert lo == (10007 * k) // W and hi == (10007 * (k + 1)) // W
+        assert len(x["mine"]) == 0 or (x["mine"].min() >= lo and x["mine"].max() < hi)
+        np.testing.assert_allclose(x["flat"], np.arange(12, dtype=np.float32) * 4.5)        # mean of 1 .. 8
+        assert x["seed"][0] == 123 + k
+        assert x["v"].tolist() == [0, 1, 0, 2]
+        assert x["recv_words"][0] == W * 48 * (5 + 1)                   # cap x world blocks of [ids | rows]
+        assert 0 <= x["packers"][0] <= 3
+    assert len({int(x["packers"][0]) for x in r}) == 1                  # every rank takes the same share of the host
+    want = np.zeros((400, 5), np.float32)
+    for x in r:                                                         # rank order; the second exchange wrote rows * 2
+        want[x["idx"]] = x["rows"] * 2
+    for x in r:
+        np.testing.assert_array_equal(x["H"], want)                     # replicas bit-identical
+        np.testing.assert_array_equal(x["H2"], want)
+    np.testing.assert_array_equal(want[5], r[7]["rows"][0] * 2)         # eight writers: the highest rank's row stays
+    np.testing.assert_array_equal(want[6], r[6]["rows"][1] * 2)
+    np.testing.assert_array_equal(want[7], r[7]["rows"][2] * 2)
+
+
+def test_default_packers_leaves_the_launching_thread_and_the_core_their_cores(monkeypatch):
+    """scheduler.default_packers: three packers on a box of its own, what is left of a rank's share with 8 ranks on one
+    host (none when the container grants 16 cores: 2 per rank)."""
+    from stochastic_gcn_amd import scheduler
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _: set(range(16)), raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert 0 <= scheduler.default_packers() <= 3            # (3 unless the container's CPU quota is under five cores)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert scheduler.default_packers() == 0
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert scheduler.default_packers() <= 2
+
+
+def test_history_cap_decides_job_wide_whether_the_library_carries_the_exchange():
+    """DataParallel.set_history_cap (ADVICE r5): the library's exchange moves a fixed cap x (d + 1) block per rank and layer;
+    above HISTORY_FIXED_LIMIT_BYTES, or without a bound, every rank leaves the history exchange to torch.distributed --
+    a function of job-wide constants only."""
+    from stochastic_gcn_amd.parallel import DataParallel
+    par = DataParallel(init=False)
+    par.native = True                       # (as if the library's communicator were up)
+    assert par.set_history_cap(512 * 2, 128) is True and par.native_history
+    assert par.set_history_cap(232965, 128) is False and not par.native_history      # the bound saturated at the graph's size
+    assert par.history_cap == 232965
+    assert par.set_history_cap(None, 128) is False
+    lim = DataParallel.HISTORY_FIXED_LIMIT_BYTES
+    cap = lim // (129 * 4) // 4 * 4
+    assert par.set_history_cap(cap, 128) is True and par.set_history_cap(cap + 4, 128) is False
+    par.native = False
+    assert par.set_history_cap(1024, 128) is False
+
+
 def test_sharding_allreduce_broadcast(tmp_path):
     r = _run("w_shard_and_allreduce", tmp_path)
     ids = np.random.RandomState(0).permutation(1001)[:700]

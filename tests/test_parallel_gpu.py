@@ -426,21 +426,23 @@ def test_rccl_one_rank_training_steps_and_allgather_equal_the_single_process_pat
     assert np.abs(ref["hist"]).sum() > 0
 
 
-def test_history_exchange_pack_and_apply_in_rank_order():
-    """sgcn_hist_pack_f32 / sgcn_hist_apply_f32 with THREE ranks' blocks in the gathered buffer (the all-gather itself is
-    the one call that needs three GPUs): padded ids are skipped, and a vertex that several ranks updated keeps the highest
-    rank's row -- what DataParallel.join_history does with one scatter call per rank."""
+@pytest.mark.parametrize("world,sizes", [(3, [64, 17, 0]), (8, [64, 17, 0, 64, 33, 1, 64, 50])])
+def test_history_exchange_pack_and_apply_in_rank_order(world, sizes):
+    """sgcn_hist_pack_f32 / sgcn_hist_apply_f32 with THREE and with EIGHT ranks' blocks in the gathered buffer (the
+    all-gather itself is the one call that needs that many GPUs): padded ids are skipped, and a vertex that several ranks
+    updated -- with eight writers on a quarter of the vertices most are -- keeps the highest rank's row: what
+    DataParallel.join_history does with one scatter call per rank."""
     from stochastic_gcn_amd._ffi import check, lib
     dev = torch.device("cuda:0")
     rng = np.random.RandomState(0)
-    N, d, cap, world = 500, 37, 64, 3
+    N, d, cap = 500, 37, 64
     H0 = rng.standard_normal((N, 40)).astype(np.float32)          # history with a pitch
     H = torch.from_numpy(H0).to(dev)
     want = H0.copy()
     recv = torch.empty(world * cap * (d + 1), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for r in range(world):
-        n = [64, 17, 0][r]
+        n = sizes[r]
         ids = rng.choice(N // 4, n, replace=False).astype(np.int32)              # a quarter of the vertices: ranks collide
         rows = rng.standard_normal((max(n, 1), 48)).astype(np.float32)           # rows with a pitch
         send = recv[r * cap * (d + 1):(r + 1) * cap * (d + 1)]

@@ -112,9 +112,10 @@ def test_gradient_variance_analysis_cv_beats_ns():
 
 
 def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monkeypatch):
-    """The PP products of the training driver (gcn/utils.py:321-322) go through sgcn_spmm_cs_f32 --
-    the kernel bench.py times -- with the host plan cached beside the dataset; the result equals
-    SciPy's (the reference's own library for this product) within 1e-4."""
+    """The PP products of the training driver (gcn/utils.py:321-322), asked for often enough that a plan pays
+    (--pp_products 1000), go through sgcn_spmm_cs_f32 -- the kernel bench.py times -- with the host plan cached beside the
+    dataset; the result equals SciPy's (the reference's own library for this product) within 1e-4.  (Run once, as in the
+    reference: test_pp_products_run_once_take_the_rows_kernel.)"""
     from stochastic_gcn_amd.flags import FLAGS
     from stochastic_gcn_amd.train import Trainer
     from oracle import oracle_np as onp
@@ -126,7 +127,7 @@ def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monk
         FLAGS.reset()
         FLAGS.update(dataset='s-reddit', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True,
                      hidden1=32, num_fc_layers=1, batch_size=256, test_batch_size=512, cv=True, cvd=True,
-                     test_cv=True, degree=1, test_degree=1)
+                     test_cv=True, degree=1, test_degree=1, pp_products=1000)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             tr = Trainer(data=data, verbose=False)
@@ -286,12 +287,36 @@ def test_pp_products_pick_the_lds_sweep_for_a_graph_with_communities():
     rng = np.random.RandomState(0)
     X = rng.standard_normal((a.shape[0], 130)).astype(np.float32)
     stats = []
-    tf, ff = train.pp_products(data[1], a, X, dev, stats=stats)
+    tf, ff = train.pp_products(data[1], a, X, dev, stats=stats, products=5000)
     assert "lds_spmm_kernel" in stats[1]["kernel"], stats
     for got, m in ((tf, data[1]), (ff, a)):
         ref = m.astype(np.float64).dot(X.astype(np.float64))
         assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     flat = synthetic.reddit_like(n=60000, m=3000000, f=8, classes=5, splits=(40000, 8000, 12000), seed=4, with_features=False)
     stats = []
-    train.pp_products(flat[1], flat[2], X, dev, stats=stats)
+    train.pp_products(flat[1], flat[2], X, dev, stats=stats, products=5000)
     assert all("cs_spmm" in s_["kernel"] for s_ in stats), stats
+
+
+def test_pp_products_run_once_take_the_rows_kernel(tmp_path, monkeypatch):
+    """The reference computes each PP product ONCE (gcn/utils.py:321-322).  For one product no plan pays (bench.py's
+    setup.products_to_break_even_vs_rows_kernel: ~83 on S-Reddit): train.pp_products then runs the row-gather kernel, writes
+    no plan cache, and agrees with SciPy; the choice flips to the column sweep where the arithmetic of
+    train.static_kernel_for says so."""
+    import torch
+    from stochastic_gcn_amd import synthetic, train
+    monkeypatch.setenv("SGCN_PLAN_CACHE_DIR", str(tmp_path))
+    dev = torch.device("cuda:0")
+    flat = synthetic.reddit_like(n=60000, m=3000000, f=8, classes=5, splits=(40000, 8000, 12000), seed=4, with_features=False)
+    X = np.random.RandomState(0).standard_normal((flat[2].shape[0], 130)).astype(np.float32)
+    stats = []
+    tf, ff = train.pp_products(flat[1], flat[2], X, dev, cache=(str(tmp_path / "a.npz"), str(tmp_path / "b.npz")), stats=stats)
+    assert all("spmm_seg_kernel" in s_["kernel"] for s_ in stats), stats
+    assert not list(tmp_path.glob("*.npz"))
+    for got, m in ((tf, flat[1]), (ff, flat[2])):
+        ref = m.astype(np.float64).dot(X.astype(np.float64))
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert train.static_kernel_for(23173306, 602, 1) == 'rows' and train.static_kernel_for(23173306, 602, 40) == 'rows'
+    assert train.static_kernel_for(23173306, 602, 120) == 'cs'
+    n = [k for k in range(1, 400) if train.static_kernel_for(23173306, 602, k) == 'cs'][0]
+    assert 70 <= n <= 100, n            # (measured: 83, profiles/r60_bench_setup.json)
