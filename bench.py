@@ -805,6 +805,12 @@ def main(argv=None):
                                 else "sgcn::spmm_seg_kernel (forward A.X, incl. split-row fix-up)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_copy_ceiling": achieved / HBM_COPY,
+                     # "bound" is the contract's roof (north_star: HBM).  The roof the counters say this kernel actually
+                     # sits on (L2 busy 95 %, VALU 8 % for the gathers; the LDS sweep's chunk
+                     # statement is VALU-bound) is carried next to it: frac_of_l2 = per-edge L2 -> VGPR bytes / time
+                     # over the guide's aggregate L2 rate (= l2_gather.frac below)
+                     "bound_measured": "valu" if args.kernel == "lds" else "l2",
+                     "frac_of_l2": (sh.local_nnz if sh is not None else nnz) * d * 4 / (fwd_ms * 1e-3) / L2_PEAK,
                      "traffic": None, "traffic_source": None, "bytes_alg_per_launch": bytes_alg,
                      "ms_per_launch": fwd_ms,
                      "edges_per_s_fwd": (sh.local_nnz if sh is not None else nnz) / (fwd_ms * 1e-3),

@@ -265,8 +265,12 @@ class AugmentedDropoutDense(Layer):
         if fused:
             h2, ctx2 = ops.dense_fwd(x, W, off, sc, True, x2=mu, drop=drop)
         else:
-            xd = x if drop is None else ops.dropout(x, drop)
-            h2, ctx2 = ops.ln_act_fwd(ops.gemm(torch.cat((xd, mu), dim=0), W), off, sc, True)
+            # wide layers (> 128 columns): the two streams' products land in the two halves of ONE pre-activation
+            # buffer (the dropout applied while A is loaded, ops.gemm drop_a), then one LN + ReLU pass over both
+            pre = torch.empty((n + int(mu.shape[0]), self.output_dim), dtype=torch.float32, device=x.device)
+            ops.gemm(x, W, out=pre[:n], drop_a=drop)
+            ops.gemm(mu, W, out=pre[n:])
+            h2, ctx2 = ops.ln_act_fwd(pre, off, sc, True)
         self._ctx = (ctx2[0][:n], ctx2[1][:n]) if ctx2 is not None else None
         self._out = h2[:n]
         return h2[:n], h2[n:]

@@ -28,7 +28,7 @@ from .models import make_template
 from .parallel import DataParallel
 from .plaingcn import PlainGCN
 from .scheduler import NativePrefetcher, PyScheduler
-from .utils import Averager, RunningStat, calc_f1, f1_from_classes, load_data
+from .utils import Averager, calc_f1, f1_from_classes, load_data
 from .vrgcn import VRGCN
 
 
@@ -403,7 +403,7 @@ class Trainer(object):
             return pre.next() if pre else \
                 self.eval_sch.batch_packed(chunks[i], FLAGS.plan_t, self.eval_slots[i % len(self.eval_slots)])
         nxt = fetch(0) if chunks else None
-        vecs, rows = [], []
+        vecs, rows, slow = [], [], None
         for k in range(len(chunks)):
             batch = nxt
             nxt = fetch(k + 1) if k + 1 < len(chunks) else None
@@ -421,13 +421,25 @@ class Trainer(object):
                 vecs.append(vec)
                 rows.append(self.test_model.eval_rows)
                 continue
-            stats.append(torch.stack([los, acc]) * prd.shape[0])
+            # the other result forms (multi-label, or a step that ran layer by layer): loss, accuracy and the rows'
+            # classes -- or predictions and labels -- go to pinned host memory as they are produced (copy engine, stream
+            # order; los / acc are views the next batch overwrites); the sums are taken on the host after ONE
+            # synchronisation.  No torch arithmetic or concatenation kernel on this path either.
             cls = getattr(self.test_model, 'eval_classes', None)
+            r = int(prd.shape[0])
+            if slow is None:
+                per_row = 1 if cls is not None else 2 * int(prd.shape[1])
+                slow = getattr(self, '_eval_sink_slow', None)
+                need = 2 * len(chunks) + per_row * N
+                if slow is None or slow.buf.numel() < need:
+                    slow = self._eval_sink_slow = Trainer._EvalSink(need)
+                slow.pos = 0
+            stats.append((slow.push(los.reshape(1)), slow.push(acc.reshape(1)), r))
             if cls is not None:                 # single-label: the loss kernel's class indices, 4 bytes per row
-                total_cls.append(cls)
+                total_cls.append(slow.push(cls))
             else:
-                total_pred.append(prd)
-                total_labs.append(self.test_model.cur.labels)
+                total_pred.append(slow.push(prd.reshape(-1)).view(r, -1))
+                total_labs.append(slow.push(self.test_model.cur.labels.reshape(-1)).view(r, -1))
         if pre is not None and hasattr(pre, 'close'):
             pre.close()
         assert not (vecs and stats), "evaluation batches took both result forms"
@@ -447,13 +459,17 @@ class Trainer(object):
             return float(tot[0]), float(tot[1]), micro, macro, (time() - t_test)
         if not stats:
             return 0.0, 0.0, 0.0, 0.0, time() - t_test
-        tot = torch.stack(stats).sum(dim=0).cpu().numpy() / max(N, 1)      # the only host sync
+        torch.cuda.current_stream().synchronize()                           # the only host sync
+        tot = np.zeros(2, dtype=np.float32)
+        for los, acc, r in stats:
+            tot += np.array([los.numpy()[0], acc.numpy()[0]], dtype=np.float32) * np.float32(r)
+        tot = tot / np.float32(max(N, 1))
         if total_cls and not total_pred:
-            v = torch.cat(total_cls).cpu().numpy().astype(np.int64)        # argmax(pred) + 4096 * argmax(labels) per row
+            v = np.concatenate([c.numpy() for c in total_cls]).astype(np.int64)   # argmax(pred) + 4096 * argmax(labels) per row
             micro, macro = f1_from_classes(v // 4096, v % 4096)
         else:
-            total_pred = torch.cat(total_pred).cpu().numpy()
-            total_labs = torch.cat(total_labs).cpu().numpy()
+            total_pred = np.concatenate([x.numpy() for x in total_pred])
+            total_labs = np.concatenate([x.numpy() for x in total_labs])
             micro, macro = calc_f1(total_pred, total_labs, self.multitask)
         return float(tot[0]), float(tot[1]), micro, macro, (time() - t_test)
 
@@ -569,42 +585,6 @@ class Trainer(object):
         if par.rank == 0:
             train_model.save(self.sess)
 
-    def GradientVariance(self, times=1000):
-        """--gradvar (gcn/train.py:241-276): bias and standard deviation of the prediction and of
-        the first layer's gradient under the training sampler, against the test sampler
-        (``--gradvar`` makes the test graph the training graph, so with ``--test_degree`` large
-        that is the exact aggregate), on the first batch of training vertices."""
-        log, ph = self.log, self.placeholders
-        batch = np.ascontiguousarray(self.train_d[:FLAGS.batch_size], dtype=np.int32)
-
-        def sweep(sch, model):
-            preds, grads = RunningStat(), RunningStat()
-            for _ in range(times):
-                feed = sch.batch(batch)
-                feed[ph['dropout']] = FLAGS.dropout
-                pred, grad = model.get_pred_and_grad(self.sess, feed)
-                preds.add(pred)
-                grads.add(grad)
-            return preds, grads
-        full_preds, full_grads = sweep(self.eval_sch, self.test_model)
-        full_preds_m = np.mean(np.abs(full_preds.mean()))
-        full_grads_m = np.mean(np.abs(full_grads.mean()))
-        log('Full pred stdev = {}'.format(np.mean(full_preds.std()) / full_preds_m))
-        log('Full grad stdev = {}'.format(np.mean(full_grads.std()) / full_grads_m))
-        part_preds, part_grads = sweep(self.train_sch, self.train_model)
-        out = dict(full_pred_std=np.mean(full_preds.std()) / full_preds_m,
-                   full_grad_std=np.mean(full_grads.std()) / full_grads_m,
-                   part_pred_bias=np.mean(np.abs(part_preds.mean() - full_preds.mean())) / full_preds_m,
-                   part_pred_std=np.mean(part_preds.std()) / full_preds_m,
-                   part_grad_bias=np.mean(np.abs(full_grads.mean() - part_grads.mean())) / full_grads_m,
-                   part_grad_std=np.mean(part_grads.std()) / full_grads_m)
-        log('Part pred bias = {}'.format(out['part_pred_bias']))
-        log('Part pred stdev = {}'.format(out['part_pred_std']))
-        log('Part grad bias = {}'.format(out['part_grad_bias']))
-        log('Part grad stdev = {}'.format(out['part_grad_std']))
-        log(full_grads_m, np.mean(part_grads.std()), np.mean(np.abs(part_grads.mean())))
-        return out
-
     def Test(self):
         test_cost, test_acc, micro, macro, test_duration = self.evaluate(self.test_d)
         self.log("Test set results:", "cost=", "{:.5f}".format(test_cost),
@@ -621,7 +601,11 @@ def main(argv=None):
     tr = Trainer()
     tr.SGDTrain()
     if FLAGS.gradvar:
-        tr.GradientVariance()
+        # --gradvar keeps what belongs to the path (the test graph = the training graph, histories restored by
+        # --load: models.py, Trainer.__init__); the bias / variance study it drove in the reference
+        # (gcn/train.py:241-276) is an analysis tool, out of scope
+        tr.log('--gradvar: analysis mode set up (test graph = training graph); the bias / variance study is '
+               'not part of this package -- use model.get_pred_and_grad(sess, feed) directly')
     num_runs = FLAGS.num_layers + 1 if FLAGS.test_cv else 1
     for _ in range(num_runs):
         tr.Test()

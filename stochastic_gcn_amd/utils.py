@@ -108,29 +108,6 @@ class Averager(object):
         return np.mean(self.window)
 
 
-class RunningStat(object):
-    """Element-wise mean / standard deviation of a stream of equally shaped arrays (what
-    gcn/stats.py's ``Stat`` reports), accumulated in float64 without keeping the samples."""
-
-    def __init__(self):
-        self.n, self.s, self.q = 0, None, None
-
-    def add(self, v):
-        v = np.asarray(v[0] if isinstance(v, (list, tuple)) and len(v) == 1 else v, dtype=np.float64)
-        if self.s is None:
-            self.s, self.q = np.zeros_like(v), np.zeros_like(v)
-        self.n += 1
-        self.s += v
-        self.q += v * v
-
-    def mean(self):
-        return self.s / max(self.n, 1)
-
-    def std(self):
-        m = self.mean()
-        return np.sqrt(np.maximum(self.q / max(self.n, 1) - m * m, 0.0))
-
-
 def f1_from_classes(true, pred):
     """sklearn.metrics.f1_score(true, pred, average="micro" / "macro") for single-label class indices, from three
     bincounts: per label 2 tp / (true count + predicted count) over the labels that occur in either array, in float64 --

@@ -93,22 +93,35 @@ def test_training_is_bit_reproducible_and_prefetch_modes_agree():
         assert torch.equal(hist, runs[0][1])
 
 
-def test_gradient_variance_analysis_cv_beats_ns():
-    """--gradvar (gcn/train.py:241-276): with the history warmed up by training, the control-variate
-    estimator's PREDICTION has a much smaller standard deviation and bias than plain neighbour
-    sampling at the same degree, against the large-degree reference (which itself is deterministic:
-    dropout 0, every neighbour taken)."""
-    res = {}
+def test_control_variate_predictions_scatter_less_than_neighbour_sampling():
+    """What the control variate is for (the property the reference's --gradvar study measured, gcn/train.py:241-276;
+    the study itself is out of scope): on one fixed batch, with the history warmed up by training and dropout off,
+    ``get_pred_and_grad`` under the degree-2 training sampler scatters far less around the every-neighbour answer
+    with the control variate than plain neighbour sampling does -- and the every-neighbour answer does not scatter."""
+    from stochastic_gcn_amd.flags import FLAGS
+    spread = {}
     for name, flags in (("ns", dict(cv=False, degree=2, test_degree=10000)),
                         ("cv", dict(cv=True, cvd=False, test_cv=False, degree=2, test_degree=10000))):
         tr, _ = _train(dict(gradvar=True, dropout=0.0, **flags), 20)
-        res[name] = tr.GradientVariance(times=60)
-    print(res)
-    for r in res.values():
-        assert r["full_pred_std"] < 1e-5 and r["full_grad_std"] < 1e-5      # the reference sweep is exact
-        assert all(np.isfinite(v) for v in r.values())
-    assert res["cv"]["part_pred_std"] < 0.5 * res["ns"]["part_pred_std"]
-    assert res["cv"]["part_pred_bias"] < res["ns"]["part_pred_bias"]
+        ids = np.ascontiguousarray(tr.train_d[:FLAGS.batch_size], dtype=np.int32)
+
+        def draws(sch, model, k):
+            out = []
+            for _ in range(k):
+                feed = sch.batch(ids)
+                feed[tr.placeholders['dropout']] = 0.0
+                pred, _grad = model.get_pred_and_grad(tr.sess, feed)
+                out.append(np.asarray(pred[0] if isinstance(pred, (list, tuple)) else pred, np.float64))
+            return np.stack(out)
+        exact = draws(tr.eval_sch, tr.test_model, 3)
+        assert np.abs(exact - exact[0]).max() <= 1e-5 * np.abs(exact[0]).mean()     # every neighbour: deterministic
+        part = draws(tr.train_sch, tr.train_model, 60)
+        unit = np.abs(exact[0]).mean()
+        spread[name] = (part.std(axis=0).mean() / unit, np.abs(part.mean(axis=0) - exact[0]).mean() / unit)
+    print(spread)
+    assert all(np.isfinite(v) for pair in spread.values() for v in pair)
+    assert spread["cv"][0] < 0.5 * spread["ns"][0]
+    assert spread["cv"][1] < spread["ns"][1]
 
 
 def test_trainer_pp_products_run_the_column_sweep_and_match_scipy(tmp_path, monkeypatch):
