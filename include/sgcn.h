@@ -33,7 +33,7 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 14.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 15.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
@@ -44,7 +44,9 @@ const char* sgcn_last_error(void);
  *   v13 sgcn_coll_* (own RCCL communicator), sgcn_hist_pack / _apply, step ops ALLREDUCE_AVG .. HIST_APPLY
  *   v14 sgcn_csplan_build / sgcn_csbuild_* (the column-sweep plan in one parallel pass), sgcn_cs_warp_table,
  *       sgcn_csr_transpose_host, sgcn_host_threads; sgcn_coll_available / _retain / _abort / _async_error,
- *       sgcn_coll_destroy counts users */
+ *       sgcn_coll_destroy counts users
+ *   v15 sgcn_coll_init_exchange / _has_exchange / sgcn_coll_allgather_x_i32 (a second communicator for the history exchange);
+ *       step ops HIST_PACK .. HIST_APPLY: aux = 2 = the library's exchange stream, joined at the end of the run */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -374,6 +376,13 @@ int sgcn_coll_abort(void);
 int sgcn_coll_async_error(void);
 int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream);                      /* in place, mean over ranks */
 int sgcn_coll_allgather_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream); /* recv = world x n */
+/* A second communicator of the same ranks (ABI v15) for collectives issued on ANOTHER stream than the gradient all-reduce's:
+ * one communicator used from two streams in turn makes RCCL order the streams itself.  Rank 0 draws a fresh id
+ * (sgcn_coll_unique_id), every rank calls _init_exchange behind sgcn_coll_init; it lives and dies with the first
+ * (_destroy / _abort).  sgcn_coll_allgather_x_i32 uses it (the first communicator when there is none). */
+int sgcn_coll_init_exchange(const void* host_id128);
+int sgcn_coll_has_exchange(void);               /* 1 = the exchange communicator exists */
+int sgcn_coll_allgather_x_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream);
 /* History exchange (policy H-a): send = [cap ids | cap x d row bits], ids[n..cap) = -1;  apply = every rank's block of the
  * gathered buffer (world x cap x (d + 1) words) scattered into H in rank order (sgcn_scatter_rows_f32 per rank: ids < 0
  * skipped; a vertex two ranks updated keeps the higher rank's row on every replica).  dev_owner (nullable): one int32 per
@@ -719,9 +728,13 @@ enum {
                                  * auxiliary stream, flushes parked reductions) */
     SGCN_OP_HIST_PACK = 30,     /* sgcn_hist_pack_f32 (ids, n, rows, ld, d, cap, send, aux) */
     SGCN_OP_ALLGATHER_I32 = 31, /* sgcn_coll_allgather_i32 (send, recv, n, aux) */
-    SGCN_OP_HIST_APPLY = 32,    /* sgcn_hist_apply_f32 (H, ldh, recv, world, cap, d, owner, aux); aux != 0 (30 - 32): on the auxiliary
-                                 * stream, forked from `stream` at the op -- an exchange issued right behind the aggregator that
-                                 * read the history runs beside the rest of the step */
+    SGCN_OP_HIST_APPLY = 32,    /* sgcn_hist_apply_f32 (H, ldh, recv, world, cap, d, owner, aux); aux = 1 (30 - 32): on the auxiliary
+                                 * stream, forked from `stream` at the op.  aux = 2 (ABI v15): on the library's EXCHANGE stream,
+                                 * which waits for `stream` once, at the run's first such op -- an exchange issued right behind the
+                                 * aggregator that read the history runs beside the loss, the backward pass, the gradient
+                                 * all-reduce and the optimizer; the all-gather goes to the exchange communicator
+                                 * (sgcn_coll_allgather_x_i32); `stream` waits for the exchange at the END of the run (the first
+                                 * reader of the history is the next run's aggregator, gcn/models.py:186-194) */
     SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD
                                  * writes its dW / doffset / dscale instead of adding to them, so the program zeroes nothing
                                  * (it must write every parameter gradient exactly once per step); and the statistics

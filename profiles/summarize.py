@@ -56,8 +56,10 @@ def main(src, tag):
     try:
         import json
         def top(dbh, counter):
+            # the kernel the bench TIMES: most time in total (dispatches x mean duration), not the longest single dispatch --
+            # since round 6 the same command also runs the row-gather kernel four times for the setup report
             q = ("select name, avg(counter_value), avg(duration) from pmc_events where counter_name=? "
-                 "and name like '%sgcn::%' group by name order by avg(duration) desc limit 1")
+                 "and name like '%sgcn::%' group by name order by sum(duration) desc limit 1")
             return dbh.execute(q, (counter,)).fetchone()
         f = top(db(os.path.join(src, "pmc_fetch")), "FETCH_SIZE")
         w = top(db(os.path.join(src, "pmc_write")), "WRITE_SIZE")
@@ -133,5 +135,34 @@ def main(src, tag):
     print("\n".join(lines))
 
 
+def traffic_from_counters(counters_path, bench_path, out_path):
+    """The traffic record of the bench's timed kernel from a ``*_counters.json`` + the bench line of the traced run (the
+    databases of the r62 passes stayed on the GPU box; their per-kernel means are in the counters file)."""
+    import json
+    c = json.load(open(counters_path))
+    bj = json.loads(open(bench_path).read().strip().splitlines()[-1])
+    name = max(c, key=lambda k: c[k]["FETCH_SIZE"]["dispatches"] * c[k]["FETCH_SIZE"]["mean_ns"])
+    k = c[name]
+    f, w = k["FETCH_SIZE"]["mean_per_dispatch"], k["WRITE_SIZE"]["mean_per_dispatch"]
+    hit, mis = k["TCC_HIT_sum"]["mean_per_dispatch"], k["TCC_MISS_sum"]["mean_per_dispatch"]
+    nl = bj["config"].get("kernel_launches_per_spmm", 1)
+    rec = {"kernel": name, "fetch_kib_raw": f, "write_kib": w, "fetch_bytes_corrected": f * 1024 * 2, "write_bytes": w * 1024,
+           "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024, "kernel_launches_per_spmm": nl,
+           "hbm_bytes_per_spmm": (f * 1024 * 2 + w * 1024) * nl, "l2_hit_rate": hit / (hit + mis),
+           "ns_per_launch_profiled": k["FETCH_SIZE"]["mean_ns"], "nnz": bj["config"]["nnz"], "d": bj["config"]["d"],
+           "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; "
+                   "rebuilt from the per-kernel means of the separate --pmc passes (profiles/summarize.py --from-counters)"}
+    if "per_gpu" in bj["config"] and "rank 0 rows" in str(bj["config"]["per_gpu"]):
+        import re
+        m = re.search(r"(\d+) nnz", bj["config"]["per_gpu"])
+        if m:
+            rec["nnz"] = int(m.group(1))            # a block of a sharded graph is identified by ITS nonzeros (bench.py)
+    json.dump(rec, open(out_path, "w"), indent=1)
+    return rec
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == "--from-counters":
+        print(traffic_from_counters(sys.argv[2], sys.argv[3], sys.argv[4]))
+    else:
+        main(sys.argv[1], sys.argv[2])

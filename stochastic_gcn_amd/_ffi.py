@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgcn.so")
 
-ABI_VERSION = 14         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
+ABI_VERSION = 15         # include/sgcn.h sgcn_abi_version(): bumped on any signature change
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -144,6 +144,9 @@ SIGNATURES = {
     "sgcn_coll_destroy": (C.c_int, []),
     "sgcn_coll_allreduce_avg_f32": (C.c_int, [P, C.c_int64, P]),
     "sgcn_coll_allgather_i32": (C.c_int, [P, P, C.c_int64, P]),
+    "sgcn_coll_init_exchange": (C.c_int, [P]),
+    "sgcn_coll_has_exchange": (C.c_int, []),
+    "sgcn_coll_allgather_x_i32": (C.c_int, [P, P, C.c_int64, P]),
     "sgcn_hist_pack_f32": (C.c_int, [P, C.c_int32, P, C.c_int64, C.c_int32, C.c_int32, P, P]),
     "sgcn_hist_apply_f32": (C.c_int, [P, C.c_int64, P, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "sgcn_csr_slice_indptr": (C.c_int, [C.c_int32, P, P, P]),

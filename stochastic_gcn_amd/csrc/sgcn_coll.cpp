@@ -39,6 +39,11 @@ struct Rccl {
     int (*CommAbort)(rcclComm_t) = nullptr;
     int (*CommGetAsyncError)(rcclComm_t, int*) = nullptr;
     rcclComm_t comm = nullptr;
+    // The EXCHANGE communicator (round 6): the step's history all-gather runs on the library's exchange stream beside the
+    // loss, the backward pass and the gradient all-reduce (csrc/sgcn_step.cpp).  One communicator used from two streams in
+    // turn makes RCCL order the two streams itself (measured in round 5: 0.177 ms per step and erratic); a communicator of
+    // its own per stream does not.
+    rcclComm_t xcomm = nullptr;
     int world = 0, rank = -1, users = 0, version = 0;
 };
 
@@ -128,6 +133,26 @@ int sgcn_coll_init(const void* id128, int32_t world, int32_t rank) {
 
 int sgcn_coll_world(void) { return R().comm ? R().world : 0; }
 
+// The second communicator of the same ranks, for collectives on the exchange stream (sgcn_coll_allgather_x_i32).  Its id
+// is drawn by rank 0 like the first (a fresh sgcn_coll_unique_id) and every rank calls this behind sgcn_coll_init; it
+// shares the first one's user count and is destroyed / aborted with it.  Optional: without it the exchange uses the first.
+int sgcn_coll_init_exchange(const void* id128) {
+    if (!id128) return sgcn::fail(SGCN_ERR_INVALID, "coll_init_exchange: bad argument");
+    std::lock_guard<std::mutex> lk(mu());
+    Rccl& r = R();
+    if (!r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_init_exchange: no communicator (sgcn_coll_init first)");
+    if (r.xcomm) return sgcn::fail(SGCN_ERR_INVALID, "coll_init_exchange: an exchange communicator exists");
+    rcclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    rcclComm_t c = nullptr;
+    const int e = check(r.CommInitRank(&c, r.world, id, r.rank), "ncclCommInitRank (exchange)");
+    if (e != SGCN_OK) return e;
+    r.xcomm = c;
+    return SGCN_OK;
+}
+
+int sgcn_coll_has_exchange(void) { return R().xcomm ? 1 : 0; }
+
 // The communicator is process-global; a second user of it (another DataParallel object of the same job) retains it and
 // the LAST sgcn_coll_destroy destroys it (the owner's shutdown used to destroy it under the others).
 int sgcn_coll_retain(void) {
@@ -143,9 +168,11 @@ int sgcn_coll_destroy(void) {
     Rccl& r = R();
     if (!r.comm) return SGCN_OK;
     if (--r.users > 0) return SGCN_OK;
-    const int e = check(r.CommDestroy(r.comm), "ncclCommDestroy");
-    r.comm = nullptr; r.world = 0; r.rank = -1; r.users = 0;
-    return e;
+    int e = SGCN_OK;
+    if (r.xcomm) e = check(r.CommDestroy(r.xcomm), "ncclCommDestroy (exchange)");
+    const int e2 = check(r.CommDestroy(r.comm), "ncclCommDestroy");
+    r.comm = r.xcomm = nullptr; r.world = 0; r.rank = -1; r.users = 0;
+    return e != SGCN_OK ? e : e2;
 }
 
 // A rank that fails ahead of a collective leaves its peers blocked inside RCCL for good (no watchdog on this
@@ -155,9 +182,11 @@ int sgcn_coll_abort(void) {
     std::lock_guard<std::mutex> lk(mu());
     Rccl& r = R();
     if (!r.comm) return SGCN_OK;
-    const int e = check(r.CommAbort(r.comm), "ncclCommAbort");
-    r.comm = nullptr; r.world = 0; r.rank = -1; r.users = 0;
-    return e;
+    int e = SGCN_OK;
+    if (r.xcomm) e = check(r.CommAbort(r.xcomm), "ncclCommAbort (exchange)");
+    const int e2 = check(r.CommAbort(r.comm), "ncclCommAbort");
+    r.comm = r.xcomm = nullptr; r.world = 0; r.rank = -1; r.users = 0;
+    return e != SGCN_OK ? e : e2;
 }
 
 // 0 = the communicator is healthy; an asynchronous error a peer's abort or a network fault left behind otherwise.
@@ -167,8 +196,13 @@ int sgcn_coll_async_error(void) {
     int err = kNcclSuccess;
     const int e = check(r.CommGetAsyncError(r.comm, &err), "ncclCommGetAsyncError");
     if (e != SGCN_OK) return e;
-    if (err == kNcclSuccess || err == kNcclInProgress) return SGCN_OK;
-    return check(err, "asynchronous error on the communicator");
+    if (err != kNcclSuccess && err != kNcclInProgress) return check(err, "asynchronous error on the communicator");
+    if (r.xcomm) {
+        const int ex = check(r.CommGetAsyncError(r.xcomm, &err), "ncclCommGetAsyncError (exchange)");
+        if (ex != SGCN_OK) return ex;
+        if (err != kNcclSuccess && err != kNcclInProgress) return check(err, "asynchronous error on the exchange communicator");
+    }
+    return SGCN_OK;
 }
 
 int sgcn_coll_allreduce_avg_f32(float* dev_buf, int64_t n, void* stream) {
@@ -185,6 +219,16 @@ int sgcn_coll_allgather_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t 
     if (n < 0 || (n > 0 && (!dev_send || !dev_recv))) return sgcn::fail(SGCN_ERR_INVALID, "coll_allgather: bad argument");
     if (n == 0) return SGCN_OK;
     return check(r.AllGather(dev_send, dev_recv, (size_t)n, kNcclInt32, r.comm, stream), "ncclAllGather");
+}
+
+// The same all-gather on the EXCHANGE communicator (the first one when there is no second): for a stream other than the
+// one the gradient all-reduce runs on.
+int sgcn_coll_allgather_x_i32(const int32_t* dev_send, int32_t* dev_recv, int64_t n, void* stream) {
+    Rccl& r = R();
+    if (!r.comm) return sgcn::fail(SGCN_ERR_INVALID, "coll_allgather_x: no communicator (sgcn_coll_init)");
+    if (n < 0 || (n > 0 && (!dev_send || !dev_recv))) return sgcn::fail(SGCN_ERR_INVALID, "coll_allgather_x: bad argument");
+    if (n == 0) return SGCN_OK;
+    return check(r.AllGather(dev_send, dev_recv, (size_t)n, kNcclInt32, r.xcomm ? r.xcomm : r.comm, stream), "ncclAllGather (exchange)");
 }
 
 }  // extern "C"

@@ -820,7 +820,7 @@ struct sgcn_mult { sgcn::FenwickMultinomial impl; };
 extern "C" {
 
 const char* sgcn_last_error(void) { return sgcn::error_slot(); }
-int sgcn_abi_version(void) { return 14; }
+int sgcn_abi_version(void) { return 15; }
 
 int sgcn_sched_create(const float* w, const int32_t* idx, const int32_t* ptr, int32_t num_data,
                       int32_t num_edges, int32_t L, int32_t cv, int32_t is, sgcn_sched_t** out) {

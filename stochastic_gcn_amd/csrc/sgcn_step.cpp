@@ -177,6 +177,53 @@ extern "C" int sgcn_copy_h2d_async(void* dst, const void* src, int64_t bytes, vo
     return SGCN_OK;
 }
 
+// ---- the exchange stream (ABI v15) -----------------------------------------------------------------------------
+// The data-parallel step's history exchange (HIST_PACK -> ALLGATHER_I32 -> HIST_APPLY, aux = 2) on a stream of its own:
+// its payload -- the aggregator's input -- is final once the aggregator has been issued, and its first reader is the NEXT
+// step's aggregator (the reference only orders the scatter behind the optimizer, gcn/models.py:186-194), so the three ops
+// need not sit on the step's dependent chain behind the optimizer.  The stream waits for `stream` once per run (at the
+// first exchange op: everything issued so far, the aggregator included), `stream` waits for it at the end of the run.
+// Unlike the auxiliary stream it is never joined in between -- the gradient all-reduce must not wait for the all-gather --
+// and its collective runs on its own communicator (sgcn_coll.cpp: xcomm).
+namespace {
+#define SGCN_XCHG_TRY(expr)                                                                                   \
+    do {                                                                                                      \
+        const hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return sgcn::fail(SGCN_ERR_HIP, "step_run (exchange stream): %s", hipGetErrorString(e_)); \
+    } while (0)
+struct XchgCtx {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, done = nullptr;
+    bool pending = false;
+};
+XchgCtx& xchg_ctx() { static XchgCtx c; return c; }
+
+int xchg_fork(void* stream, void** side) {
+    XchgCtx& c = xchg_ctx();
+    if (!c.st) {
+        SGCN_XCHG_TRY(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+        SGCN_XCHG_TRY(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+        SGCN_XCHG_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    }
+    if (!c.pending) {
+        SGCN_XCHG_TRY(hipEventRecord(c.fork, (hipStream_t)stream));
+        SGCN_XCHG_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
+        c.pending = true;
+    }
+    *side = (void*)c.st;
+    return SGCN_OK;
+}
+
+int xchg_join(void* stream) {
+    XchgCtx& c = xchg_ctx();
+    if (!c.pending) return SGCN_OK;
+    c.pending = false;
+    SGCN_XCHG_TRY(hipEventRecord(c.done, c.st));
+    SGCN_XCHG_TRY(hipStreamWaitEvent((hipStream_t)stream, c.done, 0));
+    return SGCN_OK;
+}
+}  // namespace
+
 extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int64_t* slots, int32_t nslots,
                              void* stream) {
     if (nops < 0 || (nops > 0 && !ops) || nslots < 0 || (nslots > 0 && !slots))
@@ -518,21 +565,24 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             int32_t* send = a.p<int32_t>();
             // (last argument != 0: on the auxiliary stream, forked here -- the exchange then runs beside the rest of the
             // step and is joined with the other auxiliary work in front of the gradient all-reduce / the optimizer)
-            if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
+            const int64_t where = a.next();
+            if (where != 0) { rc = where == 2 ? xchg_fork(stream, &side) : sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
             rc = sgcn_hist_pack_f32(ids, n, rows, ld, d, cap, send, side);
             break;
         }
         case SGCN_OP_ALLGATHER_I32: {
             const int32_t* send = a.p<const int32_t>(); int32_t* recv = a.p<int32_t>(); const int64_t n = a.next();
-            if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
-            rc = sgcn_coll_allgather_i32(send, recv, n, side);
+            const int64_t where = a.next();
+            if (where != 0) { rc = where == 2 ? xchg_fork(stream, &side) : sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
+            rc = where == 2 ? sgcn_coll_allgather_x_i32(send, recv, n, side) : sgcn_coll_allgather_i32(send, recv, n, side);
             break;
         }
         case SGCN_OP_HIST_APPLY: {
             float* H = a.p<float>(); const int64_t ldh = a.next();
             const int32_t* recv = a.p<const int32_t>(); const int32_t world = a.i(), cap = a.i(), d = a.i();
             int32_t* owner = a.p<int32_t>();
-            if (a.next() != 0) { rc = sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
+            const int64_t where = a.next();
+            if (where != 0) { rc = where == 2 ? xchg_fork(stream, &side) : sgcn::aux_fork(stream, &side); if (rc != SGCN_OK) break; }
             rc = sgcn_hist_apply_f32(H, ldh, recv, world, cap, d, owner, side);
             break;
         }
@@ -609,7 +659,9 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
         default:
             return sgcn::fail(SGCN_ERR_INVALID, "step_run: unknown opcode %d at op %d", op.op, k);
         }
-        if (rc != SGCN_OK) { sgcn::aux_join(stream); return rc; }       // the failing entry point has set the message
+        if (rc != SGCN_OK) { sgcn::aux_join(stream); xchg_join(stream); return rc; }       // the failing entry point has set the message
     }
-    return sgcn::aux_join(stream);          // a run never returns with work pending on the auxiliary stream
+    const int rj = sgcn::aux_join(stream);  // a run never returns with work pending on the auxiliary stream
+    const int rx = xchg_join(stream);       // ... or on the exchange stream: `stream` waits for it (its next kernel is the next run's)
+    return rj != SGCN_OK ? rj : rx;
 }

@@ -693,6 +693,7 @@ class GCN(Model):
         # history update is local: all of that is part of its identity, so a tensor re-allocated or a hook
         # attached after the first step builds a NEW program instead of leaving a stale one in use
         key = (round(float(dropout), 9), self.history_hook is None, int(getattr(self, 'native_coll', 0) or 0),
+               bool(getattr(getattr(self, '_par', None), 'exchange_overlap', False)),
                self.theta.data_ptr(), self.grad.data_ptr(),
                self.adam_m.data_ptr() if self.is_training else 0, self.adam_v.data_ptr() if self.is_training else 0,
                self.features_dev.data_ptr() if isinstance(self.features_dev, torch.Tensor) else 0,

@@ -62,11 +62,14 @@ class DataParallel(object):
             self.backend = dist.get_backend()
         self.native = False              # the library's own RCCL communicator carries the step's collectives
         self._native_owner = False
+        self.exchange_overlap = False    # ... and a second one the history exchange, on the library's exchange stream
         if self.active and self.backend == "nccl" and os.environ.get("SGCN_NATIVE_COLL", "1") != "0" and \
                 device is not None and device.type == "cuda":
             from ._ffi import lib
             if lib.sgcn_coll_world() == self.world:       # one communicator per process: a later object of the job shares it
                 self.native = lib.sgcn_coll_retain() == 0  # (by reference count: the last shutdown() destroys it)
+                self.exchange_overlap = self.native and bool(lib.sgcn_coll_has_exchange()) and \
+                    os.environ.get("SGCN_EXCHANGE_OVERLAP", "1") != "0"
             elif init:
                 self._init_native()
         self.native_history = self.native                  # the history exchange too (set_history_cap may say no)
@@ -106,6 +109,25 @@ class DataParallel(object):
                       "through torch.distributed", file=sys.stderr)
             return
         self.native = self._native_owner = True
+        # A second communicator for the history exchange, which the step program issues on the library's exchange stream
+        # beside the backward pass and the gradient all-reduce (step_program._native_exchange): one communicator used from
+        # two streams in turn makes RCCL order the streams itself (round 5: 0.177 ms per step, erratic).  Optional -- a job
+        # where it does not come up on every rank keeps the exchange behind the optimizer on the step's own stream.
+        if os.environ.get("SGCN_EXCHANGE_OVERLAP", "1") != "0":
+            buf = torch.zeros(129, dtype=torch.uint8)            # [id (128 bytes) | rank 0 drew it]
+            if self.rank == 0 and lib.sgcn_coll_unique_id(buf.data_ptr()) == 0:
+                buf[128] = 1
+            t = buf.to(dev)
+            dist.broadcast(t, src=0)
+            buf = t.cpu().contiguous()
+            if int(buf[128]) == 1:
+                ident2 = buf[:128].contiguous()
+                rc = lib.sgcn_coll_init_exchange(ident2.data_ptr())
+                flag = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                # (a rank whose second communicator failed while others' came up: those keep theirs unused -- the
+                # decision below is job-wide, and sgcn_coll_destroy takes both down)
+                self.exchange_overlap = float(flag.item()) >= 1.0
 
     @property
     def active(self):

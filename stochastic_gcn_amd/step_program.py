@@ -348,11 +348,17 @@ class StepProgram(object):
 
     def _native_exchange(self, l, nh, aux=0):
         """Policy H-a (parallel.py) as ops of the program: [cap ids | cap x d row bits] per rank, all-gathered on the
-        library's communicator, applied in rank order -- on the step's own stream behind the optimizer, where the reference
-        orders the update (gcn/models.py:186-194).  aux = 1 would put the three ops on the auxiliary stream right behind the
-        aggregator that read the history, beside the rest of the step: measured SLOWER with a one-rank communicator (0.177
-        against 0.144 ms per Reddit step, and erratic: a communicator that alternates between two streams synchronises them
-        itself; profiles/HISTORY.md round 5)."""
+        library's communicator, applied in rank order.
+          aux = 0: on the step's own stream behind the optimizer, where the reference orders the update
+                   (gcn/models.py:186-194) -- three ops on the step's dependent chain.
+          aux = 2 (round 6, DataParallel.exchange_overlap): on the library's EXCHANGE stream, issued right behind the
+                   aggregator that read the history -- its payload (the aggregator's input) is final there and its first
+                   reader is the NEXT step's aggregator, so pack + all-gather + apply run beside the loss, the backward pass,
+                   the gradient all-reduce and the optimizer; the step's stream waits for them at the end of the run.  The
+                   all-gather has a communicator of its own (sgcn_coll_init_exchange).
+          aux = 1: the round-5 form (auxiliary stream, ONE communicator for both collectives): measured slower and erratic
+                   -- 0.177 against 0.144 ms per Reddit step with a one-rank communicator; a communicator that alternates
+                   between two streams synchronises them itself (profiles/HISTORY.md round 5).  Kept for the record."""
         hist = self.model.history[l][0]
         # the capacity of a rank's block: the job-wide bound the layer-by-layer path uses too (DataParallel.history_cap,
         # >= every field's own bound) -- a rank whose minibatch did not fit its program exchanges blocks of the same size
@@ -458,6 +464,9 @@ class StepProgram(object):
         # and the history exchange are ops of THIS program -- one foreign call per step, as on one GPU -- instead of Python
         # calls between its phases
         self.native_world = int(getattr(m, 'native_coll', 0) or 0) if m.is_training else 0
+        # ... the exchange on the library's exchange stream, right behind the aggregator (needs the second communicator)
+        self.exchange_overlap = bool(self.native_world and getattr(getattr(m, '_par', None), 'exchange_overlap', False))
+        self._exchanged = set()
         local_hist = m.history_hook is None and not self.native_world
         # the history scatter: beside the step on the auxiliary stream (one event pair, a barrier on the compute queue), or
         # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
@@ -595,6 +604,9 @@ class StepProgram(object):
                         self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                                         K(mu.cols), self._p(mu), K(mu.ld)])
                     self.new_history[l] = mu
+                    if self.exchange_overlap:
+                        self._native_exchange(l, mu, aux=2)
+                        self._exchanged.add(l)
                     tape.append(('agg', l, d, concat, sptr))
                     act = (out_h, out_mu)
                 else:
@@ -617,6 +629,9 @@ class StepProgram(object):
                         self._emit('AUX_SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                                         K(x.cols), self._p(x), K(x.ld)])
                     self.new_history[l] = x
+                    if self.exchange_overlap:
+                        self._native_exchange(l, x, aux=2)
+                        self._exchanged.add(l)
                     tape.append(('agg', l, d, concat, NULL))
                     act = out_h
             elif isinstance(layer, PlainAggregator):
@@ -697,7 +712,8 @@ class StepProgram(object):
         for l, nh in ({} if (local_hist and not self._hist_last) else self.new_history).items():
             hist = m.history[l][0]
             if self.native_world:
-                self._native_exchange(l, nh)
+                if l not in self._exchanged:
+                    self._native_exchange(l, nh)
                 continue
             self._emit('SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
                                         K(nh.cols), self._p(nh), K(nh.ld)])

@@ -342,12 +342,13 @@ def test_two_rank_cvd_pp_training_steps_match_the_two_rank_oracle(tmp_path):
 
 
 # ---- RCCL itself: one rank (SGCN_FORCE_PG=1) ---------------------------------------------------------------------------
-def _rccl_worker(rank, world, port, force, out_dir, native=True, program=True):
+def _rccl_worker(rank, world, port, force, out_dir, native=True, program=True, overlap=True):
     """Three training steps + an all-gathered sharded product, with a REAL one-rank RCCL process group (force; the step's
     collectives on the library's own communicator -- native -- or as torch.distributed calls) or without any process group
     (not force): the same numbers, bit for bit."""
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      SGCN_FORCE_PG="1" if force else "0", SGCN_NATIVE_COLL="1" if native else "0")
+                      SGCN_FORCE_PG="1" if force else "0", SGCN_NATIVE_COLL="1" if native else "0",
+                      SGCN_EXCHANGE_OVERLAP="1" if overlap else "0")
     os.environ.pop("SGCN_DIST_BACKEND", None)
     import contextlib
     import io
@@ -375,7 +376,17 @@ def _rccl_worker(rank, world, port, force, out_dir, native=True, program=True):
         if native and program:                 # the collectives were ops of the step program: one foreign call per step
             progs = [p for p in m._programs.values() if p is not None]
             assert progs and all(p.native_world == 1 for p in progs)
-            assert all(any(op == 29 for op, _ in p.ops_fb) and all(any(op == o for op, _ in p.ops_hist) for o in (30, 31, 32)) for p in progs)
+            # the history exchange: on the library's exchange stream right behind the aggregator (a second communicator,
+            # round 6) -- ops of the forward / backward phase, their last argument 2 -- or behind the optimizer on the step's own
+            assert par.exchange_overlap == overlap == bool(lib.sgcn_coll_has_exchange())
+            where = (lambda p: p.ops_fb) if overlap else (lambda p: p.ops_hist)
+            assert all(any(op == 29 for op, _ in p.ops_fb) and all(any(op == o for op, _ in where(p)) for o in (30, 31, 32)) for p in progs)
+            assert all(args[-1][2] == (2 if overlap else 0) for p in progs for op, args in where(p) if op in (30, 31, 32))
+            if overlap:                        # ... in front of the loss: beside the backward pass, not behind it
+                for p in progs:
+                    codes = [op for op, _ in p.ops_fb]
+                    assert max(codes.index(o) for o in (30, 31, 32)) < min(codes.index(o) for o in (5, 13) if o in codes)
+                    assert not any(op in (30, 31, 32) for op, _ in p.ops_hist)
         assert m.grad_hook is not None and m.history_hook is not None and len(par._pending) == (0 if native else 1)
         # the last step's exchange is still in flight -- and READING the history is what lands it (the public
         # names join; nothing can see a replica that lacks this step's rows, its own included)
@@ -392,7 +403,7 @@ def _rccl_worker(rank, world, port, force, out_dir, native=True, program=True):
     full = sh.allgather_rows(X[sh.lo:sh.hi].contiguous())
     c = sh.forward_allgather(X[sh.lo:sh.hi].contiguous())
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "rccl%d%d%d.npz" % (int(force), int(native), int(program))), theta=m.theta.cpu().numpy(), hist=m.history[0][0].cpu().numpy(),
+    np.savez(os.path.join(out_dir, "rccl%d%d%d%d.npz" % (int(force), int(native), int(program), int(overlap))), theta=m.theta.cpu().numpy(), hist=m.history[0][0].cpu().numpy(),
              used_program=np.array([bool([p for p in getattr(m, '_programs', {}).values() if p is not None])]), steps=np.array([m.adam_t]),
              allreduce_ok=np.array([bool(torch.equal(flat, ref))]), gathered_ok=np.array([bool(torch.equal(full, X))]),
              c=c.cpu().numpy())
@@ -409,11 +420,13 @@ def test_rccl_one_rank_training_steps_and_allgather_equal_the_single_process_pat
     res = {}
     # (process group, the library's own communicator, step programs): native and torch collectives, compiled and eager
     # steps, against the run without a process group
-    modes = [(True, True, True), (True, False, True), (True, True, False), (False, True, True)]
+    # (+ round 6: the history exchange on the exchange stream with its own communicator -- the default -- or behind the optimizer)
+    modes = [(True, True, True, True), (True, True, True, False), (True, False, True, True), (True, True, False, True),
+             (False, True, True, True)]
     for mode in modes:
-        mp.spawn(_rccl_worker, args=(1, tg._free_port(), mode[0], str(tmp_path), mode[1], mode[2]), nprocs=1, join=True)
-        res[mode] = np.load(os.path.join(str(tmp_path), "rccl%d%d%d.npz" % tuple(int(x) for x in mode)))
-    ref = res[(False, True, True)]
+        mp.spawn(_rccl_worker, args=(1, tg._free_port(), mode[0], str(tmp_path), mode[1], mode[2], mode[3]), nprocs=1, join=True)
+        res[mode] = np.load(os.path.join(str(tmp_path), "rccl%d%d%d%d.npz" % tuple(int(x) for x in mode)))
+    ref = res[(False, True, True, True)]
     for mode in modes:
         assert res[mode]["used_program"][0] == mode[2] and res[mode]["steps"][0] == 3
         assert res[mode]["allreduce_ok"][0] and res[mode]["gathered_ok"][0]
@@ -421,7 +434,7 @@ def test_rccl_one_rank_training_steps_and_allgather_equal_the_single_process_pat
         if mode[2]:                                # (the eager path sums in another order than the program: its own check below)
             np.testing.assert_array_equal(res[mode]["theta"], ref["theta"])
             np.testing.assert_array_equal(res[mode]["hist"], ref["hist"])
-    eager = res[(True, True, False)]
+    eager = res[(True, True, False, True)]
     assert np.abs(eager["theta"] - ref["theta"]).max() <= 1e-5 and np.abs(eager["hist"] - ref["hist"]).max() <= 1e-4
     assert np.abs(ref["hist"]).sum() > 0
 
