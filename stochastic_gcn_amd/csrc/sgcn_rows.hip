@@ -159,6 +159,19 @@ __global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restr
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = src[idx[i]];
 }
 
+
+// One wavefront that does nothing for `ticks` of the 100 MHz counter: the step program's exchange stream (sgcn_step.cpp)
+// uses it once, to find out whether a candidate stream shares the step's hardware queue (HIP multiplexes streams onto a few).
+__global__ void spin_kernel(uint64_t ticks) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int spin_launch(void* stream, int64_t usec) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, (uint64_t)usec * 100u);
+    SGCN_HIP_TRY(hipGetLastError());
+    return SGCN_OK;
+}
 }  // namespace sgcn
 
 using namespace sgcn;

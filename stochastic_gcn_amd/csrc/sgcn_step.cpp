@@ -12,6 +12,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -32,6 +35,7 @@ int aux_join(void* stream);
 void step_mode_override(int overlap, int fuse);     // sgcn_spmm.hip: this thread's view of the step_overlap / step_fuse knobs
 int dense_bwd_chain(const DenseBwdArgs& up, const DenseBwdArgs& lo, void* stream);   // sgcn_gemm.hip
 int aux_fork(void* stream, void** aux_stream);
+int spin_launch(void* stream, int64_t usec);     // sgcn_rows.hip
 int dw_group_begin();                    // sgcn_gemm.hip: record the weight-gradient GEMMs of the following DENSE_BWD ops ...
 int dw_group_flush(void* stream, bool park_reduce);   // ... and issue them as one grouped launch + one reduction launch
 int reduce_flush(void* stream);          // sgcn_dense.hip: reductions parked for an optimizer launch that did not come
@@ -194,20 +198,69 @@ namespace {
 struct XchgCtx {
     hipStream_t st = nullptr;
     hipEvent_t fork = nullptr, done = nullptr;
-    bool pending = false;
+    bool pending = false, tried = false;
 };
 XchgCtx& xchg_ctx() { static XchgCtx c; return c; }
 
+// A stream whose kernels really run BESIDE the step's.  HIP multiplexes a process's streams onto a few hardware queues
+// (four per priority level by default; a new stream takes the least referenced), and two streams that share one run in
+// order: the exchange then sits on the step's chain again, behind its event packets -- measured with a one-rank job:
+// 143 - 146 us per step against 129.5 without any overlap, and the round-5 form's epochs alternating between 51 and 69 ms.
+// (A stream of another PRIORITY has a queue of its own, but two priority levels active at once cost every kernel of the
+// step ~50 us: 530 us per step.  hipExtStreamCreateWithCUMask gives a dedicated queue too, but a blocking stream, which
+// the legacy default stream -- torch's -- synchronises with.)  So: create up to eight candidates and keep the first on
+// which a tiny kernel completes while a 3 ms spin is still running on the step's stream; none -> no exchange stream, the
+// ops run on the step's own (null).
+int xchg_pick(void* stream, XchgCtx& c) {
+    c.tried = true;
+    if (getenv("SGCN_XCHG_NO_PROBE")) {            // (for the record: the first candidate, whatever queue it got)
+        SGCN_XCHG_TRY(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+        return SGCN_OK;
+    }
+    hipStream_t cand[8] = {};
+    hipEvent_t ev = nullptr;
+    SGCN_XCHG_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int got = -1, n = 0;
+    SGCN_XCHG_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (; n < 8 && got < 0; n++) {
+        SGCN_XCHG_TRY(hipStreamCreateWithFlags(&cand[n], hipStreamNonBlocking));
+        int rc = sgcn::spin_launch(stream, 3000);
+        if (rc == SGCN_OK) rc = sgcn::spin_launch(cand[n], 1);
+        if (rc != SGCN_OK) return rc;
+        SGCN_XCHG_TRY(hipEventRecord(ev, cand[n]));
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500)) {
+            if (hipEventQuery(ev) == hipSuccess) { got = n; break; }
+        }
+        SGCN_XCHG_TRY(hipStreamSynchronize((hipStream_t)stream));
+        SGCN_XCHG_TRY(hipStreamSynchronize(cand[n]));
+    }
+    for (int i = 0; i < n; i++)
+        if (i != got) (void)hipStreamDestroy(cand[i]);
+    (void)hipEventDestroy(ev);
+    c.st = got >= 0 ? cand[got] : nullptr;
+    if (getenv("SGCN_XCHG_DEBUG")) fprintf(stderr, "sgcn: exchange stream: candidate %d of %d runs beside the step's stream\n", got, n);
+    return SGCN_OK;
+}
+
 int xchg_fork(void* stream, void** side) {
     XchgCtx& c = xchg_ctx();
-    if (!c.st) {
-        SGCN_XCHG_TRY(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
-        SGCN_XCHG_TRY(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
-        SGCN_XCHG_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    if (!c.tried) {
+        const int rc = xchg_pick(stream, c);
+        if (rc != SGCN_OK) return rc;
+        // no system-scope fence at the events: both sides of either dependency are kernels of THIS device (a default event's
+        // record writes the caches back for the host and other devices -- microseconds on eight L2s, on the step's chain)
+        const unsigned flags = hipEventDisableTiming | (getenv("SGCN_XCHG_SYSFENCE") ? 0u : hipEventDisableSystemFence);
+        SGCN_XCHG_TRY(hipEventCreateWithFlags(&c.fork, flags));
+        SGCN_XCHG_TRY(hipEventCreateWithFlags(&c.done, flags));
     }
+    if (!c.st) { *side = stream; return SGCN_OK; }      // no stream beside the step's: in place, no events
     if (!c.pending) {
-        SGCN_XCHG_TRY(hipEventRecord(c.fork, (hipStream_t)stream));
-        SGCN_XCHG_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
+        static const char* skip = getenv("SGCN_XCHG_SKIP");        // MEASUREMENT ONLY (drops a dependency: results undefined)
+        if (!(skip && strstr(skip, "fork"))) {
+            SGCN_XCHG_TRY(hipEventRecord(c.fork, (hipStream_t)stream));
+            SGCN_XCHG_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
+        }
         c.pending = true;
     }
     *side = (void*)c.st;
@@ -218,6 +271,8 @@ int xchg_join(void* stream) {
     XchgCtx& c = xchg_ctx();
     if (!c.pending) return SGCN_OK;
     c.pending = false;
+    static const char* skip = getenv("SGCN_XCHG_SKIP");
+    if (skip && strstr(skip, "join")) return SGCN_OK;
     SGCN_XCHG_TRY(hipEventRecord(c.done, c.st));
     SGCN_XCHG_TRY(hipStreamWaitEvent((hipStream_t)stream, c.done, 0));
     return SGCN_OK;

@@ -68,8 +68,7 @@ class DataParallel(object):
             from ._ffi import lib
             if lib.sgcn_coll_world() == self.world:       # one communicator per process: a later object of the job shares it
                 self.native = lib.sgcn_coll_retain() == 0  # (by reference count: the last shutdown() destroys it)
-                self.exchange_overlap = self.native and bool(lib.sgcn_coll_has_exchange()) and \
-                    os.environ.get("SGCN_EXCHANGE_OVERLAP", "1") != "0"
+                self.exchange_overlap = self.native and bool(lib.sgcn_coll_has_exchange()) and self._want_exchange_overlap()
             elif init:
                 self._init_native()
         self.native_history = self.native                  # the history exchange too (set_history_cap may say no)
@@ -113,7 +112,7 @@ class DataParallel(object):
         # beside the backward pass and the gradient all-reduce (step_program._native_exchange): one communicator used from
         # two streams in turn makes RCCL order the streams itself (round 5: 0.177 ms per step, erratic).  Optional -- a job
         # where it does not come up on every rank keeps the exchange behind the optimizer on the step's own stream.
-        if os.environ.get("SGCN_EXCHANGE_OVERLAP", "1") != "0":
+        if self._want_exchange_overlap():
             buf = torch.zeros(129, dtype=torch.uint8)            # [id (128 bytes) | rank 0 drew it]
             if self.rank == 0 and lib.sgcn_coll_unique_id(buf.data_ptr()) == 0:
                 buf[128] = 1
@@ -128,6 +127,14 @@ class DataParallel(object):
                 # (a rank whose second communicator failed while others' came up: those keep theirs unused -- the
                 # decision below is job-wide, and sgcn_coll_destroy takes both down)
                 self.exchange_overlap = float(flag.item()) >= 1.0
+
+    def _want_exchange_overlap(self):
+        """SGCN_EXCHANGE_OVERLAP = 1 / 0, default: with two ranks or more.  With ONE rank (SGCN_FORCE_PG) the all-gather is a
+        4.6 us local copy and taking the exchange off the chain does not pay: 128.2 us per step in order, 132 - 135 beside
+        the step (the record on the step's stream costs 8 us, the wait at the end 3, two active queues ~8 more:
+        profiles/r63_exchange_chain_probe.jsonl); a real all-gather among eight ranks is worth more than those ~7 us."""
+        v = os.environ.get("SGCN_EXCHANGE_OVERLAP", "auto")
+        return v == "1" or (v not in ("0", "1") and self.world >= 2)
 
     @property
     def active(self):
