@@ -76,6 +76,9 @@ def parse(argv=None):
     p.add_argument("--cs-align", type=int, default=-1, help="--cs-g 2 / 4: sweep positions one bin of a wave may run ahead of the slowest (-1: a third of the L2 window, ops.ColumnSweepCSR.auto_align)")
     p.add_argument("--shard-row-weight", type=int, default=-1,
                    help="--shard: nonzero-equivalents a row adds to its block's load (-1: parallel.ShardedSpMM.ROW_WEIGHT)")
+    p.add_argument("--cs-ranges", default="auto", choices=["auto", "off"],
+                   help="a sharded block's rows split by column range when the block is small enough "
+                        "(ops.ColumnSweepCSR.choose_ranges); off: the 1-D plan")
     p.add_argument("--cs-warp", default="auto", choices=["auto", "on", "off"],
                    help="the sweep clock in work coordinates (sgcn_csplan_t.dev_warp): auto = when the nonzeros are not spread evenly over the column ids")
     p.add_argument("--cs-g", type=int, default=0, choices=[0, 1, 2, 4],
@@ -614,7 +617,8 @@ def main(argv=None):
         sh = ShardedSpMM(par, full_adj, dev, kernel="cs" if args.kernel == "lds" else args.kernel, with_transpose=not args.no_backward,
                          d=d if args.cs_g == 0 else (None if args.cs_g == 1 else d), G=args.cs_g if args.cs_g in (2, 4) else None,
                          plan_kw=dict(align=('auto' if args.cs_align < 0 else args.cs_align), T=args.cs_t,
-                                      warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp]),
+                                      warp={'auto': 'auto', 'on': True, 'off': False}[args.cs_warp],
+                                      col_ranges='auto' if args.cs_ranges == 'auto' else 0),
                          row_weight=None if args.shard_row_weight < 0 else args.shard_row_weight)
         A = sh.A
     elif args.kernel in ("cs", "lds"):
@@ -795,7 +799,8 @@ def main(argv=None):
             "kernel_launches_per_spmm": int(re.search(r" x (\d+) launches", A.variant(d)).group(1))
             if args.kernel == "cs" else 1,
             "lds_parts_ms": lds_parts,
-            "cs_plan": ({"G": int(getattr(A, "G", 1)), "align": getattr(A, "align", None),
+            "cs_plan": ({"G": int(getattr(A, "G", 1)), "col_ranges": int(getattr(A, "ranged", 0) or 0), "tiles": int(A.ntiles),
+                         "fix_rows": int(A.nfix), "align": getattr(A, "align", None),
                          "pad_fraction": round(float(getattr(A, "pad_fraction", 0.0)), 4), "T": getattr(A, "T", None),
                          "warp_table": None if getattr(A, "warp", None) is None else [int(A.warp.numel()), int(A.warp_shift)]}
                         if args.kernel == "cs" else None),

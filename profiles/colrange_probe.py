@@ -90,7 +90,9 @@ def main():
     bucket = 1 << shift
     colhist = np.bincount(blk.indices, minlength=K).astype(np.int64)
     cum = np.concatenate([[0], np.cumsum(colhist)])
-    for nr in (2, 4):
+    nrs = [int(x) for x in os.environ.get('NRS', '2,4').split(',')]
+    ts = [int(x) for x in os.environ.get('TS', '0,32').split(',')]
+    for nr in nrs:
         # range boundaries: equal nonzeros, on bucket boundaries
         cuts = [0]
         for j in range(1, nr):
@@ -109,7 +111,7 @@ def main():
         rj = np.searchsorted(cuts, first, side="right") - 1
         lo, hi = cuts[rj], cuts[rj + 1]
         table = ((first - lo) * K // np.maximum(hi - lo, 1)).astype(np.uint32)
-        for T in (0, 32):
+        for T in ts:
             A2 = ops.ColumnSweepCSR(stacked, dev, row_labels=labels, T=T)
             A2.warp = torch.from_numpy(table.view(np.int32)).to(dev)
             A2.warp_shift = shift
@@ -118,7 +120,7 @@ def main():
             key = "nr%d_T%d" % (nr, T)
             res = {}
             for xm in (1, 0):
-                for pace in (-1, 120, 140, 160, 180, 200, 220, 240, 260, 290, 320, 360, 400):
+                for pace in (-1, 220, 240, 250, 260, 270, 280, 290, 300, 320, 360):
                     ms = timed(lambda: run_plan(A2, X, C2, pace, xm), reps=6)
                     res["xcd%d_p%d" % (xm, pace)] = round(ms, 4)
             best = min((v, k) for k, v in res.items() if k.startswith("xcd1"))

@@ -702,35 +702,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
-// fix-up of split rows: ordered slot sum + epilogue (float4 path only).  A workgroup owns 64 float4 columns of one split
-// row; its four waves take consecutive quarters of the row's workspace slots (a hub row of an R-MAT block has hundreds: one
-// thread walking them all was 0.35 ms of a 4.3 ms product), each sums its quarter in slot order, and wave 0 adds the
-// four partial sums in wave order -- a fixed association, so reruns stay bit-identical (rows of up to four slots: the plain
-// slot order).
+// fix-up of split rows: ordered slot sum + epilogue (float4 path only).  An ITEM = 64 float4 columns of one split row.
+// A row of up to four slots -- every row of a column-range plan (round 6: each row of a small block has one piece per
+// range), most rows of any plan -- is summed by ONE wave in slot order; a workgroup takes four items, a wave each: no LDS,
+// no barrier, a quarter of the workgroups (an eighth of S-Reddit, 29 k rows of two or three slots: the launch was one
+// workgroup of four waves per item, two of them idle).  When one of a workgroup's four rows has more slots (a hub row of
+// an R-MAT block has hundreds: one thread walking them all was 0.35 ms of a 4.3 ms product) the workgroup does its items
+// one after the other, the four waves taking consecutive quarters of the row's slots, each summing its quarter in slot
+// order and wave 0 adding the four partial sums in wave order.  Either way a fixed association -- for up to four slots
+// both forms ARE the plain slot order, bit for bit -- so reruns stay bit-identical.
 template <int VW>
-__global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix_t* fix, int64_t nfix) {
+__device__ __forceinline__ void cs_fix_store(const CsArgs& a, const sgcn_fix_t& fx, int vi,
+                                             typename Vec<VW>::type acc) {
     typedef typename Vec<VW>::type VT;
-    __shared__ VT part[kBlock / kWave - 1][kWave];
-    const int nvblk = (a.nvec + kWave - 1) / kWave;
-    const int64_t f = blockIdx.x / nvblk;
-    if (f >= nfix) return;
-    const sgcn_fix_t fx = fix[f];
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    constexpr int NWV = kBlock / kWave;
-    const int vi = (int)(blockIdx.x % nvblk) * kWave + lane;
-    const bool live = vi < a.nvec;
-    const int q0 = (int)((int64_t)fx.nslots * w / NWV), q1 = (int)((int64_t)fx.nslots * (w + 1) / NWV);
-    VT acc = vzero<VW>();
-    if (live) {
-        const float* wp = a.ws + (int64_t)fx.first_slot * a.ldw + (int64_t)vi * VW;
-#pragma unroll 4
-        for (int q = q0; q < q1; q++) acc += vload<VW>(wp + (int64_t)q * a.ldw);
-    }
-    if (w > 0) part[w - 1][lane] = acc;
-    __syncthreads();
-    if (w > 0 || !live) return;
-#pragma unroll
-    for (int k = 0; k < NWV - 1; k++) acc += part[k][lane];
     float* out = a.C + (int64_t)fx.row * a.ldc + (int64_t)vi * VW;
     VT res = acc * (a.rscale ? a.rscale[fx.row] : 1.0f);
     const int left = a.d - vi * VW;
@@ -739,6 +723,51 @@ __global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix
         else for (int e = 0; e < left; e++) { if constexpr (VW == 1) res += a.beta * out[0]; else res[e] += a.beta * out[e]; }
     }
     if (left >= VW) vstore<VW>(out, res); else vstore_head<VW>(out, res, left);
+}
+
+template <int VW>
+__global__ __launch_bounds__(kBlock) void cs_fix_kernel(CsArgs a, const sgcn_fix_t* fix, int64_t nfix) {
+    typedef typename Vec<VW>::type VT;
+    constexpr int NWV = kBlock / kWave;
+    __shared__ VT part[NWV - 1][kWave];
+    const int nvblk = (a.nvec + kWave - 1) / kWave;
+    const int64_t nitems = nfix * nvblk, item0 = (int64_t)blockIdx.x * NWV;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int64_t mine = item0 + w;
+    sgcn_fix_t fx{0, 0, 0};
+    if (mine < nitems) fx = fix[mine / nvblk];
+    if (__syncthreads_and(fx.nslots <= NWV)) {
+        if (mine >= nitems) return;
+        const int vi = (int)(mine % nvblk) * kWave + lane;
+        if (vi >= a.nvec) return;
+        const float* wp = a.ws + (int64_t)fx.first_slot * a.ldw + (int64_t)vi * VW;
+        VT acc = vzero<VW>();
+        for (int q = 0; q < fx.nslots; q++) acc += vload<VW>(wp + (int64_t)q * a.ldw);
+        cs_fix_store<VW>(a, fx, vi, acc);
+        return;
+    }
+    for (int k = 0; k < NWV; k++) {
+        const int64_t item = item0 + k;
+        if (item >= nitems) break;                        // (uniform over the workgroup)
+        const sgcn_fix_t fk = fix[item / nvblk];
+        const int vi = (int)(item % nvblk) * kWave + lane;
+        const bool live = vi < a.nvec;
+        const int q0 = (int)((int64_t)fk.nslots * w / NWV), q1 = (int)((int64_t)fk.nslots * (w + 1) / NWV);
+        VT acc = vzero<VW>();
+        if (live) {
+            const float* wp = a.ws + (int64_t)fk.first_slot * a.ldw + (int64_t)vi * VW;
+#pragma unroll 4
+            for (int q = q0; q < q1; q++) acc += vload<VW>(wp + (int64_t)q * a.ldw);
+        }
+        if (w > 0) part[w - 1][lane] = acc;
+        __syncthreads();
+        if (w == 0 && live) {
+#pragma unroll
+            for (int j = 0; j < NWV - 1; j++) acc += part[j][lane];
+            cs_fix_store<VW>(a, fk, vi, acc);
+        }
+        __syncthreads();                                  // `part` is written again by the next item
+    }
 }
 
 }  // namespace sgcn
@@ -893,7 +922,8 @@ extern "C" int sgcn_spmm_cs_f32(const sgcn_csplan_t* plan, int32_t M, int32_t K,
     }
     SGCN_HIP_TRY(hipGetLastError());
     if (plan->nfix > 0) {
-        const int64_t nfblk = (int64_t)((a.nvec + kWave - 1) / kWave) * plan->nfix;
+        // an item = 64 float4 columns of a split row; a workgroup takes four (cs_fix_kernel)
+        const int64_t nfblk = ((int64_t)((a.nvec + kWave - 1) / kWave) * plan->nfix + kBlock / kWave - 1) / (kBlock / kWave);
         SGCN_REQUIRE(nfblk < (1ll << 31), "spmm_cs: too many split rows");
         hipLaunchKernelGGL(cs_fix_kernel<4>, dim3((unsigned)nfblk), dim3(kBlock), 0, st, a, plan->dev_fix, plan->nfix);
         SGCN_HIP_TRY(hipGetLastError());

@@ -481,7 +481,8 @@ class ColumnSweepCSR(object):
             return None, 0
         return np.ascontiguousarray(table[:nb.value]), int(shift.value)
 
-    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align='auto', warp='auto'):
+    def __init__(self, a, device, R=16, T=0, round_tiles=0, col_labels=None, row_labels=None, G=1, align='auto', warp='auto',
+                 col_ranges=0):
         """G = 2: two 16-row lane groups per wavefront on 128-column passes (sgcn_csplang_*), half the passes of
         the dense operand through every XCD per register byte; ``align``: columns one bin of a wave may run ahead
         of the slowest (the plan pads the bins that are ahead; 'auto': a third of the L2 window, ``auto_align``; with a
@@ -492,10 +493,16 @@ class ColumnSweepCSR(object):
         matrix such as the LDS sweep's residual, which is what uses it."""
         a = a.tocsr()
         self.G = int(G)
+        self.ranged = 0
         if R != 16:
             raise ValueError("the column-sweep kernels keep 16-row bins (R = 16)")
         if self.G not in (1, 2, 4):
             raise ValueError("G must be 1, 2 or 4 lane groups per wavefront")
+        if col_ranges and int(col_ranges) > 1:
+            if self.G != 1 or col_labels is not None or row_labels is not None:
+                raise ValueError("col_ranges needs an unlabelled plan with one lane group per wavefront")
+            self._init_ranged(a, device, int(col_ranges), T, round_tiles)
+            return
         if self.G != 1:
             if col_labels is not None or row_labels is not None or R != 16:
                 raise ValueError("G = 2 plans are ungrouped and use 16-row bins")
@@ -593,6 +600,128 @@ class ColumnSweepCSR(object):
             else:
                 lo = mid + 1
         return lo
+
+    # ---- a small row block with its rows split BY COLUMN RANGE (round 6) --------------------------------------------------
+    RANGE_FILL = 0.95     # virtual rows of a ranged plan: split until they fill this share of one round of resident tiles
+
+    @staticmethod
+    def choose_ranges(M, nnz, K, G, rnd=4096):
+        """2 when a block is small enough that its rows are split anyway to fill ONE round of resident tiles (auto_t) and
+        the 1-D sweep is bound by B crossing the fabric: an XCD holds M / 8 random rows whose nnz / 8 nonzeros touch
+        1 - exp(-nnz / 8K) of B's rows (an eighth of S-Reddit: 79 %, 8 x 0.79 x 561 MB = 3.5 GB for 70 MB of output);
+        with the rows cut in two column ranges, range j on XCDs 4j .. 4j + 3, an XCD holds M / 4 half-rows on K / 2
+        columns: 2.15 GB.  0 otherwise (a quarter of S-Reddit: 2 x 58 k virtual rows do not fit a round, and two rounds
+        sweep every range twice)."""
+        if G != 1 or M <= 0 or nnz <= 0 or K < 4096:
+            return 0
+        if 2 * M > ColumnSweepCSR.RANGE_FILL * int(rnd) * 16:
+            return 0
+        f1 = 1.0 - np.exp(-nnz / 8.0 / K)
+        f2 = 0.5 * (1.0 - np.exp(-nnz / 8.0 / (K / 2.0)))
+        return 2 if f2 <= 0.75 * f1 else 0
+
+    def _init_ranged(self, a, device, NR, T, round_tiles):
+        """Rows split by column range instead of by stride: piece j of a row = its nonzeros in columns [cut_j, cut_j+1)
+        (ranges of equal nonzeros, cut on warp-bucket boundaries), the pieces of range j form the tiles of XCDs
+        [8 j / NR, 8 (j + 1) / NR) (tiles in range order + the launch's tile range cut into eight contiguous pieces:
+        xcd_map), and ALL ranges are swept at once on one clock: the warp table maps a column to its position inside its
+        range, scaled to [0, K).  A row's pieces meet in the ordered fix-up like strided pieces do (range 0 first):
+        deterministic, and nothing in the kernels changes.  Built from the shipped plan builder: the NR column-restricted
+        copies of the block stacked as NR x M rows with the range as the row label, then rows and workspace slots renamed."""
+        import scipy.sparse as sp
+        a = a.tocsr()
+        a.sort_indices()
+        M, K = int(a.shape[0]), int(a.shape[1])
+        rowptr = np.ascontiguousarray(a.indptr, dtype=np.int64)
+        col = np.ascontiguousarray(a.indices, dtype=np.int32)
+        val = np.ascontiguousarray(a.data, dtype=np.float32)
+        rnd = int(round_tiles or (_ffi.lib.sgcn_tune_get(b"cs_round") or 4096))
+        shift = 0
+        while (K >> shift) > self.WARP_BUCKETS:
+            shift += 1
+        bucket = 1 << shift
+        cum = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=K).astype(np.int64))])
+        cuts = [0]
+        for j in range(1, NR):
+            c = int(np.searchsorted(cum, cum[-1] * j // NR))
+            cuts.append(max(cuts[-1], min(K, (c + bucket // 2) // bucket * bucket)))
+        cuts = np.asarray(cuts + [K], dtype=np.int64)
+        rows_of = np.repeat(np.arange(M, dtype=np.int64), np.diff(rowptr))
+        rng_id = np.searchsorted(cuts, col, side="right") - 1
+        stacked = sp.csr_matrix((val, (rows_of + rng_id * M, col)), shape=(NR * M, K))      # (columns stay sorted inside a row)
+        stacked.sort_indices()
+        srp = np.ascontiguousarray(stacked.indptr, dtype=np.int32)
+        scol = np.ascontiguousarray(stacked.indices, dtype=np.int32)
+        sval = np.ascontiguousarray(stacked.data, dtype=np.float32)
+        labels = np.ascontiguousarray(np.repeat(np.arange(NR, dtype=np.int32), M))
+        sdeg = np.diff(srp.astype(np.int64))
+        if not T:      # split further (by stride, inside a range) until the pieces fill RANGE_FILL of one round
+            cap = int(self.RANGE_FILL * rnd * 16)
+            pieces = lambda t: int(np.maximum(sdeg > 0, -(-sdeg // t)).sum())      # noqa: E731
+            lo, hi = 24, int(max(64, sdeg.max() if sdeg.size else 64))
+            if pieces(hi) > cap:
+                T = hi
+            else:
+                while lo < hi:
+                    mid = (lo + hi) // 2
+                    if pieces(mid) <= cap:
+                        hi = mid
+                    else:
+                        lo = mid + 1
+                T = lo
+        self.T, self.ranged, self.range_cuts = int(T), NR, [int(x) for x in cuts]
+        t_build = time.perf_counter()
+        tile_ptr, colrow, valout, tile_rows, tile_slots, fix, nt, nfix, _ = self._build(
+            srp, scol, sval, NR * M, 1, 16, self.T, 0, 0, labels.ctypes.data, None, 0)
+        # ---- rename: stacked row j * M + r -> row r; its workspace slots -> consecutive slots of row r, range by range
+        npieces = (sdeg > 0).astype(np.int64)                      # an empty piece takes no slot (and writes nothing)
+        old_first = np.full(NR * M, -1, dtype=np.int64)
+        if nfix:
+            npieces[fix[:, 0]] = fix[:, 2]
+            old_first[fix[:, 0]] = fix[:, 1]
+        per_row = npieces.reshape(NR, M)
+        total = per_row.sum(axis=0)                                # pieces of original row r
+        split = total >= 2
+        base = np.zeros(M, dtype=np.int64)
+        base[split] = np.cumsum(total[split]) - total[split]
+        before = np.cumsum(per_row, axis=0) - per_row              # pieces of row r in the ranges in front of j
+        new_first = (base[None, :] + before).reshape(-1)           # first new slot of stacked row j * M + r
+        tr, ts = tile_rows.astype(np.int64), tile_slots.astype(np.int64)
+        valid = tr >= 0
+        srow = np.where(valid, tr, 0)
+        q = np.where(ts >= 0, ts - old_first[srow], 0)             # piece index inside the stacked row
+        orig = srow % M
+        # (an empty piece writes nothing -- except range 0's piece of a row that is empty altogether: it is the row's one
+        # writer, C[r] = beta * C[r])
+        live = valid & ((sdeg[srow] > 0) | ((srow < M) & (total[orig] == 0)))
+        new_rows = np.where(live, orig, -1).astype(np.int32)
+        new_slots = np.where(live & split[orig], new_first[srow] + q, -1).astype(np.int32)
+        rs = np.nonzero(split)[0]
+        new_fix = np.stack([rs, base[rs], total[rs]], axis=1).astype(np.int32) if rs.size else np.zeros((0, 3), np.int32)
+        t_build = time.perf_counter() - t_build
+        self.grouped, self.pos2col = False, None
+        self.shape = (M, K)
+        self.R, self.ntiles, self.nfix, self.nslots = 16, nt, int(new_fix.shape[0]), int(total[split].sum())
+        self.round_tiles = round_tiles
+        self._tile_nnz = np.diff(tile_ptr).astype(np.int64)
+        self._hint, self._hint_round = None, None
+        self.pace, self.tuned_ms, self._guard, self._tuning = {}, {}, {}, False
+        t_up = time.perf_counter()
+        to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)          # noqa: E731
+        self.tile_ptr, self.colrow, self.val = to(tile_ptr), to(colrow), to(valout)
+        self.tile_rows, self.tile_slots = to(new_rows), to(new_slots)
+        self.fix = to(new_fix) if self.nfix else None
+        self.ws, self.device = None, device
+        self.nnz = int(col.shape[0])
+        # the clock's coordinates: a column's position INSIDE its range, scaled to [0, K) -- every range starts at 0
+        nb = -(-K // bucket)
+        first = np.arange(nb, dtype=np.int64) * bucket
+        rj = np.searchsorted(cuts, first, side="right") - 1
+        lo_, hi_ = cuts[rj], cuts[rj + 1]
+        table = ((first - lo_) * K // np.maximum(hi_ - lo_, 1)).astype(np.uint32)
+        self.warp, self.warp_shift = to(table.view(np.int32)), shift
+        self.setup_s = {"host_plan_s": t_build, "upload_s": time.perf_counter() - t_up,
+                        "host_threads": int(lib.sgcn_host_threads())}
 
     def _init_g2(self, a, device, T, round_tiles, align, warp='auto'):
         """G = 2 / 4 lane groups per wavefront (sgcn_csplang_*)"""
@@ -697,8 +826,8 @@ class ColumnSweepCSR(object):
         return 2 if -(-dp // 128) * 0.73 * r2 <= -(-dp // 320) * r1 else 1
 
     def save(self, path, key):
-        if self.grouped:
-            raise ValueError("grouped plans are not cached (they are cheap to rebuild)")
+        if self.grouped or getattr(self, 'ranged', 0):
+            raise ValueError("grouped / column-range plans are not cached (they are cheap to rebuild)")
         t = lambda x: x.cpu().numpy()          # noqa: E731
         blob = dict(key=np.array(key), G=int(getattr(self, 'G', 1)), pad_fraction=float(getattr(self, 'pad_fraction', 0.0)),
                     R=self.R, shape=np.array(self.shape, np.int64), nslots=self.nslots,
@@ -750,7 +879,7 @@ class ColumnSweepCSR(object):
         if g is not None and G != g:
             return None
         self = cls.__new__(cls)
-        self.grouped, self.pos2col, self.G = False, None, G
+        self.grouped, self.pos2col, self.G, self.ranged = False, None, G, 0
         self.pad_fraction = float(z["pad_fraction"]) if "pad_fraction" in z.files else 0.0
         self.shape = tuple(int(x) for x in z["shape"])
         self.R, self.nslots, self.round_tiles = int(z["R"]), int(z["nslots"]), int(z["round_tiles"])
@@ -816,7 +945,8 @@ class ColumnSweepCSR(object):
                            _ptr(self.fix), self.nfix, self.nslots, _ptr(self.ws),
                            0 if self.ws is None else self.ws.numel(), rnd, self._hint.ctypes.data,
                            -1 if self.grouped else int(self.pace.get(d, 0)), int(getattr(self, 'G', 1)),
-                           1 if self.grouped else 0, _ptr(getattr(self, 'warp', None)), int(getattr(self, 'warp_shift', 0)))
+                           1 if (self.grouped or getattr(self, 'ranged', 0)) else 0, _ptr(getattr(self, 'warp', None)),
+                           int(getattr(self, 'warp_shift', 0)))
 
     def variant(self, d):
         """The kernel variant / launch geometry sgcn_spmm_cs_f32 uses for this plan and width."""
@@ -838,7 +968,8 @@ class ColumnSweepCSR(object):
 
     def _autotune(self, B, d, candidates, reps, refine):
         if candidates is None:           # ns per step of the heaviest tile (a G = 2 step is one load for two nonzeros)
-            candidates = (-1, 200, 220, 240, 260, 280, 320, 380) if getattr(self, 'G', 1) == 1 else \
+            candidates = (-1, 230, 250, 270, 290, 310, 340, 380) if getattr(self, 'ranged', 0) else \
+                (-1, 200, 220, 240, 260, 280, 320, 380) if getattr(self, 'G', 1) == 1 else \
                 (-1, 130, 160, 190, 210, 230, 250, 280, 320)
         if self.grouped:                 # grouped plans run unpaced (see the class docstring)
             self.pace[d] = -1

@@ -402,8 +402,17 @@ class ShardedSpMM(object):
             kw = dict(plan_kw or {})
             if G == 1:
                 kw.pop('align', None)
-            self.A = ops.ColumnSweepCSR(blk, device, G=G, **kw)
-            self.AT = ops.ColumnSweepCSR(blk_t, device, G=G, **kw) if with_transpose else None
+            # a block small enough that its rows are split anyway to fill one round of resident tiles (an eighth of
+            # S-Reddit): split them by COLUMN RANGE, a range per half of the XCDs (ops.ColumnSweepCSR.choose_ranges)
+            def plan(m):
+                k2 = dict(kw)
+                nr = ops.ColumnSweepCSR.choose_ranges(m.shape[0], m.nnz, m.shape[1], G) if k2.pop('col_ranges', 'auto') == 'auto' else 0
+                if nr:
+                    k2.pop('warp', None)
+                    return ops.ColumnSweepCSR(m, device, G=G, col_ranges=nr, T=k2.get('T', 0))
+                return ops.ColumnSweepCSR(m, device, G=G, **k2)
+            self.A = plan(blk)
+            self.AT = plan(blk_t) if with_transpose else None
             self._mm = ops.spmm_cs
         else:
             self.A = ops.DeviceCSR.from_scipy(blk, device)

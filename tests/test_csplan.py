@@ -418,3 +418,97 @@ def test_warp_table_in_c_equals_the_numpy_expression():
             assert (w0 is None) == (w1 is None) and s0 == s1
             if w0 is not None:
                 assert np.array_equal(w0, w1)
+
+
+def _ranged_plan(a, **kw):
+    import torch
+    from stochastic_gcn_amd import ops
+    A = ops.ColumnSweepCSR(a, torch.device("cpu"), col_ranges=2, **kw)
+    tp = A.tile_ptr.numpy()
+    return A, dict(nt=A.ntiles, tile_ptr=tp, colrow=A.colrow.numpy(), val=A.val.numpy(), rows=A.tile_rows.numpy().reshape(-1, 16),
+                   slots=A.tile_slots.numpy().reshape(-1, 16), fix=A.fix.numpy() if A.fix is not None else np.zeros((0, 3), np.int32),
+                   R=16)
+
+
+@pytest.mark.parametrize("T", [0, 40])
+def test_column_range_plan_encodes_the_matrix_and_keeps_ranges_on_their_tiles(T):
+    """ops.ColumnSweepCSR(col_ranges=2) (round 6: a small row block whose rows are split by COLUMN RANGE, range j on XCDs
+    4j .. 4j + 3): every nonzero sits in exactly one tile with its row and value; a tile's columns lie in ONE range and the
+    tiles come in range order (what xcd_map turns into XCD ranges); a row's pieces take consecutive workspace slots, the
+    lower range first; a row that lives in one range only writes its output directly; empty pieces take no slot; the clock's
+    table restarts at every range."""
+    rng = np.random.RandomState(11)
+    M, K = 3000, 20000
+    a = sp.random(M, K, density=0.004, random_state=rng, format='csr', dtype=np.float32)
+    a = a.tolil()
+    a[5, :] = 0                                                   # an empty row
+    a[6, :] = 0
+    a[6, 3] = 1.5                                                 # a row in the lower range only
+    a[7, :] = 0
+    a[7, K - 2] = -2.5                                            # ... in the upper range only
+    a[8, ::7] = 1.0                                               # a long row: strided pieces inside both ranges
+    a = a.tocsr().astype(np.float32)
+    a.sort_indices()
+    A, p = _ranged_plan(a, T=T)
+    assert A.ranged == 2 and A.shape == (M, K) and A.nnz == a.nnz and p['tile_ptr'][-1] == a.nnz
+    cr = p['colrow'].view(np.uint32)
+    col, lr = (cr & ((1 << 28) - 1)).astype(np.int64), (cr >> 28).astype(np.int64)
+    tile = np.repeat(np.arange(p['nt']), np.diff(p['tile_ptr']))
+    row = p['rows'][tile, lr]
+    assert (row >= 0).all() and row.max() < M
+    b = sp.coo_matrix((p['val'], (row, col)), shape=(M, K)).tocsr()
+    assert (abs(a - b)).nnz == 0
+    cut = A.range_cuts
+    assert cut[0] == 0 and cut[-1] == K and len(cut) == 3 and cut[1] % (1 << A.warp_shift) == 0
+    nnz_lo = int((a.indices < cut[1]).sum())
+    assert abs(nnz_lo - a.nnz / 2) <= 0.02 * a.nnz                # ranges of equal nonzeros
+    rng_of_tile = []
+    for t in range(p['nt']):
+        c = col[p['tile_ptr'][t]:p['tile_ptr'][t + 1]]
+        assert (np.diff(c) >= 0).all()
+        if c.size:
+            j = {int(x >= cut[1]) for x in (c.min(), c.max())}
+            assert len(j) == 1
+            rng_of_tile.append(j.pop())
+    assert rng_of_tile == sorted(rng_of_tile) and set(rng_of_tile) == {0, 1}
+    # slots: consecutive per split row, lower range first; unsplit rows write directly
+    fixed = {int(r): (int(f), int(c)) for r, f, c in p['fix']}
+    assert A.nfix == len(fixed) and A.nslots == sum(c for _, c in fixed.values())
+    firsts = sorted(fixed.values())
+    assert firsts[0][0] == 0 and all(f0 + c0 == f1 for (f0, c0), (f1, _) in zip(firsts, firsts[1:]))
+    live = p['rows'] >= 0
+    for r in (6, 7):
+        assert r not in fixed and (p['slots'][p['rows'] == r] == -1).all() and (p['rows'] == r).sum() == 1
+    assert (p['rows'] == 5).sum() == 1 and (p['slots'][p['rows'] == 5] == -1).all()     # the empty row: ONE writer (of zeros)
+    assert 8 in fixed and fixed[8][1] >= (4 if T else 2)
+    tile_of_slot = np.repeat(np.arange(p['nt']), 16).reshape(-1, 16)
+    tile_rng = np.full(p['nt'], -1)
+    for t in range(p['nt']):
+        c = col[p['tile_ptr'][t]:p['tile_ptr'][t + 1]]
+        tile_rng[t] = int(c[0] >= cut[1]) if c.size else -1
+    for r, (first, cnt) in list(fixed.items())[:200] + [(8, fixed[8])]:
+        m = p['rows'] == r
+        got = p['slots'][m]
+        assert sorted(got.tolist()) == list(range(first, first + cnt))
+        order = np.argsort(got)
+        rngs = tile_rng[tile_of_slot[m]][order]
+        assert (np.diff(rngs) >= 0).all()                          # the fix-up adds range 0's pieces first
+    split_rows = np.array(sorted(fixed))
+    direct = np.setdiff1d(np.unique(p['rows'][live]), split_rows)
+    assert all((p['slots'][p['rows'] == r] == -1).all() for r in direct[:200])
+    # the clock in range coordinates: 0 at the first bucket of every range, non-decreasing inside a range, below K
+    w = A.warp.numpy().view(np.uint32).astype(np.int64)
+    b1 = cut[1] >> A.warp_shift
+    assert w[0] == 0 and w[b1] == 0 and (np.diff(w[:b1]) >= 0).all() and (np.diff(w[b1:]) >= 0).all() and w.max() < K
+    # and the plan's struct asks for XCD ranges and carries a pace like an ungrouped plan
+    A.pace[64] = 250
+    st = A.struct(64)
+    assert st.xcd_map == 1 and st.pace_ns_per_nnz == 250 and st.dev_warp and st.nslots == A.nslots
+
+
+def test_choose_ranges_takes_the_small_fabric_bound_block_only():
+    from stochastic_gcn_amd.ops import ColumnSweepCSR as CS
+    assert CS.choose_ranges(29211, 2896039, 232965, 1) == 2        # an eighth of S-Reddit
+    assert CS.choose_ranges(58300, 5800000, 232965, 1) == 0        # a quarter: 2 x 58 k pieces do not fit one round
+    assert CS.choose_ranges(29211, 2896039, 232965, 2) == 0        # two lane groups: not a one-group plan
+    assert CS.choose_ranges(2000, 20000, 232965, 1) == 0           # so sparse that an XCD touches few columns either way

@@ -573,6 +573,50 @@ def test_grouped_column_sweep_equals_plain_plan_and_oracle(dev, d, pad):
     assert onp.rel_err(c2.cpu().numpy(), ref[:4000]) <= TOL
 
 
+@pytest.mark.parametrize("M,K,d,pad,thr", [(700, 30000, 602, 6, 0), (3000, 20000, 70, 2, 40), (300, 8192, 128, 0, 0),
+                                           (64, 5000, 1024, 0, 24)])
+def test_column_range_plan_vs_oracle(dev, M, K, d, pad, thr):
+    """ColumnSweepCSR(col_ranges=2) (round 6: a small row block's rows split by column range, a range per half of the XCDs,
+    all ranges on one clock) against the CPU oracle: unpaced and at several clocks (pacing and placement only: the SAME bits),
+    with the fusions, beta, padded pitch untouched, empty rows, rows that live in one range, bit-identical reruns."""
+    from stochastic_gcn_amd import ops
+    a = rand_csr(M, K, 0.004, M + d, long_rows=[(0, min(K, 3000)), (M // 2, min(K, 900))]).tolil()
+    a[3, :] = 0                                                   # an empty row
+    a[4, :] = 0
+    a[4, K - 1] = 2.0                                             # a row in the upper range only
+    a = a.tocsr().astype(np.float32)
+    a.sort_indices()
+    rng = np.random.RandomState(d)
+    B = rng.standard_normal((K, d + pad)).astype(np.float32)
+    A = ops.ColumnSweepCSR(a, dev, T=thr, col_ranges=2)
+    assert A.ranged == 2 and A.nfix >= 1 and not A.grouped
+    Bd = T(B, dev)[:, :d]
+    ref = onp.spmm(a.indptr, a.indices, a.data, B[:, :d])
+    A.pace[d] = -1
+    out = ops.spmm_cs(A, Bd)
+    assert onp.rel_err(out.cpu().numpy(), ref) <= TOL
+    assert float(out[3].abs().max()) == 0.0
+    for pace in (60, 250, 2000):
+        A.pace[d] = pace
+        assert torch.equal(ops.spmm_cs(A, Bd), out)
+    best = A.autotune(Bd)
+    assert best[1] == A.pace[d] and torch.equal(ops.spmm_cs(A, Bd), out)
+    assert "true>" in A.variant(d).split(" x ")[0] or A.pace[d] <= 0          # a paced launch looks positions up (WARP form)
+    one = ops.ColumnSweepCSR(a, dev, T=thr or 64)
+    c1 = ops.spmm_cs(one, Bd)
+    assert float((c1 - out).abs().max() / c1.abs().max()) <= 1e-5             # the 1-D plan: same product, other summation order
+    H = rng.standard_normal((K + 500, d + pad)).astype(np.float32)
+    gi = rng.choice(K + 500, K, replace=False).astype(np.int32)
+    rs, cs = rng.rand(M).astype(np.float32), rng.rand(K).astype(np.float32)
+    c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
+    o2 = T(c0, dev)
+    ops.spmm_cs(A, T(H, dev)[:, :d], out=o2[:, :d], gidx=T(gi, dev), rscale=T(rs, dev), cscale=T(cs, dev), beta=0.5)
+    ref2 = onp.spmm(a.indptr, a.indices, a.data, H[:, :d], gidx=gi, rscale=rs, cscale=cs, C_in=c0[:, :d], beta=0.5)
+    assert onp.rel_err(o2[:, :d].cpu().numpy(), ref2) <= TOL
+    if pad:
+        np.testing.assert_array_equal(o2[:, d:].cpu().numpy(), c0[:, d:])
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 41, 70), (512, 128, 256), (1021, 128, 1204), (200, 300, 50),
                                    (64, 128, 128), (31, 7, 33),
                                    # weight-gradient shapes of the Reddit step: split-K (4..8 output tiles, long K)
