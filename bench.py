@@ -58,6 +58,12 @@ def parse(argv=None):
     p.add_argument("--plan-t", type=int, default=0)
     p.add_argument("--tune", action="append", default=[], help="key=value passed to sgcn_tune")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-setup-report", action="store_true", help="skip the plan-cost / row-gather comparison (no row-gather launches in the run)")
+    p.add_argument("--pmc", default="auto", choices=["auto", "live", "off"],
+                   help="roofline.traffic: live = three separate rocprofv3 --pmc passes of this same command, run as child "
+                        "processes (FETCH_SIZE / WRITE_SIZE / TCC_HIT+MISS: MI355X_MICROARCH.md's recipe), counted in THIS run; "
+                        "auto = live for the default single-GPU column-sweep line, the committed profiles/*_traffic.json record "
+                        "otherwise or when a pass fails; off = the committed record")
     p.add_argument("--no-epoch", action="store_true")
     p.add_argument("--no-strong", action="store_true", help="--gpus N > 1: skip the strong-scaling leg (ONE graph row-block sharded)")
     p.add_argument("--epoch-timeout", type=int, default=240, help="watchdog of the train-epoch leg, s")
@@ -279,6 +285,66 @@ def profiled_traffic(kernel_prefix, nnz, d):
         if j.get("kernel", "").startswith(kernel_prefix) and j.get("nnz") == nnz and j.get("d") == d:
             best = (j, os.path.basename(f))
     return best
+
+
+def live_traffic(argv, pace_fwd, pace_bwd, kernel_prefix, launches, timeout_s=150):
+    """HBM-side bytes per launch of the timed kernel, COUNTED IN THIS RUN: three separate ``rocprofv3 --pmc`` passes
+    (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum + TCC_MISS_sum -- one counter group per run with --kernel-trace only, as
+    /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes) of this same bench command as child processes, with
+    the clock the parent's autotune chose, no epoch / CPU / setup legs and a few steps.  FETCH_SIZE is KiB and reports
+    half of a wide coalesced read on gfx950 (x 2); WRITE_SIZE is KiB.  None when rocprofv3 is missing or a pass fails
+    (every pass is bounded by a timeout: the caller falls back to the committed record)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    base = tempfile.mkdtemp(prefix="sgcn_pmc_", dir=os.environ.get("TMPDIR") or "/tmp")
+    keep, skip = [], False
+    for a in argv:                       # (the parent's own --pmc choice does not travel)
+        if skip:
+            skip = False
+        elif a == "--pmc":
+            skip = True
+        elif not a.startswith("--pmc="):
+            keep.append(a)
+    child = [sys.executable, os.path.abspath(__file__)] + keep + \
+        ["--pmc", "off", "--no-epoch", "--no-cpu-baseline", "--no-setup-report", "--steps", "4", "--warmup", "1",
+         "--tune", "cs_pace=%d" % int(pace_fwd)]
+    env = dict(os.environ, TMPDIR="/tmp", SGCN_BENCH_CHILD="1")
+    got, t0 = {}, time.time()
+    try:
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+            out = os.path.join(base, name)
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "-d", out, "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None
+            dbs = glob.glob(os.path.join(out, "**", "*results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            for c in counters:
+                row = db.execute("select name, avg(counter_value), avg(duration), count(*) from pmc_events where counter_name=? "
+                                 "and name like ? group by name order by sum(duration) desc limit 1", (c, kernel_prefix + "%")).fetchone()
+                if row is None:
+                    return None
+                got[c] = row
+            db.close()
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    f, w = got["FETCH_SIZE"][1] * 1024 * 2, got["WRITE_SIZE"][1] * 1024
+    hit, mis = got["TCC_HIT_sum"][1], got["TCC_MISS_sum"][1]
+    return {"kernel": got["FETCH_SIZE"][0], "fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
+            "kernel_launches_per_spmm": launches, "hbm_bytes_per_spmm": (f + w) * launches,
+            "l2_hit_rate": hit / max(hit + mis, 1.0), "ns_per_launch_profiled": got["FETCH_SIZE"][2],
+            "dispatches_per_pass": int(got["FETCH_SIZE"][3]), "pace_ns": int(pace_fwd), "wall_s": round(time.time() - t0, 1)}
 
 
 def gather_ceiling():
@@ -831,7 +897,7 @@ def main(argv=None):
     }
     if reorder_info:
         out["config"]["reorder"] = reorder_info
-    if setup is not None:
+    if setup is not None and not args.no_setup_report:
         out["setup"] = setup_report(setup, full_adj, X, C, dev, fwd_ms, ops)
     gc = gather_ceiling()
     if gc is not None and args.kernel == "cs":
@@ -854,13 +920,32 @@ def main(argv=None):
         tr = profiled_traffic(("void " + A.variant(d).split(" x ")[0].replace("false>", "").replace("true>", "").rstrip(", "))
                               if args.kernel == "cs" else "void sgcn::spmm", sh.local_nnz if sh is not None else nnz, d) \
             if not (args.tune or reorder != "none") else None
+    # ... or, better, counted in THIS run (a committed file is the builder's number): the default single-GPU
+    # column-sweep line spends ~30 s on three child passes under rocprofv3 --pmc
+    live = None
+    want_live = args.pmc == "live" or (args.pmc == "auto" and sh is None and not args.tune and reorder == "none")
+    if want_live and args.kernel == "cs" and rank == 0 and world == 1 and not os.environ.get("SGCN_BENCH_CHILD") and tuned:
+        pf = tuned["fwd"][1] if "fwd" in tuned else tuned.get("fwd_pace")
+        pb_ = (tuned["bwd"][1] if "bwd" in tuned else tuned.get("bwd_pace")) if not args.no_backward else pf
+        if pf and pf > 0:
+            live = live_traffic(argv, pf, pb_, "void sgcn::cs_spmm16", out["config"]["kernel_launches_per_spmm"])
+    if live is not None:
+        committed = tr
+        tr = (dict(live, kernel=live["kernel"]), None)
+        out["roofline"]["traffic_live"] = {k: live[k] for k in ("fetch_bytes_corrected", "write_bytes", "l2_hit_rate", "ns_per_launch_profiled",
+                                                                 "dispatches_per_pass", "pace_ns", "wall_s")}
+        if committed is not None:
+            out["roofline"]["traffic_committed"] = {"hbm_bytes_per_spmm": committed[0]["hbm_bytes_per_spmm"], "source": "profiles/" + committed[1]}
     if tr is not None:
         out["roofline"]["traffic"] = tr[0]["hbm_bytes_per_spmm"]
         # what the memory side actually moves (profiled bytes / measured time), next to the compulsory model
         out["roofline"]["traffic_GBps"] = tr[0]["hbm_bytes_per_spmm"] / (fwd_ms * 1e-3) / 1e9
         out["roofline"]["traffic_frac_of_peak"] = tr[0]["hbm_bytes_per_spmm"] / (fwd_ms * 1e-3) / HBM_PEAK
-        out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
-            tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))
+        out["roofline"]["traffic_source"] = ("profiles/%s (separate rocprofv3 --pmc passes; kernel %s, L2 hit %.3f)" % (
+            tr[1], tr[0]["kernel"], tr[0].get("l2_hit_rate", float("nan")))) if tr[1] is not None else (
+            "live: three separate rocprofv3 --pmc passes (FETCH_SIZE x 2 [gfx950 wide-read correction]; WRITE_SIZE; TCC_HIT / TCC_MISS) of "
+            "this command as child processes inside this run, clock fixed at the autotuned %d ns; kernel %s, L2 hit %.3f, "
+            "mean over the forward and backward launches" % (tr[0]["pace_ns"], tr[0]["kernel"], tr[0]["l2_hit_rate"]))
         if gc is not None:      # the two-rate model of this kernel's own traffic
             miss_b = tr[0]["fetch_bytes_corrected"] * tr[0]["kernel_launches_per_spmm"]
             hit_b = max((sh.local_nnz if sh is not None else nnz) * (d * 4 + 8) - miss_b, 0)
