@@ -287,7 +287,7 @@ def profiled_traffic(kernel_prefix, nnz, d):
     return best
 
 
-def live_traffic(argv, pace_fwd, pace_bwd, kernel_prefix, launches, timeout_s=150):
+def live_traffic(argv, pace_fwd, pace_bwd, kernel_prefix, launches, timeout_s=60):
     """HBM-side bytes per launch of the timed kernel, COUNTED IN THIS RUN: three separate ``rocprofv3 --pmc`` passes
     (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum + TCC_MISS_sum -- one counter group per run with --kernel-trace only, as
     /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes) of this same bench command as child processes, with
