@@ -33,7 +33,7 @@ extern "C" {
 #define SGCN_ERR_NAN (-4)        /* gcn/scheduler.cpp:114-115 "nan" */
 
 const char* sgcn_last_error(void);
-/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 15.
+/* ABI version of this header (bumped on any change of a signature or of a buffer contract): 16.
  *   v6  retired the kernels measured slower (two dense layers per launch, loss / LayerNorm backward in GEMM epilogues)
  *   v7  sampler core + packer threads (sgcn_prefetch_start: lag, n_packers), SGCN_AGG_PLAN_T
  *   v8  sgcn_step_fill, sgcn_copy_h2d_async (the launching thread's per-step work as foreign calls)
@@ -46,7 +46,9 @@ const char* sgcn_last_error(void);
  *       sgcn_csr_transpose_host, sgcn_host_threads; sgcn_coll_available / _retain / _abort / _async_error,
  *       sgcn_coll_destroy counts users
  *   v15 sgcn_coll_init_exchange / _has_exchange / sgcn_coll_allgather_x_i32 (a second communicator for the history exchange);
- *       step ops HIST_PACK .. HIST_APPLY: aux = 2 = the library's exchange stream, joined at the end of the run */
+ *       step ops HIST_PACK .. HIST_APPLY: aux = 2 = the library's exchange stream, joined at the end of the run
+ *   v16 packed minibatch: + the medg weights in the order of adj^T's nonzeros (descriptors behind the CSR table); step ops
+ *       GEMM .. GATE (the --det_dropout stacks as step programs) */
 int sgcn_abi_version(void);
 
 /* ======================================================================================
@@ -615,6 +617,7 @@ int sgcn_sched_view_f32(sgcn_sched_t* s, int32_t which, const float** ptr, int64
  *   fields  (L+1) x {off,len}      scales  L x {off,len}       ffields L x {off,len}
  *   labels  {off,rows,cols}        medg_w  L x {off,len}
  *   csr     L x {adj, adj^T, fadj} x {nrows,ncols,nnz,rowptr,col,val,seg,nseg,fix,nfix,nslots}
+ *   tmedg_w L x {off,len}          (ABI v16: medg_w permuted like adj^T's values; control-variate hops only)
  * (offsets into the int32 buffer for index arrays, into the fp32 buffer for values; layer 0 =
  * input-most).  Touches no Python state, so a prefetch thread runs it outside the GIL. */
 int sgcn_sched_batch_packed(sgcn_sched_t* s, int32_t n, const int32_t* host_ids, int32_t L,

@@ -235,7 +235,8 @@ class Packer {
 public:
     enum { kCsrDesc = 11 };   // nrows ncols nnz rowptr col val seg nseg fix nfix nslots
     explicit Packer(int32_t n) : relabel_(n) {}
-    static int64_t meta_len(int32_t L) { return 4 + 2 * (L + 1) + 2 * L + 2 * L + 3 + 2 * L + 3 * L * kCsrDesc; }
+    // (... + L x (off,len) of the medg weights in TRANSPOSED order, appended behind the CSR descriptors: ABI v16)
+    static int64_t meta_len(int32_t L) { return 4 + 2 * (L + 1) + 2 * L + 2 * L + 3 + 2 * L + 3 * L * kCsrDesc + 2 * L; }
 
     void relabel(Hop& h) {
         if (h.relabelled) return;
@@ -251,11 +252,17 @@ public:
         for (size_t c = 0; c < n_in; c++) tedg_p[c + 1] += tedg_p[c];
         tedg_t.clear(); tedg_t.grow(ne);
         tedg_w.clear(); tedg_w.grow(ne);
+        // the det-dropout aggregator's third matrix (the adjacency's pattern with the medg weights, gcn/scheduler.cpp:164)
+        // needs its transpose on the way back: the same permutation applied to the medg weights (control-variate hops only)
+        const bool with_medg = h.medg_w.size() == ne;
+        tmedg_w.clear();
+        if (with_medg) tmedg_w.grow(ne);
         cur_.assign(tedg_p.data(), n_in);
         for (size_t e = 0; e < ne; e++) {
             const int32_t q = cur_[(size_t)h.edg_t[e]]++;
             tedg_t[(size_t)q] = h.edg_s[e];
             tedg_w[(size_t)q] = h.edg_w[e];
+            if (with_medg) tmedg_w[(size_t)q] = h.medg_w[e];
         }
     }
 
@@ -274,6 +281,7 @@ public:
         int64_t* labels_d = ffields_d + 2 * L;           // off, rows, cols
         int64_t* medg_d = labels_d + 3;                  // L x (off,len)
         int64_t* csr_d = medg_d + 2 * L;                 // L x 3 x kCsrDesc  (adj, adjT, fadj)
+        int64_t* tmedg_d = csr_d + 3 * (int64_t)L * kCsrDesc;   // L x (off,len): medg in the order of adjT's nonzeros
         put_i(ids, (size_t)n, fields_d + 2 * L);         // fields[L] = the batch itself
         int rc = SGCN_OK;
         for (int32_t l = 0; l < L; l++) {
@@ -287,6 +295,7 @@ public:
             transpose(h);
             put_csr(csr_d + (3 * slot + 0) * kCsrDesc, n1, n0, h.edg_p, h.edg_t, h.edg_w, plan_T);
             put_csr(csr_d + (3 * slot + 1) * kCsrDesc, n0, n1, tedg_p, tedg_t, tedg_w, plan_T);
+            put_f(tmedg_w.data(), tmedg_w.size(), tmedg_d + 2 * slot);
             if (cv) {
                 relabel(h);
                 put_i(ffield.data(), ffield.size(), ffields_d + 2 * slot);
@@ -313,7 +322,7 @@ public:
     }
 
     Buf<int32_t> ffield, tedg_p, tedg_t;     // of the hop last relabelled / transposed (the view API reads them)
-    Buf<float> tedg_w;
+    Buf<float> tedg_w, tmedg_w;
 
 private:
     void pad_i() { while (pi_.size() & 3) pi_.push_back(0); }
@@ -820,7 +829,7 @@ struct sgcn_mult { sgcn::FenwickMultinomial impl; };
 extern "C" {
 
 const char* sgcn_last_error(void) { return sgcn::error_slot(); }
-int sgcn_abi_version(void) { return 15; }
+int sgcn_abi_version(void) { return 16; }
 
 int sgcn_sched_create(const float* w, const int32_t* idx, const int32_t* ptr, int32_t num_data,
                       int32_t num_edges, int32_t L, int32_t cv, int32_t is, sgcn_sched_t** out) {

@@ -270,7 +270,8 @@ class PackedBatch(object):
         self.o_ffields = o; o += 2 * L
         self.o_labels = o; o += 3
         self.o_medg = o; o += 2 * L
-        self.o_csr = o
+        self.o_csr = o; o += 3 * L * CSR_DESC
+        self.o_tmedg = o                  # (ABI v16) medg in the order of adj^T's nonzeros, L x (off, len)
 
     # lazily built host views --------------------------------------------------------------------
     @property
@@ -317,6 +318,10 @@ class PackedBatch(object):
     @property
     def _medg(self):
         return self.meta[self.o_medg:self.o_medg + 2 * self.L].reshape(self.L, 2)
+
+    @property
+    def _tmedg(self):
+        return self.meta[self.o_tmedg:self.o_tmedg + 2 * self.L].reshape(self.L, 2)
 
     @property
     def _csr(self):

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
 
 
 def test_status_codes_and_error_message_without_gpu():
-    assert _ffi.lib.sgcn_abi_version() == _ffi.ABI_VERSION == 15
+    assert _ffi.lib.sgcn_abi_version() == _ffi.ABI_VERSION == 16
     rc = _ffi.lib.sgcn_tune(b"no_such_knob", 1)
     assert rc == -1
     assert b"unknown key" in _ffi.lib.sgcn_last_error()

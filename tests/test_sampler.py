@@ -224,6 +224,19 @@ def test_packed_batch_equals_feed_dict_path():
                             assert np.array_equal(np.asarray(x), np.asarray(y)), (cv, L, it, k)
                     else:
                         assert np.array_equal(v, w), (cv, L, it, k)
+                # ABI v16: the medg weights in the order of adj^T's nonzeros (the det-dropout aggregator's third matrix on
+                # the way back) = SciPy's transpose of the adjacency pattern carrying them, bit for bit; none without --cv
+                import scipy.sparse as sp
+                for l in range(L):
+                    h, t = pb.csr(l, 0), pb.csr(l, 1)
+                    tm = pb._f(*pb._tmedg[l])
+                    if not cv:
+                        assert tm.shape[0] == 0
+                        continue
+                    m = sp.csr_matrix((pb._f(*pb._medg[l]), h.col, h.rowptr), shape=tuple(h.shape))
+                    mt = m.T.tocsr()                                  # (stable: rows ascending inside a column)
+                    assert gu.bits_equal(mt.indptr.astype(np.int32), t.rowptr) and gu.bits_equal(mt.indices.astype(np.int32), t.col)
+                    assert gu.bits_equal(mt.data, tm)
             np.testing.assert_array_equal(a.c_sch.ivec(I_ADJ_I), b.c_sch.ivec(I_ADJ_I))
 
 
