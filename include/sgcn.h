@@ -738,6 +738,24 @@ enum {
                                  * all-reduce and the optimizer; the all-gather goes to the exchange communicator
                                  * (sgcn_coll_allgather_x_i32); `stream` waits for the exchange at the END of the run (the first
                                  * reader of the history is the next run's aggregator, gcn/models.py:186-194) */
+    /* the --det_dropout stacks (gcn/layers.py:141-202, 236-248, 320-349, 425-428) as step programs (ABI v16): the entry
+     * points of the same names with their arguments in order (element counts n = rows x pitch; floats as bit patterns) */
+    SGCN_OP_GEMM = 33,          /* sgcn_gemm_f32 (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_capacity): split-K scratch
+                                 * is passed exactly when sgcn_gemm_ws_floats(M, N, K) > 0, as the host path does */
+    SGCN_OP_DET_PRE = 34,       /* sgcn_det_pre_f32 (mu, var, n, keep, var_out) */
+    SGCN_OP_DET_PRE_BWD = 35,   /* sgcn_det_pre_bwd_f32 (mu, g, n, keep, d_mu, d_var) */
+    SGCN_OP_SQUARE = 36,        /* sgcn_square_f32 (x, n, c, y) */
+    SGCN_OP_ADDMUL = 37,        /* sgcn_addmul_f32 (acc, a, b, n, c) */
+    SGCN_OP_DET_LNVAR_FWD = 38, /* sgcn_det_lnvar_fwd_f32 (var1, rstd, scale, n, d, eps, var2) */
+    SGCN_OP_DET_LNVAR_BWD = 39, /* sgcn_det_lnvar_bwd_f32 (g, var1, xhat, rstd, scale, n, d, eps, d_var1, d_mu1, dscale, tmp) */
+    SGCN_OP_DET_RELU_FWD = 40,  /* sgcn_det_relu_fwd_f32 (mu, var, n, mu_out, var_out) */
+    SGCN_OP_DET_RELU_BWD = 41,  /* sgcn_det_relu_bwd_f32 (mu, var, g_mu, g_var, n, d_mu, d_var) */
+    SGCN_OP_GAUSS = 42,         /* sgcn_gauss_sample_f32 (mu, var, n, key, x) */
+    SGCN_OP_GAUSS_BWD = 43,     /* sgcn_gauss_sample_bwd_f32 (var, g, n, key, d_var) */
+    SGCN_OP_DET_AGG_PREP = 44,  /* sgcn_det_agg_prep_f32 (mu, var, Hm, Hv, ldh, ifield, n0, d, delta_mu, ds2, msig2, ds, sbar) */
+    SGCN_OP_DET_AGG_PREP_BWD = 45, /* sgcn_det_agg_prep_bwd_f32 (var, ds, sbar, g_ds2, g_msig2, n0, d, add, ldadd, add_rows, d_var) */
+    SGCN_OP_RELU_EPS = 46,      /* sgcn_relu_eps_f32 (raw, ldr, n, d, eps, y, ldy) */
+    SGCN_OP_GATE = 47,          /* sgcn_gate_f32 (raw, ldr, g, ldg, n, d, out) */
     SGCN_OP_GRAD_STORE = 22     /* no arguments, anywhere in the program: the run is in gradient-STORE mode -- every DENSE_BWD
                                  * writes its dW / doffset / dscale instead of adding to them, so the program zeroes nothing
                                  * (it must write every parameter gradient exactly once per step); and the statistics

@@ -502,6 +502,108 @@ extern "C" int sgcn_step_run(const sgcn_step_op_t* ops, int32_t nops, const int6
             rc = sgcn_ln_act_bwd_f32(dy, lddy, y, ldy, xhat, rstd, sc, n, d, relu, dx, lddx, doff, dsc, ws, stream);
             break;
         }
+        // ---- the --det_dropout stacks (ABI v16): the eager layers' calls, one op each ----------------------------------
+        case SGCN_OP_GEMM: {
+            const int32_t ta = a.i(), tb = a.i(), M = a.i(), N = a.i(), K = a.i();
+            const float* A = a.p<const float>(); const int64_t lda = a.next();
+            const float* B = a.p<const float>(); const int64_t ldb = a.next();
+            float* Cm = a.p<float>(); const int64_t ldc = a.next(); const int32_t acc = a.i();
+            float* ws = a.p<float>(); const int64_t ws_cap = a.next();
+            const int64_t need = sgcn_gemm_ws_floats(M, N, K);           // (ops.gemm: scratch exactly when split-K pays)
+            if (need > ws_cap) return sgcn::fail(SGCN_ERR_INVALID, "step_run: GEMM scratch too small at op %d", k);
+            rc = (M > 0 && N > 0) ? sgcn_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, Cm, ldc, acc, need > 0 ? ws : nullptr,
+                                                  nullptr, nullptr, stream) : SGCN_OK;
+            break;
+        }
+        case SGCN_OP_DET_PRE: {
+            const float* mu = a.p<const float>(); const float* var = a.p<const float>(); const int64_t n = a.next();
+            const float keep = a.f(); float* out = a.p<float>();
+            rc = sgcn_det_pre_f32(mu, var, n, keep, out, stream);
+            break;
+        }
+        case SGCN_OP_DET_PRE_BWD: {
+            const float* mu = a.p<const float>(); const float* g = a.p<const float>(); const int64_t n = a.next();
+            const float keep = a.f(); float* d_mu = a.p<float>(); float* d_var = a.p<float>();
+            rc = sgcn_det_pre_bwd_f32(mu, g, n, keep, d_mu, d_var, stream);
+            break;
+        }
+        case SGCN_OP_SQUARE: {
+            const float* x = a.p<const float>(); const int64_t n = a.next(); const float c = a.f(); float* y = a.p<float>();
+            rc = sgcn_square_f32(x, n, c, y, stream);
+            break;
+        }
+        case SGCN_OP_ADDMUL: {
+            float* acc = a.p<float>(); const float* x = a.p<const float>(); const float* y = a.p<const float>();
+            const int64_t n = a.next(); const float c = a.f();
+            rc = sgcn_addmul_f32(acc, x, y, n, c, stream);
+            break;
+        }
+        case SGCN_OP_DET_LNVAR_FWD: {
+            const float* var1 = a.p<const float>(); const float* rstd = a.p<const float>(); const float* sc = a.p<const float>();
+            const int32_t n = a.i(), d = a.i(); const float eps = a.f(); float* out = a.p<float>();
+            rc = sgcn_det_lnvar_fwd_f32(var1, rstd, sc, n, d, eps, out, stream);
+            break;
+        }
+        case SGCN_OP_DET_LNVAR_BWD: {
+            const float* g = a.p<const float>(); const float* var1 = a.p<const float>(); const float* xhat = a.p<const float>();
+            const float* rstd = a.p<const float>(); const float* sc = a.p<const float>();
+            const int32_t n = a.i(), d = a.i(); const float eps = a.f();
+            float* d_var1 = a.p<float>(); float* d_mu1 = a.p<float>(); float* dsc = a.p<float>(); float* tmp = a.p<float>();
+            rc = sgcn_det_lnvar_bwd_f32(g, var1, xhat, rstd, sc, n, d, eps, d_var1, d_mu1, dsc, tmp, stream);
+            break;
+        }
+        case SGCN_OP_DET_RELU_FWD: {
+            const float* mu = a.p<const float>(); const float* var = a.p<const float>(); const int64_t n = a.next();
+            float* mo = a.p<float>(); float* vo = a.p<float>();
+            rc = sgcn_det_relu_fwd_f32(mu, var, n, mo, vo, stream);
+            break;
+        }
+        case SGCN_OP_DET_RELU_BWD: {
+            const float* mu = a.p<const float>(); const float* var = a.p<const float>();
+            const float* gm = a.p<const float>(); const float* gv = a.p<const float>(); const int64_t n = a.next();
+            float* d_mu = a.p<float>(); float* d_var = a.p<float>();
+            rc = sgcn_det_relu_bwd_f32(mu, var, gm, gv, n, d_mu, d_var, stream);
+            break;
+        }
+        case SGCN_OP_GAUSS: {
+            const float* mu = a.p<const float>(); const float* var = a.p<const float>(); const int64_t n = a.next();
+            const uint32_t key = (uint32_t)a.next(); float* x = a.p<float>();
+            rc = sgcn_gauss_sample_f32(mu, var, n, key, x, stream);
+            break;
+        }
+        case SGCN_OP_GAUSS_BWD: {
+            const float* var = a.p<const float>(); const float* g = a.p<const float>(); const int64_t n = a.next();
+            const uint32_t key = (uint32_t)a.next(); float* d_var = a.p<float>();
+            rc = sgcn_gauss_sample_bwd_f32(var, g, n, key, d_var, stream);
+            break;
+        }
+        case SGCN_OP_DET_AGG_PREP: {
+            const float* mu = a.p<const float>(); const float* var = a.p<const float>();
+            const float* Hm = a.p<const float>(); const float* Hv = a.p<const float>(); const int64_t ldh = a.next();
+            const int32_t* ifield = a.p<const int32_t>(); const int32_t n0 = a.i(), d = a.i();
+            float* dmu = a.p<float>(); float* ds2 = a.p<float>(); float* msig2 = a.p<float>(); float* ds = a.p<float>(); float* sbar = a.p<float>();
+            rc = sgcn_det_agg_prep_f32(mu, var, Hm, Hv, ldh, ifield, n0, d, dmu, ds2, msig2, ds, sbar, stream);
+            break;
+        }
+        case SGCN_OP_DET_AGG_PREP_BWD: {
+            const float* var = a.p<const float>(); const float* ds = a.p<const float>(); const float* sbar = a.p<const float>();
+            const float* g_ds2 = a.p<const float>(); const float* g_msig2 = a.p<const float>(); const int32_t n0 = a.i(), d = a.i();
+            const float* add = a.p<const float>(); const int64_t ldadd = a.next(); const int32_t add_rows = a.i(); float* d_var = a.p<float>();
+            rc = sgcn_det_agg_prep_bwd_f32(var, ds, sbar, g_ds2, g_msig2, n0, d, add, ldadd, add_rows, d_var, stream);
+            break;
+        }
+        case SGCN_OP_RELU_EPS: {
+            const float* raw = a.p<const float>(); const int64_t ldr = a.next(); const int32_t n = a.i(), d = a.i();
+            const float eps = a.f(); float* y = a.p<float>(); const int64_t ldy = a.next();
+            rc = sgcn_relu_eps_f32(raw, ldr, n, d, eps, y, ldy, stream);
+            break;
+        }
+        case SGCN_OP_GATE: {
+            const float* raw = a.p<const float>(); const int64_t ldr = a.next();
+            const float* g = a.p<const float>(); const int64_t ldg = a.next(); const int32_t n = a.i(), d = a.i(); float* out = a.p<float>();
+            rc = sgcn_gate_f32(raw, ldr, g, ldg, n, d, out, stream);
+            break;
+        }
         case SGCN_OP_CSR_TRANSPOSE: {
             const int32_t ncols = a.i(); const int64_t nnz = a.next();
             const int32_t* col = a.p<const int32_t>(); const int32_t* row = a.p<const int32_t>();

@@ -23,14 +23,17 @@ import torch
 from . import ops
 from ._ffi import StepFill, StepOp, check, lib
 from .flags import FLAGS
-from .layers import AugmentedDropoutDense, Dense, Dropout, PlainAggregator, VRAggregator
+from .layers import AugmentedDropoutDense, Dense, DetDropoutFC, Dropout, PlainAggregator, VRAggregator
 from .scheduler import CSR_DESC, PackedBatch
 
 OP = dict(DENSE_FWD=1, DENSE_BWD=2, VR_AGG=3, SPMM=4, SOFTMAX_CE=5, ADAM=6, SCATTER_ROWS=7, MEMSET0=8,
           DROPOUT=9, L2_PENALTY=10, GATHER_ROWS=11, COPY2D=12, SIGMOID_CE=13, VR_AGG_PRE=14, VR_AGG_POST=15,
           AUX_SCATTER_ROWS=16, AUX_MEMSET0=17, DW_FLUSH=21, GRAD_STORE=22, MODE=23,
           CSR_SLICE=24, LN_ACT_FWD=25, LN_ACT_BWD=26, CSR_TRANSPOSE=27, GATHER_F32=28,       # 18-20: retired (include/sgcn.h)
-          ALLREDUCE_AVG=29, HIST_PACK=30, ALLGATHER_I32=31, HIST_APPLY=32)
+          ALLREDUCE_AVG=29, HIST_PACK=30, ALLGATHER_I32=31, HIST_APPLY=32,
+          # the --det_dropout stacks (ABI v16)
+          GEMM=33, DET_PRE=34, DET_PRE_BWD=35, SQUARE=36, ADDMUL=37, DET_LNVAR_FWD=38, DET_LNVAR_BWD=39, DET_RELU_FWD=40,
+          DET_RELU_BWD=41, GAUSS=42, GAUSS_BWD=43, DET_AGG_PREP=44, DET_AGG_PREP_BWD=45, RELU_EPS=46, GATE=47)
 MAX_ARGS = 48
 GEMM_WS_BOUND = 256 * 32 * 128 + 64    # sgcn_gemm_ws_floats(M, N, K) = S * M * N with S <= 256 / (tiles of 32 x 128): never above this
 ARENA_LIMIT_BYTES = 2 << 30
@@ -112,6 +115,14 @@ class SSparse(object):
 
     def with_vals(self, vals):
         return SSparse(self.o_p, self.o_c, self.o_d, self.o_r, self.rows, self.nnz, self.ncols, self.cap, vals, self.tbox)
+
+
+class SDet(object):
+    """(mean, variance) of a --det_dropout activation: two dense STs of one shape"""
+    __slots__ = ("mu", "var")
+
+    def __init__(self, mu, var):
+        self.mu, self.var = mu, var
 
 
 class SDropped(object):
@@ -328,11 +339,52 @@ class StepProgram(object):
                    + self._drop_args(site, K(-1), Kd) + [self._p(g_tmp), K(self._ws_gemm_ptr), K(self.gemm_ws_floats), gidx])
         return dx
 
-    def _spmm(self, b, B, out, d, cscale=NULL, add=None, add_rows=NULL):
-        """ops.spmm on the CSR described at descriptor base b"""
-        self._emit('SPMM', [self._ip(b + 3), self._ip(b + 4), self._fp(b + 5), self._n(b), self._n(b + 1), K(d),
-                            self._p(B), K(B.ld), NULL, NULL, cscale, self._p(out), K(out.ld), K(_fbits(0.0))]
+    def _spmm(self, b, B, out, d, cscale=NULL, add=None, add_rows=NULL, vals=None, gidx=NULL, beta=0.0):
+        """ops.spmm on the CSR described at descriptor base b (vals: other values on the same pattern and plan -- the
+        squared adjacency, the medg-weighted one; gidx: B rows read through an index; beta: out = A.B + beta out)"""
+        self._emit('SPMM', [self._ip(b + 3), self._ip(b + 4), self._fp(b + 5) if vals is None else vals, self._n(b), self._n(b + 1), K(d),
+                            self._p(B), K(B.ld), gidx, NULL, cscale, self._p(out), K(out.ld), K(_fbits(beta))]
                    + self._plan(b, d) + [self._p(add), K(add.ld if add is not None else 0), add_rows])
+
+    # ---- --det_dropout (layers.DetDropoutFC, the aggregators on (mean, variance), Gaussian re-sampling) ----------------
+    def _nelem(self, t):
+        """element count rows x pitch of a dense activation without a pitch gap, as an operand"""
+        if t.ld != t.cols:
+            raise Unsupported("det-dropout element-wise op on a column block")
+        return (t.rows.mul * t.ld, t.rows.slot, t.rows.add * t.ld)
+
+    def _gemm(self, A, B, out, ta=False, tb=False, accumulate=False):
+        """ops.gemm: out = op(A) @ op(B) (+ out)"""
+        M, Kd = ((K(A.cols), A.rows.op()) if ta else (A.rows.op(), K(A.cols)))
+        N = B.rows.op() if tb else K(B.cols)
+        self._ws_need = max(self._ws_need, GEMM_WS_BOUND)
+        self._emit('GEMM', [K(int(ta)), K(int(tb)), M, N, Kd, self._p(A), K(A.ld), self._p(B), K(B.ld), self._p(out), K(out.ld),
+                            K(int(accumulate)), K(self._ws_gemm_ptr), K(self.gemm_ws_floats)])
+        return out
+
+    def _sq_vals(self, b, l_rows_cap, c=1.0):
+        """tf.square of a minibatch CSR's values (layers._squared): a vector in the arena, sized by a bound the batch is
+        checked against (fits())"""
+        cap = max(int(l_rows_cap), 1)
+        self._cap_checks.append((b + 2, cap))
+        out = self._alloc_vec(cap)[0]
+        self._emit('SQUARE', [self._fp(b + 5), self._n(b + 2), K(_fbits(c)), out])
+        return out
+
+    def _nnz_cap(self, l, which):
+        """upper bound of the nonzeros of layer l's adj / adj^T (0 / 1: a sampled row has its own vertex + `degree`
+        neighbours) or fadj (2: bounded by the graph's longest rows)"""
+        deg = int(FLAGS.degree if self.model.is_training else FLAGS.test_degree)
+        if which != 2:
+            return self.caps[l + 1] * (deg + 1)
+        full = self.model.__dict__.get('_max_full_degree')
+        if full is None:
+            a = getattr(self.model, 'adj', None)
+            full = int(np.diff(a.indptr).max()) + 1 if (a is not None and hasattr(a, 'indptr')) else None
+            self.model.__dict__['_max_full_degree'] = full
+        if full is None:
+            raise Unsupported("det-dropout: no bound on the full-neighbour matrix")
+        return self.caps[l + 1] * full
 
     def _owner_words(self, hist):
         """one zeroed int32 per history row (sgcn_hist_apply_f32's claim table), shared by the program's exchanges"""
@@ -471,8 +523,11 @@ class StepProgram(object):
         # the history scatter: beside the step on the auxiliary stream (one event pair, a barrier on the compute queue), or
         # -- lean_sync -- on the step's own stream after the optimizer, where it costs its 4 us and no synchronisation
         self._hist_last = bool(FLAGS.lean_sync) and local_hist
+        self.det = bool(FLAGS.det_dropout)
+        if self.det and (self.native_world or m.history_hook is not None):
+            raise Unsupported("det-dropout with a multi-GPU history exchange")
         if m.is_training:
-            if self.sparse:
+            if self.sparse or self.det:
                 # the sparse layer's gradients are sums INTO the buffer (a transposed product with beta = 1, LayerNorm
                 # parameter sums): zeroed first, on the step's own stream
                 self._emit('MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
@@ -484,7 +539,7 @@ class StepProgram(object):
             else:
                 self._emit('AUX_MEMSET0', [K(m.grad.data_ptr()), K(m.grad.numel() * 4)])
         accP = {}
-        two_phase = bool(FLAGS.agg_overlap)
+        two_phase = bool(FLAGS.agg_overlap) and not self.det      # (a det-dropout stack keeps its plain-input aggregator fused)
         for layer in m.layers:
             if two_phase and isinstance(layer, VRAggregator):
                 l = layer.l
@@ -546,23 +601,64 @@ class StepProgram(object):
                 site = self._site(layer)
                 if site is not None:
                     act = act.with_vals(self._sparse_dropout(act, site))
-                tape.append(('dropout', None, False))
+                tape.append(('dropout', None, False, None))
             elif isinstance(layer, Dropout):
                 site = self._site(layer)
                 inp = act[0] if (layer.cvd and isinstance(act, tuple)) else act
+                gauss = None
+                if isinstance(inp, SDet):
+                    # layers.Dropout on (mu, var): x ~ N(mu, var + 1e-10) by the counter hash (key of layer index + 4096),
+                    # then the ordinary dropout below
+                    key = self._key(layer.index + 4096)
+                    x = self._alloc(inp.mu.rows, inp.mu.cols)
+                    self._emit('GAUSS', [self._p(inp.mu), self._p(inp.var), self._nelem(inp.mu), key, self._p(x)])
+                    gauss = (inp.var, key)
+                    inp = x
                 if isinstance(inp, tuple):
-                    raise Unsupported("det-dropout tuple")
+                    raise Unsupported("dropout of a tuple")
                 if not (layer.fuse_next and isinstance(inp, SGather)):
                     inp = self._materialize(inp)
                 if site is None:
                     act = inp
-                    tape.append(('dropout', None, False))
+                    tape.append(('dropout', None, False, gauss))
                 elif layer.fuse_next:
                     act = SDropped(inp, site)
-                    tape.append(('dropout', site, True))
+                    tape.append(('dropout', site, True, gauss))
                 else:
                     act = self._materialize(SDropped(inp, site))
-                    tape.append(('dropout', site, False))
+                    tape.append(('dropout', site, False, gauss))
+            elif isinstance(layer, DetDropoutFC):
+                # layers.DetDropoutFC.forward, call for call
+                if isinstance(act, SDet):
+                    mu, var = act.mu, act.var
+                else:
+                    mu, var = self._materialize(act), None
+                    if isinstance(mu, (tuple, SDropped)):
+                        raise Unsupported("DetDropoutFC input")
+                keep = 1.0 - self.dropout
+                W = self._param(layer, 'weights')
+                n, Kin, N = mu.rows, mu.cols, W.cols
+                var_in = self._alloc(n, Kin)
+                self._emit('DET_PRE', [self._p(mu), self._p(var), self._nelem(mu), K(_fbits(keep)), self._p(var_in)])
+                W2 = self._alloc(W.rows, N)
+                self._emit('SQUARE', [self._p(W), K(W.rows.cap * N), K(_fbits(1.2)), self._p(W2)])
+                mu1 = self._gemm(mu, W, self._alloc(n, N))
+                var1 = self._gemm(var_in, W2, self._alloc(n, N))
+                ctx = None
+                if layer.norm:
+                    off, sc = self._param(layer, 'offset'), self._param(layer, 'scale')
+                    mu2, xhat, rstd = self._alloc(n, N), self._alloc(n, N), self._alloc_vec(n.cap)[0]
+                    self._emit('LN_ACT_FWD', [self._p(mu1), K(mu1.ld), self._p(off), self._p(sc), n.op(), K(N), K(_fbits(layer.LN_EPS)),
+                                              K(0), self._p(mu2), K(mu2.ld), self._p(xhat), rstd])
+                    var2 = self._alloc(n, N)
+                    self._emit('DET_LNVAR_FWD', [self._p(var1), rstd, self._p(sc), n.op(), K(N), K(_fbits(layer.LN_EPS)), self._p(var2)])
+                    ctx = (xhat, rstd)
+                else:
+                    mu2, var2 = mu1, var1
+                mo, vo = self._alloc(n, N), self._alloc(n, N)
+                self._emit('DET_RELU_FWD', [self._p(mu2), self._p(var2), self._nelem(mu2), self._p(mo), self._p(vo)])
+                tape.append(('detfc', layer, mu, var is not None, var_in, W2, var1, mu2, var2, ctx, keep))
+                act = SDet(mo, vo)
             elif isinstance(layer, Dense):
                 x, site = act, None
                 if isinstance(x, SDropped):
@@ -581,7 +677,50 @@ class StepProgram(object):
                 hist = m.history[l][0]
                 H = ST(K(hist.data_ptr()), Rows(0, -1, int(hist.shape[0]), int(hist.shape[0])), int(hist.shape[1]), int(hist.stride(0)))
                 n1 = self.rows[l + 1]
-                if layer.cvd:
+                if isinstance(act, SDet):
+                    # layers.VRAggregator._forward_det, call for call: seven products on the general kernel around two
+                    # element-wise launches; the squared matrices and the medg-weighted one share the sampled matrices'
+                    # patterns and plans
+                    if layer.cvd or len(m.history[l]) < 2:
+                        raise Unsupported("det-dropout aggregator without a mean and a variance history")
+                    mu, var = act.mu, act.var
+                    Hm, Hv = m.history[l][0], m.history[l][1]
+                    d = mu.cols
+                    if d != int(Hm.shape[1]) or int(Hm.stride(0)) != int(Hv.stride(0)):
+                        raise Unsupported("det-dropout aggregator: history shape")
+                    n0 = self.rows[l]
+                    A2 = self._sq_vals(ba, self._nnz_cap(l, 0))
+                    P2 = self._sq_vals(bf, self._nnz_cap(l, 2))
+                    Mv = self._fp(self._pb.o_medg + 2 * l)
+                    ffield = self._ip(self._pb.o_ffields + 2 * l)
+                    dmu, ds2, msig2, ds, sbar = (self._alloc(n0, d) for _ in range(5))
+                    self._emit('DET_AGG_PREP', [self._p(mu), self._p(var), K(Hm.data_ptr()), K(Hv.data_ptr()), K(int(Hm.stride(0))),
+                                                self._field_ptr(l), n0.op(), K(d), self._p(dmu), self._p(ds2), self._p(msig2),
+                                                self._p(ds), self._p(sbar)])
+                    w = 2 * d if concat else d
+                    om, ov = self._alloc(n1, w), self._alloc(n1, w)
+                    nb = om.cols_from(d, d) if concat else om
+                    HmT = ST(K(Hm.data_ptr()), Rows(0, -1, int(Hm.shape[0]), int(Hm.shape[0])), d, int(Hm.stride(0)))
+                    HvT = ST(K(Hv.data_ptr()), Rows(0, -1, int(Hv.shape[0]), int(Hv.shape[0])), d, int(Hv.stride(0)))
+                    self._spmm(ba, dmu, nb, d)
+                    self._spmm(bf, HmT, nb, d, gidx=ffield, beta=1.0)
+                    raw = self._alloc(n1, d)
+                    self._spmm(ba, ds2, raw, d, vals=A2)
+                    self._spmm(bf, HvT, raw, d, vals=P2, gidx=ffield, beta=1.0)
+                    self._spmm(ba, msig2, raw, d, vals=Mv, beta=1.0)
+                    ovn = ov.cols_from(d, d) if concat else ov
+                    self._emit('RELU_EPS', [self._p(raw), K(raw.ld), n1.op(), K(d), K(_fbits(1e-10)), self._p(ovn), K(ovn.ld)])
+                    if concat:
+                        self._emit('COPY2D', [self._p(om), K(om.ld), self._p(mu), K(mu.ld), n1.op(), K(d)])
+                        self._emit('COPY2D', [self._p(ov), K(ov.ld), self._p(var), K(var.ld), n1.op(), K(d)])
+                    if local_hist and not self._hist_last:
+                        for hist_t, src in ((Hm, mu), (Hv, var)):
+                            self._emit('AUX_SCATTER_ROWS', [K(hist_t.data_ptr()), K(hist_t.stride(0)), self._field_ptr(l), n0.op(),
+                                                            K(src.cols), self._p(src), K(src.ld)])
+                    self.new_history[l] = [mu, var]
+                    tape.append(('vagg_det', l, d, concat, var, ds, sbar, raw))
+                    act = SDet(om, ov)
+                elif layer.cvd:
                     h, mu = (self._materialize(t) for t in act)
                     d = h.cols
                     if mu.ld != h.ld:
@@ -634,6 +773,24 @@ class StepProgram(object):
                         self._exchanged.add(l)
                     tape.append(('agg', l, d, concat, NULL))
                     act = out_h
+            elif isinstance(layer, PlainAggregator) and isinstance(act, SDet):
+                # layers.PlainAggregator on (mu, var): A mu and A^2 var (gcn/layers.py:236-248)
+                l = layer.l
+                mu, var = act.mu, act.var
+                d, n1, ba = mu.cols, self.rows[l + 1], self._csr(l, 0)
+                A2 = self._sq_vals(ba, self._nnz_cap(l, 0))
+                if not concat:
+                    om, ov = self._alloc(n1, d), self._alloc(n1, d)
+                    self._spmm(ba, mu, om, d)
+                    self._spmm(ba, var, ov, d, vals=A2)
+                else:
+                    om, ov = self._alloc(n1, 2 * d), self._alloc(n1, 2 * d)
+                    self._emit('COPY2D', [self._p(om), K(om.ld), self._p(mu), K(mu.ld), n1.op(), K(d)])
+                    self._emit('COPY2D', [self._p(ov), K(ov.ld), self._p(var), K(var.ld), n1.op(), K(d)])
+                    self._spmm(ba, mu, om.cols_from(d, d), d)
+                    self._spmm(ba, var, ov.cols_from(d, d), d, vals=A2)
+                tape.append(('pagg_det', l, d, concat))
+                act = SDet(om, ov)
             elif isinstance(layer, PlainAggregator):
                 l = layer.l
                 x = self._materialize(act)
@@ -652,7 +809,7 @@ class StepProgram(object):
             else:
                 raise Unsupported("layer %r" % type(layer).__name__)
         logits = act
-        if isinstance(logits, (tuple, SDropped, SGather)):
+        if isinstance(logits, (tuple, SDropped, SGather, SDet)):
             raise Unsupported("model output is not a plain activation")
         nL = self.rows[self.L]
         c = logits.cols
@@ -682,12 +839,87 @@ class StepProgram(object):
                                         self._param(lay, 'offset', True) if lay.norm else None,
                                         self._param(lay, 'scale', True) if lay.norm else None, lay.need_dx, site)
                 elif rec[0] == 'dropout':
-                    _, site, fused = rec
+                    _, site, fused, gauss = rec
                     if g is not None and site is not None and not fused:
                         out = self._alloc(g.rows, g.cols)
                         self._emit('DROPOUT', [self._p(g), K(g.ld), g.rows.op(), K(g.cols)] + self._drop_args(site, K(-1), g.cols)
                                    + [self._p(out), K(out.ld)])
                         g = out
+                    if gauss is not None and g is not None:          # d/d(mu, var) of the Gaussian draw: (g, g eps / (2 sigma))
+                        var, key = gauss
+                        d_var = self._alloc(g.rows, g.cols)
+                        self._emit('GAUSS_BWD', [self._p(var), self._p(g), self._nelem(g), key, self._p(d_var)])
+                        g = (g, d_var)
+                elif rec[0] == 'detfc':
+                    # layers.DetDropoutFC.backward, call for call
+                    _, lay, mu, had_var, var_in, W2, var1, mu2, var2, ctx, keep = rec
+                    g0, g1 = g
+                    n, N, Kin = mu2.rows, mu2.cols, mu.cols
+                    W, dW = self._param(lay, 'weights'), self._param(lay, 'weights', True)
+                    g_mu, g_var = self._alloc(n, N), self._alloc(n, N)
+                    self._emit('DET_RELU_BWD', [self._p(mu2), self._p(var2), self._p(g0), self._p(g1), self._nelem(mu2),
+                                                self._p(g_mu), self._p(g_var)])
+                    if g0.ld != g0.cols or g1.ld != g1.cols:
+                        raise Unsupported("det-dropout gradient with a pitch")
+                    if lay.norm:
+                        sc = self._param(lay, 'scale')
+                        self._ws_need = max(self._ws_need, (int(lib.sgcn_ln_act_bwd_ws_floats(n.cap, N)) + 3) // 4 * 4 + GEMM_WS_BOUND)
+                        g_mu1 = self._alloc(n, N)
+                        self._emit('LN_ACT_BWD', [self._p(g_mu), K(g_mu.ld), self._p(mu2), K(mu2.ld), self._p(ctx[0]), ctx[1], self._p(sc),
+                                                  n.op(), K(N), K(0), self._p(g_mu1), K(g_mu1.ld),
+                                                  self._p(self._param(lay, 'offset', True)), self._p(self._param(lay, 'scale', True)),
+                                                  K(self._ws_gemm_ptr), K(self.gemm_ws_floats)])
+                        d_var1, tmp = self._alloc(n, N), self._alloc(n, N)
+                        self._emit('DET_LNVAR_BWD', [self._p(g_var), self._p(var1), self._p(ctx[0]), ctx[1], self._p(sc), n.op(), K(N),
+                                                     K(_fbits(lay.LN_EPS)), self._p(d_var1), self._p(g_mu1),
+                                                     self._p(self._param(lay, 'scale', True)), self._p(tmp)])
+                        g_mu, g_var = g_mu1, d_var1
+                    # dW = mu^T d_mu1 + 2.4 W (.) (var_in^T d_var1)
+                    self._gemm(mu, g_mu, dW, ta=True, accumulate=True)
+                    t = self._gemm(var_in, g_var, self._alloc(W.rows, N), ta=True)
+                    self._emit('ADDMUL', [self._p(dW), self._p(W), self._p(t), K(W.rows.cap * N), K(_fbits(2.4))])
+                    if not lay.need_dx:
+                        g = None
+                    else:
+                        d_mu = self._gemm(g_mu, W, self._alloc(n, Kin), tb=True)
+                        t2 = self._gemm(g_var, W2, self._alloc(n, Kin), tb=True)
+                        d_var = self._alloc(n, Kin) if had_var else None
+                        self._emit('DET_PRE_BWD', [self._p(mu), self._p(t2), self._nelem(mu), K(_fbits(keep)), self._p(d_mu), self._p(d_var)])
+                        g = (d_mu, d_var) if had_var else d_mu
+                elif rec[0] == 'pagg_det':
+                    _, l, d, cc = rec
+                    bt, n1 = self._csr(l, 1), self.rows[l + 1]
+                    A2t = self._sq_vals(bt, self._nnz_cap(l, 1))
+                    dm, dv = self._alloc(self.rows[l], d), self._alloc(self.rows[l], d)
+                    if not cc:
+                        self._spmm(bt, g[0], dm, d)
+                        self._spmm(bt, g[1], dv, d, vals=A2t)
+                    else:
+                        self._spmm(bt, g[0].cols_from(d, d), dm, d, add=g[0].cols_from(0, d), add_rows=n1.op())
+                        self._spmm(bt, g[1].cols_from(d, d), dv, d, vals=A2t, add=g[1].cols_from(0, d), add_rows=n1.op())
+                    g = (dm, dv)
+                elif rec[0] == 'vagg_det':
+                    # layers.VRAggregator._backward_det
+                    _, l, d, cc, var, ds, sbar, raw = rec
+                    bt, n1, n0 = self._csr(l, 1), self.rows[l + 1], self.rows[l]
+                    gm, gv = (g[0].cols_from(d, d), g[1].cols_from(d, d)) if cc else g
+                    gvg = self._alloc(n1, d)
+                    self._emit('GATE', [self._p(raw), K(raw.ld), self._p(gv), K(gv.ld), n1.op(), K(d), self._p(gvg)])
+                    d_mu = self._alloc(n0, d)
+                    if cc:
+                        self._spmm(bt, gm, d_mu, d, add=g[0].cols_from(0, d), add_rows=n1.op())
+                    else:
+                        self._spmm(bt, gm, d_mu, d)
+                    A2t = self._sq_vals(bt, self._nnz_cap(l, 1))
+                    g_ds2, g_msig2 = self._alloc(n0, d), self._alloc(n0, d)
+                    self._spmm(bt, gvg, g_ds2, d, vals=A2t)
+                    self._spmm(bt, gvg, g_msig2, d, vals=self._fp(self._pb.o_tmedg + 2 * l))
+                    d_var = self._alloc(n0, d)
+                    addv = g[1].cols_from(0, d) if cc else None
+                    self._emit('DET_AGG_PREP_BWD', [self._p(var), self._p(ds), self._p(sbar), self._p(g_ds2), self._p(g_msig2), n0.op(), K(d),
+                                                    self._p(addv), K(addv.ld if addv is not None else 0), n1.op() if cc else K(0),
+                                                    self._p(d_var)])
+                    g = (d_mu, d_var)
                 elif rec[0] == 'agg':
                     _, l, d, cc, sptr = rec
                     bt = self._csr(l, 1)
@@ -710,13 +942,14 @@ class StepProgram(object):
                                 K(m.theta.numel()), self._lr(), K(_fbits(FLAGS.beta1)), K(_fbits(FLAGS.beta2)), K(_fbits(1e-8))])
         self._cur = self.ops_hist
         for l, nh in ({} if (local_hist and not self._hist_last) else self.new_history).items():
-            hist = m.history[l][0]
             if self.native_world:
                 if l not in self._exchanged:
                     self._native_exchange(l, nh)
                 continue
-            self._emit('SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
-                                        K(nh.cols), self._p(nh), K(nh.ld)])
+            # (a det-dropout aggregator updates a mean AND a variance history: models.update_history's zip)
+            for hist, src in zip(m.history[l], nh if isinstance(nh, list) else [nh]):
+                self._emit('SCATTER_ROWS', [K(hist.data_ptr()), K(hist.stride(0)), self._field_ptr(l), self.rows[l].op(),
+                                            K(src.cols), self._p(src), K(src.ld)])
 
     # ---- build the ctypes program ------------------------------------------------------------------
     def _finalize(self):

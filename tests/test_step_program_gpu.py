@@ -80,6 +80,34 @@ def test_program_is_bit_identical_to_the_eager_path(name, slot, group):
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
 
 
+@pytest.mark.parametrize("name", sorted(mc.DET_CASES))
+@pytest.mark.parametrize("slot,group", [(False, True), (True, True), (False, False)])
+def test_det_dropout_stacks_run_as_programs_bit_identical_to_the_eager_path(name, slot, group):
+    """--det_dropout (gcn/layers.py:141-202, 236-248, 320-349, 425-428; round 6, ABI v16): DetDropoutFC, both aggregators on
+    (mean, variance) with a mean and a variance history, the medg-weighted third matrix and its transpose (its values travel in
+    the packed minibatch in both orders), Gaussian re-sampling -- the eager layers' calls as ops GEMM .. GATE of the step program:
+    the same weights, Adam moments, BOTH histories, losses, bit for bit."""
+    case = mc.build_case(name)
+    a, la = _run(case, False, 4, slot)
+    b, lb = _run(case, True, 4, slot, group=group)
+    progs = getattr(b, '_programs', {})
+    assert progs and all(p is not None for p in progs.values()), getattr(b, '_program_note', 'no program was compiled')
+    assert not getattr(a, '_programs', {})
+    for (l1, a1), (l2, a2) in zip(la, lb):
+        assert torch.equal(l1, l2) and torch.equal(a1, a2), (l1, l2)
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    for ha, hb in zip(a.history, b.history):
+        assert len(ha) == len(hb) and all(torch.equal(x, y) for x, y in zip(ha, hb))
+    assert any(float(h.abs().sum()) > 0 for hs in b.history for h in hs) or not b.history
+    prog = next(iter(progs.values()))
+    from stochastic_gcn_amd.step_program import OP
+    codes = [o for o, _ in prog.ops_fb]
+    n_fc = sum(1 for l in b.layers if type(l).__name__ == 'DetDropoutFC')
+    assert prog.det and codes.count(OP['DET_RELU_FWD']) == n_fc == codes.count(OP['DET_RELU_BWD']) and codes.count(OP['GAUSS']) == 1
+    assert codes.count(OP['MEMSET0']) == 1 and codes.count(OP['GRAD_STORE']) == 0
+    print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
+
+
 def test_dropout_zero_and_weight_decay_variants():
     for name, extra in (('reddit_cvd_pp', dict(dropout=0.0)), ('reddit_cv_pp', dict(weight_decay=5e-3)),
                         ('ns_nopp_L2', dict(weight_decay=1e-3, dropout=0.0))):
