@@ -224,13 +224,18 @@ int xchg_pick(void* stream, XchgCtx& c) {
     SGCN_XCHG_TRY(hipStreamSynchronize((hipStream_t)stream));
     for (; n < 8 && got < 0; n++) {
         SGCN_XCHG_TRY(hipStreamCreateWithFlags(&cand[n], hipStreamNonBlocking));
+        // the clock starts BEFORE the spin is launched: a host thread that is descheduled between the launches can only make
+        // a good candidate look bad (rejected, the next one is tried), never a queue-sharing one look good
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = sgcn::spin_launch(stream, 3000);
         if (rc == SGCN_OK) rc = sgcn::spin_launch(cand[n], 1);
         if (rc != SGCN_OK) return rc;
         SGCN_XCHG_TRY(hipEventRecord(ev, cand[n]));
-        const auto t0 = std::chrono::steady_clock::now();
         while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500)) {
-            if (hipEventQuery(ev) == hipSuccess) { got = n; break; }
+            if (hipEventQuery(ev) == hipSuccess) {
+                if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(1500)) got = n;
+                break;
+            }
         }
         SGCN_XCHG_TRY(hipStreamSynchronize((hipStream_t)stream));
         SGCN_XCHG_TRY(hipStreamSynchronize(cand[n]));

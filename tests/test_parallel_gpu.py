@@ -189,6 +189,51 @@ def test_rmat_10m_one_block_of_eight_full_size_vs_oracle():
     assert float((lin - (2 * c + sh.forward(dC))).abs().max() / lin.abs().max()) <= TOL
 
 
+def test_reddit_eighth_block_on_a_column_range_plan_full_size_vs_oracle():
+    """BASELINE config 4's strong scaling at 8 GPUs, ONE rank's block at full size (S-Reddit N = 232,965, d = 602): the block
+    ShardedSpMM gives rank 3 of 8 is small enough for a column-range plan (round 6: rows split by column range, a range per half
+    of the XCDs) in both directions; forward and backward on the autotuned plans against the CPU oracle on sampled rows
+    including the heaviest, A . 1 = row sums and linearity on ALL rows, the 1-D plan of the same block as a second opinion,
+    bit-identical reruns."""
+    import types
+    from stochastic_gcn_amd import ops, synthetic
+    from stochastic_gcn_amd.parallel import ShardedSpMM
+    dev = torch.device("cuda:0")
+    n, _, adj, *_ = synthetic.reddit_like(with_features=False)
+    d = 602
+    sh = ShardedSpMM(types.SimpleNamespace(rank=3, world=8, active=False), adj, dev, d=d)
+    assert sh.A.ranged == 2 and sh.AT.ranged == 2 and sh.A.G == 1 and sh.A.nfix > 0.9 * (sh.hi - sh.lo)
+    assert sh.A.ntiles <= 4096 and sh.AT.ntiles <= 4096                        # one round of resident tiles
+    adj_t = adj.T.tocsr()
+    blk, blk_t = adj[sh.lo:sh.hi].tocsr(), adj_t[sh.lo:sh.hi].tocsr()
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    Bp = torch.zeros((n, 608), device=dev); Bp[:, :d] = torch.randn((n, d), device=dev, generator=g)
+    dCp = torch.zeros((n, 608), device=dev); dCp[:, :d] = torch.randn((n, d), device=dev, generator=g)
+    B, dC = Bp[:, :d], dCp[:, :d]
+    sh.autotune(B, dC)
+    assert sh.A.pace[d] > 0 and sh.AT.pace[d] > 0
+    c, db = sh.forward(B), sh.backward(dC)
+    assert torch.equal(sh.forward(B), c) and torch.equal(sh.backward(dC), db)
+    rng = np.random.RandomState(11)
+    for name, m, X, got in (("fwd", blk, B, c), ("bwd", blk_t, dC, db)):
+        deg = np.diff(m.indptr)
+        rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.argsort(deg)[:20], rng.choice(m.shape[0], 600, replace=False)]))
+        e, _ = _sampled_rows_vs_oracle(m, rows, X, got, dev)
+        assert e <= TOL, (name, e)
+        print("S-Reddit block 3/8 (column-range plan) %s: %d sampled rows (heaviest %d nnz), rel err %.1e" % (name, rows.shape[0], deg.max(), e))
+    one_d = ops.ColumnSweepCSR(blk, dev, G=1)
+    assert not one_d.ranged
+    c1 = ops.spmm_cs(one_d, B)
+    assert float((c1 - c).abs().max() / c1.abs().max()) <= 1e-5
+    ones = torch.ones((n, 4), device=dev)
+    s1 = sh.forward(ones)[:, 0].cpu().numpy().astype(np.float64)
+    want = np.asarray(blk.astype(np.float64).sum(axis=1)).ravel()
+    assert np.abs(s1 - want).max() <= TOL * max(1.0, np.abs(want).max())
+    mixp = 2 * Bp + dCp                                                        # (rows stay 16-byte aligned: pitch 608)
+    lin = sh.forward(mixp[:, :d])
+    assert float((lin - (2 * c + sh.forward(dC))).abs().max() / lin.abs().max()) <= TOL
+
+
 def _train_worker(rank, world, port, native, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGCN_DIST_BACKEND="gloo")
