@@ -1,5 +1,5 @@
-"""Randomised parity of the column sweep (one / two / four lane groups per wave) against the oracle: shapes around the bin /
-tile boundaries, split rows, gathered operand rows, row / column scales, beta, pitch padding, paced and unpaced.
+"""Randomised parity of the column sweep (one / two / four lane groups per wave; round 6: + column-range plans) against the oracle: shapes
+around the bin / tile boundaries, split rows, gathered operand rows, row / column scales, beta, pitch padding, paced and unpaced.
 usage: python profiles/cs_fuzz.py [seed] [cases]"""
 import sys
 import numpy as np
@@ -31,8 +31,13 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     cs = rng.rand(K).astype(np.float32) if rng.rand() < 0.5 else None
     beta = float(rng.choice([0.0, 0.5, 1.0]))
     c0 = rng.standard_normal((M, d + pad)).astype(np.float32)
+    ranged = G == 1 and rng.rand() < 0.5            # rows split by column range (ops.ColumnSweepCSR col_ranges)
     try:
-        A = ops.ColumnSweepCSR(a, dev, T=T, G=G, warp=warp, **({} if G == 1 else {"align": align if rng.rand() < 0.7 else 'auto'}))
+        if ranged:
+            A = ops.ColumnSweepCSR(a, dev, T=T, col_ranges=int(rng.choice([2, 2, 3, 4])))
+            assert A.ranged >= 2
+        else:
+            A = ops.ColumnSweepCSR(a, dev, T=T, G=G, warp=warp, **({} if G == 1 else {"align": align if rng.rand() < 0.7 else 'auto'}))
         A.pace[d] = int(rng.choice([-1, 100, 300]))
         t = lambda x: None if x is None else torch.from_numpy(x).to(dev)     # noqa: E731
         out = t(c0.copy())
@@ -43,8 +48,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         okpad = np.array_equal(out[:, d:].cpu().numpy(), c0[:, d:])
         if not (err <= 1e-4 and okpad):
             bad += 1
-            print("FAIL", case, M, K, dens, G, d, pad, T, align, beta, "err", err, "pad", okpad)
+            print("FAIL", case, M, K, dens, G, "ranged" if ranged else "", d, pad, T, align, beta, "err", err, "pad", okpad)
     except Exception as e:
         bad += 1
-        print("EXC", case, M, K, dens, G, d, pad, T, align, beta, repr(e)[:200])
+        print("EXC", case, M, K, dens, G, "ranged" if ranged else "", d, pad, T, align, beta, repr(e)[:200])
 print("done, failures:", bad)
