@@ -245,6 +245,49 @@ def test_f1_scores_from_the_loss_kernels_class_indices_are_sklearns():
         assert abs(micro - want[0]) < 1e-12 and abs(macro - want[1]) < 1e-12 and 0 < micro < 1
 
 
+def test_multilabel_evaluation_sums_on_the_host_and_matches_sklearn():
+    """--dataset ppi (multi-label: sigmoid cross-entropy, gcn/models.py:77-94): Trainer.evaluate's prediction / label form
+    -- every batch's loss, accuracy, predictions and labels go to pinned host memory as they are produced, the sums are
+    taken on the host after ONE synchronisation (round 6: no torch.stack / cat / sum on this path) -- gives sklearn's
+    micro / macro F1 of the thresholded predictions, the row-weighted mean loss, and the same numbers program or eager."""
+    import torch
+    from sklearn.metrics import f1_score
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.train import Trainer
+    res = {}
+    for native in (True, False):
+        data = list(_data())               # (fresh per trainer: the sampler shuffles the training ids in place)
+        data[6] = (np.random.RandomState(0).rand(*data[6].shape) < 0.3).astype(np.float32)      # several labels per vertex
+        FLAGS.reset()
+        FLAGS.update(dataset='ppi', normalization='graphsage', weight_decay=0.0, dropout=0.1, layer_norm=True, hidden1=64,
+                     num_fc_layers=1, batch_size=256, test_batch_size=300, learning_rate=0.01, seed=1, prefetch=2, cv=True, cvd=True,
+                     test_cv=True, degree=1, test_degree=1, native_step=native)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Trainer(data=tuple(data), verbose=False)
+            assert tr.multitask
+            tr.train_epoch()
+            preds, labs, stats = [], [], []
+            orig = tr.test_model.run_one_step
+
+            def spy(sess, batch, sync=True):
+                out = orig(sess, batch, sync=sync)
+                preds.append(out[2].clone()); labs.append(tr.test_model.cur.labels.clone())
+                stats.append((float(out[0]), float(out[1]), int(out[2].shape[0])))
+                return out
+            tr.test_model.run_one_step = spy
+            cost, acc, micro, macro, _ = tr.evaluate(tr.val_d)
+        pred, lab = torch.cat(preds).cpu().numpy(), torch.cat(labs).cpu().numpy()
+        n = sum(r for _, _, r in stats)
+        assert n == len(tr.val_d) and len(stats) == -(-n // 300)
+        assert abs(cost - sum(c * r for c, _, r in stats) / n) <= 1e-5 * max(1.0, abs(cost))
+        assert abs(acc - sum(a * r for _, a, r in stats) / n) <= 1e-6
+        hard = (pred > 0.5).astype(np.int64)
+        assert abs(micro - f1_score(lab, hard, average="micro")) < 1e-9 and abs(macro - f1_score(lab, hard, average="macro")) < 1e-9
+        assert 0 < micro < 1
+        res[native] = (cost, acc, micro, macro)
+    assert np.allclose(res[True], res[False], rtol=1e-5)
+
+
 def test_no_library_gemm_on_the_product_path(monkeypatch):
     """the size-keyed rocBLAS path (torch.mm above 512 M multiply-adds: Exact mode, large
     evaluation batches) is gone.  With every torch matmul entry point booby-trapped, the Reddit recipe (CVD+PP,
