@@ -3,6 +3,7 @@ exchange: behind the optimizer on the step's stream (SGCN_EXCHANGE_OVERLAP=0), o
 the aggregator with a communicator of its own (=1, round 6) -- with default events (SGCN_XCHG_SYSFENCE=1) or fence-free ones.
 
     for cfg in "0" "1" "1 SGCN_XCHG_SYSFENCE=1"; do env SGCN_FORCE_PG=1 SGCN_EXCHANGE_OVERLAP=$cfg python profiles/exchange_chain_probe.py; done
+    (the cost of each dependency: SGCN_XCHG_DROPS_A_DEPENDENCY=1 SGCN_XCHG_SKIP=fork | join | forkjoin -- results undefined)
 """
 import contextlib
 import json

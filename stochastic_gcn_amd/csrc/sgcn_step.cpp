@@ -261,7 +261,9 @@ int xchg_fork(void* stream, void** side) {
     }
     if (!c.st) { *side = stream; return SGCN_OK; }      // no stream beside the step's: in place, no events
     if (!c.pending) {
-        static const char* skip = getenv("SGCN_XCHG_SKIP");        // MEASUREMENT ONLY (drops a dependency: results undefined)
+        // MEASUREMENT ONLY (profiles/r63_exchange_chain_probe.jsonl: what each dependency costs): dropping one makes the
+        // results undefined, so the knob needs its companion variable spelled out
+        static const char* skip = getenv("SGCN_XCHG_DROPS_A_DEPENDENCY") ? getenv("SGCN_XCHG_SKIP") : nullptr;
         if (!(skip && strstr(skip, "fork"))) {
             SGCN_XCHG_TRY(hipEventRecord(c.fork, (hipStream_t)stream));
             SGCN_XCHG_TRY(hipStreamWaitEvent(c.st, c.fork, 0));
@@ -276,7 +278,7 @@ int xchg_join(void* stream) {
     XchgCtx& c = xchg_ctx();
     if (!c.pending) return SGCN_OK;
     c.pending = false;
-    static const char* skip = getenv("SGCN_XCHG_SKIP");
+    static const char* skip = getenv("SGCN_XCHG_DROPS_A_DEPENDENCY") ? getenv("SGCN_XCHG_SKIP") : nullptr;
     if (skip && strstr(skip, "join")) return SGCN_OK;
     SGCN_XCHG_TRY(hipEventRecord(c.done, c.st));
     SGCN_XCHG_TRY(hipStreamWaitEvent((hipStream_t)stream, c.done, 0));

@@ -630,7 +630,9 @@ class ColumnSweepCSR(object):
         copies of the block stacked as NR x M rows with the range as the row label, then rows and workspace slots renamed."""
         import scipy.sparse as sp
         a = a.tocsr()
-        a.sort_indices()
+        if not a.has_sorted_indices:         # (a private copy: the caller's matrix is not reordered behind its back)
+            a = a.copy()
+            a.sort_indices()
         M, K = int(a.shape[0]), int(a.shape[1])
         rowptr = np.ascontiguousarray(a.indptr, dtype=np.int64)
         col = np.ascontiguousarray(a.indices, dtype=np.int32)
