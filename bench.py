@@ -557,6 +557,9 @@ def strong_leg(args, dev, world, rank, full_adj0, d, pitch, steps):
                    "output, all-gathered (RCCL) before each product" % (nnz, world, d))
     res["steps"] = steps
     res["rows_rank0"] = [int(sh.lo), int(sh.hi)]
+    if sh.A is not None and hasattr(sh.A, "ntiles"):      # rank 0's plan: lane groups, column ranges (a block that does not fill one round of tiles), clock
+        res["plan_rank0"] = {"G": int(getattr(sh.A, "G", 1)), "col_ranges": int(getattr(sh.A, "ranged", 0) or 0),
+                             "tiles": int(sh.A.ntiles), "pace_ns": {"fwd": sh.A.pace.get(d), "bwd": sh.AT.pace.get(d) if sh.AT is not None else None}}
     return res
 
 
