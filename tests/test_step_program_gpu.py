@@ -108,6 +108,42 @@ def test_det_dropout_stacks_run_as_programs_bit_identical_to_the_eager_path(name
     print("%s: %d ops per step, arena %.1f MB" % (name, prog.n_all, prog.arena.numel() * 4 / 2 ** 20))
 
 
+@pytest.mark.parametrize("name", ['det_cv_pp_L3', 'det_ns_nopp_L2'])
+def test_det_dropout_evaluation_model_runs_as_a_program_too(name):
+    """The TEST model of a det-dropout stack (is_training False: forward, Gaussian re-sampling, loss, prediction, both test
+    histories' scatter; dropout 0 -> keep 1) as a forward-only program against its layer-by-layer run: the same loss,
+    accuracy, predictions and histories, bit for bit, over consecutive evaluation batches (the second reads what the first
+    wrote)."""
+    from stochastic_gcn_amd.flags import FLAGS
+    from stochastic_gcn_amd.vrgcn import VRGCN
+    from stochastic_gcn_amd.plaingcn import PlainGCN
+    case = mc.build_case(name)
+    params = mc.make_oracle_model(case, seed=3).params
+    res = {}
+    for native in (False, True):
+        FLAGS.reset()
+        FLAGS.update(**{k: v for k, v in case['flags'].items() if hasattr(FLAGS, k)})
+        FLAGS.update(native_step=native, batch_size=case['cfg']['batch'], test_batch_size=case['cfg']['batch'],
+                     test_degree=case['flags']['degree'])
+        cls = VRGCN if case['cfg']['model'] == 'vr' else PlainGCN
+        fl = case['flags']
+        m = cls(fl['num_layers'], fl['preprocess'], case['ph'], case['feats'], case['nbr'], case['adj'], fl['cvd'],
+                is_training=False, device=torch.device('cuda:0'))
+        m.set_params({k: v.copy() for k, v in params.items()})
+        sch = mc.make_scheduler(case, 1)
+        outs = []
+        for _ in range(3):
+            pb = sch.minibatch_packed(case['cfg']['batch'], FLAGS.plan_t, None)
+            o = m.run_one_step(None, pb, sync=True)
+            outs.append((o[0], o[1], np.array(o[2])))
+        progs = [p for p in getattr(m, '_programs', {}).values()]
+        assert bool(progs and all(p is not None and p.det for p in progs)) == native, getattr(m, '_program_note', None)
+        res[native] = (outs, [h.clone() for hs in m.history for h in hs])
+    for (l0, a0, p0), (l1, a1, p1) in zip(res[False][0], res[True][0]):
+        assert l0 == l1 and a0 == a1 and np.array_equal(p0, p1)
+    assert len(res[False][1]) == len(res[True][1]) and all(torch.equal(x, y) for x, y in zip(res[False][1], res[True][1]))
+
+
 def test_dropout_zero_and_weight_decay_variants():
     for name, extra in (('reddit_cvd_pp', dict(dropout=0.0)), ('reddit_cv_pp', dict(weight_decay=5e-3)),
                         ('ns_nopp_L2', dict(weight_decay=1e-3, dropout=0.0))):
