@@ -30,13 +30,22 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     feats = torch.randn((n, 602), device=dev, generator=g)
+    # SGCN_PROBE_SIDE_STREAM=1: the whole job on a NON-default (non-blocking) torch stream -- is an event record cheaper there
+    # than on the legacy default stream (8 us of the step's chain)?
+    side = torch.cuda.Stream() if os.environ.get("SGCN_PROBE_SIDE_STREAM") else None
+    ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+    with ctx:
+        return _body(dev, n, train_adj, full_adj, feats, labels, tr, va, te, side is not None)
+
+
+def _body(dev, n, train_adj, full_adj, feats, labels, tr, va, te, side):
     with contextlib.redirect_stdout(sys.stderr):
         trn = Trainer(data=(n, train_adj, full_adj, feats, None, None, labels, tr, va, te), verbose=False)
     walls = []
     for _ in range(6):
         trn.train_epoch()
         walls.append(trn.last_epoch['train_wall_s'])
-    rec = dict(overlap=os.environ.get("SGCN_EXCHANGE_OVERLAP", "1"), sysfence=os.environ.get("SGCN_XCHG_SYSFENCE"),
+    rec = dict(side_stream=side, overlap=os.environ.get("SGCN_EXCHANGE_OVERLAP", "1"), sysfence=os.environ.get("SGCN_XCHG_SYSFENCE"),
                forced_pg=os.environ.get("SGCN_FORCE_PG"), exchange_overlap=bool(trn.par.exchange_overlap),
                native=bool(trn.par.native), epoch_ms=round(min(walls) * 1e3, 3), steps=trn.last_epoch['steps'],
                ms_per_step=round(min(walls) * 1e3 / trn.last_epoch['steps'], 5))
